@@ -1,0 +1,198 @@
+// TEST INFRASTRUCTURE — live-reference harness (not product code, never shipped).
+//
+// A fake "plotly.js" for kaleido's headless Chromium + SwiftShader: kaleido calls
+// Plotly.toImage(fig, opts) and returns whatever string the promise resolves to.
+// We use that hook to load the UNMODIFIED reference page script
+// (/root/reference/script.js) into a synthetic DOM, drive its own globals
+// (config, initFramebuffers, splat, multipleSplats, step, framebufferToTexture, the
+// *Program objects and blit) and hand back fp32 dumps of its five simulation fields.
+//
+// fig.layout is the scenario:
+//   canvasW, canvasH   CSS px size of the canvas (sets the aspect ratio)
+//   config             overrides for the reference's `config` object
+//   seed               mulberry32 seed that replaces Math.random
+//   randomSplats       n -> multipleSplats(n) after the fields are re-created
+//   splats             [[x,y,dx,dy,r,g,b], ...] explicit splat() calls
+//   inject             {velocity|pressure|divergence|curl|dye: base64 fp32} exact state upload
+//   passes             ["curl","vorticity",...] run single passes instead of step()
+//   resizeTo           {SIM_RESOLUTION, DYE_RESOLUTION} -> initFramebuffers() again after the steps
+//   steps, dt, timing, noDump
+(function () {
+  function load(src) {
+    return new Promise(function (ok, no) {
+      var s = document.createElement('script'); s.src = src; s.onload = ok;
+      s.onerror = function () { no(new Error('cannot load ' + src)); };
+      document.head.appendChild(s);
+    });
+  }
+  function b64(f32) {
+    var u = new Uint8Array(f32.buffer, f32.byteOffset, f32.byteLength), s = '';
+    for (var i = 0; i < u.length; i += 32768) s += String.fromCharCode.apply(null, u.subarray(i, i + 32768));
+    return btoa(s);
+  }
+  function unb64(str) {
+    var bin = atob(str), u = new Uint8Array(bin.length);
+    for (var i = 0; i < bin.length; i++) u[i] = bin.charCodeAt(i);
+    return new Float32Array(u.buffer);
+  }
+  function el(tag, cls, id) {
+    var e = document.createElement(tag); if (cls) e.className = cls; if (id) e.id = id;
+    document.body.appendChild(e); return e;
+  }
+
+  window.Plotly = { version: '2.0.0', toImage: function (fig) {
+    var P = fig.layout, out = {};
+    el('div', 'promo').appendChild(document.createElement('span')).className = 'promo-close';
+    el('a', null, 'apple_link'); el('a', null, 'google_link');
+    var cv = document.createElement('canvas'); cv.style.display = 'block';
+    cv.style.width = (P.canvasW || 512) + 'px'; cv.style.height = (P.canvasH || 512) + 'px';
+    document.body.insertBefore(cv, document.body.firstChild);
+    window.ga = function () {}; window.requestAnimationFrame = function () { return 0; };
+    var seed = 0;
+    function reseed() { seed = (P.seed === undefined ? 1234 : P.seed) >>> 0; }
+    var draws = [];
+    Math.random = function () {
+      seed |= 0; seed = seed + 0x6D2B79F5 | 0;
+      var t = Math.imul(seed ^ seed >>> 15, 1 | seed);
+      t = t + Math.imul(t ^ t >>> 7, 61 | t) ^ t;
+      var r = ((t ^ t >>> 14) >>> 0) / 4294967296;
+      draws.push(r); return r;
+    };
+    reseed();
+    var refdir = P.refdir || 'file:///root/reference/';
+    return load(refdir + 'dat.gui.min.js').then(function () { return load(refdir + 'script.js'); }).then(function () {
+      var k;
+      for (k in (P.config || {})) config[k] = P.config[k];
+      dye = null; velocity = null; initFramebuffers();
+      reseed(); draws.length = 0;
+
+      // record every splat() the reference issues (multipleSplats goes through the global)
+      var splatLog = [], refSplat = window.splat;
+      window.splat = function (x, y, dx, dy, c) { splatLog.push([x, y, dx, dy, c.r, c.g, c.b]); return refSplat(x, y, dx, dy, c); };
+
+      function upload(target, comps, data) {
+        // exact fp32 upload: a harness-owned 32F NEAREST texture drawn through the
+        // reference's own copyProgram into the (half-float-declared, fp32-stored) target
+        var ifmt = comps === 1 ? gl.R32F : comps === 2 ? gl.RG32F : gl.RGBA32F;
+        var fmt = comps === 1 ? gl.RED : comps === 2 ? gl.RG : gl.RGBA;
+        gl.activeTexture(gl.TEXTURE0);
+        var tex = gl.createTexture(); gl.bindTexture(gl.TEXTURE_2D, tex);
+        gl.texParameteri(gl.TEXTURE_2D, gl.TEXTURE_MIN_FILTER, gl.NEAREST);
+        gl.texParameteri(gl.TEXTURE_2D, gl.TEXTURE_MAG_FILTER, gl.NEAREST);
+        gl.texParameteri(gl.TEXTURE_2D, gl.TEXTURE_WRAP_S, gl.CLAMP_TO_EDGE);
+        gl.texParameteri(gl.TEXTURE_2D, gl.TEXTURE_WRAP_T, gl.CLAMP_TO_EDGE);
+        gl.texImage2D(gl.TEXTURE_2D, 0, ifmt, target.width, target.height, 0, fmt, gl.FLOAT, data);
+        copyProgram.bind();
+        gl.uniform1i(copyProgram.uniforms.uTexture, 0);
+        gl.activeTexture(gl.TEXTURE0); gl.bindTexture(gl.TEXTURE_2D, tex);
+        blit(target);
+        gl.deleteTexture(tex);
+      }
+      var inj = P.inject || {};
+      if (inj.velocity) upload(velocity.read, 2, unb64(inj.velocity));
+      if (inj.pressure) upload(pressure.read, 1, unb64(inj.pressure));
+      if (inj.divergence) upload(divergence, 1, unb64(inj.divergence));
+      if (inj.curl) upload(curl, 1, unb64(inj.curl));
+      if (inj.dye) upload(dye.read, 4, unb64(inj.dye));
+
+      if (P.randomSplats) multipleSplats(P.randomSplats);
+      (P.splats || []).forEach(function (s) { splat(s[0], s[1], s[2], s[3], { r: s[4], g: s[5], b: s[6] }); });
+
+      var dt = P.dt === undefined ? 0.016666 : P.dt;
+      // single-pass replays: the bind/uniform/blit sequence of the matching block of step()
+      var PASS = {
+        curl: function () {
+          curlProgram.bind();
+          gl.uniform2f(curlProgram.uniforms.texelSize, velocity.texelSizeX, velocity.texelSizeY);
+          gl.uniform1i(curlProgram.uniforms.uVelocity, velocity.read.attach(0));
+          blit(curl);
+        },
+        vorticity: function () {
+          vorticityProgram.bind();
+          gl.uniform2f(vorticityProgram.uniforms.texelSize, velocity.texelSizeX, velocity.texelSizeY);
+          gl.uniform1i(vorticityProgram.uniforms.uVelocity, velocity.read.attach(0));
+          gl.uniform1i(vorticityProgram.uniforms.uCurl, curl.attach(1));
+          gl.uniform1f(vorticityProgram.uniforms.curl, config.CURL);
+          gl.uniform1f(vorticityProgram.uniforms.dt, dt);
+          blit(velocity.write); velocity.swap();
+        },
+        divergence: function () {
+          divergenceProgram.bind();
+          gl.uniform2f(divergenceProgram.uniforms.texelSize, velocity.texelSizeX, velocity.texelSizeY);
+          gl.uniform1i(divergenceProgram.uniforms.uVelocity, velocity.read.attach(0));
+          blit(divergence);
+        },
+        clear: function () {
+          clearProgram.bind();
+          gl.uniform1i(clearProgram.uniforms.uTexture, pressure.read.attach(0));
+          gl.uniform1f(clearProgram.uniforms.value, config.PRESSURE);
+          blit(pressure.write); pressure.swap();
+        },
+        jacobi: function () {
+          pressureProgram.bind();
+          gl.uniform2f(pressureProgram.uniforms.texelSize, velocity.texelSizeX, velocity.texelSizeY);
+          gl.uniform1i(pressureProgram.uniforms.uDivergence, divergence.attach(0));
+          gl.uniform1i(pressureProgram.uniforms.uPressure, pressure.read.attach(1));
+          blit(pressure.write); pressure.swap();
+        },
+        gradsub: function () {
+          gradienSubtractProgram.bind();
+          gl.uniform2f(gradienSubtractProgram.uniforms.texelSize, velocity.texelSizeX, velocity.texelSizeY);
+          gl.uniform1i(gradienSubtractProgram.uniforms.uPressure, pressure.read.attach(0));
+          gl.uniform1i(gradienSubtractProgram.uniforms.uVelocity, velocity.read.attach(1));
+          blit(velocity.write); velocity.swap();
+        },
+        advect_velocity: function () {
+          advectionProgram.bind();
+          gl.uniform2f(advectionProgram.uniforms.texelSize, velocity.texelSizeX, velocity.texelSizeY);
+          var id = velocity.read.attach(0);
+          gl.uniform1i(advectionProgram.uniforms.uVelocity, id);
+          gl.uniform1i(advectionProgram.uniforms.uSource, id);
+          gl.uniform1f(advectionProgram.uniforms.dt, dt);
+          gl.uniform1f(advectionProgram.uniforms.dissipation, config.VELOCITY_DISSIPATION);
+          blit(velocity.write); velocity.swap();
+        },
+        advect_dye: function () {
+          advectionProgram.bind();
+          gl.uniform2f(advectionProgram.uniforms.texelSize, velocity.texelSizeX, velocity.texelSizeY);
+          gl.uniform1i(advectionProgram.uniforms.uVelocity, velocity.read.attach(0));
+          gl.uniform1i(advectionProgram.uniforms.uSource, dye.read.attach(1));
+          gl.uniform1f(advectionProgram.uniforms.dt, dt);
+          gl.uniform1f(advectionProgram.uniforms.dissipation, config.DENSITY_DISSIPATION);
+          blit(dye.write); dye.swap();
+        }
+      };
+
+      var px = new Float32Array(4), ms = [];
+      function sync() {
+        [velocity.read, dye.read].forEach(function (t) {
+          gl.bindFramebuffer(gl.FRAMEBUFFER, t.fbo); gl.readPixels(0, 0, 1, 1, gl.RGBA, gl.FLOAT, px);
+        });
+      }
+      sync();
+      gl.disable(gl.BLEND);
+      (P.passes || []).forEach(function (name) { PASS[name](); });
+      for (var i = 0; i < (P.steps || 0); i++) {
+        var t0 = performance.now(); step(dt);
+        if (P.timing) { sync(); ms.push(performance.now() - t0); }
+      }
+      if (P.resizeTo) {
+        for (k in P.resizeTo) config[k] = P.resizeTo[k];
+        initFramebuffers();
+      }
+      out.ms = ms; out.sim = [velocity.width, velocity.height]; out.dye = [dye.width, dye.height];
+      out.splats = splatLog; out.draws = draws.length;
+      out.canvas = [canvas.width, canvas.height];
+      out.gl = { version: gl.getParameter(gl.VERSION), cores: navigator.hardwareConcurrency,
+                 maxTex: gl.getParameter(gl.MAX_TEXTURE_SIZE), linear: !!ext.supportLinearFiltering };
+      var dbg = gl.getExtension('WEBGL_debug_renderer_info');
+      if (dbg) out.gl.renderer = gl.getParameter(dbg.UNMASKED_RENDERER_WEBGL);
+      if (!P.noDump) out.fields = {
+        velocity: b64(framebufferToTexture(velocity.read)), pressure: b64(framebufferToTexture(pressure.read)),
+        divergence: b64(framebufferToTexture(divergence)), curl: b64(framebufferToTexture(curl)),
+        dye: b64(framebufferToTexture(dye.read)) };
+      out.glError = gl.getError();
+      return JSON.stringify(out);
+    }).catch(function (e) { return JSON.stringify({ error: '' + e + '\n' + (e.stack || '') }); });
+  } };
+})();
