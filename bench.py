@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X stable-fluids hot path.
+
+Metric (BASELINE.json): sim steps/s and cell-updates/s (GLUPS = W*H*steps/s / 1e9) at 4096^2,
+50 Jacobi iterations per step, fp32, dye resolution = sim resolution.
+
+A "step" is one reference step(dt) (script.js:1231-1294) over the whole grid.  Inputs are resident in
+HBM before the timed region (20 seeded splats applied on the device); the timed region is K steps
+enqueued back to back, bracketed by barrier + device sync on both sides, max over ranks.
+
+  N = 1 : one whole-domain context, 4096 x 4096.
+  N > 1 : weak scaling — N row stripes of 4096 x 4096 each (global grid 4096 x 4096*N), one process
+          per GPU, ghost rows exchanged with torch.distributed (RCCL) send/recv.  No collective
+          on the data path other than neighbour exchange.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "webgl-fluid-simulation_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
+DT = 0.016666           # the reference's dt clamp, script.js:1191
+
+
+def algorithmic_bytes_per_cell(iters: int) -> int:
+    # curl 12 + vorticity 20 + divergence 12 + clear 8 + Jacobi 12/iter + gradsub 20
+    # + advect velocity 16 + advect dye 40 (fp32, dye res = sim res, RGBA dye)
+    return 128 + 12 * iters
+
+
+def cpu_baseline(size: int, iters: int, budget_s: float):
+    """The CPU oracle (a port of the reference's algorithm, OpenMP over rows) timed on this host's
+    cores on a bounded sample of the same workload: same grid, same splats, whole steps."""
+    from oracle import oracle as O
+    cfg = {"SIM_RESOLUTION": size, "DYE_RESOLUTION": size, "PRESSURE_ITERATIONS": iters}
+    ref = O.RefSim(canvas=(size, size), config=cfg, seed=1234)
+    ref.multiple_splats(20)
+    t0 = time.perf_counter()
+    ref.step(DT, 1)  # first step also pays first-touch; kept if it is the only one
+    first = time.perf_counter() - t0
+    steps, spent = 0, 0.0
+    while spent < budget_s and steps < 50:
+        t0 = time.perf_counter()
+        ref.step(DT, 1)
+        spent += time.perf_counter() - t0
+        steps += 1
+        if spent + spent / steps > budget_s:
+            break
+    per = spent / steps if steps else first
+    return {"value": round(size * size / per / 1e9, 6), "unit": "GLUPS", "steps_per_sec": round(1.0 / per, 4),
+            "cores": O.num_threads(), "kind": "port",
+            "sample": "%d whole step(s) of the same %dx%d / %d-iteration workload after 1 warm-up step, oracle/fluid_oracle.c "
+                      "(OpenMP); the live reference (Chromium+SwiftShader) cannot run here: /root/reference is absent on the GPU box"
+                      % (steps or 1, size, size, iters)}
+
+
+def load_traffic():
+    """HBM bytes per Jacobi launch from the rocprofv3 PMC passes (profiles/traffic_latest.json, written by
+    tools/pmc_traffic.py from the counter CSVs with the guide's gfx950 corrections); None if not collected."""
+    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--size", type=int, default=4096, help="grid edge per GPU (BASELINE config: 4096)")
+    ap.add_argument("--iters", type=int, default=50, help="PRESSURE_ITERATIONS (BASELINE config: 50)")
+    ap.add_argument("--schedule", default="fused", choices=["fused", "passes"])
+    ap.add_argument("--halo", type=int, default=32, help="ghost rows per stripe side (N > 1)")
+    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-oracle work for cpu_baseline (0 = skip)")
+    ap.add_argument("--no-profile-pass", action="store_true", help="skip the HIP-event instrumented pass")
+    args = ap.parse_args()
+
+    import torch
+    import fluid_hip
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print("bench.py: --gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus), file=sys.stderr)
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+
+    N, size, iters = world, args.size, args.iters
+    cfg = {"SIM_RESOLUTION": size, "DYE_RESOLUTION": size, "PRESSURE_ITERATIONS": iters}
+
+    if N == 1:
+        sim = fluid_hip.FluidSim(canvas=(size, size), config=cfg, device=local_rank, schedule=args.schedule,
+                                 random=fluid_hip.mulberry32(1234))
+        sim.multipleSplats(20)
+
+        def run(k):
+            sim.step(DT, k)
+
+        def sync():
+            sim.sync()
+            torch.cuda.synchronize()
+        barrier = lambda: None  # noqa: E731
+        grid_w, grid_h = size, size
+    else:
+        import torch.distributed as dist
+        from fluid_hip.stripes import StripeSim
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl")
+        # global grid: `size` columns x `size * N` rows -> canvas of the same aspect, SIM_RESOLUTION = short side
+        sim = StripeSim(canvas=(size, size * N), config=cfg, halo=args.halo, schedule=args.schedule,
+                        random=fluid_hip.mulberry32(1234), device=local_rank)
+        sim.multipleSplats(20)
+
+        def run(k):
+            for _ in range(k):
+                sim.step(DT)
+
+        def sync():
+            sim.sync()
+            torch.cuda.synchronize()
+        barrier = dist.barrier
+        grid_w, grid_h = size, size * N
+
+    run(args.warmup)
+    sync(); barrier(); sync()
+    t0 = time.perf_counter()
+    run(args.steps)
+    sync(); barrier(); sync()
+    elapsed = time.perf_counter() - t0
+    if N > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        sim.check_halo()
+
+    steps_per_s = args.steps / elapsed
+    glups = grid_w * grid_h * steps_per_s / 1e9
+    alg_step_bytes = algorithmic_bytes_per_cell(iters) * grid_w * grid_h
+    out = {
+        "metric": "cell-updates/sec (GLUPS) at %d^2 per GPU, %d Jacobi iters/step" % (size, iters),
+        "value": round(glups, 4), "unit": "GLUPS",
+        "steps_per_sec": round(steps_per_s, 3),
+        "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[2]: %dx%d sim = dye grid%s, %d Jacobi iters/step, dt=%.6f, 20 splats mulberry32(1234), defaults otherwise"
+                               % (grid_w, grid_h, "" if N == 1 else " (%d row stripes of %dx%d, halo %d)" % (N, size, size, args.halo), iters, DT),
+                   "schedule": args.schedule, "parallelism": "single" if N == 1 else "stripes%d" % N},
+        "step_algorithmic_GBps": round(alg_step_bytes * steps_per_s / 1e9, 1),
+        "step_roofline_frac": round(alg_step_bytes * steps_per_s / 1e9 / (HBM_PEAK_GBPS * N), 4),
+    }
+
+    # ---- roofline of the dominant kernel (the Jacobi loop), HIP events on the solver's own stream ----
+    if rank == 0 and N == 1 and not args.no_profile_pass:
+        sim.set_timing(True)
+        sim.step(DT, min(args.steps, 20))
+        sim.sync()
+        tm = sim.timings()
+        sim.set_timing(False)
+        launches = max(tm["jacobi_launches"], 1)
+        avg_ms = tm["jacobi_ms"] / launches
+        alg_launch = 12.0 * iters * size * size * tm["steps"] / launches  # 12 B/cell/iteration, SURVEY.md §8(d)
+        achieved = alg_launch / (avg_ms * 1e-3) / 1e9
+        traffic = load_traffic()
+        out["roofline"] = {
+            "kernel": "k_jacobi_tb (temporally blocked Jacobi)" if args.schedule == "fused" else "k_jacobi",
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4),
+            "traffic": (traffic or {}).get("bytes_per_launch"),
+            "algorithmic_bytes_per_launch": int(alg_launch), "avg_launch_ms": round(avg_ms, 5),
+            "launches_per_step": launches / max(tm["steps"], 1),
+            "note": "achieved = algorithmic bytes of the reference's pass structure (12 B/cell/iteration) / measured launch time; "
+                    "temporal blocking moves fewer real bytes than that, so frac may exceed the HBM copy ceiling",
+        }
+        per_step = {k: round(v / max(tm["steps"], 1), 4) for k, v in tm.items() if k.endswith("_ms")}
+        out["pass_ms_per_step"] = per_step
+
+    if rank == 0 and N == 1 and args.cpu_budget > 0:
+        out["cpu_baseline"] = cpu_baseline(size, iters, args.cpu_budget)
+
+    if rank == 0:
+        print(json.dumps(out))
+    if N > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

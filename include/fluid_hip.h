@@ -1,0 +1,169 @@
+/*
+ * fluid_hip.h — C ABI of libfluid_hip.so: the MI355X (gfx950) stable-fluids hot path.
+ *
+ * This is the drop-in boundary for the simulation path of PavelDoGreat/WebGL-Fluid-Simulation.
+ * The reference has no FFI of its own (its passes are WebGL draw calls issued from one
+ * script), so each entry point below names the reference code it replaces; a binding for
+ * the reference's host language (JavaScript, N-API) is in webgl-fluid-simulation_amd/addon/
+ * and INTEGRATION.md shows how script.js would call it.
+ *
+ * Conventions
+ *   - Every function returns 0 (FLUID_OK) or a negative fluid_status; fluid_last_error()
+ *     gives text.  The reference has no error convention (it only console.trace()s GL
+ *     failures, script.js:402-403, 425-426), so nothing is mirrored there.
+ *   - A context owns all device memory.  Host pointers are caller-owned.  Calls are
+ *     asynchronous on the context's HIP stream except fluid_read_field / fluid_sync.
+ *     Not thread-safe per context (the reference is single-threaded, script.js:1176-1186).
+ *   - Fields are row-major, row 0 = BOTTOM (uv.y smallest), like gl.readPixels
+ *     (script.js:301-307).  velocity = 2 floats/texel (RG), dye = 4 (RGBA), pressure /
+ *     divergence / curl = 1.  All fp32 (what the SwiftShader reference stores).
+ *   - Scalars arrive as float: the caller rounds its doubles exactly like gl.uniform1f does.
+ *
+ * Stripe decomposition (multi-GPU): a context may own `part` of `parts` equal row stripes of
+ * the global grid plus `halo` ghost rows on each side.  part = 0, parts = 1, halo = 0 is the
+ * whole domain.  The per-pass entry points take `ext`: how many ghost rows beyond the owned
+ * rows are (re)computed, so a rank can trade halo exchanges for redundant rows.
+ */
+#ifndef FLUID_HIP_H
+#define FLUID_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLUID_ABI_VERSION 1
+
+typedef enum fluid_status {
+    FLUID_OK = 0,
+    FLUID_ERR_INVALID = -1,       /* bad argument / size / state                  */
+    FLUID_ERR_HIP = -2,           /* a HIP runtime call failed (see last_error)   */
+    FLUID_ERR_NO_DEVICE = -3,     /* no gfx950-capable device visible             */
+    FLUID_ERR_OOM = -4,           /* device allocation failed                     */
+    FLUID_ERR_HALO = -5,          /* an advection back-trace left the ghost rows  */
+    FLUID_ERR_UNSUPPORTED = -6
+} fluid_status;
+
+/* the reference's five simulation fields: `let dye; let velocity; ...` script.js:950-954 */
+typedef enum fluid_field {
+    FLUID_VELOCITY = 0,   /* velocity.read   RG   */
+    FLUID_PRESSURE = 1,   /* pressure.read   R    */
+    FLUID_DIVERGENCE = 2, /* divergence      R    */
+    FLUID_CURL = 3,       /* curl            R    */
+    FLUID_DYE = 4,        /* dye.read        RGBA */
+    FLUID_FIELD_COUNT = 5
+} fluid_field;
+
+/* how fluid_step() maps the reference's passes onto kernels */
+typedef enum fluid_schedule {
+    FLUID_SCHED_PASSES = 0, /* one kernel per reference pass (7 + ITERS launches)        */
+    FLUID_SCHED_FUSED = 1   /* fused / temporally blocked kernels; same results bit for bit */
+} fluid_schedule;
+
+/* replaces the size / format part of initFramebuffers(), script.js:982-1010 */
+typedef struct fluid_desc {
+    int sim_w, sim_h;   /* GLOBAL velocity/pressure/divergence/curl size (getResolution(SIM_RESOLUTION)) */
+    int dye_w, dye_h;   /* GLOBAL dye size (getResolution(DYE_RESOLUTION))                               */
+    int device;         /* HIP device ordinal                                                            */
+    int part, parts;    /* row-stripe decomposition; 0, 1 for a whole-domain context                    */
+    int halo;           /* ghost rows (in sim rows) on each side of the stripe; 0 for whole domain       */
+    int schedule;       /* fluid_schedule for fluid_step()                                               */
+} fluid_desc;
+
+/* the per-step uniforms step() reads from `config`, script.js:1243, 1255, 1262, 1283, 1291 */
+typedef struct fluid_params {
+    float curl;                 /* config.CURL                  */
+    float pressure;             /* config.PRESSURE              */
+    int iterations;             /* config.PRESSURE_ITERATIONS   */
+    float velocity_dissipation; /* config.VELOCITY_DISSIPATION  */
+    float density_dissipation;  /* config.DENSITY_DISSIPATION   */
+} fluid_params;
+
+typedef struct fluid_field_info {
+    int width, height;  /* global size                                   */
+    int channels;       /* floats per texel                              */
+    int row0, rows;     /* owned global rows [row0, row0 + rows)         */
+    int halo;           /* ghost rows each side, in this field's rows    */
+} fluid_field_info;
+
+/* per-pass device time of the last fluid_step*(), filled when timing is enabled */
+typedef struct fluid_timings {
+    float curl_ms, vorticity_ms, divergence_ms, clear_ms, jacobi_ms, gradsub_ms, advect_velocity_ms, advect_dye_ms;
+    float total_ms;
+    int jacobi_launches;   /* kernel launches the Jacobi loop took (ITERS, or fewer when temporally blocked) */
+    int steps;             /* steps the sums cover */
+} fluid_timings;
+
+typedef struct fluid_ctx fluid_ctx;
+
+int fluid_abi_version(void);
+const char *fluid_error_string(int status);
+const char *fluid_last_error(const fluid_ctx *ctx); /* ctx may be NULL: last create() failure */
+int fluid_device_count(int *count);
+
+/* createDoubleFBO / createFBO for the five fields, script.js:1045-1106 + 982-1010: zero fields, dye alpha = 1 */
+int fluid_create(const fluid_desc *desc, fluid_ctx **out);
+int fluid_destroy(fluid_ctx *ctx);
+
+/* initFramebuffers() after a resolution change, script.js:982-1010 + resizeDoubleFBO 1116-1126:
+ * velocity and dye are bilinearly resampled (copyShader, 496-506) unless their size is unchanged;
+ * pressure, divergence and curl are recreated zero.  Whole-domain contexts only. */
+int fluid_resize(fluid_ctx *ctx, int sim_w, int sim_h, int dye_w, int dye_h);
+
+int fluid_set_schedule(fluid_ctx *ctx, int schedule);
+/* external != 0: run on the caller-owned hipStream_t `hip_stream` (e.g. torch's current stream; NULL is the
+ * HIP null stream); external == 0: back to the context's own non-blocking stream */
+int fluid_set_stream(fluid_ctx *ctx, void *hip_stream, int external);
+
+/* splat(x, y, dx, dy, color), script.js:1441-1455: velocity pass then dye pass.
+ * aspect = canvas.width / canvas.height (1444); radius = correctRadius(SPLAT_RADIUS / 100) (1447, 1457-1462) */
+int fluid_splat(fluid_ctx *ctx, float x, float y, float dx, float dy, float r, float g, float b,
+                float aspect, float radius);
+
+/* step(dt), script.js:1231-1294 */
+int fluid_step(fluid_ctx *ctx, float dt, const fluid_params *params);
+/* n consecutive step(dt) without returning to the host (the benchmark loop) */
+int fluid_step_n(fluid_ctx *ctx, int n, float dt, const fluid_params *params);
+
+int fluid_sync(fluid_ctx *ctx);
+
+/* framebufferToTexture(target), script.js:301-307, in the field's native channel count.
+ * Whole-domain: the full field.  Stripe context: the owned rows only. `bytes` must match. */
+int fluid_read_field(fluid_ctx *ctx, int field, float *host, size_t bytes);
+/* state injection / checkpoint restore (no reference equivalent; the test port) */
+int fluid_write_field(fluid_ctx *ctx, int field, const float *host, size_t bytes);
+int fluid_field_info_get(const fluid_ctx *ctx, int field, fluid_field_info *out);
+
+/* ---- single passes: one reference program each, for per-pass parity tests and for the
+ *      stripe driver.  ext = ghost rows beyond the owned rows to compute as well. ---- */
+int fluid_pass_curl(fluid_ctx *ctx, int ext);                        /* curlProgram        script.js:1234-1237 */
+int fluid_pass_vorticity(fluid_ctx *ctx, float curl, float dt, int ext); /* vorticityProgram 1239-1246 (swaps velocity) */
+int fluid_pass_divergence(fluid_ctx *ctx, int ext);                  /* divergenceProgram  1248-1251 */
+int fluid_pass_clear(fluid_ctx *ctx, float value, int ext);          /* clearProgram       1253-1257 (swaps pressure) */
+/* `iters` Jacobi iterations (pressureProgram, 1259-1266); input must be valid `ext_out + iters`
+ * rows beyond the owned rows, output is valid `ext_out` rows beyond.  Uses the context's schedule. */
+int fluid_pass_jacobi(fluid_ctx *ctx, int iters, int ext_out);
+int fluid_pass_gradsub(fluid_ctx *ctx, int ext);                     /* gradienSubtractProgram 1268-1273 (swaps velocity) */
+int fluid_pass_advect_velocity(fluid_ctx *ctx, float dt, float dissipation, int ext); /* advectionProgram 1275-1285 */
+int fluid_pass_advect_dye(fluid_ctx *ctx, float dt, float dissipation);               /* advectionProgram 1287-1293 */
+/* one splatProgram draw (script.js:1442-1454) into FLUID_VELOCITY (c2 ignored) or FLUID_DYE, owned + ghost rows */
+int fluid_pass_splat(fluid_ctx *ctx, int field, float x, float y, float aspect, float radius,
+                     float c0, float c1, float c2);
+
+/* ---- ghost-row staging for the stripe driver (rows are contiguous, so this is a D2D copy) ----
+ * side: 0 = bottom (low rows), 1 = top.  pack: copy the `nrows` OWNED rows nearest that side into
+ * dev_buf; unpack: copy dev_buf into the `nrows` GHOST rows nearest the owned rows on that side.
+ * nrows counts rows of that field (dye rows for FLUID_DYE). dev_buf is device memory. */
+int fluid_halo_pack(fluid_ctx *ctx, int field, int side, int nrows, void *dev_buf);
+int fluid_halo_unpack(fluid_ctx *ctx, int field, int side, int nrows, const void *dev_buf);
+/* synchronises, then returns FLUID_ERR_HALO if any advection tap since the last check fell outside the stripe's rows */
+int fluid_halo_check(fluid_ctx *ctx);
+
+int fluid_set_timing(fluid_ctx *ctx, int enabled);
+int fluid_get_timings(fluid_ctx *ctx, fluid_timings *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLUID_HIP_H */

@@ -1,0 +1,261 @@
+// fluid.js — JavaScript host of the MI355X stable-fluids hot path.
+//
+// Mirrors the simulation surface of PavelDoGreat/WebGL-Fluid-Simulation's script.js so a caller of
+// the reference's globals can switch to this module: same names, same argument meaning, same
+// call order into Math.random.  Everything that touched `gl` for simulation in the reference
+// (programs, FBOs, blit) is replaced by calls into fluid_napi.node -> libfluid_hip.so (HIP, gfx950).
+//
+//   reference (script.js)                      here
+//   ---------------------------------------   ------------------------------------------------
+//   config                       59-85         sim.config            (live plain object, sim keys)
+//   canvas.width / canvas.height 56, 1196      sim.canvas            ({width, height} stand-in)
+//   pointers, splatStack         100-102       sim.pointers, sim.splatStack
+//   initFramebuffers()           982-1010      sim.initFramebuffers()
+//   getResolution(resolution)    1612-1624     sim.getResolution(resolution)
+//   update()                     1176-1186     sim.update()          (no render; returns dt)
+//   calcDeltaTime()              1188-1194     sim.calcDeltaTime()
+//   applyInputs()                1219-1229     sim.applyInputs()
+//   step(dt)                     1231-1294     sim.step(dt)
+//   splatPointer(pointer)        1421-1425     sim.splatPointer(pointer)
+//   multipleSplats(amount)       1427-1439     sim.multipleSplats(amount)
+//   splat(x, y, dx, dy, color)   1441-1455     sim.splat(x, y, dx, dy, color)
+//   correctRadius(radius)        1457-1462     sim.correctRadius(radius)
+//   generateColor()              1565-1571     sim.generateColor()
+//   HSVtoRGB(h, s, v)            1573-1595     HSVtoRGB(h, s, v)
+//   framebufferToTexture(target) 301-307       sim.framebufferToTexture(target)
+//   velocity, dye, pressure, divergence, curl  950-954   sim.velocity ... (width/height/texelSize views)
+//
+// There is no CPU path: without the addon / a HIP device, createFluid() throws.
+'use strict';
+
+const FIELD = { velocity: 0, pressure: 1, divergence: 2, curl: 3, dye: 4 };
+const SCHEDULE = { passes: 0, fused: 1 };
+
+function loadBackend () {
+    // the native addon; a missing build is an error, not a reason to fall back
+    return require('./fluid_napi.node');
+}
+
+function defaultConfig () {
+    return {
+        SIM_RESOLUTION: 128,
+        DYE_RESOLUTION: 1024,
+        DENSITY_DISSIPATION: 1,
+        VELOCITY_DISSIPATION: 0.2,
+        PRESSURE: 0.8,
+        PRESSURE_ITERATIONS: 20,
+        CURL: 30,
+        SPLAT_RADIUS: 0.25,
+        SPLAT_FORCE: 6000,
+        COLORFUL: true,
+        COLOR_UPDATE_SPEED: 10,
+        PAUSED: false,
+    };
+}
+
+function pointerPrototype () {
+    this.id = -1;
+    this.texcoordX = 0;
+    this.texcoordY = 0;
+    this.prevTexcoordX = 0;
+    this.prevTexcoordY = 0;
+    this.deltaX = 0;
+    this.deltaY = 0;
+    this.down = false;
+    this.moved = false;
+    this.color = { r: 30, g: 0, b: 300 };
+}
+
+function HSVtoRGB (h, s, v) {
+    const i = Math.floor(h * 6);
+    const f = h * 6 - i;
+    const p = v * (1 - s);
+    const q = v * (1 - f * s);
+    const t = v * (1 - (1 - f) * s);
+    const table = [[v, t, p], [q, v, p], [p, v, t], [p, q, v], [t, p, v], [v, p, q]];
+    const c = table[i % 6];
+    return { r: c[0], g: c[1], b: c[2] };
+}
+
+// seedable stand-in for Math.random (the stream BASELINE.md's measurement plan names)
+function mulberry32 (seed) {
+    let s = seed >>> 0;
+    return function () {
+        s |= 0; s = s + 0x6D2B79F5 | 0;
+        let t = Math.imul(s ^ s >>> 15, 1 | s);
+        t = t + Math.imul(t ^ t >>> 7, 61 | t) ^ t;
+        return ((t ^ t >>> 14) >>> 0) / 4294967296;
+    };
+}
+
+function wrap (value, min, max) {
+    const range = max - min;
+    if (range == 0) return min;
+    return (value - min) % range + min;
+}
+
+// options: { canvas: {width, height}, config: {...overrides}, device, schedule: 'fused'|'passes',
+//            random: () => number (defaults to Math.random), backend: <object with the addon's functions> }
+function createFluid (options) {
+    options = options || {};
+    const native = options.backend || loadBackend();
+    const random = options.random || Math.random;
+    const sim = {};
+
+    sim.config = Object.assign(defaultConfig(), options.config || {});
+    sim.canvas = Object.assign({ width: 512, height: 512 }, options.canvas || {});
+    sim.pointers = [new pointerPrototype()];
+    sim.splatStack = [];
+
+    let handle = null;
+    let lastUpdateTime = Date.now();
+    let colorUpdateTimer = 0.0;
+    const schedule = SCHEDULE[options.schedule || 'fused'];
+    const device = options.device || 0;
+
+    function fieldView (name, isDouble) {
+        const view = {
+            get width () { return native.fieldInfo(handle, FIELD[name]).width; },
+            get height () { return native.fieldInfo(handle, FIELD[name]).height; },
+            get texelSizeX () { return 1.0 / this.width; },
+            get texelSizeY () { return 1.0 / this.height; },
+            name,
+        };
+        if (isDouble) {
+            // the library swaps read/write internally; `.read` always names the current read side
+            Object.defineProperty(view, 'read', { get () { return view; } });
+            view.swap = function () {};
+        }
+        return view;
+    }
+    sim.velocity = fieldView('velocity', true);
+    sim.dye = fieldView('dye', true);
+    sim.pressure = fieldView('pressure', true);
+    sim.divergence = fieldView('divergence', false);
+    sim.curl = fieldView('curl', false);
+
+    sim.getResolution = function (resolution) {
+        let aspectRatio = sim.canvas.width / sim.canvas.height;
+        if (aspectRatio < 1) aspectRatio = 1.0 / aspectRatio;
+        const min = Math.round(resolution);
+        const max = Math.round(resolution * aspectRatio);
+        if (sim.canvas.width > sim.canvas.height) return { width: max, height: min };
+        return { width: min, height: max };
+    };
+
+    // dye and velocity survive a resolution change (bilinear copy); pressure / divergence / curl restart at 0
+    sim.initFramebuffers = function () {
+        const simRes = sim.getResolution(sim.config.SIM_RESOLUTION);
+        const dyeRes = sim.getResolution(sim.config.DYE_RESOLUTION);
+        if (handle == null) handle = native.create(simRes.width, simRes.height, dyeRes.width, dyeRes.height, device, schedule);
+        else native.resize(handle, simRes.width, simRes.height, dyeRes.width, dyeRes.height);
+    };
+
+    sim.correctRadius = function (radius) {
+        const aspectRatio = sim.canvas.width / sim.canvas.height;
+        if (aspectRatio > 1) radius *= aspectRatio;
+        return radius;
+    };
+
+    sim.splat = function (x, y, dx, dy, color) {
+        native.splat(handle, x, y, dx, dy, color.r, color.g, color.b,
+            sim.canvas.width / sim.canvas.height, sim.correctRadius(sim.config.SPLAT_RADIUS / 100.0));
+    };
+
+    sim.generateColor = function () {
+        const c = HSVtoRGB(random(), 1.0, 1.0);
+        c.r *= 0.15;
+        c.g *= 0.15;
+        c.b *= 0.15;
+        return c;
+    };
+
+    sim.multipleSplats = function (amount) {
+        for (let i = 0; i < amount; i++) {
+            const color = sim.generateColor();
+            color.r *= 10.0;
+            color.g *= 10.0;
+            color.b *= 10.0;
+            const x = random();
+            const y = random();
+            const dx = 1000 * (random() - 0.5);
+            const dy = 1000 * (random() - 0.5);
+            sim.splat(x, y, dx, dy, color);
+        }
+    };
+
+    sim.splatPointer = function (pointer) {
+        const dx = pointer.deltaX * sim.config.SPLAT_FORCE;
+        const dy = pointer.deltaY * sim.config.SPLAT_FORCE;
+        sim.splat(pointer.texcoordX, pointer.texcoordY, dx, dy, pointer.color);
+    };
+
+    sim.applyInputs = function () {
+        if (sim.splatStack.length > 0) sim.multipleSplats(sim.splatStack.pop());
+        sim.pointers.forEach(p => {
+            if (p.moved) {
+                p.moved = false;
+                sim.splatPointer(p);
+            }
+        });
+    };
+
+    sim.updateColors = function (dt) {
+        if (!sim.config.COLORFUL) return;
+        colorUpdateTimer += dt * sim.config.COLOR_UPDATE_SPEED;
+        if (colorUpdateTimer >= 1) {
+            colorUpdateTimer = wrap(colorUpdateTimer, 0, 1);
+            sim.pointers.forEach(p => { p.color = sim.generateColor(); });
+        }
+    };
+
+    sim.calcDeltaTime = function () {
+        const now = Date.now();
+        let dt = (now - lastUpdateTime) / 1000;
+        dt = Math.min(dt, 0.016666);
+        lastUpdateTime = now;
+        return dt;
+    };
+
+    // one reference step(dt) with the CURRENT config values (they are read every step, like the reference)
+    sim.step = function (dt, n) {
+        const c = sim.config;
+        native.step(handle, n === undefined ? 1 : n, dt, c.CURL, c.PRESSURE, c.PRESSURE_ITERATIONS,
+            c.VELOCITY_DISSIPATION, c.DENSITY_DISSIPATION);
+    };
+
+    // update() without render(null) / requestAnimationFrame: the caller owns the frame loop
+    sim.update = function (fixedDt) {
+        const dt = fixedDt === undefined ? sim.calcDeltaTime() : Math.min(fixedDt, 0.016666);
+        sim.updateColors(dt);
+        sim.applyInputs();
+        if (!sim.config.PAUSED) sim.step(dt);
+        return dt;
+    };
+
+    // readPixels(RGBA, FLOAT): R and RG targets come back padded to (r, g, 0, 1); row 0 = bottom
+    sim.framebufferToTexture = function (target) {
+        const name = typeof target === 'string' ? target : target.name;
+        const info = native.fieldInfo(handle, FIELD[name]);
+        const src = native.readField(handle, FIELD[name]);
+        if (info.channels === 4) return src;
+        const n = info.width * info.height, out = new Float32Array(n * 4);
+        for (let i = 0; i < n; i++) {
+            for (let k = 0; k < info.channels; k++) out[4 * i + k] = src[info.channels * i + k];
+            out[4 * i + 3] = 1.0;
+        }
+        return out;
+    };
+
+    sim.readField = function (name) { return native.readField(handle, FIELD[name]); };
+    sim.writeField = function (name, data) { native.writeField(handle, FIELD[name], data); };
+    sim.sync = function () { native.sync(handle); };
+    sim.setTiming = function (on) { native.setTiming(handle, on ? 1 : 0); };
+    sim.getTimings = function () { return native.getTimings(handle); };
+    sim.destroy = function () { if (handle != null) { native.destroy(handle); handle = null; } };
+
+    sim.initFramebuffers();
+    return sim;
+}
+
+module.exports = { createFluid, HSVtoRGB, mulberry32, pointerPrototype, defaultConfig, FIELD, SCHEDULE };

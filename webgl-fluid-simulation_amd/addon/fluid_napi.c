@@ -1,0 +1,306 @@
+/*
+ * fluid_napi.c — Node N-API addon over the C ABI of libfluid_hip.so (include/fluid_hip.h).
+ *
+ * The reference's host language is JavaScript; this is the thin native layer that lets a
+ * JavaScript host (addon/fluid.js, which mirrors the reference's config / splat / multipleSplats /
+ * step / initFramebuffers surface) call the HIP hot path.  One exported function per C-ABI entry
+ * point the shim needs; numbers arrive as JS doubles and are narrowed to float here exactly like
+ * gl.uniform1f does in the reference.  Errors become JS exceptions carrying fluid_last_error().
+ *
+ * Build: gcc -shared -fPIC -I/usr/include/node -I../../include fluid_napi.c -L.. -lfluid_hip
+ */
+#include <node_api.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "fluid_hip.h"
+
+#define NAPI_OK(call)                                                         \
+    do {                                                                      \
+        if ((call) != napi_ok) {                                              \
+            napi_throw_error(env, NULL, "fluid_napi: N-API call failed: " #call); \
+            return NULL;                                                      \
+        }                                                                     \
+    } while (0)
+
+static napi_value throw_status(napi_env env, fluid_ctx *ctx, int rc)
+{
+    char msg[512];
+    const char *detail = fluid_last_error(ctx);
+    snprintf(msg, sizeof msg, "libfluid_hip: %s: %s", fluid_error_string(rc), detail ? detail : "");
+    char code[16];
+    snprintf(code, sizeof code, "%d", rc);
+    napi_throw_error(env, code, msg);
+    return NULL;
+}
+
+static int get_args(napi_env env, napi_callback_info info, size_t want, napi_value *argv)
+{
+    size_t argc = want;
+    if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) != napi_ok || argc < want) {
+        napi_throw_type_error(env, NULL, "fluid_napi: wrong number of arguments");
+        return 0;
+    }
+    return 1;
+}
+
+static int get_ctx(napi_env env, napi_value v, fluid_ctx **out)
+{
+    void *p = NULL;
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p) {
+        napi_throw_type_error(env, NULL, "fluid_napi: expected a fluid context handle");
+        return 0;
+    }
+    *out = *(fluid_ctx **)p; /* the external holds a heap cell so destroy() can null it */
+    if (!*out) {
+        napi_throw_error(env, NULL, "fluid_napi: context already destroyed");
+        return 0;
+    }
+    return 1;
+}
+
+static int get_f(napi_env env, napi_value v, float *out)
+{
+    double d;
+    if (napi_get_value_double(env, v, &d) != napi_ok) {
+        napi_throw_type_error(env, NULL, "fluid_napi: expected a number");
+        return 0;
+    }
+    *out = (float)d;
+    return 1;
+}
+
+static int get_i(napi_env env, napi_value v, int *out)
+{
+    int32_t i;
+    if (napi_get_value_int32(env, v, &i) != napi_ok) {
+        napi_throw_type_error(env, NULL, "fluid_napi: expected an integer");
+        return 0;
+    }
+    *out = (int)i;
+    return 1;
+}
+
+static void finalize_ctx(napi_env env, void *data, void *hint)
+{
+    fluid_ctx **cell = (fluid_ctx **)data;
+    (void)env; (void)hint;
+    if (cell) {
+        if (*cell) fluid_destroy(*cell);
+        free(cell);
+    }
+}
+
+/* create(simW, simH, dyeW, dyeH, device, schedule) -> handle */
+static napi_value n_create(napi_env env, napi_callback_info info)
+{
+    napi_value a[6];
+    if (!get_args(env, info, 6, a)) return NULL;
+    fluid_desc d;
+    memset(&d, 0, sizeof d);
+    d.parts = 1;
+    if (!get_i(env, a[0], &d.sim_w) || !get_i(env, a[1], &d.sim_h) || !get_i(env, a[2], &d.dye_w) ||
+        !get_i(env, a[3], &d.dye_h) || !get_i(env, a[4], &d.device) || !get_i(env, a[5], &d.schedule))
+        return NULL;
+    fluid_ctx *ctx = NULL;
+    int rc = fluid_create(&d, &ctx);
+    if (rc != FLUID_OK) return throw_status(env, NULL, rc);
+    fluid_ctx **cell = (fluid_ctx **)malloc(sizeof *cell);
+    *cell = ctx;
+    napi_value ext;
+    NAPI_OK(napi_create_external(env, cell, finalize_ctx, NULL, &ext));
+    return ext;
+}
+
+static napi_value n_destroy(napi_env env, napi_callback_info info)
+{
+    napi_value a[1];
+    if (!get_args(env, info, 1, a)) return NULL;
+    void *p = NULL;
+    if (napi_get_value_external(env, a[0], &p) == napi_ok && p) {
+        fluid_ctx **cell = (fluid_ctx **)p;
+        if (*cell) fluid_destroy(*cell);
+        *cell = NULL;
+    }
+    return NULL;
+}
+
+static napi_value n_resize(napi_env env, napi_callback_info info)
+{
+    napi_value a[5];
+    fluid_ctx *c;
+    int v[4];
+    if (!get_args(env, info, 5, a) || !get_ctx(env, a[0], &c)) return NULL;
+    for (int k = 0; k < 4; k++)
+        if (!get_i(env, a[k + 1], &v[k])) return NULL;
+    int rc = fluid_resize(c, v[0], v[1], v[2], v[3]);
+    return rc == FLUID_OK ? NULL : throw_status(env, c, rc);
+}
+
+/* splat(h, x, y, dx, dy, r, g, b, aspect, radius) */
+static napi_value n_splat(napi_env env, napi_callback_info info)
+{
+    napi_value a[10];
+    fluid_ctx *c;
+    float f[9];
+    if (!get_args(env, info, 10, a) || !get_ctx(env, a[0], &c)) return NULL;
+    for (int k = 0; k < 9; k++)
+        if (!get_f(env, a[k + 1], &f[k])) return NULL;
+    int rc = fluid_splat(c, f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7], f[8]);
+    return rc == FLUID_OK ? NULL : throw_status(env, c, rc);
+}
+
+/* step(h, n, dt, curl, pressure, iterations, velocityDissipation, densityDissipation) */
+static napi_value n_step(napi_env env, napi_callback_info info)
+{
+    napi_value a[8];
+    fluid_ctx *c;
+    int n;
+    float dt;
+    fluid_params P;
+    if (!get_args(env, info, 8, a) || !get_ctx(env, a[0], &c)) return NULL;
+    if (!get_i(env, a[1], &n) || !get_f(env, a[2], &dt) || !get_f(env, a[3], &P.curl) || !get_f(env, a[4], &P.pressure) ||
+        !get_i(env, a[5], &P.iterations) || !get_f(env, a[6], &P.velocity_dissipation) || !get_f(env, a[7], &P.density_dissipation))
+        return NULL;
+    int rc = fluid_step_n(c, n, dt, &P);
+    return rc == FLUID_OK ? NULL : throw_status(env, c, rc);
+}
+
+static napi_value n_sync(napi_env env, napi_callback_info info)
+{
+    napi_value a[1];
+    fluid_ctx *c;
+    if (!get_args(env, info, 1, a) || !get_ctx(env, a[0], &c)) return NULL;
+    int rc = fluid_sync(c);
+    return rc == FLUID_OK ? NULL : throw_status(env, c, rc);
+}
+
+static napi_value n_set_schedule(napi_env env, napi_callback_info info)
+{
+    napi_value a[2];
+    fluid_ctx *c;
+    int s;
+    if (!get_args(env, info, 2, a) || !get_ctx(env, a[0], &c) || !get_i(env, a[1], &s)) return NULL;
+    int rc = fluid_set_schedule(c, s);
+    return rc == FLUID_OK ? NULL : throw_status(env, c, rc);
+}
+
+/* fieldInfo(h, field) -> {width, height, channels} */
+static napi_value n_field_info(napi_env env, napi_callback_info info)
+{
+    napi_value a[2], obj, v;
+    fluid_ctx *c;
+    int field;
+    fluid_field_info fi;
+    if (!get_args(env, info, 2, a) || !get_ctx(env, a[0], &c) || !get_i(env, a[1], &field)) return NULL;
+    int rc = fluid_field_info_get(c, field, &fi);
+    if (rc != FLUID_OK) return throw_status(env, c, rc);
+    NAPI_OK(napi_create_object(env, &obj));
+    NAPI_OK(napi_create_int32(env, fi.width, &v));
+    NAPI_OK(napi_set_named_property(env, obj, "width", v));
+    NAPI_OK(napi_create_int32(env, fi.height, &v));
+    NAPI_OK(napi_set_named_property(env, obj, "height", v));
+    NAPI_OK(napi_create_int32(env, fi.channels, &v));
+    NAPI_OK(napi_set_named_property(env, obj, "channels", v));
+    return obj;
+}
+
+/* readField(h, field) -> Float32Array(width * height * channels), row 0 = bottom */
+static napi_value n_read_field(napi_env env, napi_callback_info info)
+{
+    napi_value a[2], buf, arr;
+    fluid_ctx *c;
+    int field;
+    fluid_field_info fi;
+    if (!get_args(env, info, 2, a) || !get_ctx(env, a[0], &c) || !get_i(env, a[1], &field)) return NULL;
+    int rc = fluid_field_info_get(c, field, &fi);
+    if (rc != FLUID_OK) return throw_status(env, c, rc);
+    size_t n = (size_t)fi.width * fi.rows * fi.channels;
+    void *data = NULL;
+    NAPI_OK(napi_create_arraybuffer(env, n * sizeof(float), &data, &buf));
+    rc = fluid_read_field(c, field, (float *)data, n * sizeof(float));
+    if (rc != FLUID_OK) return throw_status(env, c, rc);
+    NAPI_OK(napi_create_typedarray(env, napi_float32_array, n, buf, 0, &arr));
+    return arr;
+}
+
+/* writeField(h, field, Float32Array) */
+static napi_value n_write_field(napi_env env, napi_callback_info info)
+{
+    napi_value a[3], ab;
+    fluid_ctx *c;
+    int field;
+    napi_typedarray_type t;
+    size_t len, off;
+    void *data;
+    if (!get_args(env, info, 3, a) || !get_ctx(env, a[0], &c) || !get_i(env, a[1], &field)) return NULL;
+    if (napi_get_typedarray_info(env, a[2], &t, &len, &data, &ab, &off) != napi_ok || t != napi_float32_array) {
+        napi_throw_type_error(env, NULL, "fluid_napi: writeField expects a Float32Array");
+        return NULL;
+    }
+    int rc = fluid_write_field(c, field, (const float *)data, len * sizeof(float));
+    return rc == FLUID_OK ? NULL : throw_status(env, c, rc);
+}
+
+static napi_value n_device_count(napi_env env, napi_callback_info info)
+{
+    napi_value v;
+    int n = 0;
+    (void)info;
+    fluid_device_count(&n);
+    NAPI_OK(napi_create_int32(env, n, &v));
+    return v;
+}
+
+static napi_value n_set_timing(napi_env env, napi_callback_info info)
+{
+    napi_value a[2];
+    fluid_ctx *c;
+    int on;
+    if (!get_args(env, info, 2, a) || !get_ctx(env, a[0], &c) || !get_i(env, a[1], &on)) return NULL;
+    int rc = fluid_set_timing(c, on);
+    return rc == FLUID_OK ? NULL : throw_status(env, c, rc);
+}
+
+static napi_value n_get_timings(napi_env env, napi_callback_info info)
+{
+    napi_value a[1], obj, v;
+    fluid_ctx *c;
+    fluid_timings t;
+    if (!get_args(env, info, 1, a) || !get_ctx(env, a[0], &c)) return NULL;
+    int rc = fluid_get_timings(c, &t);
+    if (rc != FLUID_OK) return throw_status(env, c, rc);
+    NAPI_OK(napi_create_object(env, &obj));
+    const char *names[] = { "curl", "vorticity", "divergence", "clear", "jacobi", "gradsub", "advectVelocity", "advectDye", "total" };
+    const float vals[] = { t.curl_ms, t.vorticity_ms, t.divergence_ms, t.clear_ms, t.jacobi_ms, t.gradsub_ms,
+                           t.advect_velocity_ms, t.advect_dye_ms, t.total_ms };
+    for (int k = 0; k < 9; k++) {
+        NAPI_OK(napi_create_double(env, vals[k], &v));
+        NAPI_OK(napi_set_named_property(env, obj, names[k], v));
+    }
+    NAPI_OK(napi_create_int32(env, t.jacobi_launches, &v));
+    NAPI_OK(napi_set_named_property(env, obj, "jacobiLaunches", v));
+    NAPI_OK(napi_create_int32(env, t.steps, &v));
+    NAPI_OK(napi_set_named_property(env, obj, "steps", v));
+    return obj;
+}
+
+static napi_value init(napi_env env, napi_value exports)
+{
+    const struct { const char *name; napi_callback fn; } fns[] = {
+        { "create", n_create }, { "destroy", n_destroy }, { "resize", n_resize }, { "splat", n_splat },
+        { "step", n_step }, { "sync", n_sync }, { "setSchedule", n_set_schedule }, { "fieldInfo", n_field_info },
+        { "readField", n_read_field }, { "writeField", n_write_field }, { "deviceCount", n_device_count },
+        { "setTiming", n_set_timing }, { "getTimings", n_get_timings },
+    };
+    for (size_t k = 0; k < sizeof fns / sizeof fns[0]; k++) {
+        napi_value f;
+        if (napi_create_function(env, fns[k].name, NAPI_AUTO_LENGTH, fns[k].fn, NULL, &f) != napi_ok) return NULL;
+        if (napi_set_named_property(env, exports, fns[k].name, f) != napi_ok) return NULL;
+    }
+    napi_value v;
+    if (napi_create_int32(env, fluid_abi_version(), &v) == napi_ok) napi_set_named_property(env, exports, "abiVersion", v);
+    return exports;
+}
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, init)

@@ -1,0 +1,45 @@
+// fluid_kernels.h — launch interface between the solver core (fluid_solver.cpp) and the
+// gfx950 kernels (fluid_kernels.hip).  Internal; the public boundary is include/fluid_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace fluid {
+
+// A window onto one field: the device array holds `rows` rows of a field whose global size is
+// W x H; array row r is global row g0 + r (g0 < 0 is allowed: ghost rows below the domain are
+// allocated but never addressed).  Whole domain: g0 = 0, rows = H.
+struct Win {
+    int W, H;
+    int g0;
+    int rows;
+};
+
+// All launchers enqueue on `s` and return hipGetLastError().  Row ranges [ga, gb) are GLOBAL rows.
+hipError_t launch_curl(hipStream_t s, Win w, const float2* vel, float* curl, int ga, int gb);
+hipError_t launch_vorticity(hipStream_t s, Win w, const float2* vel, const float* curl, float2* vel_out,
+                            float curl_strength, float dt, int ga, int gb);
+hipError_t launch_divergence(hipStream_t s, Win w, const float2* vel, float* div, int ga, int gb);
+hipError_t launch_clear(hipStream_t s, Win w, const float* p, float* p_out, float value, int ga, int gb);
+hipError_t launch_jacobi(hipStream_t s, Win w, const float* p, const float* div, float* p_out, int ga, int gb);
+hipError_t launch_gradsub(hipStream_t s, Win w, const float* p, const float2* vel, float2* vel_out, int ga, int gb);
+hipError_t launch_advect_velocity(hipStream_t s, Win w, const float2* vel, float2* out, float dt, float dissipation,
+                                  int ga, int gb, unsigned int* miss);
+hipError_t launch_advect_dye(hipStream_t s, Win vw, const float2* vel, Win dw, const float4* dye, float4* out,
+                             float dt, float dissipation, int ga, int gb, unsigned int* miss);
+hipError_t launch_splat_velocity(hipStream_t s, Win w, const float2* base, float2* out, float x, float y, float aspect,
+                                 float radius, float c0, float c1, int ga, int gb);
+hipError_t launch_splat_dye(hipStream_t s, Win w, const float4* base, float4* out, float x, float y, float aspect,
+                            float radius, float c0, float c1, float c2, int ga, int gb);
+hipError_t launch_resample(hipStream_t s, Win sw, const float* src, int nc, Win dw, float* dst);
+hipError_t launch_fill(hipStream_t s, float* dst, size_t n_vec, int nc, float v0, float v1, float v2, float v3);
+
+// Temporally blocked Jacobi: `iters` (<= jacobi_tb_max_iters()) iterations in one launch, every input
+// value scaled by `pscale` on load (pscale = config.PRESSURE folds the clear pass, 1.0f otherwise).
+// Reads p rows [ga - iters, gb + iters) (clamped to the domain), writes p_out rows [ga, gb).
+// Requires W % 4 == 0.  Bitwise equal to `iters` launches of launch_jacobi.
+int jacobi_tb_max_iters();
+bool jacobi_tb_supported(Win w);
+hipError_t launch_jacobi_tb(hipStream_t s, Win w, const float* p, const float* div, float* p_out, float pscale,
+                            int iters, int ga, int gb);
+
+}  // namespace fluid

@@ -1,0 +1,542 @@
+// fluid_kernels.hip — gfx950 (MI355X / CDNA4) kernels for the stable-fluids hot path.
+//
+// Every kernel re-expresses one GLSL fragment program of the reference
+// (PavelDoGreat/WebGL-Fluid-Simulation, script.js) as a coalesced fp32 stencil over the field
+// arrays; the arithmetic (operand order, no FMA contraction: built with -ffp-contract=off)
+// follows the shader source line by line so results match the reference pipeline bit for bit
+// wherever the reference itself is bit-reproducible.
+//
+// Two families:
+//   * one kernel per reference pass ("PASSES" schedule) — also the per-pass test entry points;
+//   * fused / temporally blocked kernels ("FUSED" schedule) that produce the same bits with
+//     fewer trips through HBM.  The path is ~0.5 flop/byte: HBM-bound, so no MFMA anywhere.
+//
+// Conventions: F[j][i], row j = 0 is the bottom row; texel centre uv = ((i+.5)/W, (j+.5)/H);
+// CLAMP_TO_EDGE everywhere (script.js:1051-1052).  `Win` = window of a stripe-decomposed field.
+#include "fluid_kernels.h"
+
+namespace fluid {
+
+namespace {
+
+constexpr int BX = 256;  // threads per block for the per-pass kernels: 4 waves along a row
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// array index of the clamped global texel (gj, gi)
+__device__ __forceinline__ long widx(const Win& w, int gj, int gi)
+{
+    return (long)(clampi(gj, 0, w.H - 1) - w.g0) * w.W + clampi(gi, 0, w.W - 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1 curl — curlShader script.js:814-833
+__global__ void __launch_bounds__(BX) k_curl(Win w, const float2* __restrict__ vel, float* __restrict__ curl, int ga)
+{
+    const int i = blockIdx.x * BX + threadIdx.x;
+    const int gj = ga + blockIdx.y;
+    if (i >= w.W) return;
+    const float L = vel[widx(w, gj, i - 1)].y;
+    const float R = vel[widx(w, gj, i + 1)].y;
+    const float T = vel[widx(w, gj + 1, i)].x;
+    const float B = vel[widx(w, gj - 1, i)].x;
+    const float vort = R - L - T + B;
+    curl[(long)(gj - w.g0) * w.W + i] = 0.5f * vort;
+}
+
+// K2 vorticity confinement — vorticityShader script.js:835-866
+__device__ __forceinline__ float2 vorticity_cell(float L, float R, float T, float B, float C, float2 v, float curl_strength, float dt)
+{
+    float fx = 0.5f * (fabsf(T) - fabsf(B));
+    float fy = 0.5f * (fabsf(R) - fabsf(L));
+    const float len = sqrtf(fx * fx + fy * fy) + 0.0001f;
+    fx = fx / len;
+    fy = fy / len;
+    const float s = curl_strength * C;
+    fx = fx * s;
+    fy = fy * s;
+    fy = fy * -1.0f;
+    float vx = v.x + fx * dt;
+    float vy = v.y + fy * dt;
+    vx = fminf(fmaxf(vx, -1000.0f), 1000.0f);
+    vy = fminf(fmaxf(vy, -1000.0f), 1000.0f);
+    return make_float2(vx, vy);
+}
+
+__global__ void __launch_bounds__(BX) k_vorticity(Win w, const float2* __restrict__ vel, const float* __restrict__ curl,
+                                                   float2* __restrict__ vel_out, float curl_strength, float dt, int ga)
+{
+    const int i = blockIdx.x * BX + threadIdx.x;
+    const int gj = ga + blockIdx.y;
+    if (i >= w.W) return;
+    const long c = (long)(gj - w.g0) * w.W + i;
+    const float L = curl[widx(w, gj, i - 1)];
+    const float R = curl[widx(w, gj, i + 1)];
+    const float T = curl[widx(w, gj + 1, i)];
+    const float B = curl[widx(w, gj - 1, i)];
+    vel_out[c] = vorticity_cell(L, R, T, B, curl[c], vel[c], curl_strength, dt);
+}
+
+// K3 divergence with the reflecting-wall rule — divergenceShader script.js:786-812
+__global__ void __launch_bounds__(BX) k_divergence(Win w, const float2* __restrict__ vel, float* __restrict__ div, int ga)
+{
+    const int i = blockIdx.x * BX + threadIdx.x;
+    const int gj = ga + blockIdx.y;
+    if (i >= w.W) return;
+    const long c = (long)(gj - w.g0) * w.W + i;
+    float L = vel[widx(w, gj, i - 1)].x;
+    float R = vel[widx(w, gj, i + 1)].x;
+    float T = vel[widx(w, gj + 1, i)].y;
+    float B = vel[widx(w, gj - 1, i)].y;
+    const float2 C = vel[c];
+    if (i == 0) L = -C.x;
+    if (i == w.W - 1) R = -C.x;
+    if (gj == w.H - 1) T = -C.y;
+    if (gj == 0) B = -C.y;
+    div[c] = 0.5f * (R - L + T - B);
+}
+
+// K4 clear — clearShader script.js:508-519
+__global__ void __launch_bounds__(BX) k_clear(Win w, const float* __restrict__ p, float* __restrict__ p_out, float value, int ga)
+{
+    const int i = blockIdx.x * BX + threadIdx.x;
+    const int gj = ga + blockIdx.y;
+    if (i >= w.W) return;
+    const long c = (long)(gj - w.g0) * w.W + i;
+    p_out[c] = value * p[c];
+}
+
+// K5 one Jacobi iteration — pressureShader script.js:868-890 (operand order of line 887)
+__global__ void __launch_bounds__(BX) k_jacobi(Win w, const float* __restrict__ p, const float* __restrict__ div,
+                                                float* __restrict__ p_out, int ga)
+{
+    const int i = blockIdx.x * BX + threadIdx.x;
+    const int gj = ga + blockIdx.y;
+    if (i >= w.W) return;
+    const long c = (long)(gj - w.g0) * w.W + i;
+    const float L = p[widx(w, gj, i - 1)];
+    const float R = p[widx(w, gj, i + 1)];
+    const float T = p[widx(w, gj + 1, i)];
+    const float B = p[widx(w, gj - 1, i)];
+    p_out[c] = (L + R + B + T - div[c]) * 0.25f;
+}
+
+// K6 gradient subtract — gradientSubtractShader script.js:892-913
+__global__ void __launch_bounds__(BX) k_gradsub(Win w, const float* __restrict__ p, const float2* __restrict__ vel,
+                                                 float2* __restrict__ vel_out, int ga)
+{
+    const int i = blockIdx.x * BX + threadIdx.x;
+    const int gj = ga + blockIdx.y;
+    if (i >= w.W) return;
+    const long c = (long)(gj - w.g0) * w.W + i;
+    const float L = p[widx(w, gj, i - 1)];
+    const float R = p[widx(w, gj, i + 1)];
+    const float T = p[widx(w, gj + 1, i)];
+    const float B = p[widx(w, gj - 1, i)];
+    const float2 v = vel[c];
+    vel_out[c] = make_float2(v.x - (R - L), v.y - (T - B));
+}
+
+// ------------------------------------------------------------------------------------------------
+// GL LINEAR fetch with CLAMP_TO_EDGE (what texture2D does on the LINEAR-filtered velocity / dye
+// textures).  mix(a, b, t) = a + (b - a) * t — the form validated against SwiftShader.
+struct Taps {
+    long a, b, c, d;  // array indices of the four taps
+    float fx, fy;
+    int miss;  // taps whose row is outside the window (stripe ghost rows exhausted)
+};
+
+__device__ __forceinline__ Taps bil_taps(const Win& w, float u, float v)
+{
+    const float x = u * (float)w.W - 0.5f;
+    const float y = v * (float)w.H - 0.5f;
+    const float fi = floorf(x), fj = floorf(y);
+    Taps t;
+    t.fx = x - fi;
+    t.fy = y - fj;
+    const int i0 = (int)fi, j0 = (int)fj;
+    const int ia = clampi(i0, 0, w.W - 1), ib = clampi(i0 + 1, 0, w.W - 1);
+    int la = clampi(j0, 0, w.H - 1) - w.g0, lb = clampi(j0 + 1, 0, w.H - 1) - w.g0;
+    t.miss = 0;
+    if (la < 0 || la >= w.rows) { t.miss++; la = clampi(la, 0, w.rows - 1); }
+    if (lb < 0 || lb >= w.rows) { t.miss++; lb = clampi(lb, 0, w.rows - 1); }
+    t.a = (long)la * w.W + ia;
+    t.b = (long)la * w.W + ib;
+    t.c = (long)lb * w.W + ia;
+    t.d = (long)lb * w.W + ib;
+    return t;
+}
+
+__device__ __forceinline__ float mixf(float a, float b, float t) { return a + (b - a) * t; }
+
+__device__ __forceinline__ float2 bil2(const Win& w, const float2* __restrict__ F, float u, float v, int& miss)
+{
+    const Taps t = bil_taps(w, u, v);
+    miss += t.miss;
+    const float2 a = F[t.a], b = F[t.b], c = F[t.c], d = F[t.d];
+    return make_float2(mixf(mixf(a.x, b.x, t.fx), mixf(c.x, d.x, t.fx), t.fy),
+                       mixf(mixf(a.y, b.y, t.fx), mixf(c.y, d.y, t.fx), t.fy));
+}
+
+__device__ __forceinline__ float4 bil4(const Win& w, const float4* __restrict__ F, float u, float v, int& miss)
+{
+    const Taps t = bil_taps(w, u, v);
+    miss += t.miss;
+    const float4 a = F[t.a], b = F[t.b], c = F[t.c], d = F[t.d];
+    return make_float4(mixf(mixf(a.x, b.x, t.fx), mixf(c.x, d.x, t.fx), t.fy),
+                       mixf(mixf(a.y, b.y, t.fx), mixf(c.y, d.y, t.fx), t.fy),
+                       mixf(mixf(a.z, b.z, t.fx), mixf(c.z, d.z, t.fx), t.fy),
+                       mixf(mixf(a.w, b.w, t.fx), mixf(c.w, d.w, t.fx), t.fy));
+}
+
+// K7a velocity self-advection — advectionShader script.js:746-784, call 1275-1285
+__global__ void __launch_bounds__(BX) k_advect_velocity(Win w, const float2* __restrict__ vel, float2* __restrict__ out,
+                                                         float dt, float dissipation, float tsx, float tsy, int ga,
+                                                         unsigned int* __restrict__ miss_out)
+{
+    const int i = blockIdx.x * BX + threadIdx.x;
+    const int gj = ga + blockIdx.y;
+    if (i >= w.W) return;
+    const float u = ((float)i + 0.5f) / (float)w.W;
+    const float v = ((float)gj + 0.5f) / (float)w.H;
+    const long c = (long)(gj - w.g0) * w.W + i;
+    const float2 vv = vel[c];
+    const float cu = u - dt * vv.x * tsx;
+    const float cv = v - dt * vv.y * tsy;
+    int miss = 0;
+    const float2 r = bil2(w, vel, cu, cv, miss);
+    const float decay = 1.0f + dissipation * dt;
+    out[c] = make_float2(r.x / decay, r.y / decay);
+    if (miss) atomicAdd(miss_out, (unsigned)miss);
+}
+
+// K7b dye advection — same program, call script.js:1287-1293: the back-trace uses the SIM texel size (1276)
+template <bool SAME_RES>
+__global__ void __launch_bounds__(BX) k_advect_dye(Win vw, const float2* __restrict__ vel, Win dw, const float4* __restrict__ dye,
+                                                    float4* __restrict__ out, float dt, float dissipation, float tsx, float tsy,
+                                                    int ga, unsigned int* __restrict__ miss_out)
+{
+    const int i = blockIdx.x * BX + threadIdx.x;
+    const int gj = ga + blockIdx.y;
+    if (i >= dw.W) return;
+    const float u = ((float)i + 0.5f) / (float)dw.W;
+    const float v = ((float)gj + 0.5f) / (float)dw.H;
+    int miss = 0;
+    float2 vv;
+    if (SAME_RES) vv = vel[(long)(gj - vw.g0) * vw.W + i];
+    else vv = bil2(vw, vel, u, v, miss);
+    const float cu = u - dt * vv.x * tsx;
+    const float cv = v - dt * vv.y * tsy;
+    const float4 r = bil4(dw, dye, cu, cv, miss);
+    const float decay = 1.0f + dissipation * dt;
+    out[(long)(gj - dw.g0) * dw.W + i] = make_float4(r.x / decay, r.y / decay, r.z / decay, r.w / decay);
+    if (miss) atomicAdd(miss_out, (unsigned)miss);
+}
+
+// K8 splat — splatShader script.js:726-744
+__device__ __forceinline__ float splat_weight(const Win& w, int i, int gj, float x, float y, float aspect, float radius)
+{
+    const float u = ((float)i + 0.5f) / (float)w.W;
+    const float v = ((float)gj + 0.5f) / (float)w.H;
+    const float px = (u - x) * aspect;
+    const float py = v - y;
+    return expf(-(px * px + py * py) / radius);
+}
+
+__global__ void __launch_bounds__(BX) k_splat_velocity(Win w, const float2* __restrict__ base, float2* __restrict__ out, float x, float y,
+                                                        float aspect, float radius, float c0, float c1, int ga)
+{
+    const int i = blockIdx.x * BX + threadIdx.x;
+    const int gj = ga + blockIdx.y;
+    if (i >= w.W) return;
+    const long c = (long)(gj - w.g0) * w.W + i;
+    const float g = splat_weight(w, i, gj, x, y, aspect, radius);
+    const float2 b = base[c];
+    out[c] = make_float2(b.x + g * c0, b.y + g * c1);
+}
+
+__global__ void __launch_bounds__(BX) k_splat_dye(Win w, const float4* __restrict__ base, float4* __restrict__ out, float x, float y,
+                                                   float aspect, float radius, float c0, float c1, float c2, int ga)
+{
+    const int i = blockIdx.x * BX + threadIdx.x;
+    const int gj = ga + blockIdx.y;
+    if (i >= w.W) return;
+    const long c = (long)(gj - w.g0) * w.W + i;
+    const float g = splat_weight(w, i, gj, x, y, aspect, radius);
+    const float4 b = base[c];
+    out[c] = make_float4(b.x + g * c0, b.y + g * c1, b.z + g * c2, 1.0f);
+}
+
+// copyShader resample for resizeFBO — script.js:496-506, 1108-1114
+template <int NC>
+__global__ void __launch_bounds__(BX) k_resample(Win sw, const float* __restrict__ src, Win dw, float* __restrict__ dst)
+{
+    const int i = blockIdx.x * BX + threadIdx.x;
+    const int gj = blockIdx.y;
+    if (i >= dw.W) return;
+    const float u = ((float)i + 0.5f) / (float)dw.W;
+    const float v = ((float)gj + 0.5f) / (float)dw.H;
+    const Taps t = bil_taps(sw, u, v);
+    for (int k = 0; k < NC; k++) {
+        const float a = src[t.a * NC + k], b = src[t.b * NC + k], c = src[t.c * NC + k], d = src[t.d * NC + k];
+        dst[((long)gj * dw.W + i) * NC + k] = mixf(mixf(a, b, t.fx), mixf(c, d, t.fx), t.fy);
+    }
+}
+
+template <int NC>
+__global__ void __launch_bounds__(BX) k_fill(float* __restrict__ dst, size_t n, float v0, float v1, float v2, float v3)
+{
+    const float vals[4] = { v0, v1, v2, v3 };
+    for (size_t i = (size_t)blockIdx.x * BX + threadIdx.x; i < n; i += (size_t)gridDim.x * BX)
+        for (int k = 0; k < NC; k++) dst[i * NC + k] = vals[k];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Temporally blocked Jacobi (the hot loop: 82 % of the reference's bytes at 50 iterations).
+//
+// A workgroup of NW waves owns a tile of 256 columns x NW*RY rows, held ENTIRELY IN REGISTERS:
+// lane l of wave wv keeps columns 4l..4l+3 (one float4 per row, loaded with one coalesced 1 KiB
+// wave transaction) of rows wv*RY..wv*RY+RY-1, for both pressure and divergence.  One iteration:
+//   * left/right neighbours come from the adjacent lanes through full-wave DPP shifts
+//     (wave_shr:1 / wave_shl:1 — folded into the v_add, no LDS traffic);
+//   * top/bottom neighbours are the thread's own registers, except at the wave's first/last row,
+//     which the neighbouring waves publish through a double-buffered 2-row LDS mailbox
+//     (one barrier per iteration);
+//   * rows are updated in place with a one-row delay register, so no second copy of the tile.
+// After k iterations the outer k columns/rows of the tile are stale; the tile carries a HALO-deep
+// apron so that up to HALO iterations fit in one launch and only the inner (256-2*HALO) x
+// (NW*RY-2*HALO) texels are stored.  HBM traffic per launch is ~12 B/texel (+apron re-reads that
+// hit L2 / Infinity Cache) for `iters` reference passes instead of 12 B each.
+//
+// Domain edges: CLAMP_TO_EDGE means an off-domain neighbour equals the centre texel; handled by
+// selects in the EDGE instantiation, which only workgroups touching the domain border run.
+template <int NW, int RY, int HALO>
+struct JacobiTB {
+    static constexpr int TX = 256;          // columns per tile (64 lanes x float4)
+    static constexpr int TY = NW * RY;      // rows per tile
+    static constexpr int VX = TX - 2 * HALO;
+    static constexpr int VY = TY - 2 * HALO;
+    static_assert(HALO % 4 == 0, "apron must keep float4 alignment");
+    static_assert(VX > 0 && VY > 0, "tile smaller than its apron");
+};
+
+__device__ __forceinline__ float from_left_lane(float v)  // value held by lane-1 (garbage in lane 0)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float from_right_lane(float v)  // value held by lane+1 (garbage in lane 63)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
+
+template <int NW, int RY, int HALO, bool EDGE>
+__device__ __forceinline__ void jacobi_tb_body(const Win& w, const float* __restrict__ p, const float* __restrict__ div,
+                                               float* __restrict__ p_out, float pscale, int iters, int ga, int gb,
+                                               float4 (*mail)[NW][2][64])
+{
+    using G = JacobiTB<NW, RY, HALO>;
+    const int lane = threadIdx.x;
+    const int wv = threadIdx.y;
+    const int cx = (int)blockIdx.x * G::VX - HALO + 4 * lane;         // first of this lane's 4 columns
+    const int gy = ga + (int)blockIdx.y * G::VY - HALO + wv * RY;     // global row of this wave's row 0
+    const bool col_in = (cx >= 0) && (cx + 3 < w.W);
+
+    float4 P[RY], D[RY];
+#pragma unroll
+    for (int r = 0; r < RY; r++) {
+        const int gj = gy + r;
+        const int lr = gj - w.g0;
+        const bool ok = col_in && gj >= 0 && gj < w.H && lr >= 0 && lr < w.rows;
+        if (ok) {
+            const long c = (long)lr * w.W + cx;
+            const float4 pv = *reinterpret_cast<const float4*>(p + c);
+            D[r] = *reinterpret_cast<const float4*>(div + c);
+            P[r] = make_float4(pscale * pv.x, pscale * pv.y, pscale * pv.z, pscale * pv.w);
+        } else {
+            P[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            D[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+
+    const bool at_left = (cx == 0), at_right = (cx + 3 == w.W - 1);
+
+    for (int it = 0; it < iters; it++) {
+        // publish this wave's first and last row, fetch the neighbours' adjacent rows
+        mail[it & 1][wv][0][lane] = P[0];
+        mail[it & 1][wv][1][lane] = P[RY - 1];
+        __syncthreads();
+        float4 below = (wv > 0) ? mail[it & 1][wv - 1][1][lane] : P[0];            // tile edge: stale apron anyway
+        const float4 above = (wv < NW - 1) ? mail[it & 1][wv + 1][0][lane] : P[RY - 1];
+
+#pragma unroll
+        for (int r = 0; r < RY; r++) {
+            const float4 C = P[r];
+            float4 T = (r < RY - 1) ? P[r + 1] : above;
+            float4 B = below;
+            float Lx = from_left_lane(C.w);
+            float Rw = from_right_lane(C.x);
+            if (EDGE) {
+                const int gj = gy + r;
+                if (at_left) Lx = C.x;
+                if (at_right) Rw = C.w;
+                if (gj == 0) B = C;
+                if (gj == w.H - 1) T = C;
+            }
+            float4 n;
+            n.x = (Lx + C.y + B.x + T.x - D[r].x) * 0.25f;
+            n.y = (C.x + C.z + B.y + T.y - D[r].y) * 0.25f;
+            n.z = (C.y + C.w + B.z + T.z - D[r].z) * 0.25f;
+            n.w = (C.z + Rw + B.w + T.w - D[r].w) * 0.25f;
+            below = C;
+            P[r] = n;
+        }
+    }
+
+    // store the texels the apron kept exact: tile-interior columns/rows inside [ga, gb)
+    const bool col_store = col_in && (4 * lane >= HALO) && (4 * lane < G::TX - HALO);
+    const int out_lo = ga + (int)blockIdx.y * G::VY;
+    const int out_hi = min(out_lo + G::VY, gb);
+#pragma unroll
+    for (int r = 0; r < RY; r++) {
+        const int gj = gy + r;
+        if (col_store && gj >= out_lo && gj < out_hi)
+            *reinterpret_cast<float4*>(p_out + (long)(gj - w.g0) * w.W + cx) = P[r];
+    }
+}
+
+template <int NW, int RY, int HALO>
+__global__ void __launch_bounds__(64 * NW) k_jacobi_tb(Win w, const float* __restrict__ p, const float* __restrict__ div,
+                                                        float* __restrict__ p_out, float pscale, int iters, int ga, int gb)
+{
+    using G = JacobiTB<NW, RY, HALO>;
+    __shared__ float4 mail[2][NW][2][64];
+    const int x0 = (int)blockIdx.x * G::VX - HALO, y0 = ga + (int)blockIdx.y * G::VY - HALO;
+    const bool edge = (x0 <= 0) || (x0 + G::TX >= w.W) || (y0 <= 0) || (y0 + G::TY >= w.H);
+    if (edge) jacobi_tb_body<NW, RY, HALO, true>(w, p, div, p_out, pscale, iters, ga, gb, mail);
+    else jacobi_tb_body<NW, RY, HALO, false>(w, p, div, p_out, pscale, iters, ga, gb, mail);
+}
+
+constexpr int TB_NW = 4, TB_RY = 16, TB_HALO = 8;
+
+inline dim3 row_grid(int W, int ga, int gb) { return dim3((W + BX - 1) / BX, gb - ga, 1); }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+#define ROWS_OR_RETURN() \
+    if (gb <= ga) return hipSuccess
+
+hipError_t launch_curl(hipStream_t s, Win w, const float2* vel, float* curl, int ga, int gb)
+{
+    ROWS_OR_RETURN();
+    k_curl<<<row_grid(w.W, ga, gb), BX, 0, s>>>(w, vel, curl, ga);
+    return hipGetLastError();
+}
+
+hipError_t launch_vorticity(hipStream_t s, Win w, const float2* vel, const float* curl, float2* vel_out, float curl_strength,
+                            float dt, int ga, int gb)
+{
+    ROWS_OR_RETURN();
+    k_vorticity<<<row_grid(w.W, ga, gb), BX, 0, s>>>(w, vel, curl, vel_out, curl_strength, dt, ga);
+    return hipGetLastError();
+}
+
+hipError_t launch_divergence(hipStream_t s, Win w, const float2* vel, float* div, int ga, int gb)
+{
+    ROWS_OR_RETURN();
+    k_divergence<<<row_grid(w.W, ga, gb), BX, 0, s>>>(w, vel, div, ga);
+    return hipGetLastError();
+}
+
+hipError_t launch_clear(hipStream_t s, Win w, const float* p, float* p_out, float value, int ga, int gb)
+{
+    ROWS_OR_RETURN();
+    k_clear<<<row_grid(w.W, ga, gb), BX, 0, s>>>(w, p, p_out, value, ga);
+    return hipGetLastError();
+}
+
+hipError_t launch_jacobi(hipStream_t s, Win w, const float* p, const float* div, float* p_out, int ga, int gb)
+{
+    ROWS_OR_RETURN();
+    k_jacobi<<<row_grid(w.W, ga, gb), BX, 0, s>>>(w, p, div, p_out, ga);
+    return hipGetLastError();
+}
+
+hipError_t launch_gradsub(hipStream_t s, Win w, const float* p, const float2* vel, float2* vel_out, int ga, int gb)
+{
+    ROWS_OR_RETURN();
+    k_gradsub<<<row_grid(w.W, ga, gb), BX, 0, s>>>(w, p, vel, vel_out, ga);
+    return hipGetLastError();
+}
+
+hipError_t launch_advect_velocity(hipStream_t s, Win w, const float2* vel, float2* out, float dt, float dissipation, int ga,
+                                  int gb, unsigned int* miss)
+{
+    ROWS_OR_RETURN();
+    k_advect_velocity<<<row_grid(w.W, ga, gb), BX, 0, s>>>(w, vel, out, dt, dissipation, (float)(1.0 / w.W), (float)(1.0 / w.H), ga, miss);
+    return hipGetLastError();
+}
+
+hipError_t launch_advect_dye(hipStream_t s, Win vw, const float2* vel, Win dw, const float4* dye, float4* out, float dt,
+                             float dissipation, int ga, int gb, unsigned int* miss)
+{
+    ROWS_OR_RETURN();
+    const float tsx = (float)(1.0 / vw.W), tsy = (float)(1.0 / vw.H);  // velocity.texelSizeX/Y, script.js:1061-1062, 1276
+    if (vw.W == dw.W && vw.H == dw.H)
+        k_advect_dye<true><<<row_grid(dw.W, ga, gb), BX, 0, s>>>(vw, vel, dw, dye, out, dt, dissipation, tsx, tsy, ga, miss);
+    else
+        k_advect_dye<false><<<row_grid(dw.W, ga, gb), BX, 0, s>>>(vw, vel, dw, dye, out, dt, dissipation, tsx, tsy, ga, miss);
+    return hipGetLastError();
+}
+
+hipError_t launch_splat_velocity(hipStream_t s, Win w, const float2* base, float2* out, float x, float y, float aspect,
+                                 float radius, float c0, float c1, int ga, int gb)
+{
+    ROWS_OR_RETURN();
+    k_splat_velocity<<<row_grid(w.W, ga, gb), BX, 0, s>>>(w, base, out, x, y, aspect, radius, c0, c1, ga);
+    return hipGetLastError();
+}
+
+hipError_t launch_splat_dye(hipStream_t s, Win w, const float4* base, float4* out, float x, float y, float aspect, float radius,
+                            float c0, float c1, float c2, int ga, int gb)
+{
+    ROWS_OR_RETURN();
+    k_splat_dye<<<row_grid(w.W, ga, gb), BX, 0, s>>>(w, base, out, x, y, aspect, radius, c0, c1, c2, ga);
+    return hipGetLastError();
+}
+
+hipError_t launch_resample(hipStream_t s, Win sw, const float* src, int nc, Win dw, float* dst)
+{
+    const dim3 g((dw.W + BX - 1) / BX, dw.H, 1);
+    if (nc == 2) k_resample<2><<<g, BX, 0, s>>>(sw, src, dw, dst);
+    else if (nc == 4) k_resample<4><<<g, BX, 0, s>>>(sw, src, dw, dst);
+    else k_resample<1><<<g, BX, 0, s>>>(sw, src, dw, dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill(hipStream_t s, float* dst, size_t n, int nc, float v0, float v1, float v2, float v3)
+{
+    if (n == 0) return hipSuccess;
+    const unsigned g = (unsigned)((n + BX - 1) / BX < 4096 ? (n + BX - 1) / BX : 4096);
+    if (nc == 2) k_fill<2><<<g, BX, 0, s>>>(dst, n, v0, v1, v2, v3);
+    else if (nc == 4) k_fill<4><<<g, BX, 0, s>>>(dst, n, v0, v1, v2, v3);
+    else k_fill<1><<<g, BX, 0, s>>>(dst, n, v0, v1, v2, v3);
+    return hipGetLastError();
+}
+
+int jacobi_tb_max_iters() { return TB_HALO; }
+
+bool jacobi_tb_supported(Win w) { return w.W % 4 == 0 && w.W >= 4; }
+
+hipError_t launch_jacobi_tb(hipStream_t s, Win w, const float* p, const float* div, float* p_out, float pscale, int iters,
+                            int ga, int gb)
+{
+    ROWS_OR_RETURN();
+    using G = JacobiTB<TB_NW, TB_RY, TB_HALO>;
+    if (iters < 1 || iters > TB_HALO || !jacobi_tb_supported(w)) return hipErrorInvalidValue;
+    const dim3 grid((w.W + G::VX - 1) / G::VX, (gb - ga + G::VY - 1) / G::VY, 1);
+    k_jacobi_tb<TB_NW, TB_RY, TB_HALO><<<grid, dim3(64, TB_NW, 1), 0, s>>>(w, p, div, p_out, pscale, iters, ga, gb);
+    return hipGetLastError();
+}
+
+}  // namespace fluid

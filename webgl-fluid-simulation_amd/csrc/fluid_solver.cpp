@@ -1,0 +1,685 @@
+// fluid_solver.cpp — solver core behind the C ABI of include/fluid_hip.h.
+//
+// Owns the five simulation fields of the reference (`dye, velocity, divergence, curl, pressure`,
+// script.js:950-954) as fp32 arrays in HBM, their read/write ping-pong (createDoubleFBO,
+// script.js:1079-1106), the pass sequencing of step() (script.js:1231-1294) and splat()
+// (script.js:1441-1455), and the row-stripe window used by the multi-GPU driver.
+// There is NO CPU path here: without a HIP device fluid_create() fails.
+#include "../../include/fluid_hip.h"
+#include "fluid_kernels.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace fluid;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+
+enum PassId { P_CURL, P_VORT, P_DIV, P_CLEAR, P_JACOBI, P_GRADSUB, P_ADVV, P_ADVD, P_COUNT };
+
+}  // namespace
+
+struct fluid_ctx {
+    fluid_desc desc{};
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // local windows (sim grid, dye grid); rows include the ghost rows of a stripe
+    Win sim{}, dye{};
+    int sim_row0 = 0, sim_rows = 0, dye_row0 = 0, dye_rows = 0, dye_halo = 0;
+
+    float2* vel[2] = { nullptr, nullptr };   // velocity.read / velocity.write
+    float* prs[2] = { nullptr, nullptr };    // pressure.read / pressure.write
+    float4* dyeb[2] = { nullptr, nullptr };  // dye.read / dye.write
+    float* div = nullptr;
+    float* curl = nullptr;
+    unsigned int* miss = nullptr;  // advection taps that fell outside the window
+
+    bool timing = false;
+    hipEvent_t ev[P_COUNT + 1] = {};
+    double acc_ms[P_COUNT] = {};
+    double acc_total = 0;
+    int acc_steps = 0, acc_jacobi_launches = 0;
+
+    int fail(int code, const std::string& what)
+    {
+        err = what;
+        return code;
+    }
+    int hip(hipError_t e, const char* what)
+    {
+        if (e == hipSuccess) return FLUID_OK;
+        err = std::string(what) + ": " + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? FLUID_ERR_OOM : FLUID_ERR_HIP;
+    }
+};
+
+#define CK(expr)                                   \
+    do {                                           \
+        int _rc = (expr);                          \
+        if (_rc != FLUID_OK) return _rc;           \
+    } while (0)
+#define HIPCK(ctx, expr) CK((ctx)->hip((expr), #expr))
+
+namespace {
+
+size_t cells(const Win& w) { return (size_t)w.rows * (size_t)w.W; }
+
+void free_fields(fluid_ctx* c)
+{
+    for (int k = 0; k < 2; k++) {
+        if (c->vel[k]) (void)hipFree(c->vel[k]);
+        if (c->prs[k]) (void)hipFree(c->prs[k]);
+        if (c->dyeb[k]) (void)hipFree(c->dyeb[k]);
+        c->vel[k] = nullptr;
+        c->prs[k] = nullptr;
+        c->dyeb[k] = nullptr;
+    }
+    if (c->div) (void)hipFree(c->div);
+    if (c->curl) (void)hipFree(c->curl);
+    c->div = c->curl = nullptr;
+}
+
+// window geometry of this context's stripe for a (sim_w, sim_h, dye_w, dye_h) grid
+int set_geometry(fluid_ctx* c, int sw, int sh, int dw, int dh)
+{
+    const fluid_desc& d = c->desc;
+    if (sw < 1 || sh < 1 || dw < 1 || dh < 1) return c->fail(FLUID_ERR_INVALID, "field sizes must be >= 1");
+    if (d.parts < 1 || d.part < 0 || d.part >= d.parts) return c->fail(FLUID_ERR_INVALID, "bad stripe index");
+    if (d.halo < 0) return c->fail(FLUID_ERR_INVALID, "negative halo");
+    if (d.parts > 1) {
+        if (sh % d.parts || dh % d.parts) return c->fail(FLUID_ERR_INVALID, "sim_h and dye_h must divide by parts");
+        if (d.halo < 4) return c->fail(FLUID_ERR_INVALID, "a stripe needs halo >= 4");
+        if (d.halo > sh / d.parts) return c->fail(FLUID_ERR_INVALID, "halo deeper than a stripe");
+    }
+    c->sim_rows = sh / d.parts;
+    c->sim_row0 = d.part * c->sim_rows;
+    c->dye_rows = dh / d.parts;
+    c->dye_row0 = d.part * c->dye_rows;
+    c->dye_halo = d.parts > 1 ? (int)(((long)d.halo * dh + sh - 1) / sh) : 0;
+    const int sh_halo = d.parts > 1 ? d.halo : 0;
+    c->sim = Win{ sw, sh, c->sim_row0 - sh_halo, c->sim_rows + 2 * sh_halo };
+    c->dye = Win{ dw, dh, c->dye_row0 - c->dye_halo, c->dye_rows + 2 * c->dye_halo };
+    return FLUID_OK;
+}
+
+// gl.clear after createFBO (script.js:1059) with clearColor (0,0,0,1) (script.js:136): dye alpha starts at 1
+int zero_scalar_fields(fluid_ctx* c)
+{
+    HIPCK(c, hipMemsetAsync(c->prs[0], 0, cells(c->sim) * sizeof(float), c->stream));
+    HIPCK(c, hipMemsetAsync(c->prs[1], 0, cells(c->sim) * sizeof(float), c->stream));
+    HIPCK(c, hipMemsetAsync(c->div, 0, cells(c->sim) * sizeof(float), c->stream));
+    HIPCK(c, hipMemsetAsync(c->curl, 0, cells(c->sim) * sizeof(float), c->stream));
+    return FLUID_OK;
+}
+
+int alloc_fields(fluid_ctx* c)
+{
+    const size_t ns = cells(c->sim), nd = cells(c->dye);
+    for (int k = 0; k < 2; k++) {
+        HIPCK(c, hipMalloc((void**)&c->vel[k], ns * sizeof(float2)));
+        HIPCK(c, hipMalloc((void**)&c->prs[k], ns * sizeof(float)));
+        HIPCK(c, hipMalloc((void**)&c->dyeb[k], nd * sizeof(float4)));
+    }
+    HIPCK(c, hipMalloc((void**)&c->div, ns * sizeof(float)));
+    HIPCK(c, hipMalloc((void**)&c->curl, ns * sizeof(float)));
+    for (int k = 0; k < 2; k++) {
+        HIPCK(c, hipMemsetAsync(c->vel[k], 0, ns * sizeof(float2), c->stream));
+        HIPCK(c, launch_fill(c->stream, (float*)c->dyeb[k], nd, 4, 0.f, 0.f, 0.f, 1.f));
+    }
+    return zero_scalar_fields(c);
+}
+
+// clip [row0 - ext, row0 + rows + ext) to the domain and to the window
+void row_range(const Win& w, int row0, int rows, int ext, int& ga, int& gb)
+{
+    ga = std::max(std::max(row0 - ext, 0), w.g0);
+    gb = std::min(std::min(row0 + rows + ext, w.H), w.g0 + w.rows);
+}
+
+int check_ext(fluid_ctx* c, int ext, int need_in)
+{
+    // every neighbour row a pass reads must exist in the window (rows beyond the domain edge are clamped,
+    // and row_range() clips the computed rows to the domain, so a whole-domain context accepts any ext)
+    if (ext < 0) return c->fail(FLUID_ERR_INVALID, "negative ext");
+    if (c->desc.parts > 1 && ext + need_in > c->desc.halo)
+        return c->fail(FLUID_ERR_INVALID, "ext exceeds the ghost rows available to this pass");
+    return FLUID_OK;
+}
+
+struct Timer {
+    fluid_ctx* c;
+    int idx = 0;
+    explicit Timer(fluid_ctx* ctx) : c(ctx)
+    {
+        if (c->timing) (void)hipEventRecord(c->ev[0], c->stream);
+    }
+    void mark(int pass)  // closes `pass`: time since the previous mark is charged to it
+    {
+        if (!c->timing) return;
+        (void)hipEventRecord(c->ev[1], c->stream);
+        (void)hipEventSynchronize(c->ev[1]);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
+        c->acc_ms[pass] += ms;
+        c->acc_total += ms;
+        (void)hipEventRecord(c->ev[0], c->stream);
+    }
+};
+
+// ---- passes -------------------------------------------------------------------------------------
+int pass_curl(fluid_ctx* c, int ext)
+{
+    CK(check_ext(c, ext, 1));
+    int ga, gb;
+    row_range(c->sim, c->sim_row0, c->sim_rows, ext, ga, gb);
+    return c->hip(launch_curl(c->stream, c->sim, c->vel[0], c->curl, ga, gb), "curl");
+}
+
+int pass_vorticity(fluid_ctx* c, float curl, float dt, int ext)
+{
+    CK(check_ext(c, ext, 1));
+    int ga, gb;
+    row_range(c->sim, c->sim_row0, c->sim_rows, ext, ga, gb);
+    CK(c->hip(launch_vorticity(c->stream, c->sim, c->vel[0], c->curl, c->vel[1], curl, dt, ga, gb), "vorticity"));
+    std::swap(c->vel[0], c->vel[1]);
+    return FLUID_OK;
+}
+
+int pass_divergence(fluid_ctx* c, int ext)
+{
+    CK(check_ext(c, ext, 1));
+    int ga, gb;
+    row_range(c->sim, c->sim_row0, c->sim_rows, ext, ga, gb);
+    return c->hip(launch_divergence(c->stream, c->sim, c->vel[0], c->div, ga, gb), "divergence");
+}
+
+int pass_clear(fluid_ctx* c, float value, int ext)
+{
+    CK(check_ext(c, ext, 0));
+    int ga, gb;
+    row_range(c->sim, c->sim_row0, c->sim_rows, ext, ga, gb);
+    CK(c->hip(launch_clear(c->stream, c->sim, c->prs[0], c->prs[1], value, ga, gb), "clear"));
+    std::swap(c->prs[0], c->prs[1]);
+    return FLUID_OK;
+}
+
+// `iters` Jacobi iterations; pscale != 1 folds the clear pass into the first load (FUSED only)
+int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launches)
+{
+    if (iters < 0) return c->fail(FLUID_ERR_INVALID, "negative iteration count");
+    CK(check_ext(c, ext_out, iters));
+    const bool tb = c->desc.schedule == FLUID_SCHED_FUSED && jacobi_tb_supported(c->sim);
+    int done = 0;
+    if (!tb && pscale != 1.0f) return c->fail(FLUID_ERR_INVALID, "pscale needs the fused schedule");
+    while (done < iters) {
+        int ga, gb;
+        if (tb) {
+            const int k = std::min(iters - done, jacobi_tb_max_iters());
+            row_range(c->sim, c->sim_row0, c->sim_rows, ext_out + (iters - done - k), ga, gb);
+            CK(c->hip(launch_jacobi_tb(c->stream, c->sim, c->prs[0], c->div, c->prs[1], done == 0 ? pscale : 1.0f, k, ga, gb),
+                      "jacobi_tb"));
+            done += k;
+        } else {
+            row_range(c->sim, c->sim_row0, c->sim_rows, ext_out + (iters - done - 1), ga, gb);
+            CK(c->hip(launch_jacobi(c->stream, c->sim, c->prs[0], c->div, c->prs[1], ga, gb), "jacobi"));
+            done += 1;
+        }
+        std::swap(c->prs[0], c->prs[1]);
+        if (launches) (*launches)++;
+    }
+    return FLUID_OK;
+}
+
+int pass_gradsub(fluid_ctx* c, int ext)
+{
+    CK(check_ext(c, ext, 1));
+    int ga, gb;
+    row_range(c->sim, c->sim_row0, c->sim_rows, ext, ga, gb);
+    CK(c->hip(launch_gradsub(c->stream, c->sim, c->prs[0], c->vel[0], c->vel[1], ga, gb), "gradsub"));
+    std::swap(c->vel[0], c->vel[1]);
+    return FLUID_OK;
+}
+
+int pass_advect_velocity(fluid_ctx* c, float dt, float dissipation, int ext)
+{
+    CK(check_ext(c, ext, 0));
+    int ga, gb;
+    row_range(c->sim, c->sim_row0, c->sim_rows, ext, ga, gb);
+    CK(c->hip(launch_advect_velocity(c->stream, c->sim, c->vel[0], c->vel[1], dt, dissipation, ga, gb, c->miss), "advect velocity"));
+    std::swap(c->vel[0], c->vel[1]);
+    return FLUID_OK;
+}
+
+int pass_advect_dye(fluid_ctx* c, float dt, float dissipation)
+{
+    int ga, gb;
+    row_range(c->dye, c->dye_row0, c->dye_rows, 0, ga, gb);
+    CK(c->hip(launch_advect_dye(c->stream, c->sim, c->vel[0], c->dye, c->dyeb[0], c->dyeb[1], dt, dissipation, ga, gb, c->miss),
+              "advect dye"));
+    std::swap(c->dyeb[0], c->dyeb[1]);
+    return FLUID_OK;
+}
+
+// step(dt), script.js:1231-1294 — whole-domain contexts (a stripe is driven pass by pass from the host,
+// with ghost-row exchanges in between)
+int step_once(fluid_ctx* c, float dt, const fluid_params* P)
+{
+    Timer t(c);
+    CK(pass_curl(c, 0));
+    t.mark(P_CURL);
+    CK(pass_vorticity(c, P->curl, dt, 0));
+    t.mark(P_VORT);
+    CK(pass_divergence(c, 0));
+    t.mark(P_DIV);
+    int launches = 0;
+    const bool fold_clear = c->desc.schedule == FLUID_SCHED_FUSED && jacobi_tb_supported(c->sim) && P->iterations > 0;
+    if (!fold_clear) {
+        CK(pass_clear(c, P->pressure, 0));
+        t.mark(P_CLEAR);
+    }
+    CK(pass_jacobi(c, P->iterations, 0, fold_clear ? P->pressure : 1.0f, &launches));
+    t.mark(P_JACOBI);
+    CK(pass_gradsub(c, 0));
+    t.mark(P_GRADSUB);
+    CK(pass_advect_velocity(c, dt, P->velocity_dissipation, 0));
+    t.mark(P_ADVV);
+    CK(pass_advect_dye(c, dt, P->density_dissipation));
+    t.mark(P_ADVD);
+    if (c->timing) {
+        c->acc_steps++;
+        c->acc_jacobi_launches += launches;
+    }
+    return FLUID_OK;
+}
+
+struct FieldRef {
+    void* ptr;
+    const Win* win;
+    int row0, rows, halo, nc;
+};
+
+int field_ref(fluid_ctx* c, int field, FieldRef* f)
+{
+    const int h = c->desc.parts > 1 ? c->desc.halo : 0;
+    switch (field) {
+    case FLUID_VELOCITY: *f = { c->vel[0], &c->sim, c->sim_row0, c->sim_rows, h, 2 }; break;
+    case FLUID_PRESSURE: *f = { c->prs[0], &c->sim, c->sim_row0, c->sim_rows, h, 1 }; break;
+    case FLUID_DIVERGENCE: *f = { c->div, &c->sim, c->sim_row0, c->sim_rows, h, 1 }; break;
+    case FLUID_CURL: *f = { c->curl, &c->sim, c->sim_row0, c->sim_rows, h, 1 }; break;
+    case FLUID_DYE: *f = { c->dyeb[0], &c->dye, c->dye_row0, c->dye_rows, c->dye_halo, 4 }; break;
+    default: return c->fail(FLUID_ERR_INVALID, "unknown field id");
+    }
+    return FLUID_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+int fluid_abi_version(void) { return FLUID_ABI_VERSION; }
+
+const char* fluid_error_string(int status)
+{
+    switch (status) {
+    case FLUID_OK: return "ok";
+    case FLUID_ERR_INVALID: return "invalid argument";
+    case FLUID_ERR_HIP: return "HIP runtime error";
+    case FLUID_ERR_NO_DEVICE: return "no HIP device";
+    case FLUID_ERR_OOM: return "out of device memory";
+    case FLUID_ERR_HALO: return "advection back-trace left the stripe's ghost rows";
+    case FLUID_ERR_UNSUPPORTED: return "unsupported";
+    default: return "unknown status";
+    }
+}
+
+const char* fluid_last_error(const fluid_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int fluid_device_count(int* count)
+{
+    if (!count) return FLUID_ERR_INVALID;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *count = n;
+    return FLUID_OK;
+}
+
+int fluid_create(const fluid_desc* desc, fluid_ctx** out)
+{
+    if (!desc || !out) return FLUID_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) {
+        (void)hipGetLastError();
+        g_create_error = "no HIP device visible: libfluid_hip has no CPU path";
+        return FLUID_ERR_NO_DEVICE;
+    }
+    if (desc->device < 0 || desc->device >= n) {
+        g_create_error = "device ordinal out of range";
+        return FLUID_ERR_INVALID;
+    }
+    fluid_ctx* c = new (std::nothrow) fluid_ctx();
+    if (!c) return FLUID_ERR_OOM;
+    c->desc = *desc;
+    if (c->desc.parts < 1) c->desc.parts = 1;
+    if (c->desc.parts == 1) c->desc.halo = 0;
+    c->device = desc->device;
+    int rc = FLUID_OK;
+    do {
+        if ((rc = c->hip(hipSetDevice(c->device), "hipSetDevice"))) break;
+        if ((rc = c->hip(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking), "hipStreamCreate"))) break;
+        c->stream = c->own_stream;
+        if ((rc = set_geometry(c, desc->sim_w, desc->sim_h, desc->dye_w, desc->dye_h))) break;
+        if ((rc = c->hip(hipMalloc((void**)&c->miss, sizeof(unsigned int)), "hipMalloc"))) break;
+        if ((rc = c->hip(hipMemsetAsync(c->miss, 0, sizeof(unsigned int), c->stream), "memset"))) break;
+        for (auto& e : c->ev)
+            if ((rc = c->hip(hipEventCreate(&e), "hipEventCreate"))) break;
+        if (rc) break;
+        if ((rc = alloc_fields(c))) break;
+        if ((rc = c->hip(hipStreamSynchronize(c->stream), "sync"))) break;
+    } while (0);
+    if (rc != FLUID_OK) {
+        g_create_error = c->err;
+        fluid_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return FLUID_OK;
+}
+
+int fluid_destroy(fluid_ctx* c)
+{
+    if (!c) return FLUID_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_fields(c);
+    if (c->miss) (void)hipFree(c->miss);
+    for (auto& e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return FLUID_OK;
+}
+
+int fluid_resize(fluid_ctx* c, int sw, int sh, int dw, int dh)
+{
+    if (!c) return FLUID_ERR_INVALID;
+    if (c->desc.parts != 1) return c->fail(FLUID_ERR_UNSUPPORTED, "resize of a stripe context");
+    if (sw < 1 || sh < 1 || dw < 1 || dh < 1) return c->fail(FLUID_ERR_INVALID, "field sizes must be >= 1");
+    HIPCK(c, hipSetDevice(c->device));
+    const Win osim = c->sim, odye = c->dye;
+    const bool sim_changed = (sw != osim.W || sh != osim.H), dye_changed = (dw != odye.W || dh != odye.H);
+    // resizeDoubleFBO (script.js:1116-1126): read <- bilinear copy of the old read, write <- fresh zero texture
+    if (dye_changed) {
+        const Win nd{ dw, dh, 0, dh };
+        float4 *nr = nullptr, *nw = nullptr;
+        HIPCK(c, hipMalloc((void**)&nr, cells(nd) * sizeof(float4)));
+        HIPCK(c, hipMalloc((void**)&nw, cells(nd) * sizeof(float4)));
+        HIPCK(c, launch_resample(c->stream, odye, (const float*)c->dyeb[0], 4, nd, (float*)nr));
+        HIPCK(c, launch_fill(c->stream, (float*)nw, cells(nd), 4, 0.f, 0.f, 0.f, 1.f));
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->dyeb[0]);
+        (void)hipFree(c->dyeb[1]);
+        c->dyeb[0] = nr;
+        c->dyeb[1] = nw;
+    }
+    if (sim_changed) {
+        const Win ns{ sw, sh, 0, sh };
+        float2 *nr = nullptr, *nw = nullptr;
+        HIPCK(c, hipMalloc((void**)&nr, cells(ns) * sizeof(float2)));
+        HIPCK(c, hipMalloc((void**)&nw, cells(ns) * sizeof(float2)));
+        HIPCK(c, launch_resample(c->stream, osim, (const float*)c->vel[0], 2, ns, (float*)nr));
+        HIPCK(c, hipMemsetAsync(nw, 0, cells(ns) * sizeof(float2), c->stream));
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->vel[0]);
+        (void)hipFree(c->vel[1]);
+        c->vel[0] = nr;
+        c->vel[1] = nw;
+        for (int k = 0; k < 2; k++) {
+            (void)hipFree(c->prs[k]);
+            c->prs[k] = nullptr;
+        }
+        (void)hipFree(c->div);
+        (void)hipFree(c->curl);
+        c->div = c->curl = nullptr;
+        for (int k = 0; k < 2; k++) HIPCK(c, hipMalloc((void**)&c->prs[k], cells(ns) * sizeof(float)));
+        HIPCK(c, hipMalloc((void**)&c->div, cells(ns) * sizeof(float)));
+        HIPCK(c, hipMalloc((void**)&c->curl, cells(ns) * sizeof(float)));
+    }
+    c->desc.sim_w = sw;
+    c->desc.sim_h = sh;
+    c->desc.dye_w = dw;
+    c->desc.dye_h = dh;
+    CK(set_geometry(c, sw, sh, dw, dh));
+    // divergence, curl and pressure are recreated on every initFramebuffers() (script.js:1004-1006)
+    CK(zero_scalar_fields(c));
+    return FLUID_OK;
+}
+
+int fluid_set_schedule(fluid_ctx* c, int schedule)
+{
+    if (!c) return FLUID_ERR_INVALID;
+    if (schedule != FLUID_SCHED_PASSES && schedule != FLUID_SCHED_FUSED) return c->fail(FLUID_ERR_INVALID, "unknown schedule");
+    c->desc.schedule = schedule;
+    return FLUID_OK;
+}
+
+int fluid_set_stream(fluid_ctx* c, void* hip_stream, int external)
+{
+    if (!c) return FLUID_ERR_INVALID;
+    HIPCK(c, hipSetDevice(c->device));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    c->stream = external ? (hipStream_t)hip_stream : c->own_stream;
+    return FLUID_OK;
+}
+
+int fluid_pass_splat(fluid_ctx* c, int field, float x, float y, float aspect, float radius, float c0, float c1, float c2)
+{
+    if (!c) return FLUID_ERR_INVALID;
+    HIPCK(c, hipSetDevice(c->device));
+    int ga, gb;
+    if (field == FLUID_VELOCITY) {
+        row_range(c->sim, c->sim.g0, c->sim.rows, 0, ga, gb);
+        CK(c->hip(launch_splat_velocity(c->stream, c->sim, c->vel[0], c->vel[1], x, y, aspect, radius, c0, c1, ga, gb), "splat velocity"));
+        std::swap(c->vel[0], c->vel[1]);
+    } else if (field == FLUID_DYE) {
+        row_range(c->dye, c->dye.g0, c->dye.rows, 0, ga, gb);
+        CK(c->hip(launch_splat_dye(c->stream, c->dye, c->dyeb[0], c->dyeb[1], x, y, aspect, radius, c0, c1, c2, ga, gb), "splat dye"));
+        std::swap(c->dyeb[0], c->dyeb[1]);
+    } else {
+        return c->fail(FLUID_ERR_INVALID, "splat target must be velocity or dye");
+    }
+    return FLUID_OK;
+}
+
+int fluid_splat(fluid_ctx* c, float x, float y, float dx, float dy, float r, float g, float b, float aspect, float radius)
+{
+    CK(fluid_pass_splat(c, FLUID_VELOCITY, x, y, aspect, radius, dx, dy, 0.0f));
+    return fluid_pass_splat(c, FLUID_DYE, x, y, aspect, radius, r, g, b);
+}
+
+int fluid_step_n(fluid_ctx* c, int n, float dt, const fluid_params* P)
+{
+    if (!c || !P) return FLUID_ERR_INVALID;
+    if (n < 0) return c->fail(FLUID_ERR_INVALID, "negative step count");
+    if (c->desc.parts != 1) return c->fail(FLUID_ERR_UNSUPPORTED, "a stripe context is stepped pass by pass by the host driver");
+    if (P->iterations < 0) return c->fail(FLUID_ERR_INVALID, "negative PRESSURE_ITERATIONS");
+    HIPCK(c, hipSetDevice(c->device));
+    for (int k = 0; k < n; k++) CK(step_once(c, dt, P));
+    return FLUID_OK;
+}
+
+int fluid_step(fluid_ctx* c, float dt, const fluid_params* P) { return fluid_step_n(c, 1, dt, P); }
+
+int fluid_sync(fluid_ctx* c)
+{
+    if (!c) return FLUID_ERR_INVALID;
+    HIPCK(c, hipSetDevice(c->device));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return FLUID_OK;
+}
+
+int fluid_field_info_get(const fluid_ctx* c, int field, fluid_field_info* out)
+{
+    if (!c || !out) return FLUID_ERR_INVALID;
+    FieldRef f;
+    CK(field_ref(const_cast<fluid_ctx*>(c), field, &f));
+    *out = fluid_field_info{ f.win->W, f.win->H, f.nc, f.row0, f.rows, f.halo };
+    return FLUID_OK;
+}
+
+int fluid_read_field(fluid_ctx* c, int field, float* host, size_t bytes)
+{
+    if (!c || !host) return FLUID_ERR_INVALID;
+    FieldRef f;
+    CK(field_ref(c, field, &f));
+    const size_t want = (size_t)f.rows * f.win->W * f.nc * sizeof(float);
+    if (bytes != want) return c->fail(FLUID_ERR_INVALID, "read_field: byte count does not match the owned rows");
+    HIPCK(c, hipSetDevice(c->device));
+    const char* src = (const char*)f.ptr + (size_t)(f.row0 - f.win->g0) * f.win->W * f.nc * sizeof(float);
+    HIPCK(c, hipMemcpyAsync(host, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return FLUID_OK;
+}
+
+int fluid_write_field(fluid_ctx* c, int field, const float* host, size_t bytes)
+{
+    if (!c || !host) return FLUID_ERR_INVALID;
+    FieldRef f;
+    CK(field_ref(c, field, &f));
+    const size_t want = (size_t)f.rows * f.win->W * f.nc * sizeof(float);
+    if (bytes != want) return c->fail(FLUID_ERR_INVALID, "write_field: byte count does not match the owned rows");
+    HIPCK(c, hipSetDevice(c->device));
+    char* dst = (char*)f.ptr + (size_t)(f.row0 - f.win->g0) * f.win->W * f.nc * sizeof(float);
+    HIPCK(c, hipMemcpyAsync(dst, host, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return FLUID_OK;
+}
+
+#define PASS_PROLOGUE()                      \
+    if (!c) return FLUID_ERR_INVALID;        \
+    HIPCK(c, hipSetDevice(c->device))
+
+int fluid_pass_curl(fluid_ctx* c, int ext)
+{
+    PASS_PROLOGUE();
+    return pass_curl(c, ext);
+}
+int fluid_pass_vorticity(fluid_ctx* c, float curl, float dt, int ext)
+{
+    PASS_PROLOGUE();
+    return pass_vorticity(c, curl, dt, ext);
+}
+int fluid_pass_divergence(fluid_ctx* c, int ext)
+{
+    PASS_PROLOGUE();
+    return pass_divergence(c, ext);
+}
+int fluid_pass_clear(fluid_ctx* c, float value, int ext)
+{
+    PASS_PROLOGUE();
+    return pass_clear(c, value, ext);
+}
+int fluid_pass_jacobi(fluid_ctx* c, int iters, int ext_out)
+{
+    PASS_PROLOGUE();
+    return pass_jacobi(c, iters, ext_out, 1.0f, nullptr);
+}
+int fluid_pass_gradsub(fluid_ctx* c, int ext)
+{
+    PASS_PROLOGUE();
+    return pass_gradsub(c, ext);
+}
+int fluid_pass_advect_velocity(fluid_ctx* c, float dt, float dissipation, int ext)
+{
+    PASS_PROLOGUE();
+    return pass_advect_velocity(c, dt, dissipation, ext);
+}
+int fluid_pass_advect_dye(fluid_ctx* c, float dt, float dissipation)
+{
+    PASS_PROLOGUE();
+    return pass_advect_dye(c, dt, dissipation);
+}
+
+static int halo_copy(fluid_ctx* c, int field, int side, int nrows, void* buf, bool pack)
+{
+    if (!c || !buf) return FLUID_ERR_INVALID;
+    FieldRef f;
+    CK(field_ref(c, field, &f));
+    if (nrows < 1 || nrows > f.halo || nrows > f.rows) return c->fail(FLUID_ERR_INVALID, "halo rows out of range");
+    if (side != 0 && side != 1) return c->fail(FLUID_ERR_INVALID, "side must be 0 (bottom) or 1 (top)");
+    HIPCK(c, hipSetDevice(c->device));
+    const size_t row_bytes = (size_t)f.win->W * f.nc * sizeof(float);
+    int first;  // first array row of the block
+    if (pack) first = side == 0 ? f.halo : f.halo + f.rows - nrows;
+    else first = side == 0 ? f.halo - nrows : f.halo + f.rows;
+    char* p = (char*)f.ptr + (size_t)first * row_bytes;
+    if (pack) HIPCK(c, hipMemcpyAsync(buf, p, nrows * row_bytes, hipMemcpyDeviceToDevice, c->stream));
+    else HIPCK(c, hipMemcpyAsync(p, buf, nrows * row_bytes, hipMemcpyDeviceToDevice, c->stream));
+    return FLUID_OK;
+}
+
+int fluid_halo_pack(fluid_ctx* c, int field, int side, int nrows, void* dev_buf) { return halo_copy(c, field, side, nrows, dev_buf, true); }
+
+int fluid_halo_unpack(fluid_ctx* c, int field, int side, int nrows, const void* dev_buf)
+{
+    return halo_copy(c, field, side, nrows, const_cast<void*>(dev_buf), false);
+}
+
+int fluid_halo_check(fluid_ctx* c)
+{
+    if (!c) return FLUID_ERR_INVALID;
+    HIPCK(c, hipSetDevice(c->device));
+    unsigned int m = 0;
+    HIPCK(c, hipMemcpyAsync(&m, c->miss, sizeof(m), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    if (m) {
+        HIPCK(c, hipMemsetAsync(c->miss, 0, sizeof(unsigned int), c->stream));
+        char msg[128];
+        std::snprintf(msg, sizeof msg, "%u advection taps fell outside the stripe's ghost rows (raise halo)", m);
+        return c->fail(FLUID_ERR_HALO, msg);
+    }
+    return FLUID_OK;
+}
+
+int fluid_set_timing(fluid_ctx* c, int enabled)
+{
+    if (!c) return FLUID_ERR_INVALID;
+    c->timing = enabled != 0;
+    std::fill(std::begin(c->acc_ms), std::end(c->acc_ms), 0.0);
+    c->acc_total = 0;
+    c->acc_steps = c->acc_jacobi_launches = 0;
+    return FLUID_OK;
+}
+
+int fluid_get_timings(fluid_ctx* c, fluid_timings* out)
+{
+    if (!c || !out) return FLUID_ERR_INVALID;
+    out->curl_ms = (float)c->acc_ms[P_CURL];
+    out->vorticity_ms = (float)c->acc_ms[P_VORT];
+    out->divergence_ms = (float)c->acc_ms[P_DIV];
+    out->clear_ms = (float)c->acc_ms[P_CLEAR];
+    out->jacobi_ms = (float)c->acc_ms[P_JACOBI];
+    out->gradsub_ms = (float)c->acc_ms[P_GRADSUB];
+    out->advect_velocity_ms = (float)c->acc_ms[P_ADVV];
+    out->advect_dye_ms = (float)c->acc_ms[P_ADVD];
+    out->total_ms = (float)c->acc_total;
+    out->jacobi_launches = c->acc_jacobi_launches;
+    out->steps = c->acc_steps;
+    return FLUID_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,122 @@
+"""ctypes binding of the C ABI in include/fluid_hip.h (libfluid_hip.so).
+
+No fallback: if the shared library is missing or no HIP device is visible, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(PKG_DIR, "libfluid_hip.so")
+
+FLUID_OK = 0
+ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_OOM, ERR_HALO, ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6
+VELOCITY, PRESSURE, DIVERGENCE, CURL, DYE = 0, 1, 2, 3, 4
+FIELD_IDS = {"velocity": VELOCITY, "pressure": PRESSURE, "divergence": DIVERGENCE, "curl": CURL, "dye": DYE}
+FIELD_CHANNELS = {VELOCITY: 2, PRESSURE: 1, DIVERGENCE: 1, CURL: 1, DYE: 4}
+SCHED_PASSES, SCHED_FUSED = 0, 1
+
+
+class FluidError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__("libfluid_hip: %s (status %d)" % (message, status))
+        self.status = status
+
+
+class Desc(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("sim_w", "sim_h", "dye_w", "dye_h", "device", "part", "parts", "halo", "schedule")]
+
+
+class Params(C.Structure):
+    _fields_ = [("curl", C.c_float), ("pressure", C.c_float), ("iterations", C.c_int),
+                ("velocity_dissipation", C.c_float), ("density_dissipation", C.c_float)]
+
+
+class FieldInfo(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("width", "height", "channels", "row0", "rows", "halo")]
+
+
+class Timings(C.Structure):
+    _fields_ = [(k, C.c_float) for k in ("curl_ms", "vorticity_ms", "divergence_ms", "clear_ms", "jacobi_ms", "gradsub_ms",
+                                         "advect_velocity_ms", "advect_dye_ms", "total_ms")] + \
+               [("jacobi_launches", C.c_int), ("steps", C.c_int)]
+
+
+# every symbol include/fluid_hip.h declares: name -> (restype, argtypes)
+_CTX = C.c_void_p
+_F = C.c_float
+_I = C.c_int
+SYMBOLS = {
+    "fluid_abi_version": (_I, []),
+    "fluid_error_string": (C.c_char_p, [_I]),
+    "fluid_last_error": (C.c_char_p, [_CTX]),
+    "fluid_device_count": (_I, [C.POINTER(_I)]),
+    "fluid_create": (_I, [C.POINTER(Desc), C.POINTER(_CTX)]),
+    "fluid_destroy": (_I, [_CTX]),
+    "fluid_resize": (_I, [_CTX, _I, _I, _I, _I]),
+    "fluid_set_schedule": (_I, [_CTX, _I]),
+    "fluid_set_stream": (_I, [_CTX, C.c_void_p, _I]),
+    "fluid_splat": (_I, [_CTX] + [_F] * 9),
+    "fluid_step": (_I, [_CTX, _F, C.POINTER(Params)]),
+    "fluid_step_n": (_I, [_CTX, _I, _F, C.POINTER(Params)]),
+    "fluid_sync": (_I, [_CTX]),
+    "fluid_read_field": (_I, [_CTX, _I, C.c_void_p, C.c_size_t]),
+    "fluid_write_field": (_I, [_CTX, _I, C.c_void_p, C.c_size_t]),
+    "fluid_field_info_get": (_I, [_CTX, _I, C.POINTER(FieldInfo)]),
+    "fluid_pass_curl": (_I, [_CTX, _I]),
+    "fluid_pass_vorticity": (_I, [_CTX, _F, _F, _I]),
+    "fluid_pass_divergence": (_I, [_CTX, _I]),
+    "fluid_pass_clear": (_I, [_CTX, _F, _I]),
+    "fluid_pass_jacobi": (_I, [_CTX, _I, _I]),
+    "fluid_pass_gradsub": (_I, [_CTX, _I]),
+    "fluid_pass_advect_velocity": (_I, [_CTX, _F, _F, _I]),
+    "fluid_pass_advect_dye": (_I, [_CTX, _F, _F]),
+    "fluid_pass_splat": (_I, [_CTX, _I] + [_F] * 7),
+    "fluid_halo_pack": (_I, [_CTX, _I, _I, _I, C.c_void_p]),
+    "fluid_halo_unpack": (_I, [_CTX, _I, _I, _I, C.c_void_p]),
+    "fluid_halo_check": (_I, [_CTX]),
+    "fluid_set_timing": (_I, [_CTX, _I]),
+    "fluid_get_timings": (_I, [_CTX, C.POINTER(Timings)]),
+}
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """(Re)build libfluid_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", PKG_DIR, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", PKG_DIR, "-j4"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    """Load libfluid_hip.so and bind every declared symbol; raises if the library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FluidError(ERR_UNSUPPORTED, "%s not built (run `make -C %s`); there is no CPU fallback" % (LIB_PATH, PKG_DIR))
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the header and the library disagree
+            fn.restype = res
+            fn.argtypes = args
+        if L.fluid_abi_version() != 1:
+            raise FluidError(ERR_UNSUPPORTED, "ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(ctx, status: int):
+    if status != FLUID_OK:
+        L = lib()
+        detail = L.fluid_last_error(ctx) or b""
+        raise FluidError(status, "%s: %s" % (L.fluid_error_string(status).decode(), detail.decode()))
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    lib().fluid_device_count(C.byref(n))
+    return n.value

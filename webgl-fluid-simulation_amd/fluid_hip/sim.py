@@ -1,0 +1,312 @@
+"""Host-side mirror of the reference's simulation surface over libfluid_hip.so.
+
+The reference keeps its simulation API as page-level globals (script.js): `config` (59-85),
+`initFramebuffers()` (982-1010), `splat()` (1441-1455), `multipleSplats()` (1427-1439),
+`step(dt)` (1231-1294), `update()` (1176-1186), `framebufferToTexture()` (301-307) and the field
+objects `velocity, dye, pressure, divergence, curl` (950-954).  `FluidSim` exposes the same names
+with the same argument meaning, one instance per "page".  The JavaScript twin of this class is
+webgl-fluid-simulation_amd/addon/fluid.js (Node N-API); both sit on the same C ABI.
+
+All arithmetic happens in the HIP library; this file only holds the reference's host logic
+(resolution rule, splat parameter rules, the Math.random call order, the dt clamp).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import random as _random
+from typing import Callable, Dict, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import _abi
+from ._abi import FIELD_CHANNELS, FIELD_IDS, FluidError
+
+# config keys the simulation path reads (script.js:59-85); display-only keys are not modelled
+DEFAULT_CONFIG = {
+    "SIM_RESOLUTION": 128,
+    "DYE_RESOLUTION": 1024,
+    "DENSITY_DISSIPATION": 1,
+    "VELOCITY_DISSIPATION": 0.2,
+    "PRESSURE": 0.8,
+    "PRESSURE_ITERATIONS": 20,
+    "CURL": 30,
+    "SPLAT_RADIUS": 0.25,
+    "SPLAT_FORCE": 6000,
+    "PAUSED": False,
+}
+
+SCHEDULES = {"passes": _abi.SCHED_PASSES, "fused": _abi.SCHED_FUSED}
+
+
+def mulberry32(seed: int) -> Callable[[], float]:
+    """Seedable stand-in for Math.random (the stream BASELINE.md's measurement plan names)."""
+    state = seed & 0xFFFFFFFF
+
+    def imul(a: int, b: int) -> int:
+        return ((a & 0xFFFFFFFF) * (b & 0xFFFFFFFF)) & 0xFFFFFFFF
+
+    def rnd() -> float:
+        nonlocal state
+        state = (state + 0x6D2B79F5) & 0xFFFFFFFF
+        t = imul(state ^ (state >> 15), 1 | state)
+        t = ((t + imul(t ^ (t >> 7), 61 | t)) & 0xFFFFFFFF) ^ t
+        return ((t ^ (t >> 14)) & 0xFFFFFFFF) / 4294967296.0
+
+    return rnd
+
+
+def HSVtoRGB(h: float, s: float, v: float) -> Dict[str, float]:
+    """script.js:1573-1595"""
+    i = math.floor(h * 6)
+    f = h * 6 - i
+    p = v * (1 - s)
+    q = v * (1 - f * s)
+    t = v * (1 - (1 - f) * s)
+    r, g, b = ((v, t, p), (q, v, p), (p, v, t), (p, q, v), (t, p, v), (v, p, q))[int(i % 6)]
+    return {"r": r, "g": g, "b": b}
+
+
+def getResolution(resolution: float, drawing_w: int, drawing_h: int) -> Dict[str, int]:
+    """script.js:1612-1624 (gl.drawingBufferWidth/Height = the canvas size)"""
+    aspect = drawing_w / drawing_h
+    if aspect < 1:
+        aspect = 1.0 / aspect
+    mn = int(math.floor(resolution + 0.5))           # Math.round
+    mx = int(math.floor(resolution * aspect + 0.5))
+    if drawing_w > drawing_h:
+        return {"width": mx, "height": mn}
+    return {"width": mn, "height": mx}
+
+
+def _f32(x: float) -> float:
+    """what gl.uniform1f does to a JS number"""
+    return float(np.float32(x))
+
+
+class Canvas:
+    """stand-in for the page's <canvas> (only width/height are used by the simulation path)"""
+
+    def __init__(self, width: int, height: int):
+        self.width = int(width)
+        self.height = int(height)
+
+
+class FieldView:
+    """width/height/texelSize view of one field, like the FBO objects of script.js:1064-1076"""
+
+    def __init__(self, sim: "FluidSim", name: str, double: bool):
+        self._sim, self._name, self._double = sim, name, double
+
+    @property
+    def width(self) -> int:
+        return self._sim._info(self._name).width
+
+    @property
+    def height(self) -> int:
+        return self._sim._info(self._name).height
+
+    @property
+    def texelSizeX(self) -> float:
+        return 1.0 / self.width
+
+    @property
+    def texelSizeY(self) -> float:
+        return 1.0 / self.height
+
+    @property
+    def read(self) -> "FieldView":
+        # the library swaps read/write itself; the view always names the current read side
+        if not self._double:
+            raise AttributeError("%s is a single FBO" % self._name)
+        return self
+
+
+class FluidSim:
+    def __init__(self, canvas: Union[Canvas, Tuple[int, int]] = (512, 512), config: Optional[dict] = None,
+                 device: int = 0, schedule: str = "fused", random: Optional[Callable[[], float]] = None):
+        self._lib = _abi.lib()
+        self.canvas = canvas if isinstance(canvas, Canvas) else Canvas(*canvas)
+        self.config = dict(DEFAULT_CONFIG)
+        if config:
+            self.config.update(config)
+        self.random = random or _random.random  # Math.random
+        self.splatStack = []
+        self._device = device
+        self._schedule = SCHEDULES[schedule]
+        self._ctx = None
+        self.initFramebuffers()
+        self.velocity = FieldView(self, "velocity", True)
+        self.dye = FieldView(self, "dye", True)
+        self.pressure = FieldView(self, "pressure", True)
+        self.divergence = FieldView(self, "divergence", False)
+        self.curl = FieldView(self, "curl", False)
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        if self._ctx is not None:
+            self._lib.fluid_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, status: int):
+        _abi.check(self._ctx, status)
+
+    def _info(self, name: str) -> _abi.FieldInfo:
+        fi = _abi.FieldInfo()
+        self._check(self._lib.fluid_field_info_get(self._ctx, FIELD_IDS[name], C.byref(fi)))
+        return fi
+
+    # -- initFramebuffers(), script.js:982-1010 ---------------------------------------------
+    def initFramebuffers(self):
+        sim = getResolution(self.config["SIM_RESOLUTION"], self.canvas.width, self.canvas.height)
+        dye = getResolution(self.config["DYE_RESOLUTION"], self.canvas.width, self.canvas.height)
+        if self._ctx is None:
+            d = _abi.Desc(sim["width"], sim["height"], dye["width"], dye["height"], self._device, 0, 1, 0, self._schedule)
+            ctx = C.c_void_p()
+            rc = self._lib.fluid_create(C.byref(d), C.byref(ctx))
+            if rc != _abi.FLUID_OK:
+                _abi.check(None, rc)
+            self._ctx = ctx
+        else:
+            self._check(self._lib.fluid_resize(self._ctx, sim["width"], sim["height"], dye["width"], dye["height"]))
+
+    def set_schedule(self, schedule: str):
+        self._schedule = SCHEDULES[schedule]
+        self._check(self._lib.fluid_set_schedule(self._ctx, self._schedule))
+
+    # -- splat(), script.js:1441-1462 ---------------------------------------------------------
+    def correctRadius(self, radius: float) -> float:
+        aspect = self.canvas.width / self.canvas.height
+        if aspect > 1:
+            radius *= aspect
+        return radius
+
+    def splat(self, x: float, y: float, dx: float, dy: float, color):
+        if isinstance(color, dict):
+            r, g, b = color["r"], color["g"], color["b"]
+        else:
+            r, g, b = color
+        aspect = self.canvas.width / self.canvas.height
+        radius = self.correctRadius(self.config["SPLAT_RADIUS"] / 100.0)
+        self._check(self._lib.fluid_splat(self._ctx, x, y, dx, dy, r, g, b, aspect, radius))
+
+    # -- generateColor / multipleSplats, script.js:1565-1571, 1427-1439 ------------------------
+    def generateColor(self) -> Dict[str, float]:
+        c = HSVtoRGB(self.random(), 1.0, 1.0)
+        c["r"] *= 0.15
+        c["g"] *= 0.15
+        c["b"] *= 0.15
+        return c
+
+    def multipleSplats(self, amount: int):
+        issued = []
+        for _ in range(int(amount)):
+            color = self.generateColor()
+            color["r"] *= 10.0
+            color["g"] *= 10.0
+            color["b"] *= 10.0
+            x = self.random()
+            y = self.random()
+            dx = 1000 * (self.random() - 0.5)
+            dy = 1000 * (self.random() - 0.5)
+            self.splat(x, y, dx, dy, color)
+            issued.append([x, y, dx, dy, color["r"], color["g"], color["b"]])
+        return issued
+
+    # -- step(dt), script.js:1231-1294 -----------------------------------------------------------
+    def params(self) -> _abi.Params:
+        c = self.config
+        return _abi.Params(c["CURL"], c["PRESSURE"], int(c["PRESSURE_ITERATIONS"]),
+                           c["VELOCITY_DISSIPATION"], c["DENSITY_DISSIPATION"])
+
+    def step(self, dt: float, n: int = 1):
+        P = self.params()
+        self._check(self._lib.fluid_step_n(self._ctx, int(n), dt, C.byref(P)))
+
+    # -- update(), script.js:1176-1186, without the render: dt clamp (1191), inputs, PAUSED gate ----
+    def update(self, wall_dt: float):
+        dt = min(wall_dt, 0.016666)
+        if self.splatStack:
+            self.multipleSplats(self.splatStack.pop())
+        if not self.config["PAUSED"]:
+            self.step(dt)
+        return dt
+
+    def sync(self):
+        self._check(self._lib.fluid_sync(self._ctx))
+
+    # -- field access ------------------------------------------------------------------------------
+    def read(self, name: str) -> np.ndarray:
+        """field in its native channel count: velocity [H,W,2], dye [H,W,4], others [H,W]; row 0 = bottom"""
+        fi = self._info(name)
+        shape = (fi.rows, fi.width) if fi.channels == 1 else (fi.rows, fi.width, fi.channels)
+        out = np.empty(shape, np.float32)
+        self._check(self._lib.fluid_read_field(self._ctx, FIELD_IDS[name], out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out
+
+    def write(self, name: str, arr: np.ndarray):
+        fi = self._info(name)
+        shape = (fi.rows, fi.width) if fi.channels == 1 else (fi.rows, fi.width, fi.channels)
+        a = np.ascontiguousarray(arr, dtype=np.float32)
+        if a.shape != shape:
+            raise ValueError("%s expects shape %s, got %s" % (name, shape, a.shape))
+        self._check(self._lib.fluid_write_field(self._ctx, FIELD_IDS[name], a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+    def framebufferToTexture(self, target: Union[str, FieldView]) -> np.ndarray:
+        """script.js:301-307: readPixels(RGBA, FLOAT) — R and RG fields come back padded to (r, g, 0, 1)"""
+        name = target._name if isinstance(target, FieldView) else target
+        a = self.read(name)
+        if a.ndim == 2:
+            a = a[..., None]
+        h, w, nc = a.shape
+        out = np.zeros((h, w, 4), np.float32)
+        out[..., 3] = 1.0
+        out[..., :nc] = a
+        return out.reshape(-1)
+
+    def fields(self) -> Dict[str, np.ndarray]:
+        return {k: self.read(k) for k in FIELD_IDS}
+
+    # -- single passes (test / stripe-driver port) -------------------------------------------------
+    def run_pass(self, name: str, dt: float = 0.016666, iters: int = 1, ext: int = 0):
+        L, c, P = self._lib, self._ctx, self.params()
+        if name == "curl":
+            rc = L.fluid_pass_curl(c, ext)
+        elif name == "vorticity":
+            rc = L.fluid_pass_vorticity(c, P.curl, dt, ext)
+        elif name == "divergence":
+            rc = L.fluid_pass_divergence(c, ext)
+        elif name == "clear":
+            rc = L.fluid_pass_clear(c, P.pressure, ext)
+        elif name == "jacobi":
+            rc = L.fluid_pass_jacobi(c, iters, ext)
+        elif name == "gradsub":
+            rc = L.fluid_pass_gradsub(c, ext)
+        elif name == "advect_velocity":
+            rc = L.fluid_pass_advect_velocity(c, dt, P.velocity_dissipation, ext)
+        elif name == "advect_dye":
+            rc = L.fluid_pass_advect_dye(c, dt, P.density_dissipation)
+        else:
+            raise ValueError("unknown pass " + name)
+        self._check(rc)
+
+    # -- timing ------------------------------------------------------------------------------------
+    def set_timing(self, on: bool):
+        self._check(self._lib.fluid_set_timing(self._ctx, 1 if on else 0))
+
+    def timings(self) -> Dict[str, float]:
+        t = _abi.Timings()
+        self._check(self._lib.fluid_get_timings(self._ctx, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in _abi.Timings._fields_}

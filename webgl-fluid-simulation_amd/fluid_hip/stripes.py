@@ -1,0 +1,323 @@
+"""Row-stripe domain decomposition of the reference's step() across GPUs (one process per GPU).
+
+The global grid is cut into `world` equal row stripes.  Each rank owns one stripe plus `halo` ghost
+rows on each side and runs the SAME kernels as the single-GPU path on its window (the C ABI's
+`part/parts/halo`).  Between passes, ghost rows are refreshed from the neighbouring ranks with
+point-to-point send/recv — torch.distributed, i.e. RCCL over xGMI on MI355X, gloo on CPU for the
+tests.  There is no global collective on the data path.
+
+Communication-avoiding schedule (MI355X-first: xGMI is point-to-point and a neighbour message is
+tiny, so the cost is per-exchange latency, not bytes): instead of one single-row exchange before
+each of the 7 + ITERS passes, a rank recomputes a few ghost rows redundantly and exchanges `halo`
+rows at a time:
+
+    exchange velocity (halo rows)
+    curl (ext halo-1) -> vorticity (ext halo-2) -> divergence (ext halo-3)     no exchange
+    clear (ext 0)
+    repeat: exchange pressure (D = min(remaining, halo-3) rows, +1 for the last block); D Jacobi iterations
+    gradient subtract (ext 0; the last Jacobi block left one valid ghost row of pressure)
+    exchange velocity (halo rows)   -- the advection gather reaches up to dt*|v| rows away
+    advect velocity (ext 1)
+    exchange dye (dye-halo rows); advect dye
+
+With halo = 32 and 50 iterations that is 5 exchanges per step instead of 57.  Every recomputed ghost
+row is the same arithmetic on the same inputs as the owner's, so the decomposed result is BITWISE
+equal to the single-domain result (tests/test_stripes_*.py).  `halo` must cover the advection
+back-trace (dt * max|v_y| + 2 rows); kernels count taps that leave the window and `check_halo()`
+raises instead of returning a wrong field.
+
+The compute engine is injectable (`engine_factory`) so the host logic here can be exercised on CPU
+by the tests with the oracle as the engine; the default engine is the HIP C ABI and nothing else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import queue
+import random as _random
+from typing import Callable, Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import _abi
+from ._abi import FIELD_IDS
+from .sim import Canvas, DEFAULT_CONFIG, HSVtoRGB, getResolution
+
+VELOCITY, PRESSURE, DYE = "velocity", "pressure", "dye"
+
+
+# ---------------------------------------------------------------------------------------------------
+class HipStripeEngine:
+    """One stripe context of libfluid_hip.so; ghost rows are staged through torch device tensors and all
+    work is enqueued on torch's current stream so RCCL send/recv order correctly against the kernels."""
+
+    def __init__(self, sim_wh, dye_wh, part, parts, halo, schedule, device):
+        import torch
+        self.torch = torch
+        self.lib = _abi.lib()
+        self.device = device
+        d = _abi.Desc(sim_wh[0], sim_wh[1], dye_wh[0], dye_wh[1], device, part, parts, halo, schedule)
+        ctx = C.c_void_p()
+        rc = self.lib.fluid_create(C.byref(d), C.byref(ctx))
+        if rc != _abi.FLUID_OK:
+            _abi.check(None, rc)
+        self.ctx = ctx
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream().cuda_stream
+        self._ck(self.lib.fluid_set_stream(self.ctx, C.c_void_p(stream), 1))
+
+    def _ck(self, rc):
+        _abi.check(self.ctx, rc)
+
+    def close(self):
+        if self.ctx is not None:
+            self.lib.fluid_destroy(self.ctx)
+            self.ctx = None
+
+    def info(self, name):
+        fi = _abi.FieldInfo()
+        self._ck(self.lib.fluid_field_info_get(self.ctx, FIELD_IDS[name], C.byref(fi)))
+        return fi
+
+    def new_buffer(self, name, nrows):
+        fi = self.info(name)
+        return self.torch.empty((nrows, fi.width, fi.channels), dtype=self.torch.float32, device="cuda:%d" % self.device)
+
+    def halo_pack(self, name, side, nrows):
+        buf = self.new_buffer(name, nrows)
+        self._ck(self.lib.fluid_halo_pack(self.ctx, FIELD_IDS[name], side, nrows, C.c_void_p(buf.data_ptr())))
+        return buf
+
+    def halo_unpack(self, name, side, nrows, buf):
+        self._ck(self.lib.fluid_halo_unpack(self.ctx, FIELD_IDS[name], side, nrows, C.c_void_p(buf.data_ptr())))
+
+    def curl(self, ext): self._ck(self.lib.fluid_pass_curl(self.ctx, ext))
+    def vorticity(self, curl, dt, ext): self._ck(self.lib.fluid_pass_vorticity(self.ctx, curl, dt, ext))
+    def divergence(self, ext): self._ck(self.lib.fluid_pass_divergence(self.ctx, ext))
+    def clear(self, value, ext): self._ck(self.lib.fluid_pass_clear(self.ctx, value, ext))
+    def jacobi(self, iters, ext_out): self._ck(self.lib.fluid_pass_jacobi(self.ctx, iters, ext_out))
+    def gradsub(self, ext): self._ck(self.lib.fluid_pass_gradsub(self.ctx, ext))
+    def advect_velocity(self, dt, diss, ext): self._ck(self.lib.fluid_pass_advect_velocity(self.ctx, dt, diss, ext))
+    def advect_dye(self, dt, diss): self._ck(self.lib.fluid_pass_advect_dye(self.ctx, dt, diss))
+
+    def splat(self, x, y, dx, dy, r, g, b, aspect, radius):
+        self._ck(self.lib.fluid_splat(self.ctx, x, y, dx, dy, r, g, b, aspect, radius))
+
+    def read(self, name):
+        fi = self.info(name)
+        shape = (fi.rows, fi.width) if fi.channels == 1 else (fi.rows, fi.width, fi.channels)
+        out = np.empty(shape, np.float32)
+        self._ck(self.lib.fluid_read_field(self.ctx, FIELD_IDS[name], out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out
+
+    def write(self, name, arr):
+        a = np.ascontiguousarray(arr, np.float32)
+        self._ck(self.lib.fluid_write_field(self.ctx, FIELD_IDS[name], a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+    def sync(self): self._ck(self.lib.fluid_sync(self.ctx))
+    def check_halo(self): self._ck(self.lib.fluid_halo_check(self.ctx))
+
+
+# ---------------------------------------------------------------------------------------------------
+class TorchDistComm:
+    """neighbour exchange over torch.distributed point-to-point (backend nccl = RCCL over xGMI; gloo on CPU)"""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    def exchange(self, send_lo, send_hi, like):
+        """send_lo -> rank-1, send_hi -> rank+1; returns (recv_lo, recv_hi) tensors (None at the domain ends)"""
+        import torch
+        dist, ops = self.dist, []
+        recv_lo = torch.empty_like(like) if self.rank > 0 else None
+        recv_hi = torch.empty_like(like) if self.rank < self.world - 1 else None
+        if self.rank > 0:
+            ops += [dist.P2POp(dist.isend, send_lo, self.rank - 1, self.group), dist.P2POp(dist.irecv, recv_lo, self.rank - 1, self.group)]
+        if self.rank < self.world - 1:
+            ops += [dist.P2POp(dist.isend, send_hi, self.rank + 1, self.group), dist.P2POp(dist.irecv, recv_hi, self.rank + 1, self.group)]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return recv_lo, recv_hi
+
+    def gather_rows(self, arr: np.ndarray) -> Optional[np.ndarray]:
+        parts = [None] * self.world
+        self.dist.all_gather_object(parts, arr, group=self.group)
+        return np.concatenate(parts, axis=0)
+
+
+class LocalComm:
+    """all stripes inside ONE process (one thread per stripe, all contexts on one device): the way the
+    decomposition is validated bit-for-bit on a single-GPU box.  Blocking mailboxes between neighbours."""
+
+    class Hub:
+        def __init__(self, world):
+            self.world = world
+            self.box = {(s, d): queue.Queue() for s in range(world) for d in (s - 1, s + 1) if 0 <= d < world}
+
+    def __init__(self, hub: "LocalComm.Hub", rank: int):
+        self.hub, self.rank, self.world = hub, rank, hub.world
+
+    def exchange(self, send_lo, send_hi, like):
+        r = self.rank
+        if r > 0:
+            self.hub.box[(r, r - 1)].put(send_lo)
+        if r < self.world - 1:
+            self.hub.box[(r, r + 1)].put(send_hi)
+        recv_lo = self.hub.box[(r - 1, r)].get(timeout=120) if r > 0 else None
+        recv_hi = self.hub.box[(r + 1, r)].get(timeout=120) if r < self.world - 1 else None
+        return recv_lo, recv_hi
+
+    def gather_rows(self, arr):
+        raise NotImplementedError("gather the per-stripe reads in the caller")
+
+
+# ---------------------------------------------------------------------------------------------------
+class StripeSim:
+    """This rank's stripe of a FluidSim: same surface (config / splat / multipleSplats / step / read)."""
+
+    def __init__(self, canvas=(512, 512), config: Optional[dict] = None, halo: int = 32, schedule: str = "fused",
+                 random: Optional[Callable[[], float]] = None, device: int = 0, comm=None,
+                 engine_factory: Optional[Callable] = None):
+        self.canvas = canvas if isinstance(canvas, Canvas) else Canvas(*canvas)
+        self.config = dict(DEFAULT_CONFIG)
+        if config:
+            self.config.update(config)
+        self.random = random or _random.random
+        self.comm = comm if comm is not None else TorchDistComm()
+        self.rank, self.world = self.comm.rank, self.comm.world
+        sim = getResolution(self.config["SIM_RESOLUTION"], self.canvas.width, self.canvas.height)
+        dye = getResolution(self.config["DYE_RESOLUTION"], self.canvas.width, self.canvas.height)
+        self.sim_wh = (sim["width"], sim["height"])
+        self.dye_wh = (dye["width"], dye["height"])
+        if self.sim_wh[1] % self.world or self.dye_wh[1] % self.world:
+            raise ValueError("grid heights %d / %d do not divide into %d stripes" % (self.sim_wh[1], self.dye_wh[1], self.world))
+        self.halo = int(halo) if self.world > 1 else 0
+        if self.world > 1 and self.halo < 4:
+            raise ValueError("halo must be >= 4")
+        sched = {"passes": _abi.SCHED_PASSES, "fused": _abi.SCHED_FUSED}[schedule]
+        factory = engine_factory or HipStripeEngine
+        self.engine = factory(self.sim_wh, self.dye_wh, self.rank, self.world, self.halo, sched, device)
+        self.same_res = self.sim_wh == self.dye_wh
+        self.exchanges = 0
+
+    def close(self):
+        self.engine.close()
+
+    # -- ghost-row refresh -------------------------------------------------------------------------
+    def exchange(self, name: str, nrows: int):
+        if self.world == 1 or nrows < 1:
+            return
+        e = self.engine
+        send_lo = e.halo_pack(name, 0, nrows) if self.rank > 0 else None
+        send_hi = e.halo_pack(name, 1, nrows) if self.rank < self.world - 1 else None
+        like = send_lo if send_lo is not None else send_hi
+        recv_lo, recv_hi = self.comm.exchange(send_lo, send_hi, like)
+        if recv_lo is not None:
+            e.halo_unpack(name, 0, nrows, recv_lo)
+        if recv_hi is not None:
+            e.halo_unpack(name, 1, nrows, recv_hi)
+        self.exchanges += 1
+
+    # -- splat / multipleSplats: script.js:1441-1462, 1427-1439 (every rank evaluates its own rows) ----
+    def splat(self, x, y, dx, dy, color):
+        r, g, b = (color["r"], color["g"], color["b"]) if isinstance(color, dict) else color
+        aspect = self.canvas.width / self.canvas.height
+        radius = self.config["SPLAT_RADIUS"] / 100.0
+        if aspect > 1:
+            radius *= aspect
+        self.engine.splat(x, y, dx, dy, r, g, b, aspect, radius)
+
+    def multipleSplats(self, amount: int):
+        issued = []
+        for _ in range(int(amount)):  # same Math.random call order on every rank (same seed -> same stream)
+            c = HSVtoRGB(self.random(), 1.0, 1.0)
+            color = {k: v * 0.15 * 10.0 for k, v in c.items()}
+            x = self.random()
+            y = self.random()
+            dx = 1000 * (self.random() - 0.5)
+            dy = 1000 * (self.random() - 0.5)
+            self.splat(x, y, dx, dy, color)
+            issued.append([x, y, dx, dy, color["r"], color["g"], color["b"]])
+        return issued
+
+    # -- step(dt): script.js:1231-1294 with ghost-row exchanges between pass groups ---------------------
+    def step(self, dt: float):
+        c, e, H = self.config, self.engine, self.halo
+        iters = int(c["PRESSURE_ITERATIONS"])
+        if self.world == 1:
+            e.curl(0); e.vorticity(c["CURL"], dt, 0); e.divergence(0); e.clear(c["PRESSURE"], 0)
+            e.jacobi(iters, 0); e.gradsub(0)
+            e.advect_velocity(dt, c["VELOCITY_DISSIPATION"], 0); e.advect_dye(dt, c["DENSITY_DISSIPATION"])
+            return
+        self.exchange(VELOCITY, H)
+        e.curl(H - 1)
+        e.vorticity(c["CURL"], dt, H - 2)
+        e.divergence(H - 3)
+        e.clear(c["PRESSURE"], 0)
+        remaining = iters
+        while remaining > 0:
+            # divergence is valid H-3 rows out and iteration k of a block needs it d-k+ext rows out -> d <= H-3.
+            # The last block also produces one ghost row (ext 1): gradient subtract reads pressure one row out.
+            d = min(remaining, H - 3)
+            ext = 1 if d == remaining else 0
+            self.exchange(PRESSURE, d + ext)
+            e.jacobi(d, ext)
+            remaining -= d
+        if iters == 0:
+            self.exchange(PRESSURE, 1)
+        e.gradsub(0)
+        self.exchange(VELOCITY, H)
+        e.advect_velocity(dt, c["VELOCITY_DISSIPATION"], 0 if self.same_res else 1)
+        self.exchange(DYE, e.info(DYE).halo)
+        e.advect_dye(dt, c["DENSITY_DISSIPATION"])
+
+    def sync(self):
+        self.engine.sync()
+
+    def check_halo(self):
+        self.engine.check_halo()
+
+    # -- field access ------------------------------------------------------------------------------------
+    def read_local(self, name: str) -> np.ndarray:
+        return self.engine.read(name)
+
+    def read(self, name: str) -> np.ndarray:
+        """the GLOBAL field on every rank (test / checkpoint path; goes through the host)"""
+        local = self.read_local(name)
+        return local if self.world == 1 else self.comm.gather_rows(local)
+
+    def write(self, name: str, global_arr: np.ndarray):
+        fi = self.engine.info(name)
+        self.engine.write(name, np.ascontiguousarray(global_arr[fi.row0:fi.row0 + fi.rows]))
+
+
+def run_local_stripes(world: int, body: Callable[["StripeSim"], object], **kw) -> List[object]:
+    """Run `body(stripe_sim)` for every stripe in one process, one thread per stripe (LocalComm)."""
+    import threading
+    hub = LocalComm.Hub(world)
+    results: List[object] = [None] * world
+    errors: List[BaseException] = []
+
+    def worker(r):
+        sim = None
+        try:
+            sim = StripeSim(comm=LocalComm(hub, r), **kw)
+            results[r] = body(sim)
+        except BaseException as ex:  # noqa: BLE001
+            errors.append(ex)
+        finally:
+            if sim is not None:
+                sim.close()
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return results
