@@ -140,6 +140,10 @@ int fluid_field_info_get(const fluid_ctx *ctx, int field, fluid_field_info *out)
 int fluid_pass_curl(fluid_ctx *ctx, int ext);                        /* curlProgram        script.js:1234-1237 */
 int fluid_pass_vorticity(fluid_ctx *ctx, float curl, float dt, int ext); /* vorticityProgram 1239-1246 (swaps velocity) */
 int fluid_pass_divergence(fluid_ctx *ctx, int ext);                  /* divergenceProgram  1248-1251 */
+/* curl + vorticity + divergence (script.js:1234-1251) as ONE kernel under the fused schedule (three under
+ * the per-pass schedule): velocity must be valid ext + 3 ghost rows out; curl, the confined velocity and its
+ * divergence come back valid ext rows out.  Bit-identical to the three passes run in turn. */
+int fluid_pass_curl_vorticity_divergence(fluid_ctx *ctx, float curl, float dt, int ext);
 int fluid_pass_clear(fluid_ctx *ctx, float value, int ext);          /* clearProgram       1253-1257 (swaps pressure) */
 /* `iters` Jacobi iterations (pressureProgram, 1259-1266); input must be valid `ext_out + iters`
  * rows beyond the owned rows, output is valid `ext_out` rows beyond.  Uses the context's schedule. */
@@ -147,6 +151,9 @@ int fluid_pass_jacobi(fluid_ctx *ctx, int iters, int ext_out);
 int fluid_pass_gradsub(fluid_ctx *ctx, int ext);                     /* gradienSubtractProgram 1268-1273 (swaps velocity) */
 int fluid_pass_advect_velocity(fluid_ctx *ctx, float dt, float dissipation, int ext); /* advectionProgram 1275-1285 */
 int fluid_pass_advect_dye(fluid_ctx *ctx, float dt, float dissipation);               /* advectionProgram 1287-1293 */
+/* both advection draws (script.js:1275-1293): one kernel under the fused schedule when the dye grid equals the
+ * sim grid, else the two passes.  Velocity AND dye ghost rows must be valid before the call. */
+int fluid_pass_advect(fluid_ctx *ctx, float dt, float velocity_dissipation, float density_dissipation);
 /* one splatProgram draw (script.js:1442-1454) into FLUID_VELOCITY (c2 ignored) or FLUID_DYE, owned + ghost rows */
 int fluid_pass_splat(fluid_ctx *ctx, int field, float x, float y, float aspect, float radius,
                      float c0, float c1, float c2);

@@ -74,6 +74,11 @@ class OracleStripeEngine:
         out = O.divergence(self.vel, H=self.H, g0=self.g0, ra=ra, rb=rb)
         self.div[ra:rb] = out[ra:rb]
 
+    def curl_vorticity_divergence(self, curl, dt, ext):
+        self.curl(ext + 2)
+        self.vorticity(curl, dt, ext + 1)
+        self.divergence(ext)
+
     def clear(self, value, ext):
         ra, rb = self._range(ext)
         self.prs = O.clear(self.prs, O.f32(value), ra=ra, rb=rb)
@@ -98,6 +103,11 @@ class OracleStripeEngine:
         self.dye, m = O.advect(self.vel, self.dye, O.f32(dt), O.f32(diss), vH=self.H, vg0=self.g0, sH=self.DH, sg0=self.dg0,
                                ra=ra, rb=rb, return_misses=True)
         self.misses += m
+
+    def advect(self, dt, vdiss, ddiss):
+        same = (self.W, self.H) == (self.DW, self.DH)
+        self.advect_velocity(dt, vdiss, 1 if (self.parts > 1 and not same) else 0)
+        self.advect_dye(dt, ddiss)
 
     def splat(self, x, y, dx, dy, r, g, b, aspect, radius):
         f = O.f32

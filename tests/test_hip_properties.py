@@ -26,6 +26,25 @@ def test_fused_equals_passes_bitwise(N):
         a.close(); b.close()
 
 
+@pytest.mark.parametrize("canvas,res,dye", [((512, 512), 64, 64), ((520, 300), 300, 300), ((1000, 40), 40, 40), ((4096, 128), 128, 128),
+                                            ((256, 3000), 256, 256), ((640, 480), 240, 480), ((250, 130), 130, 130)])
+def test_fused_equals_passes_bitwise_odd_shapes(canvas, res, dye):
+    """tile-boundary coverage of the fused kernels: widths/heights that are not multiples of the tile, grids
+    smaller than one tile, W % 4 != 0 (falls back to the per-pass kernels), dye grid != sim grid"""
+    import fluid_hip
+    cfg = {"SIM_RESOLUTION": res, "DYE_RESOLUTION": dye, "PRESSURE_ITERATIONS": 23}
+    sims = [fluid_hip.FluidSim(canvas=canvas, config=cfg, schedule=s, random=fluid_hip.mulberry32(5)) for s in ("passes", "fused")]
+    try:
+        for s in sims:
+            s.multipleSplats(7)
+            s.step(0.016666, 3)
+        for k in ("velocity", "pressure", "divergence", "curl", "dye"):
+            assert np.array_equal(sims[0].read(k), sims[1].read(k)), k
+    finally:
+        for s in sims:
+            s.close()
+
+
 def test_zero_state_is_a_fixed_point_4096():
     s = sim_of(4096, "fused")
     try:

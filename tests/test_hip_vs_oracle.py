@@ -217,3 +217,37 @@ def test_framebuffer_to_texture_padding():
     assert np.all(v[..., 2] == 0) and np.all(v[..., 3] == 1) and v[..., 0].max() > 0
     assert np.all(p[..., 0] == 0) and np.all(p[..., 3] == 1)
     assert np.all(d[..., 3] == 1)
+
+
+@pytest.mark.parametrize("W,H", [(64, 64), (256, 64), (512, 300), (1000, 40), (2048, 70), (1024, 1024)])
+def test_fused_curl_vorticity_divergence(oracle, W, H):
+    """the fused K1+K2+K3 kernel: curl bitwise; velocity to libm ulps; divergence bitwise GIVEN the kernel's own velocity"""
+    st = rand_state(W, H, 300 + W)
+    dt = np.float32(0.016666)
+    sim = make_sim(W, H, "fused")
+    try:
+        load_state(sim, st)
+        sim.run_pass("curl_vorticity_divergence")
+        crl, vel, div = sim.read("curl"), sim.read("velocity"), sim.read("divergence")
+    finally:
+        sim.close()
+    want_curl = oracle.curl(st["velocity"])
+    assert np.array_equal(crl, want_curl)
+    assert S.rel_err(vel, oracle.vorticity(st["velocity"], want_curl, np.float32(30), dt)) <= HIP_VS_ORACLE_ULP_PASSES
+    assert np.array_equal(div, oracle.divergence(vel))
+
+
+@pytest.mark.parametrize("W,H", [(64, 64), (250, 130), (512, 300), (1024, 1024)])
+def test_fused_advect(oracle, W, H):
+    st = rand_state(W, H, 400 + W)
+    dt = np.float32(0.016666)
+    sim = make_sim(W, H, "fused")
+    try:
+        load_state(sim, st)
+        sim.run_pass("advect")
+        vel, dye = sim.read("velocity"), sim.read("dye")
+    finally:
+        sim.close()
+    assert S.rel_err(vel, oracle.advect(st["velocity"], st["velocity"], dt, np.float32(0.2))) <= HIP_VS_ORACLE_ULP_PASSES
+    # the dye back-trace uses the kernel's own new velocity: feed that to the oracle
+    assert S.rel_err(dye, oracle.advect(vel, st["dye"], dt, np.float32(1.0))) <= HIP_VS_ORACLE_ULP_PASSES

@@ -34,4 +34,7 @@ def golden_tolerance(name: str) -> float:
 #   Jacobi / clear / gradient subtract / curl / divergence: bitwise
 #   vorticity (sqrt, divide), advection (divide), splat (exp): a few ulp
 HIP_VS_ORACLE_ULP_PASSES = 4e-7
-HIP_VS_ORACLE_STEP = 2e-6        # one full step, relative to max|field|
+# one full step, relative to max|field|.  With CURL = 30 the vorticity force f/(|f|+1e-4) is discontinuous
+# where grad|curl| ~ 0 (script.js:856-857), so the 1-ulp exp() difference between ocml and glibc in the splats
+# is amplified locally (measured <= 7.7e-6 at 1024^2); with CURL = 0 the step agrees to ~1e-7.
+HIP_VS_ORACLE_STEP = 3e-5

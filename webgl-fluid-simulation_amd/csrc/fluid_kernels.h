@@ -26,12 +26,22 @@ hipError_t launch_advect_velocity(hipStream_t s, Win w, const float2* vel, float
                                   int ga, int gb, unsigned int* miss);
 hipError_t launch_advect_dye(hipStream_t s, Win vw, const float2* vel, Win dw, const float4* dye, float4* out,
                              float dt, float dissipation, int ga, int gb, unsigned int* miss);
+// K7a + K7b in one kernel; only when the dye grid equals the sim grid (same window)
+hipError_t launch_advect_both(hipStream_t s, Win w, const float2* vel, float2* vel_out, const float4* dye, float4* dye_out,
+                              float dt, float vel_dissipation, float dye_dissipation, int ga, int gb, unsigned int* miss);
 hipError_t launch_splat_velocity(hipStream_t s, Win w, const float2* base, float2* out, float x, float y, float aspect,
                                  float radius, float c0, float c1, int ga, int gb);
 hipError_t launch_splat_dye(hipStream_t s, Win w, const float4* base, float4* out, float x, float y, float aspect,
                             float radius, float c0, float c1, float c2, int ga, int gb);
 hipError_t launch_resample(hipStream_t s, Win sw, const float* src, int nc, Win dw, float* dst);
 hipError_t launch_fill(hipStream_t s, float* dst, size_t n_vec, int nc, float v0, float v1, float v2, float v3);
+
+// Fused curl -> vorticity -> divergence (K1+K2+K3): reads velocity rows [ga-3, gb+3) (clamped), writes curl,
+// the confined velocity and its divergence for rows [ga, gb).  Requires W % 4 == 0.  Bitwise equal to the three
+// single-pass kernels run in turn.
+bool fused_supported(Win w);
+hipError_t launch_curl_vort_div(hipStream_t s, Win w, const float2* vel, float* curl, float2* vel_out, float* div,
+                                float curl_strength, float dt, int ga, int gb);
 
 // Temporally blocked Jacobi: `iters` (<= jacobi_tb_max_iters()) iterations in one launch, every input
 // value scaled by `pscale` on load (pscale = config.PRESSURE folds the clear pass, 1.0f otherwise).

@@ -15,6 +15,8 @@
 // CLAMP_TO_EDGE everywhere (script.js:1051-1052).  `Win` = window of a stripe-decomposed field.
 #include "fluid_kernels.h"
 
+#include <cstdlib>
+
 namespace fluid {
 
 namespace {
@@ -233,6 +235,33 @@ __global__ void __launch_bounds__(BX) k_advect_dye(Win vw, const float2* __restr
     if (miss) atomicAdd(miss_out, (unsigned)miss);
 }
 
+// K7a + K7b fused (dye grid == sim grid): the dye back-trace needs the NEW velocity only at its own texel
+// (script.js:1289: uVelocity sampled at vUv), so one thread advects the velocity texel, stores it, and
+// advects the dye texel with it — the new velocity is not re-read from HBM (48 B/texel instead of 56).
+// Same per-texel arithmetic as the two kernels above, hence the same bits.
+__global__ void __launch_bounds__(BX) k_advect_both(Win w, const float2* __restrict__ vel, float2* __restrict__ vel_out,
+                                                     const float4* __restrict__ dye, float4* __restrict__ dye_out, float dt,
+                                                     float vel_dissipation, float dye_dissipation, float tsx, float tsy, int ga,
+                                                     unsigned int* __restrict__ miss_out)
+{
+    const int i = blockIdx.x * BX + threadIdx.x;
+    const int gj = ga + blockIdx.y;
+    if (i >= w.W) return;
+    const float u = ((float)i + 0.5f) / (float)w.W;
+    const float v = ((float)gj + 0.5f) / (float)w.H;
+    const long c = (long)(gj - w.g0) * w.W + i;
+    int miss = 0;
+    const float2 vv = vel[c];
+    const float2 r = bil2(w, vel, u - dt * vv.x * tsx, v - dt * vv.y * tsy, miss);
+    const float vdecay = 1.0f + vel_dissipation * dt;
+    const float2 nv = make_float2(r.x / vdecay, r.y / vdecay);
+    vel_out[c] = nv;
+    const float4 d = bil4(w, dye, u - dt * nv.x * tsx, v - dt * nv.y * tsy, miss);
+    const float ddecay = 1.0f + dye_dissipation * dt;
+    dye_out[c] = make_float4(d.x / ddecay, d.y / ddecay, d.z / ddecay, d.w / ddecay);
+    if (miss) atomicAdd(miss_out, (unsigned)miss);
+}
+
 // K8 splat — splatShader script.js:726-744
 __device__ __forceinline__ float splat_weight(const Win& w, int i, int gj, float x, float y, float aspect, float radius)
 {
@@ -292,6 +321,37 @@ __global__ void __launch_bounds__(BX) k_fill(float* __restrict__ dst, size_t n, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Tiling of an output range [lo, hi) of a domain [0, dom) by tiles of span T that lose an apron A on each
+// side — except on a side where the tile contains the domain edge: CLAMP_TO_EDGE makes the edge exact, so
+// no apron is needed there (at W = 4096, T = 256, A = 8 exactly 17 column tiles cover the row instead of 18).
+// Tile b spans [S + b*V, S + b*V + T) with V = T - 2A and S = max(lo - A, 0).
+struct Axis {
+    int S, V, n;
+};
+
+__host__ __device__ inline int ceil_div_pos(int a, int b) { return a <= 0 ? 0 : (a + b - 1) / b; }
+
+__host__ inline Axis make_axis(int lo, int hi, int dom, int T, int A)
+{
+    Axis ax;
+    ax.V = T - 2 * A;
+    ax.S = lo - A > 0 ? lo - A : 0;
+    const int n1 = ceil_div_pos(hi - ax.S - T + A, ax.V) + 1;  // last tile's exact range reaches hi
+    const int n2 = ceil_div_pos(dom - ax.S - T, ax.V) + 1;     // or the last tile contains the far domain edge
+    ax.n = n1 < n2 ? n1 : n2;
+    return ax;
+}
+
+// exact (storable) global range [a, b) of the tile starting at t0, intersected with [lo, hi)
+__device__ __forceinline__ void tile_exact(int t0, int T, int A, int dom, int lo, int hi, int& a, int& b)
+{
+    a = t0 <= 0 ? 0 : t0 + A;
+    b = t0 + T >= dom ? dom : t0 + T - A;
+    a = max(a, lo);
+    b = min(b, hi);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Temporally blocked Jacobi (the hot loop: 82 % of the reference's bytes at 50 iterations).
 //
 // A workgroup of NW waves owns a tile of 256 columns x NW*RY rows, held ENTIRELY IN REGISTERS:
@@ -331,32 +391,31 @@ __device__ __forceinline__ float from_right_lane(float v)  // value held by lane
 
 template <int NW, int RY, int HALO, bool EDGE>
 __device__ __forceinline__ void jacobi_tb_body(const Win& w, const float* __restrict__ p, const float* __restrict__ div,
-                                               float* __restrict__ p_out, float pscale, int iters, int ga, int gb,
-                                               float4 (*mail)[NW][2][64])
+                                               float* __restrict__ p_out, float pscale, int iters, int ga, int gb, int x0,
+                                               int y0, float4 (*mail)[NW][2][64])
 {
     using G = JacobiTB<NW, RY, HALO>;
     const int lane = threadIdx.x;
     const int wv = threadIdx.y;
-    const int cx = (int)blockIdx.x * G::VX - HALO + 4 * lane;         // first of this lane's 4 columns
-    const int gy = ga + (int)blockIdx.y * G::VY - HALO + wv * RY;     // global row of this wave's row 0
-    const bool col_in = (cx >= 0) && (cx + 3 < w.W);
+    const int cx = x0 + 4 * lane;     // first of this lane's 4 columns
+    const int gy = y0 + wv * RY;      // global row of this wave's row 0
 
+    // Load the whole tile with UNCONDITIONAL loads from clamped addresses (no per-row branch, so the 2*RY
+    // 1 KiB wave loads are all in flight together).  Apron texels outside the domain or outside the
+    // stripe's window then hold some other texel's finite value; that is fine: they are never stored,
+    // and no in-domain texel reads an off-domain neighbour (EDGE selects below) or a texel deeper in
+    // the apron than `iters`.
     float4 P[RY], D[RY];
+    const int cxs = min(max(cx, 0), w.W - 4);
 #pragma unroll
     for (int r = 0; r < RY; r++) {
-        const int gj = gy + r;
-        const int lr = gj - w.g0;
-        const bool ok = col_in && gj >= 0 && gj < w.H && lr >= 0 && lr < w.rows;
-        if (ok) {
-            const long c = (long)lr * w.W + cx;
-            const float4 pv = *reinterpret_cast<const float4*>(p + c);
-            D[r] = *reinterpret_cast<const float4*>(div + c);
-            P[r] = make_float4(pscale * pv.x, pscale * pv.y, pscale * pv.z, pscale * pv.w);
-        } else {
-            P[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-            D[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        const int lr = min(max(gy + r - w.g0, 0), w.rows - 1);
+        const long c = (long)lr * w.W + cxs;
+        P[r] = *reinterpret_cast<const float4*>(p + c);
+        D[r] = *reinterpret_cast<const float4*>(div + c);
     }
+#pragma unroll
+    for (int r = 0; r < RY; r++) P[r] = make_float4(pscale * P[r].x, pscale * P[r].y, pscale * P[r].z, pscale * P[r].w);
 
     const bool at_left = (cx == 0), at_right = (cx + 3 == w.W - 1);
 
@@ -365,8 +424,9 @@ __device__ __forceinline__ void jacobi_tb_body(const Win& w, const float* __rest
         mail[it & 1][wv][0][lane] = P[0];
         mail[it & 1][wv][1][lane] = P[RY - 1];
         __syncthreads();
-        float4 below = (wv > 0) ? mail[it & 1][wv - 1][1][lane] : P[0];            // tile edge: stale apron anyway
-        const float4 above = (wv < NW - 1) ? mail[it & 1][wv + 1][0][lane] : P[RY - 1];
+        // unconditional b128 reads: the first/last wave reads its own mailbox, which only feeds the stale apron
+        float4 below = mail[it & 1][wv > 0 ? wv - 1 : 0][1][lane];
+        const float4 above = mail[it & 1][wv < NW - 1 ? wv + 1 : NW - 1][0][lane];
 
 #pragma unroll
         for (int r = 0; r < RY; r++) {
@@ -392,10 +452,11 @@ __device__ __forceinline__ void jacobi_tb_body(const Win& w, const float* __rest
         }
     }
 
-    // store the texels the apron kept exact: tile-interior columns/rows inside [ga, gb)
-    const bool col_store = col_in && (4 * lane >= HALO) && (4 * lane < G::TX - HALO);
-    const int out_lo = ga + (int)blockIdx.y * G::VY;
-    const int out_hi = min(out_lo + G::VY, gb);
+    // store the texels the apron kept exact
+    int xa, xb, out_lo, out_hi;
+    tile_exact(x0, G::TX, HALO, w.W, 0, w.W, xa, xb);
+    tile_exact(y0, G::TY, HALO, w.H, ga, gb, out_lo, out_hi);
+    const bool col_store = (cx >= xa) && (cx < xb);
 #pragma unroll
     for (int r = 0; r < RY; r++) {
         const int gj = gy + r;
@@ -406,17 +467,208 @@ __device__ __forceinline__ void jacobi_tb_body(const Win& w, const float* __rest
 
 template <int NW, int RY, int HALO>
 __global__ void __launch_bounds__(64 * NW) k_jacobi_tb(Win w, const float* __restrict__ p, const float* __restrict__ div,
-                                                        float* __restrict__ p_out, float pscale, int iters, int ga, int gb)
+                                                        float* __restrict__ p_out, float pscale, int iters, int ga, int gb,
+                                                        int ys)
 {
     using G = JacobiTB<NW, RY, HALO>;
     __shared__ float4 mail[2][NW][2][64];
-    const int x0 = (int)blockIdx.x * G::VX - HALO, y0 = ga + (int)blockIdx.y * G::VY - HALO;
+    const int x0 = (int)blockIdx.x * G::VX, y0 = ys + (int)blockIdx.y * G::VY;
     const bool edge = (x0 <= 0) || (x0 + G::TX >= w.W) || (y0 <= 0) || (y0 + G::TY >= w.H);
-    if (edge) jacobi_tb_body<NW, RY, HALO, true>(w, p, div, p_out, pscale, iters, ga, gb, mail);
-    else jacobi_tb_body<NW, RY, HALO, false>(w, p, div, p_out, pscale, iters, ga, gb, mail);
+    if (edge) jacobi_tb_body<NW, RY, HALO, true>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
+    else jacobi_tb_body<NW, RY, HALO, false>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
 }
 
-constexpr int TB_NW = 4, TB_RY = 16, TB_HALO = 8;
+// ------------------------------------------------------------------------------------------------
+// Fused K1 + K2 + K3: curl -> vorticity confinement -> divergence in one trip through HBM
+// (reads velocity once: 8 B/texel; writes curl 4, velocity 8, divergence 4 = 24 B/texel instead of
+// 12 + 20 + 12 = 44).  Same register-tile layout as the Jacobi kernel: lane l of wave wv holds 4
+// consecutive texels (two float4 = four RG pairs) of RY rows; x neighbours by full-wave DPP shifts,
+// y neighbours in registers, wave-boundary rows through LDS mailboxes (one barrier per stage).
+// Each stage shrinks the exact region by one ring, so the tile carries a 3-row / 4-column apron
+// (4 keeps float4 alignment) and stores only its interior.  The per-texel arithmetic is the same
+// device code as the single-pass kernels, so the result is bit-identical to running them in turn.
+template <int NW, int RY>
+struct VortDiv {
+    static constexpr int TX = 256, TY = NW * RY, AX = 4, AY = 3;
+    static constexpr int VX = TX - 2 * AX, VY = TY - 2 * AY;
+};
+
+struct Row4 {  // four texels of one row held by a lane
+    float x[4], y[4];
+};
+
+template <int NW, int RY, bool EDGE>
+__device__ __forceinline__ void vort_div_body(const Win& w, const float2* __restrict__ vel, float* __restrict__ curl_out,
+                                              float2* __restrict__ vel_out, float* __restrict__ div_out, float curl_strength,
+                                              float dt, int ga, int gb, int x0, int y0, float4 (*mail)[2][2][64])
+{
+    using G = VortDiv<NW, RY>;
+    const int lane = threadIdx.x, wv = threadIdx.y;
+    const int cx = x0 + 4 * lane;
+    const int gy = y0 + wv * RY;
+    const int cxs = min(max(cx, 0), w.W - 4);
+    const bool at_left = (cx == 0), at_right = (cx + 3 == w.W - 1);
+    const int wb = wv > 0 ? wv - 1 : 0, wa = wv < NW - 1 ? wv + 1 : NW - 1;
+
+    // ---- load velocity (unconditional, clamped addresses; see the Jacobi kernel) ----
+    Row4 V[RY];
+#pragma unroll
+    for (int r = 0; r < RY; r++) {
+        const int lr = min(max(gy + r - w.g0, 0), w.rows - 1);
+        const float4* src = reinterpret_cast<const float4*>(vel + (long)lr * w.W + cxs);
+        const float4 a = src[0], b = src[1];
+        V[r].x[0] = a.x; V[r].y[0] = a.y; V[r].x[1] = a.z; V[r].y[1] = a.w;
+        V[r].x[2] = b.x; V[r].y[2] = b.y; V[r].x[3] = b.z; V[r].y[3] = b.w;
+    }
+
+    // ---- stage 1: curl (needs vx of the rows above/below, vy of the columns left/right) ----
+    mail[wv][0][0][lane] = make_float4(V[0].x[0], V[0].x[1], V[0].x[2], V[0].x[3]);
+    mail[wv][1][0][lane] = make_float4(V[RY - 1].x[0], V[RY - 1].x[1], V[RY - 1].x[2], V[RY - 1].x[3]);
+    __syncthreads();
+    const float4 vxb = mail[wb][1][0][lane], vxa = mail[wa][0][0][lane];
+    float C[RY][4];
+#pragma unroll
+    for (int r = 0; r < RY; r++) {
+        const int gj = gy + r;
+        float Lq = from_left_lane(V[r].y[3]), Rq = from_right_lane(V[r].y[0]);
+        if (EDGE) {
+            if (at_left) Lq = V[r].y[0];
+            if (at_right) Rq = V[r].y[3];
+        }
+        const float bx[4] = { r > 0 ? V[r - 1].x[0] : vxb.x, r > 0 ? V[r - 1].x[1] : vxb.y, r > 0 ? V[r - 1].x[2] : vxb.z,
+                              r > 0 ? V[r - 1].x[3] : vxb.w };
+        const float tx[4] = { r < RY - 1 ? V[r + 1].x[0] : vxa.x, r < RY - 1 ? V[r + 1].x[1] : vxa.y,
+                              r < RY - 1 ? V[r + 1].x[2] : vxa.z, r < RY - 1 ? V[r + 1].x[3] : vxa.w };
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float L = k > 0 ? V[r].y[k - 1] : Lq;
+            const float R = k < 3 ? V[r].y[k + 1] : Rq;
+            float T = tx[k], B = bx[k];
+            if (EDGE) {
+                if (gj == 0) B = V[r].x[k];
+                if (gj == w.H - 1) T = V[r].x[k];
+            }
+            const float vort = R - L - T + B;
+            C[r][k] = 0.5f * vort;
+        }
+    }
+
+    // ---- stage 2: vorticity confinement (needs curl of the four neighbours) ----
+    mail[wv][0][1][lane] = make_float4(C[0][0], C[0][1], C[0][2], C[0][3]);
+    mail[wv][1][1][lane] = make_float4(C[RY - 1][0], C[RY - 1][1], C[RY - 1][2], C[RY - 1][3]);
+    __syncthreads();
+    const float4 cb = mail[wb][1][1][lane], ca = mail[wa][0][1][lane];
+    Row4 N[RY];
+#pragma unroll
+    for (int r = 0; r < RY; r++) {
+        const int gj = gy + r;
+        float Lq = from_left_lane(C[r][3]), Rq = from_right_lane(C[r][0]);
+        if (EDGE) {
+            if (at_left) Lq = C[r][0];
+            if (at_right) Rq = C[r][3];
+        }
+        const float bc[4] = { r > 0 ? C[r - 1][0] : cb.x, r > 0 ? C[r - 1][1] : cb.y, r > 0 ? C[r - 1][2] : cb.z, r > 0 ? C[r - 1][3] : cb.w };
+        const float tc[4] = { r < RY - 1 ? C[r + 1][0] : ca.x, r < RY - 1 ? C[r + 1][1] : ca.y, r < RY - 1 ? C[r + 1][2] : ca.z,
+                              r < RY - 1 ? C[r + 1][3] : ca.w };
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float L = k > 0 ? C[r][k - 1] : Lq;
+            const float R = k < 3 ? C[r][k + 1] : Rq;
+            float T = tc[k], B = bc[k];
+            if (EDGE) {
+                if (gj == 0) B = C[r][k];
+                if (gj == w.H - 1) T = C[r][k];
+            }
+            const float2 nv = vorticity_cell(L, R, T, B, C[r][k], make_float2(V[r].x[k], V[r].y[k]), curl_strength, dt);
+            N[r].x[k] = nv.x;
+            N[r].y[k] = nv.y;
+        }
+    }
+
+    // ---- stage 3: divergence of the new velocity (vy of the rows above/below, vx of the columns left/right) ----
+    __syncthreads();  // everyone is done reading the stage-1 mailboxes (slot 0) before they are reused
+    mail[wv][0][0][lane] = make_float4(N[0].y[0], N[0].y[1], N[0].y[2], N[0].y[3]);
+    mail[wv][1][0][lane] = make_float4(N[RY - 1].y[0], N[RY - 1].y[1], N[RY - 1].y[2], N[RY - 1].y[3]);
+    __syncthreads();
+    const float4 nyb = mail[wb][1][0][lane], nya = mail[wa][0][0][lane];
+
+    int xa, xb, out_lo, out_hi;
+    tile_exact(x0, G::TX, G::AX, w.W, 0, w.W, xa, xb);
+    tile_exact(y0, G::TY, G::AY, w.H, ga, gb, out_lo, out_hi);
+    const bool col_store = (cx >= xa) && (cx < xb);
+#pragma unroll
+    for (int r = 0; r < RY; r++) {
+        const int gj = gy + r;
+        float Lq = from_left_lane(N[r].x[3]), Rq = from_right_lane(N[r].x[0]);
+        const float by[4] = { r > 0 ? N[r - 1].y[0] : nyb.x, r > 0 ? N[r - 1].y[1] : nyb.y, r > 0 ? N[r - 1].y[2] : nyb.z,
+                              r > 0 ? N[r - 1].y[3] : nyb.w };
+        const float ty[4] = { r < RY - 1 ? N[r + 1].y[0] : nya.x, r < RY - 1 ? N[r + 1].y[1] : nya.y,
+                              r < RY - 1 ? N[r + 1].y[2] : nya.z, r < RY - 1 ? N[r + 1].y[3] : nya.w };
+        float dv[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float L = k > 0 ? N[r].x[k - 1] : Lq;
+            float R = k < 3 ? N[r].x[k + 1] : Rq;
+            float T = ty[k], B = by[k];
+            if (EDGE) {  // reflecting walls: an off-domain neighbour is MINUS the centre component (script.js:804-807)
+                if (at_left && k == 0) L = -N[r].x[0];
+                if (at_right && k == 3) R = -N[r].x[3];
+                if (gj == w.H - 1) T = -N[r].y[k];
+                if (gj == 0) B = -N[r].y[k];
+            }
+            dv[k] = 0.5f * (R - L + T - B);
+        }
+        if (col_store && gj >= out_lo && gj < out_hi) {
+            const long c = (long)(gj - w.g0) * w.W + cx;
+            *reinterpret_cast<float4*>(curl_out + c) = make_float4(C[r][0], C[r][1], C[r][2], C[r][3]);
+            *reinterpret_cast<float4*>(div_out + c) = make_float4(dv[0], dv[1], dv[2], dv[3]);
+            float4* vo = reinterpret_cast<float4*>(vel_out + c);
+            vo[0] = make_float4(N[r].x[0], N[r].y[0], N[r].x[1], N[r].y[1]);
+            vo[1] = make_float4(N[r].x[2], N[r].y[2], N[r].x[3], N[r].y[3]);
+        }
+    }
+}
+
+template <int NW, int RY>
+__global__ void __launch_bounds__(64 * NW) k_curl_vort_div(Win w, const float2* __restrict__ vel, float* __restrict__ curl_out,
+                                                            float2* __restrict__ vel_out, float* __restrict__ div_out,
+                                                            float curl_strength, float dt, int ga, int gb, int ys)
+{
+    using G = VortDiv<NW, RY>;
+    __shared__ float4 mail[NW][2][2][64];
+    const int x0 = (int)blockIdx.x * G::VX, y0 = ys + (int)blockIdx.y * G::VY;
+    const bool edge = (x0 <= 0) || (x0 + G::TX >= w.W) || (y0 <= 0) || (y0 + G::TY >= w.H);
+    if (edge) vort_div_body<NW, RY, true>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
+    else vort_div_body<NW, RY, false>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
+}
+
+constexpr int VD_NW = 8, VD_RY = 8;
+
+// tile-shape variants (NW waves x RY rows per wave, apron HALO); FLUID_TB_VARIANT picks one (tuning knob,
+// read once); the default is the shape that measured best on MI355X at 4096^2 (profiles/)
+struct TBVariant { int nw, ry, halo; };
+constexpr TBVariant kTB[] = { {4, 16, 8}, {8, 8, 8}, {8, 16, 8}, {4, 24, 8}, {8, 12, 12}, {8, 16, 16}, {4, 16, 4}, {8, 8, 4} };
+constexpr int kNumTB = sizeof(kTB) / sizeof(kTB[0]);
+constexpr int kDefaultTB = 0;
+
+int tb_variant()
+{
+    static const int v = [] {
+        const char* e = getenv("FLUID_TB_VARIANT");
+        const int k = e ? atoi(e) : kDefaultTB;
+        return (k >= 0 && k < kNumTB) ? k : kDefaultTB;
+    }();
+    return v;
+}
+
+template <int NW, int RY, int HALO>
+hipError_t launch_tb(hipStream_t s, Win w, const float* p, const float* div, float* p_out, float pscale, int iters, int ga, int gb)
+{
+    using G = JacobiTB<NW, RY, HALO>;
+    const Axis ax = make_axis(0, w.W, w.W, G::TX, HALO), ay = make_axis(ga, gb, w.H, G::TY, HALO);
+    k_jacobi_tb<NW, RY, HALO><<<dim3(ax.n, ay.n, 1), dim3(64, NW, 1), 0, s>>>(w, p, div, p_out, pscale, iters, ga, gb, ay.S);
+    return hipGetLastError();
+}
 
 inline dim3 row_grid(int W, int ga, int gb) { return dim3((W + BX - 1) / BX, gb - ga, 1); }
 
@@ -489,6 +741,15 @@ hipError_t launch_advect_dye(hipStream_t s, Win vw, const float2* vel, Win dw, c
     return hipGetLastError();
 }
 
+hipError_t launch_advect_both(hipStream_t s, Win w, const float2* vel, float2* vel_out, const float4* dye, float4* dye_out,
+                              float dt, float vel_dissipation, float dye_dissipation, int ga, int gb, unsigned int* miss)
+{
+    ROWS_OR_RETURN();
+    k_advect_both<<<row_grid(w.W, ga, gb), BX, 0, s>>>(w, vel, vel_out, dye, dye_out, dt, vel_dissipation, dye_dissipation,
+                                                       (float)(1.0 / w.W), (float)(1.0 / w.H), ga, miss);
+    return hipGetLastError();
+}
+
 hipError_t launch_splat_velocity(hipStream_t s, Win w, const float2* base, float2* out, float x, float y, float aspect,
                                  float radius, float c0, float c1, int ga, int gb)
 {
@@ -524,7 +785,21 @@ hipError_t launch_fill(hipStream_t s, float* dst, size_t n, int nc, float v0, fl
     return hipGetLastError();
 }
 
-int jacobi_tb_max_iters() { return TB_HALO; }
+bool fused_supported(Win w) { return w.W % 4 == 0 && w.W >= 4; }
+
+hipError_t launch_curl_vort_div(hipStream_t s, Win w, const float2* vel, float* curl, float2* vel_out, float* div,
+                                float curl_strength, float dt, int ga, int gb)
+{
+    ROWS_OR_RETURN();
+    if (!fused_supported(w)) return hipErrorInvalidValue;
+    using G = VortDiv<VD_NW, VD_RY>;
+    const Axis ax = make_axis(0, w.W, w.W, G::TX, G::AX), ay = make_axis(ga, gb, w.H, G::TY, G::AY);
+    k_curl_vort_div<VD_NW, VD_RY><<<dim3(ax.n, ay.n, 1), dim3(64, VD_NW, 1), 0, s>>>(w, vel, curl, vel_out, div, curl_strength, dt,
+                                                                                ga, gb, ay.S);
+    return hipGetLastError();
+}
+
+int jacobi_tb_max_iters() { return kTB[tb_variant()].halo; }
 
 bool jacobi_tb_supported(Win w) { return w.W % 4 == 0 && w.W >= 4; }
 
@@ -532,11 +807,17 @@ hipError_t launch_jacobi_tb(hipStream_t s, Win w, const float* p, const float* d
                             int ga, int gb)
 {
     ROWS_OR_RETURN();
-    using G = JacobiTB<TB_NW, TB_RY, TB_HALO>;
-    if (iters < 1 || iters > TB_HALO || !jacobi_tb_supported(w)) return hipErrorInvalidValue;
-    const dim3 grid((w.W + G::VX - 1) / G::VX, (gb - ga + G::VY - 1) / G::VY, 1);
-    k_jacobi_tb<TB_NW, TB_RY, TB_HALO><<<grid, dim3(64, TB_NW, 1), 0, s>>>(w, p, div, p_out, pscale, iters, ga, gb);
-    return hipGetLastError();
+    if (iters < 1 || iters > jacobi_tb_max_iters() || !jacobi_tb_supported(w)) return hipErrorInvalidValue;
+    switch (tb_variant()) {
+    case 1: return launch_tb<8, 8, 8>(s, w, p, div, p_out, pscale, iters, ga, gb);
+    case 2: return launch_tb<8, 16, 8>(s, w, p, div, p_out, pscale, iters, ga, gb);
+    case 3: return launch_tb<4, 24, 8>(s, w, p, div, p_out, pscale, iters, ga, gb);
+    case 4: return launch_tb<8, 12, 12>(s, w, p, div, p_out, pscale, iters, ga, gb);
+    case 5: return launch_tb<8, 16, 16>(s, w, p, div, p_out, pscale, iters, ga, gb);
+    case 6: return launch_tb<4, 16, 4>(s, w, p, div, p_out, pscale, iters, ga, gb);
+    case 7: return launch_tb<8, 8, 4>(s, w, p, div, p_out, pscale, iters, ga, gb);
+    default: return launch_tb<4, 16, 8>(s, w, p, div, p_out, pscale, iters, ga, gb);
+    }
 }
 
 }  // namespace fluid

@@ -203,6 +203,27 @@ int pass_divergence(fluid_ctx* c, int ext)
     return c->hip(launch_divergence(c->stream, c->sim, c->vel[0], c->div, ga, gb), "divergence");
 }
 
+// K1 + K2 + K3; one kernel when the fused schedule applies, the three passes otherwise (same bits either way)
+int pass_curl_vort_div(fluid_ctx* c, float curl, float dt, int ext, Timer* t)
+{
+    if (c->desc.schedule == FLUID_SCHED_FUSED && fused_supported(c->sim)) {
+        CK(check_ext(c, ext, 3));
+        int ga, gb;
+        row_range(c->sim, c->sim_row0, c->sim_rows, ext, ga, gb);
+        CK(c->hip(launch_curl_vort_div(c->stream, c->sim, c->vel[0], c->curl, c->vel[1], c->div, curl, dt, ga, gb), "curl_vort_div"));
+        std::swap(c->vel[0], c->vel[1]);
+        if (t) t->mark(P_VORT);
+        return FLUID_OK;
+    }
+    CK(pass_curl(c, ext + 2));
+    if (t) t->mark(P_CURL);
+    CK(pass_vorticity(c, curl, dt, ext + 1));
+    if (t) t->mark(P_VORT);
+    CK(pass_divergence(c, ext));
+    if (t) t->mark(P_DIV);
+    return FLUID_OK;
+}
+
 int pass_clear(fluid_ctx* c, float value, int ext)
 {
     CK(check_ext(c, ext, 0));
@@ -221,10 +242,13 @@ int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launche
     const bool tb = c->desc.schedule == FLUID_SCHED_FUSED && jacobi_tb_supported(c->sim);
     int done = 0;
     if (!tb && pscale != 1.0f) return c->fail(FLUID_ERR_INVALID, "pscale needs the fused schedule");
+    // balanced blocks: ceil(iters / max) launches of nearly equal depth (50 with max 8 -> 8,7,7,7,7,7,7)
+    int launches_left = tb ? (iters + jacobi_tb_max_iters() - 1) / jacobi_tb_max_iters() : iters;
     while (done < iters) {
         int ga, gb;
         if (tb) {
-            const int k = std::min(iters - done, jacobi_tb_max_iters());
+            const int k = (iters - done + launches_left - 1) / launches_left;
+            launches_left--;
             row_range(c->sim, c->sim_row0, c->sim_rows, ext_out + (iters - done - k), ga, gb);
             CK(c->hip(launch_jacobi_tb(c->stream, c->sim, c->prs[0], c->div, c->prs[1], done == 0 ? pscale : 1.0f, k, ga, gb),
                       "jacobi_tb"));
@@ -270,17 +294,35 @@ int pass_advect_dye(fluid_ctx* c, float dt, float dissipation)
     return FLUID_OK;
 }
 
+// K7a + K7b: one kernel under the fused schedule when the dye grid is the sim grid, two launches otherwise.
+// (In a stripe the velocity is advected one ghost row out when the grids differ: the dye pass then samples it bilinearly.)
+int pass_advect(fluid_ctx* c, float dt, float vel_diss, float dye_diss, Timer* t)
+{
+    const bool same = c->sim.W == c->dye.W && c->sim.H == c->dye.H;
+    if (c->desc.schedule == FLUID_SCHED_FUSED && same) {
+        int ga, gb;
+        row_range(c->sim, c->sim_row0, c->sim_rows, 0, ga, gb);
+        CK(c->hip(launch_advect_both(c->stream, c->sim, c->vel[0], c->vel[1], c->dyeb[0], c->dyeb[1], dt, vel_diss, dye_diss, ga, gb,
+                                     c->miss),
+                  "advect"));
+        std::swap(c->vel[0], c->vel[1]);
+        std::swap(c->dyeb[0], c->dyeb[1]);
+        if (t) t->mark(P_ADVD);
+        return FLUID_OK;
+    }
+    CK(pass_advect_velocity(c, dt, vel_diss, (c->desc.parts > 1 && !same) ? 1 : 0));
+    if (t) t->mark(P_ADVV);
+    CK(pass_advect_dye(c, dt, dye_diss));
+    if (t) t->mark(P_ADVD);
+    return FLUID_OK;
+}
+
 // step(dt), script.js:1231-1294 — whole-domain contexts (a stripe is driven pass by pass from the host,
 // with ghost-row exchanges in between)
 int step_once(fluid_ctx* c, float dt, const fluid_params* P)
 {
     Timer t(c);
-    CK(pass_curl(c, 0));
-    t.mark(P_CURL);
-    CK(pass_vorticity(c, P->curl, dt, 0));
-    t.mark(P_VORT);
-    CK(pass_divergence(c, 0));
-    t.mark(P_DIV);
+    CK(pass_curl_vort_div(c, P->curl, dt, 0, &t));
     int launches = 0;
     const bool fold_clear = c->desc.schedule == FLUID_SCHED_FUSED && jacobi_tb_supported(c->sim) && P->iterations > 0;
     if (!fold_clear) {
@@ -291,10 +333,7 @@ int step_once(fluid_ctx* c, float dt, const fluid_params* P)
     t.mark(P_JACOBI);
     CK(pass_gradsub(c, 0));
     t.mark(P_GRADSUB);
-    CK(pass_advect_velocity(c, dt, P->velocity_dissipation, 0));
-    t.mark(P_ADVV);
-    CK(pass_advect_dye(c, dt, P->density_dissipation));
-    t.mark(P_ADVD);
+    CK(pass_advect(c, dt, P->velocity_dissipation, P->density_dissipation, &t));
     if (c->timing) {
         c->acc_steps++;
         c->acc_jacobi_launches += launches;
@@ -588,6 +627,11 @@ int fluid_pass_divergence(fluid_ctx* c, int ext)
     PASS_PROLOGUE();
     return pass_divergence(c, ext);
 }
+int fluid_pass_curl_vorticity_divergence(fluid_ctx* c, float curl, float dt, int ext)
+{
+    PASS_PROLOGUE();
+    return pass_curl_vort_div(c, curl, dt, ext, nullptr);
+}
 int fluid_pass_clear(fluid_ctx* c, float value, int ext)
 {
     PASS_PROLOGUE();
@@ -612,6 +656,12 @@ int fluid_pass_advect_dye(fluid_ctx* c, float dt, float dissipation)
 {
     PASS_PROLOGUE();
     return pass_advect_dye(c, dt, dissipation);
+}
+
+int fluid_pass_advect(fluid_ctx* c, float dt, float velocity_dissipation, float density_dissipation)
+{
+    PASS_PROLOGUE();
+    return pass_advect(c, dt, velocity_dissipation, density_dissipation, nullptr);
 }
 
 static int halo_copy(fluid_ctx* c, int field, int side, int nrows, void* buf, bool pack)

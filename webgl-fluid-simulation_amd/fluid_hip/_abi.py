@@ -68,11 +68,13 @@ SYMBOLS = {
     "fluid_pass_curl": (_I, [_CTX, _I]),
     "fluid_pass_vorticity": (_I, [_CTX, _F, _F, _I]),
     "fluid_pass_divergence": (_I, [_CTX, _I]),
+    "fluid_pass_curl_vorticity_divergence": (_I, [_CTX, _F, _F, _I]),
     "fluid_pass_clear": (_I, [_CTX, _F, _I]),
     "fluid_pass_jacobi": (_I, [_CTX, _I, _I]),
     "fluid_pass_gradsub": (_I, [_CTX, _I]),
     "fluid_pass_advect_velocity": (_I, [_CTX, _F, _F, _I]),
     "fluid_pass_advect_dye": (_I, [_CTX, _F, _F]),
+    "fluid_pass_advect": (_I, [_CTX, _F, _F, _F]),
     "fluid_pass_splat": (_I, [_CTX, _I] + [_F] * 7),
     "fluid_halo_pack": (_I, [_CTX, _I, _I, _I, C.c_void_p]),
     "fluid_halo_unpack": (_I, [_CTX, _I, _I, _I, C.c_void_p]),
@@ -92,10 +94,26 @@ def build(force: bool = False) -> str:
     return LIB_PATH
 
 
+def _share_torch_hip_runtime():
+    """PyTorch wheels bundle their own libamdhip64.so.7 / libhsa-runtime64.so.1.  If libfluid_hip.so is loaded
+    first it binds /opt/rocm's copies, torch then maps its bundled ones as well, and the process ends up with
+    TWO HIP runtimes that cannot share streams, events or device pointers (torch then even fails with "No HIP
+    GPUs are available").  Importing torch first makes the loader resolve our NEEDED libamdhip64.so.7 to the
+    copy that is already mapped, so kernels, torch tensors and RCCL all live in one runtime.
+    FLUID_HIP_NO_TORCH=1 skips this (pure ctypes / non-torch hosts)."""
+    if os.environ.get("FLUID_HIP_NO_TORCH") == "1":
+        return
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+
+
 def lib():
     """Load libfluid_hip.so and bind every declared symbol; raises if the library is absent."""
     global _lib
     if _lib is None:
+        _share_torch_hip_runtime()
         if not os.path.exists(LIB_PATH):
             raise FluidError(ERR_UNSUPPORTED, "%s not built (run `make -C %s`); there is no CPU fallback" % (LIB_PATH, PKG_DIR))
         L = C.CDLL(LIB_PATH)

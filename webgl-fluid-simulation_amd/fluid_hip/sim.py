@@ -288,6 +288,8 @@ class FluidSim:
             rc = L.fluid_pass_vorticity(c, P.curl, dt, ext)
         elif name == "divergence":
             rc = L.fluid_pass_divergence(c, ext)
+        elif name == "curl_vorticity_divergence":
+            rc = L.fluid_pass_curl_vorticity_divergence(c, P.curl, dt, ext)
         elif name == "clear":
             rc = L.fluid_pass_clear(c, P.pressure, ext)
         elif name == "jacobi":
@@ -298,6 +300,8 @@ class FluidSim:
             rc = L.fluid_pass_advect_velocity(c, dt, P.velocity_dissipation, ext)
         elif name == "advect_dye":
             rc = L.fluid_pass_advect_dye(c, dt, P.density_dissipation)
+        elif name == "advect":
+            rc = L.fluid_pass_advect(c, dt, P.velocity_dissipation, P.density_dissipation)
         else:
             raise ValueError("unknown pass " + name)
         self._check(rc)

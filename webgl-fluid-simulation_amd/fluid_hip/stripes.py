@@ -17,8 +17,8 @@ rows at a time:
     repeat: exchange pressure (D = min(remaining, halo-3) rows, +1 for the last block); D Jacobi iterations
     gradient subtract (ext 0; the last Jacobi block left one valid ghost row of pressure)
     exchange velocity (halo rows)   -- the advection gather reaches up to dt*|v| rows away
-    advect velocity (ext 1)
-    exchange dye (dye-halo rows); advect dye
+    exchange dye (dye-halo rows)
+    advect velocity + dye (one kernel when the dye grid is the sim grid)
 
 With halo = 32 and 50 iterations that is 5 exchanges per step instead of 57.  Every recomputed ghost
 row is the same arithmetic on the same inputs as the owner's, so the decomposed result is BITWISE
@@ -93,11 +93,13 @@ class HipStripeEngine:
     def curl(self, ext): self._ck(self.lib.fluid_pass_curl(self.ctx, ext))
     def vorticity(self, curl, dt, ext): self._ck(self.lib.fluid_pass_vorticity(self.ctx, curl, dt, ext))
     def divergence(self, ext): self._ck(self.lib.fluid_pass_divergence(self.ctx, ext))
+    def curl_vorticity_divergence(self, curl, dt, ext): self._ck(self.lib.fluid_pass_curl_vorticity_divergence(self.ctx, curl, dt, ext))
     def clear(self, value, ext): self._ck(self.lib.fluid_pass_clear(self.ctx, value, ext))
     def jacobi(self, iters, ext_out): self._ck(self.lib.fluid_pass_jacobi(self.ctx, iters, ext_out))
     def gradsub(self, ext): self._ck(self.lib.fluid_pass_gradsub(self.ctx, ext))
     def advect_velocity(self, dt, diss, ext): self._ck(self.lib.fluid_pass_advect_velocity(self.ctx, dt, diss, ext))
     def advect_dye(self, dt, diss): self._ck(self.lib.fluid_pass_advect_dye(self.ctx, dt, diss))
+    def advect(self, dt, vdiss, ddiss): self._ck(self.lib.fluid_pass_advect(self.ctx, dt, vdiss, ddiss))
 
     def splat(self, x, y, dx, dy, r, g, b, aspect, radius):
         self._ck(self.lib.fluid_splat(self.ctx, x, y, dx, dy, r, g, b, aspect, radius))
@@ -249,14 +251,12 @@ class StripeSim:
         c, e, H = self.config, self.engine, self.halo
         iters = int(c["PRESSURE_ITERATIONS"])
         if self.world == 1:
-            e.curl(0); e.vorticity(c["CURL"], dt, 0); e.divergence(0); e.clear(c["PRESSURE"], 0)
+            e.curl_vorticity_divergence(c["CURL"], dt, 0); e.clear(c["PRESSURE"], 0)
             e.jacobi(iters, 0); e.gradsub(0)
-            e.advect_velocity(dt, c["VELOCITY_DISSIPATION"], 0); e.advect_dye(dt, c["DENSITY_DISSIPATION"])
+            e.advect(dt, c["VELOCITY_DISSIPATION"], c["DENSITY_DISSIPATION"])
             return
         self.exchange(VELOCITY, H)
-        e.curl(H - 1)
-        e.vorticity(c["CURL"], dt, H - 2)
-        e.divergence(H - 3)
+        e.curl_vorticity_divergence(c["CURL"], dt, H - 3)   # curl to H-1, vorticity to H-2, divergence to H-3 rows out
         e.clear(c["PRESSURE"], 0)
         remaining = iters
         while remaining > 0:
@@ -271,9 +271,8 @@ class StripeSim:
             self.exchange(PRESSURE, 1)
         e.gradsub(0)
         self.exchange(VELOCITY, H)
-        e.advect_velocity(dt, c["VELOCITY_DISSIPATION"], 0 if self.same_res else 1)
         self.exchange(DYE, e.info(DYE).halo)
-        e.advect_dye(dt, c["DENSITY_DISSIPATION"])
+        e.advect(dt, c["VELOCITY_DISSIPATION"], c["DENSITY_DISSIPATION"])   # velocity then dye (one kernel when the grids match)
 
     def sync(self):
         self.engine.sync()
@@ -298,6 +297,9 @@ class StripeSim:
 def run_local_stripes(world: int, body: Callable[["StripeSim"], object], **kw) -> List[object]:
     """Run `body(stripe_sim)` for every stripe in one process, one thread per stripe (LocalComm)."""
     import threading
+    if kw.get("engine_factory") is None:
+        import torch
+        torch.cuda.init()  # initialise torch's HIP context once, on the main thread, before the stripe threads race for it
     hub = LocalComm.Hub(world)
     results: List[object] = [None] * world
     errors: List[BaseException] = []
