@@ -164,6 +164,9 @@ int fluid_pass_splat(fluid_ctx *ctx, int field, float x, float y, float aspect, 
  * nrows counts rows of that field (dye rows for FLUID_DYE). dev_buf is device memory. */
 int fluid_halo_pack(fluid_ctx *ctx, int field, int side, int nrows, void *dev_buf);
 int fluid_halo_unpack(fluid_ctx *ctx, int field, int side, int nrows, const void *dev_buf);
+/* device address of array row 0 (ghost rows included) of the field's CURRENT read buffer, for zero-copy ghost-row
+ * send/recv by the stripe driver.  Passes that swap read/write invalidate it: query after each pass. */
+int fluid_field_device_ptr(fluid_ctx *ctx, int field, void **dev_ptr);
 /* synchronises, then returns FLUID_ERR_HALO if any advection tap since the last check fell outside the stripe's rows */
 int fluid_halo_check(fluid_ctx *ctx);
 

@@ -50,15 +50,11 @@ class OracleStripeEngine:
         ga, gb = max(row0 - ext, 0), min(row0 + rows + ext, H)
         return ga - g0, gb - g0
 
-    def halo_pack(self, name, side, nrows):
-        fi, a = self.info(name), self._arr(name)
-        first = fi.halo if side == 0 else fi.halo + fi.rows - nrows
-        return torch.from_numpy(a[first:first + nrows].copy())
-
-    def halo_unpack(self, name, side, nrows, buf):
-        fi, a = self.info(name), self._arr(name)
-        first = fi.halo - nrows if side == 0 else fi.halo + fi.rows
-        a[first:first + nrows] = buf.numpy().reshape(a[first:first + nrows].shape)
+    def view(self, name):
+        """torch tensor aliasing the numpy window array (zero copy), [array rows, W, channels]"""
+        a = self._arr(name)
+        t = torch.from_numpy(a)
+        return t if a.ndim == 3 else t.unsqueeze(-1)
 
     def curl(self, ext):
         ra, rb = self._range(ext)

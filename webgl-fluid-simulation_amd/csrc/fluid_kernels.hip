@@ -342,6 +342,23 @@ __host__ inline Axis make_axis(int lo, int hi, int dom, int T, int A)
     return ax;
 }
 
+// XCD-aware tile order (MI355X: 8 XCDs with private 4 MiB L2s; workgroup b is dispatched to XCD b % 8).
+// Vertically adjacent tiles share 2*apron rows, so each XCD is handed a CONTIGUOUS run of the column-major
+// tile sequence: the ~64 workgroups resident on an XCD at any time are then vertical neighbours and the
+// shared apron rows hit that XCD's L2 instead of being fetched once per tile.  Bijective for any tile count;
+// placement only affects speed, never results.  remap == 0: plain column-major order.
+__device__ __forceinline__ void tile_of_block(int b, int nx, int ny, int remap, int& bx, int& by)
+{
+    const int n = nx * ny;
+    int t = b;
+    if (remap) {
+        const int q = n >> 3, r = n & 7, xcd = b & 7, slot = b >> 3;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    bx = t / ny;
+    by = t - bx * ny;
+}
+
 // exact (storable) global range [a, b) of the tile starting at t0, intersected with [lo, hi)
 __device__ __forceinline__ void tile_exact(int t0, int T, int A, int dom, int lo, int hi, int& a, int& b)
 {
@@ -468,11 +485,13 @@ __device__ __forceinline__ void jacobi_tb_body(const Win& w, const float* __rest
 template <int NW, int RY, int HALO>
 __global__ void __launch_bounds__(64 * NW) k_jacobi_tb(Win w, const float* __restrict__ p, const float* __restrict__ div,
                                                         float* __restrict__ p_out, float pscale, int iters, int ga, int gb,
-                                                        int ys)
+                                                        int ys, int nx, int ny, int remap)
 {
     using G = JacobiTB<NW, RY, HALO>;
     __shared__ float4 mail[2][NW][2][64];
-    const int x0 = (int)blockIdx.x * G::VX, y0 = ys + (int)blockIdx.y * G::VY;
+    int bx, by;
+    tile_of_block((int)blockIdx.x, nx, ny, remap, bx, by);
+    const int x0 = bx * G::VX, y0 = ys + by * G::VY;
     const bool edge = (x0 <= 0) || (x0 + G::TX >= w.W) || (y0 <= 0) || (y0 + G::TY >= w.H);
     if (edge) jacobi_tb_body<NW, RY, HALO, true>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
     else jacobi_tb_body<NW, RY, HALO, false>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
@@ -632,11 +651,14 @@ __device__ __forceinline__ void vort_div_body(const Win& w, const float2* __rest
 template <int NW, int RY>
 __global__ void __launch_bounds__(64 * NW) k_curl_vort_div(Win w, const float2* __restrict__ vel, float* __restrict__ curl_out,
                                                             float2* __restrict__ vel_out, float* __restrict__ div_out,
-                                                            float curl_strength, float dt, int ga, int gb, int ys)
+                                                            float curl_strength, float dt, int ga, int gb, int ys, int nx, int ny,
+                                                            int remap)
 {
     using G = VortDiv<NW, RY>;
     __shared__ float4 mail[NW][2][2][64];
-    const int x0 = (int)blockIdx.x * G::VX, y0 = ys + (int)blockIdx.y * G::VY;
+    int bx, by;
+    tile_of_block((int)blockIdx.x, nx, ny, remap, bx, by);
+    const int x0 = bx * G::VX, y0 = ys + by * G::VY;
     const bool edge = (x0 <= 0) || (x0 + G::TX >= w.W) || (y0 <= 0) || (y0 + G::TY >= w.H);
     if (edge) vort_div_body<NW, RY, true>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
     else vort_div_body<NW, RY, false>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
@@ -649,7 +671,16 @@ constexpr int VD_NW = 8, VD_RY = 8;
 struct TBVariant { int nw, ry, halo; };
 constexpr TBVariant kTB[] = { {4, 16, 8}, {8, 8, 8}, {8, 16, 8}, {4, 24, 8}, {8, 12, 12}, {8, 16, 16}, {4, 16, 4}, {8, 8, 4} };
 constexpr int kNumTB = sizeof(kTB) / sizeof(kTB[0]);
-constexpr int kDefaultTB = 0;
+constexpr int kDefaultTB = 1;  // 8 waves x 8 rows, apron 8: 110 VGPRs, best of the table at 4096^2 (profiles/r01)
+
+int xcd_remap()  // FLUID_XCD_REMAP=0 switches the XCD-aware tile order off (A/B knob)
+{
+    static const int v = [] {
+        const char* e = getenv("FLUID_XCD_REMAP");
+        return e ? atoi(e) : 1;
+    }();
+    return v;
+}
 
 int tb_variant()
 {
@@ -666,7 +697,8 @@ hipError_t launch_tb(hipStream_t s, Win w, const float* p, const float* div, flo
 {
     using G = JacobiTB<NW, RY, HALO>;
     const Axis ax = make_axis(0, w.W, w.W, G::TX, HALO), ay = make_axis(ga, gb, w.H, G::TY, HALO);
-    k_jacobi_tb<NW, RY, HALO><<<dim3(ax.n, ay.n, 1), dim3(64, NW, 1), 0, s>>>(w, p, div, p_out, pscale, iters, ga, gb, ay.S);
+    k_jacobi_tb<NW, RY, HALO><<<dim3(ax.n * ay.n, 1, 1), dim3(64, NW, 1), 0, s>>>(w, p, div, p_out, pscale, iters, ga, gb, ay.S, ax.n,
+                                                                                 ay.n, xcd_remap());
     return hipGetLastError();
 }
 
@@ -794,8 +826,8 @@ hipError_t launch_curl_vort_div(hipStream_t s, Win w, const float2* vel, float* 
     if (!fused_supported(w)) return hipErrorInvalidValue;
     using G = VortDiv<VD_NW, VD_RY>;
     const Axis ax = make_axis(0, w.W, w.W, G::TX, G::AX), ay = make_axis(ga, gb, w.H, G::TY, G::AY);
-    k_curl_vort_div<VD_NW, VD_RY><<<dim3(ax.n, ay.n, 1), dim3(64, VD_NW, 1), 0, s>>>(w, vel, curl, vel_out, div, curl_strength, dt,
-                                                                                ga, gb, ay.S);
+    k_curl_vort_div<VD_NW, VD_RY><<<dim3(ax.n * ay.n, 1, 1), dim3(64, VD_NW, 1), 0, s>>>(w, vel, curl, vel_out, div, curl_strength, dt,
+                                                                                    ga, gb, ay.S, ax.n, ay.n, xcd_remap());
     return hipGetLastError();
 }
 

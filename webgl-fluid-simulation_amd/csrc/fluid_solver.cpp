@@ -689,6 +689,15 @@ int fluid_halo_unpack(fluid_ctx* c, int field, int side, int nrows, const void* 
     return halo_copy(c, field, side, nrows, const_cast<void*>(dev_buf), false);
 }
 
+int fluid_field_device_ptr(fluid_ctx* c, int field, void** dev_ptr)
+{
+    if (!c || !dev_ptr) return FLUID_ERR_INVALID;
+    FieldRef f;
+    CK(field_ref(c, field, &f));
+    *dev_ptr = f.ptr;
+    return FLUID_OK;
+}
+
 int fluid_halo_check(fluid_ctx* c)
 {
     if (!c) return FLUID_ERR_INVALID;

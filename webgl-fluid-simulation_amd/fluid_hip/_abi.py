@@ -78,6 +78,7 @@ SYMBOLS = {
     "fluid_pass_splat": (_I, [_CTX, _I] + [_F] * 7),
     "fluid_halo_pack": (_I, [_CTX, _I, _I, _I, C.c_void_p]),
     "fluid_halo_unpack": (_I, [_CTX, _I, _I, _I, C.c_void_p]),
+    "fluid_field_device_ptr": (_I, [_CTX, _I, C.POINTER(C.c_void_p)]),
     "fluid_halo_check": (_I, [_CTX]),
     "fluid_set_timing": (_I, [_CTX, _I]),
     "fluid_get_timings": (_I, [_CTX, C.POINTER(Timings)]),

@@ -11,16 +11,18 @@ tiny, so the cost is per-exchange latency, not bytes): instead of one single-row
 each of the 7 + ITERS passes, a rank recomputes a few ghost rows redundantly and exchanges `halo`
 rows at a time:
 
-    exchange velocity (halo rows)
-    curl (ext halo-1) -> vorticity (ext halo-2) -> divergence (ext halo-3)     no exchange
-    clear (ext 0)
-    repeat: exchange pressure (D = min(remaining, halo-3) rows, +1 for the last block); D Jacobi iterations
-    gradient subtract (ext 0; the last Jacobi block left one valid ghost row of pressure)
-    exchange velocity (halo rows)   -- the advection gather reaches up to dt*|v| rows away
-    exchange dye (dye-halo rows)
+    exchange { velocity (halo rows), pressure (D+e rows) }         one batched send/recv
+    curl -> vorticity -> divergence, fused (ext halo-3)           no exchange
+    clear (ext D+e: the ghost rows hold the neighbour's pre-clear pressure)
+    D Jacobi iterations; if iterations remain: exchange pressure, next block   (D = min(remaining, halo-3))
+    gradient subtract (ext 0; the last Jacobi block left e = 1 valid ghost row of pressure)
+    exchange { velocity (halo rows), dye (dye-halo rows) }       one batched send/recv
     advect velocity + dye (one kernel when the dye grid is the sim grid)
 
-With halo = 32 and 50 iterations that is 5 exchanges per step instead of 57.  Every recomputed ghost
+With halo = 32 and 50 iterations that is 3 batched exchanges per step (2 with halo >= 54) instead of 57
+single-row ones.  Ghost rows are sent and received IN PLACE: the exchange operates on torch views of the field
+arrays (rows are contiguous), so there is no pack/unpack copy and no staging allocation in the step loop.
+Every recomputed ghost
 row is the same arithmetic on the same inputs as the owner's, so the decomposed result is BITWISE
 equal to the single-domain result (tests/test_stripes_*.py).  `halo` must cover the advection
 back-trace (dt * max|v_y| + 2 rows); kernels count taps that leave the window and `check_halo()`
@@ -61,6 +63,8 @@ class HipStripeEngine:
         if rc != _abi.FLUID_OK:
             _abi.check(None, rc)
         self.ctx = ctx
+        self._views = {}
+        self._info = {}
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream().cuda_stream
         self._ck(self.lib.fluid_set_stream(self.ctx, C.c_void_p(stream), 1))
@@ -74,21 +78,30 @@ class HipStripeEngine:
             self.ctx = None
 
     def info(self, name):
-        fi = _abi.FieldInfo()
-        self._ck(self.lib.fluid_field_info_get(self.ctx, FIELD_IDS[name], C.byref(fi)))
+        fi = self._info.get(name)
+        if fi is None:
+            fi = _abi.FieldInfo()
+            self._ck(self.lib.fluid_field_info_get(self.ctx, FIELD_IDS[name], C.byref(fi)))
+            self._info[name] = fi
         return fi
 
-    def new_buffer(self, name, nrows):
-        fi = self.info(name)
-        return self.torch.empty((nrows, fi.width, fi.channels), dtype=self.torch.float32, device="cuda:%d" % self.device)
+    def view(self, name):
+        """torch tensor [array rows (ghost rows included), W, channels] aliasing the field's CURRENT read buffer
+        (zero copy, through __cuda_array_interface__; both ping-pong buffers are cached by address)"""
+        ptr = C.c_void_p()
+        self._ck(self.lib.fluid_field_device_ptr(self.ctx, FIELD_IDS[name], C.byref(ptr)))
+        key = (name, ptr.value)
+        t = self._views.get(key)
+        if t is None:
+            fi = self.info(name)
+            shape = (fi.rows + 2 * fi.halo, fi.width, fi.channels)
 
-    def halo_pack(self, name, side, nrows):
-        buf = self.new_buffer(name, nrows)
-        self._ck(self.lib.fluid_halo_pack(self.ctx, FIELD_IDS[name], side, nrows, C.c_void_p(buf.data_ptr())))
-        return buf
+            class _DeviceArray:  # minimal CUDA-array-interface carrier
+                __cuda_array_interface__ = {"shape": shape, "typestr": "<f4", "data": (ptr.value, False), "version": 2}
 
-    def halo_unpack(self, name, side, nrows, buf):
-        self._ck(self.lib.fluid_halo_unpack(self.ctx, FIELD_IDS[name], side, nrows, C.c_void_p(buf.data_ptr())))
+            t = self.torch.as_tensor(_DeviceArray(), device="cuda:%d" % self.device)
+            self._views[key] = t
+        return t
 
     def curl(self, ext): self._ck(self.lib.fluid_pass_curl(self.ctx, ext))
     def vorticity(self, curl, dt, ext): self._ck(self.lib.fluid_pass_vorticity(self.ctx, curl, dt, ext))
@@ -121,7 +134,8 @@ class HipStripeEngine:
 
 # ---------------------------------------------------------------------------------------------------
 class TorchDistComm:
-    """neighbour exchange over torch.distributed point-to-point (backend nccl = RCCL over xGMI; gloo on CPU)"""
+    """neighbour exchange over torch.distributed point-to-point (backend nccl = RCCL over xGMI; gloo on CPU).
+    One batch_isend_irecv per exchange, operating in place on views of the field arrays."""
 
     def __init__(self, group=None):
         import torch.distributed as dist
@@ -130,20 +144,18 @@ class TorchDistComm:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
 
-    def exchange(self, send_lo, send_hi, like):
-        """send_lo -> rank-1, send_hi -> rank+1; returns (recv_lo, recv_hi) tensors (None at the domain ends)"""
-        import torch
+    def exchange(self, send_lo, send_hi, recv_lo, recv_hi):
+        """lists of tensors: send_lo[i] -> rank-1 (lands in its recv_hi[i]); send_hi[i] -> rank+1 (its recv_lo[i])"""
         dist, ops = self.dist, []
-        recv_lo = torch.empty_like(like) if self.rank > 0 else None
-        recv_hi = torch.empty_like(like) if self.rank < self.world - 1 else None
         if self.rank > 0:
-            ops += [dist.P2POp(dist.isend, send_lo, self.rank - 1, self.group), dist.P2POp(dist.irecv, recv_lo, self.rank - 1, self.group)]
+            for snd, rcv in zip(send_lo, recv_lo):
+                ops += [dist.P2POp(dist.isend, snd, self.rank - 1, self.group), dist.P2POp(dist.irecv, rcv, self.rank - 1, self.group)]
         if self.rank < self.world - 1:
-            ops += [dist.P2POp(dist.isend, send_hi, self.rank + 1, self.group), dist.P2POp(dist.irecv, recv_hi, self.rank + 1, self.group)]
+            for snd, rcv in zip(send_hi, recv_hi):
+                ops += [dist.P2POp(dist.isend, snd, self.rank + 1, self.group), dist.P2POp(dist.irecv, rcv, self.rank + 1, self.group)]
         if ops:
             for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        return recv_lo, recv_hi
+                req.wait()  # nccl: the current stream waits for the transfer; gloo: blocks the host
 
     def gather_rows(self, arr: np.ndarray) -> Optional[np.ndarray]:
         parts = [None] * self.world
@@ -153,7 +165,8 @@ class TorchDistComm:
 
 class LocalComm:
     """all stripes inside ONE process (one thread per stripe, all contexts on one device): the way the
-    decomposition is validated bit-for-bit on a single-GPU box.  Blocking mailboxes between neighbours."""
+    decomposition is validated bit-for-bit on a single-GPU box.  Blocking mailboxes between neighbours;
+    the sender posts CLONES (taken in its own stream order), the receiver copies them into its ghost rows."""
 
     class Hub:
         def __init__(self, world):
@@ -163,15 +176,18 @@ class LocalComm:
     def __init__(self, hub: "LocalComm.Hub", rank: int):
         self.hub, self.rank, self.world = hub, rank, hub.world
 
-    def exchange(self, send_lo, send_hi, like):
+    def exchange(self, send_lo, send_hi, recv_lo, recv_hi):
         r = self.rank
         if r > 0:
-            self.hub.box[(r, r - 1)].put(send_lo)
+            self.hub.box[(r, r - 1)].put([t.clone() for t in send_lo])
         if r < self.world - 1:
-            self.hub.box[(r, r + 1)].put(send_hi)
-        recv_lo = self.hub.box[(r - 1, r)].get(timeout=120) if r > 0 else None
-        recv_hi = self.hub.box[(r + 1, r)].get(timeout=120) if r < self.world - 1 else None
-        return recv_lo, recv_hi
+            self.hub.box[(r, r + 1)].put([t.clone() for t in send_hi])
+        if r > 0:
+            for dst, src in zip(recv_lo, self.hub.box[(r - 1, r)].get(timeout=120)):
+                dst.copy_(src)
+        if r < self.world - 1:
+            for dst, src in zip(recv_hi, self.hub.box[(r + 1, r)].get(timeout=120)):
+                dst.copy_(src)
 
     def gather_rows(self, arr):
         raise NotImplementedError("gather the per-stripe reads in the caller")
@@ -210,18 +226,23 @@ class StripeSim:
         self.engine.close()
 
     # -- ghost-row refresh -------------------------------------------------------------------------
-    def exchange(self, name: str, nrows: int):
-        if self.world == 1 or nrows < 1:
+    def exchange(self, *items):
+        """items: (field name, rows) pairs refreshed in ONE batched neighbour exchange, in place"""
+        items = [(n, k) for n, k in items if k > 0]
+        if self.world == 1 or not items:
             return
         e = self.engine
-        send_lo = e.halo_pack(name, 0, nrows) if self.rank > 0 else None
-        send_hi = e.halo_pack(name, 1, nrows) if self.rank < self.world - 1 else None
-        like = send_lo if send_lo is not None else send_hi
-        recv_lo, recv_hi = self.comm.exchange(send_lo, send_hi, like)
-        if recv_lo is not None:
-            e.halo_unpack(name, 0, nrows, recv_lo)
-        if recv_hi is not None:
-            e.halo_unpack(name, 1, nrows, recv_hi)
+        send_lo, send_hi, recv_lo, recv_hi = [], [], [], []
+        for name, n in items:
+            t, fi = e.view(name), e.info(name)
+            h, r = fi.halo, fi.rows
+            if n > h or n > r:
+                raise ValueError("exchange of %d rows exceeds halo %d / stripe %d" % (n, h, r))
+            send_lo.append(t[h:h + n])              # my lowest owned rows  -> lower neighbour's top ghost rows
+            recv_lo.append(t[h - n:h])              # my bottom ghost rows  <- lower neighbour's highest owned rows
+            send_hi.append(t[h + r - n:h + r])
+            recv_hi.append(t[h + r:h + r + n])
+        self.comm.exchange(send_lo, send_hi, recv_lo, recv_hi)
         self.exchanges += 1
 
     # -- splat / multipleSplats: script.js:1441-1462, 1427-1439 (every rank evaluates its own rows) ----
@@ -255,23 +276,23 @@ class StripeSim:
             e.jacobi(iters, 0); e.gradsub(0)
             e.advect(dt, c["VELOCITY_DISSIPATION"], c["DENSITY_DISSIPATION"])
             return
-        self.exchange(VELOCITY, H)
-        e.curl_vorticity_divergence(c["CURL"], dt, H - 3)   # curl to H-1, vorticity to H-2, divergence to H-3 rows out
-        e.clear(c["PRESSURE"], 0)
-        remaining = iters
+        # pressure blocks: divergence is valid H-3 rows out and iteration k of a block needs it d-k+e rows out
+        # -> d <= H-3; the last block also produces e = 1 ghost row (gradient subtract reads pressure one row out)
+        blocks, remaining = [], iters
         while remaining > 0:
-            # divergence is valid H-3 rows out and iteration k of a block needs it d-k+ext rows out -> d <= H-3.
-            # The last block also produces one ghost row (ext 1): gradient subtract reads pressure one row out.
             d = min(remaining, H - 3)
-            ext = 1 if d == remaining else 0
-            self.exchange(PRESSURE, d + ext)
-            e.jacobi(d, ext)
             remaining -= d
-        if iters == 0:
-            self.exchange(PRESSURE, 1)
+            blocks.append((d, 1 if remaining == 0 else 0))
+        first = blocks[0][0] + blocks[0][1] if blocks else 1
+        self.exchange((VELOCITY, H), (PRESSURE, first))
+        e.curl_vorticity_divergence(c["CURL"], dt, H - 3)   # curl to H-1, vorticity to H-2, divergence to H-3 rows out
+        e.clear(c["PRESSURE"], first)                        # ghost rows hold the neighbour's pre-clear pressure
+        for k, (d, ext) in enumerate(blocks):
+            if k > 0:
+                self.exchange((PRESSURE, d + ext))
+            e.jacobi(d, ext)
         e.gradsub(0)
-        self.exchange(VELOCITY, H)
-        self.exchange(DYE, e.info(DYE).halo)
+        self.exchange((VELOCITY, H), (DYE, e.info(DYE).halo))
         e.advect(dt, c["VELOCITY_DISSIPATION"], c["DENSITY_DISSIPATION"])   # velocity then dye (one kernel when the grids match)
 
     def sync(self):
