@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--halo", type=int, default=32, help="ghost rows per stripe side (N > 1)")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-oracle work for cpu_baseline (0 = skip)")
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the HIP-event instrumented pass")
+    ap.add_argument("--stripes", action="store_true", help="use the multi-GPU stripe driver even at N = 1 (exercises that code path)")
     args = ap.parse_args()
 
     import torch
@@ -107,7 +108,7 @@ def main():
     N, size, iters = world, args.size, args.iters
     cfg = {"SIM_RESOLUTION": size, "DYE_RESOLUTION": size, "PRESSURE_ITERATIONS": iters}
 
-    if N == 1:
+    if N == 1 and not args.stripes:
         sim = fluid_hip.FluidSim(canvas=(size, size), config=cfg, device=local_rank, schedule=args.schedule,
                                  random=fluid_hip.mulberry32(1234))
         sim.multipleSplats(20)
@@ -124,7 +125,10 @@ def main():
         import torch.distributed as dist
         from fluid_hip.stripes import StripeSim
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl")
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world)
         # global grid: `size` columns x `size * N` rows -> canvas of the same aspect, SIM_RESOLUTION = short side
         sim = StripeSim(canvas=(size, size * N), config=cfg, halo=args.halo, schedule=args.schedule,
                         random=fluid_hip.mulberry32(1234), device=local_rank)
@@ -146,7 +150,8 @@ def main():
     run(args.steps)
     sync(); barrier(); sync()
     elapsed = time.perf_counter() - t0
-    if N > 1:
+    striped = N > 1 or args.stripes
+    if striped:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -171,7 +176,7 @@ def main():
     }
 
     # ---- roofline of the dominant kernel (the Jacobi loop), HIP events on the solver's own stream ----
-    if rank == 0 and N == 1 and not args.no_profile_pass:
+    if rank == 0 and N == 1 and not args.stripes and not args.no_profile_pass:
         sim.set_timing(True)
         sim.step(DT, min(args.steps, 20))
         sim.sync()
@@ -198,9 +203,11 @@ def main():
     if rank == 0 and N == 1 and args.cpu_budget > 0:
         out["cpu_baseline"] = cpu_baseline(size, iters, args.cpu_budget)
 
+    if striped:
+        out["config"]["exchanges_per_step"] = sim.exchanges / max(args.steps + args.warmup, 1)
     if rank == 0:
         print(json.dumps(out))
-    if N > 1:
+    if striped:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

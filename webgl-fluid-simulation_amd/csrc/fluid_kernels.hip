@@ -826,8 +826,10 @@ hipError_t launch_curl_vort_div(hipStream_t s, Win w, const float2* vel, float* 
     if (!fused_supported(w)) return hipErrorInvalidValue;
     using G = VortDiv<VD_NW, VD_RY>;
     const Axis ax = make_axis(0, w.W, w.W, G::TX, G::AX), ay = make_axis(ga, gb, w.H, G::TY, G::AY);
+    // plain column-major tile order here: with a 3-row apron there is little to share, and the XCD-contiguous
+    // order measured 11 % slower for this kernel (profiles/r01/xcd_remap_ab.txt)
     k_curl_vort_div<VD_NW, VD_RY><<<dim3(ax.n * ay.n, 1, 1), dim3(64, VD_NW, 1), 0, s>>>(w, vel, curl, vel_out, div, curl_strength, dt,
-                                                                                    ga, gb, ay.S, ax.n, ay.n, xcd_remap());
+                                                                                    ga, gb, ay.S, ax.n, ay.n, 0);
     return hipGetLastError();
 }
 
