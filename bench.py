@@ -90,6 +90,11 @@ def main():
     ap.add_argument("--stripes", action="store_true", help="use the multi-GPU stripe driver even at N = 1 (exercises that code path)")
     args = ap.parse_args()
 
+    # stdout must carry exactly ONE JSON line: RCCL / HIP libraries print banners to fd 1 from C, so everything
+    # else is routed to stderr and the JSON is written to the saved descriptor at the end
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import fluid_hip
 
@@ -128,7 +133,7 @@ def main():
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         # global grid: `size` columns x `size * N` rows -> canvas of the same aspect, SIM_RESOLUTION = short side
         sim = StripeSim(canvas=(size, size * N), config=cfg, halo=args.halo, schedule=args.schedule,
                         random=fluid_hip.mulberry32(1234), device=local_rank)
@@ -206,7 +211,7 @@ def main():
     if striped:
         out["config"]["exchanges_per_step"] = sim.exchanges / max(args.steps + args.warmup, 1)
     if rank == 0:
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if striped:
         import torch.distributed as dist
         dist.barrier()

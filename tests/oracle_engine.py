@@ -33,6 +33,10 @@ class OracleStripeEngine:
     def close(self):
         pass
 
+    def stream_ctx(self):
+        import contextlib
+        return contextlib.nullcontext()
+
     def _arr(self, name):
         return {"velocity": self.vel, "pressure": self.prs, "divergence": self.div, "curl": self.crl, "dye": self.dye}[name]
 

@@ -65,9 +65,13 @@ class HipStripeEngine:
         self.ctx = ctx
         self._views = {}
         self._info = {}
-        with torch.cuda.device(device):
-            stream = torch.cuda.current_stream().cuda_stream
-        self._ck(self.lib.fluid_set_stream(self.ctx, C.c_void_p(stream), 1))
+        # a dedicated non-blocking torch stream: kernels, ghost-row views and the RCCL send/recv issued under
+        # `stream_ctx()` are all ordered on it (launches on the legacy null stream cost far more host time)
+        self.stream = torch.cuda.Stream(device=device)
+        self._ck(self.lib.fluid_set_stream(self.ctx, C.c_void_p(self.stream.cuda_stream), 1))
+
+    def stream_ctx(self):
+        return self.torch.cuda.stream(self.stream)
 
     def _ck(self, rc):
         _abi.check(self.ctx, rc)
@@ -176,18 +180,32 @@ class LocalComm:
     def __init__(self, hub: "LocalComm.Hub", rank: int):
         self.hub, self.rank, self.world = hub, rank, hub.world
 
+    def _post(self, dst, tensors):
+        clones, ev = [t.clone() for t in tensors], None
+        if clones and clones[0].is_cuda:  # each stripe runs on its own stream: hand the clones over with an event
+            import torch
+            ev = torch.cuda.Event()
+            ev.record()
+        self.hub.box[(self.rank, dst)].put((clones, ev))
+
+    def _take(self, src, recvs):
+        clones, ev = self.hub.box[(src, self.rank)].get(timeout=120)
+        if ev is not None:
+            import torch
+            torch.cuda.current_stream().wait_event(ev)
+        for dst, c in zip(recvs, clones):
+            dst.copy_(c)
+
     def exchange(self, send_lo, send_hi, recv_lo, recv_hi):
         r = self.rank
         if r > 0:
-            self.hub.box[(r, r - 1)].put([t.clone() for t in send_lo])
+            self._post(r - 1, send_lo)
         if r < self.world - 1:
-            self.hub.box[(r, r + 1)].put([t.clone() for t in send_hi])
+            self._post(r + 1, send_hi)
         if r > 0:
-            for dst, src in zip(recv_lo, self.hub.box[(r - 1, r)].get(timeout=120)):
-                dst.copy_(src)
+            self._take(r - 1, recv_lo)
         if r < self.world - 1:
-            for dst, src in zip(recv_hi, self.hub.box[(r + 1, r)].get(timeout=120)):
-                dst.copy_(src)
+            self._take(r + 1, recv_hi)
 
     def gather_rows(self, arr):
         raise NotImplementedError("gather the per-stripe reads in the caller")
@@ -242,7 +260,8 @@ class StripeSim:
             recv_lo.append(t[h - n:h])              # my bottom ghost rows  <- lower neighbour's highest owned rows
             send_hi.append(t[h + r - n:h + r])
             recv_hi.append(t[h + r:h + r + n])
-        self.comm.exchange(send_lo, send_hi, recv_lo, recv_hi)
+        with e.stream_ctx():
+            self.comm.exchange(send_lo, send_hi, recv_lo, recv_hi)
         self.exchanges += 1
 
     # -- splat / multipleSplats: script.js:1441-1462, 1427-1439 (every rank evaluates its own rows) ----
