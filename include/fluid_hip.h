@@ -148,6 +148,9 @@ int fluid_pass_clear(fluid_ctx *ctx, float value, int ext);          /* clearPro
 /* `iters` Jacobi iterations (pressureProgram, 1259-1266); input must be valid `ext_out + iters`
  * rows beyond the owned rows, output is valid `ext_out` rows beyond.  Uses the context's schedule. */
 int fluid_pass_jacobi(fluid_ctx *ctx, int iters, int ext_out);
+/* clear (x value) followed by `iters` Jacobi iterations, script.js:1253-1266; under the fused schedule the clear is
+ * folded into the first iteration's loads (same rounding).  Pressure must be valid ext_out + iters rows out. */
+int fluid_pass_clear_jacobi(fluid_ctx *ctx, float value, int iters, int ext_out);
 int fluid_pass_gradsub(fluid_ctx *ctx, int ext);                     /* gradienSubtractProgram 1268-1273 (swaps velocity) */
 int fluid_pass_advect_velocity(fluid_ctx *ctx, float dt, float dissipation, int ext); /* advectionProgram 1275-1285 */
 int fluid_pass_advect_dye(fluid_ctx *ctx, float dt, float dissipation);               /* advectionProgram 1287-1293 */

@@ -88,6 +88,10 @@ class OracleStripeEngine:
             ra, rb = self._range(ext_out + iters - 1 - k)
             self.prs = O.jacobi(self.prs, self.div, H=self.H, g0=self.g0, ra=ra, rb=rb)
 
+    def clear_jacobi(self, value, iters, ext_out):
+        self.clear(value, ext_out + iters)
+        self.jacobi(iters, ext_out)
+
     def gradsub(self, ext):
         ra, rb = self._range(ext)
         self.vel = O.gradsub(self.prs, self.vel, H=self.H, g0=self.g0, ra=ra, rb=rb)

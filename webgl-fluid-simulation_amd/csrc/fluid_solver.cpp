@@ -264,6 +264,16 @@ int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launche
     return FLUID_OK;
 }
 
+// K4 + K5 x iters; the clear rides on the first temporally blocked launch when that kernel applies
+int pass_clear_jacobi(fluid_ctx* c, float value, int iters, int ext_out, int* launches)
+{
+    if (iters < 0) return c->fail(FLUID_ERR_INVALID, "negative iteration count");
+    const bool fold = c->desc.schedule == FLUID_SCHED_FUSED && jacobi_tb_supported(c->sim) && iters > 0;
+    if (fold) return pass_jacobi(c, iters, ext_out, value, launches);
+    CK(pass_clear(c, value, ext_out + iters));
+    return pass_jacobi(c, iters, ext_out, 1.0f, launches);
+}
+
 int pass_gradsub(fluid_ctx* c, int ext)
 {
     CK(check_ext(c, ext, 1));
@@ -641,6 +651,11 @@ int fluid_pass_jacobi(fluid_ctx* c, int iters, int ext_out)
 {
     PASS_PROLOGUE();
     return pass_jacobi(c, iters, ext_out, 1.0f, nullptr);
+}
+int fluid_pass_clear_jacobi(fluid_ctx* c, float value, int iters, int ext_out)
+{
+    PASS_PROLOGUE();
+    return pass_clear_jacobi(c, value, iters, ext_out, nullptr);
 }
 int fluid_pass_gradsub(fluid_ctx* c, int ext)
 {

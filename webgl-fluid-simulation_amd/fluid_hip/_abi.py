@@ -71,6 +71,7 @@ SYMBOLS = {
     "fluid_pass_curl_vorticity_divergence": (_I, [_CTX, _F, _F, _I]),
     "fluid_pass_clear": (_I, [_CTX, _F, _I]),
     "fluid_pass_jacobi": (_I, [_CTX, _I, _I]),
+    "fluid_pass_clear_jacobi": (_I, [_CTX, _F, _I, _I]),
     "fluid_pass_gradsub": (_I, [_CTX, _I]),
     "fluid_pass_advect_velocity": (_I, [_CTX, _F, _F, _I]),
     "fluid_pass_advect_dye": (_I, [_CTX, _F, _F]),

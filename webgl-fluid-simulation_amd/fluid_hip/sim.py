@@ -294,6 +294,8 @@ class FluidSim:
             rc = L.fluid_pass_clear(c, P.pressure, ext)
         elif name == "jacobi":
             rc = L.fluid_pass_jacobi(c, iters, ext)
+        elif name == "clear_jacobi":
+            rc = L.fluid_pass_clear_jacobi(c, P.pressure, iters, ext)
         elif name == "gradsub":
             rc = L.fluid_pass_gradsub(c, ext)
         elif name == "advect_velocity":

@@ -113,6 +113,7 @@ class HipStripeEngine:
     def curl_vorticity_divergence(self, curl, dt, ext): self._ck(self.lib.fluid_pass_curl_vorticity_divergence(self.ctx, curl, dt, ext))
     def clear(self, value, ext): self._ck(self.lib.fluid_pass_clear(self.ctx, value, ext))
     def jacobi(self, iters, ext_out): self._ck(self.lib.fluid_pass_jacobi(self.ctx, iters, ext_out))
+    def clear_jacobi(self, value, iters, ext_out): self._ck(self.lib.fluid_pass_clear_jacobi(self.ctx, value, iters, ext_out))
     def gradsub(self, ext): self._ck(self.lib.fluid_pass_gradsub(self.ctx, ext))
     def advect_velocity(self, dt, diss, ext): self._ck(self.lib.fluid_pass_advect_velocity(self.ctx, dt, diss, ext))
     def advect_dye(self, dt, diss): self._ck(self.lib.fluid_pass_advect_dye(self.ctx, dt, diss))
@@ -291,8 +292,8 @@ class StripeSim:
         c, e, H = self.config, self.engine, self.halo
         iters = int(c["PRESSURE_ITERATIONS"])
         if self.world == 1:
-            e.curl_vorticity_divergence(c["CURL"], dt, 0); e.clear(c["PRESSURE"], 0)
-            e.jacobi(iters, 0); e.gradsub(0)
+            e.curl_vorticity_divergence(c["CURL"], dt, 0)
+            e.clear_jacobi(c["PRESSURE"], iters, 0); e.gradsub(0)
             e.advect(dt, c["VELOCITY_DISSIPATION"], c["DENSITY_DISSIPATION"])
             return
         # pressure blocks: divergence is valid H-3 rows out and iteration k of a block needs it d-k+e rows out
@@ -305,11 +306,14 @@ class StripeSim:
         first = blocks[0][0] + blocks[0][1] if blocks else 1
         self.exchange((VELOCITY, H), (PRESSURE, first))
         e.curl_vorticity_divergence(c["CURL"], dt, H - 3)   # curl to H-1, vorticity to H-2, divergence to H-3 rows out
-        e.clear(c["PRESSURE"], first)                        # ghost rows hold the neighbour's pre-clear pressure
+        if not blocks:
+            e.clear(c["PRESSURE"], 1)
         for k, (d, ext) in enumerate(blocks):
-            if k > 0:
+            if k == 0:   # the exchanged ghost rows hold the neighbour's PRE-clear pressure: clear covers them too
+                e.clear_jacobi(c["PRESSURE"], d, ext)
+            else:
                 self.exchange((PRESSURE, d + ext))
-            e.jacobi(d, ext)
+                e.jacobi(d, ext)
         e.gradsub(0)
         self.exchange((VELOCITY, H), (DYE, e.info(DYE).halo))
         e.advect(dt, c["VELOCITY_DISSIPATION"], c["DENSITY_DISSIPATION"])   # velocity then dye (one kernel when the grids match)
