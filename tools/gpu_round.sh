@@ -1,0 +1,70 @@
+#!/bin/bash
+# One GPU-box visit: parity tests, smoke, headline bench, rocprofv3 kernel stats, PMC traffic passes.
+# Usage (from the repo root, on the GPU box via gpurun):  bash tools/gpu_round.sh <tag> [quick]
+# Everything lands in gpurun_out/<tag>/ ; copy what should be judged into profiles/.
+set -u
+TAG=${1:-run}
+MODE=${2:-full}
+OUT=$PWD/gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+export PYTHONUNBUFFERED=1
+
+echo "== build check (prebuilt .so must load) ==" | tee "$OUT/log.txt"
+python -c "import sys; sys.path.insert(0,'webgl-fluid-simulation_amd'); import fluid_hip; fluid_hip.lib(); print('libfluid_hip ok')" >>"$OUT/log.txt" 2>&1
+
+if [ "$MODE" != "quick" ]; then
+  echo "== pytest -m gpu ==" | tee -a "$OUT/log.txt"
+  timeout 1500 python -m pytest tests -m gpu -x -q >"$OUT/pytest_gpu.txt" 2>&1
+  echo "pytest exit $?" | tee -a "$OUT/log.txt"
+  tail -5 "$OUT/pytest_gpu.txt" | tee -a "$OUT/log.txt"
+
+  echo "== smoke ==" | tee -a "$OUT/log.txt"
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" >>"$OUT/log.txt" 2>&1
+  echo "smoke exit $?" | tee -a "$OUT/log.txt"
+fi
+
+echo "== bench (headline) ==" | tee -a "$OUT/log.txt"
+timeout 600 python bench.py >"$OUT/bench.json" 2>"$OUT/bench.err"
+echo "bench exit $?" | tee -a "$OUT/log.txt"
+cat "$OUT/bench.json" | tee -a "$OUT/log.txt"
+
+echo "== bench passes schedule ==" | tee -a "$OUT/log.txt"
+timeout 600 python bench.py --schedule passes --cpu-budget 0 >"$OUT/bench_passes.json" 2>>"$OUT/bench.err"
+cat "$OUT/bench_passes.json" | tee -a "$OUT/log.txt"
+
+echo "== bench --stripes (stripe driver at N=1) ==" | tee -a "$OUT/log.txt"
+timeout 600 python bench.py --stripes --cpu-budget 0 >"$OUT/bench_stripes1.json" 2>>"$OUT/bench.err"
+cat "$OUT/bench_stripes1.json" | tee -a "$OUT/log.txt"
+
+echo "== rocprofv3 kernel trace ==" | tee -a "$OUT/log.txt"
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o ks -- \
+    python "$GRAFT_REPO_ROOT/bench.py" --steps 20 --warmup 3 --cpu-budget 0 >"$OUT/bench_under_rocprof.json" 2>"$OUT/rocprof.err" )
+echo "rocprof exit $?" | tee -a "$OUT/log.txt"
+find "$OUT/prof" -name '*kernel_stats*' | head | tee -a "$OUT/log.txt"
+KS=$(find "$OUT/prof" -name '*kernel_stats.csv' | head -1)
+[ -n "$KS" ] && cp "$KS" "$OUT/kernel_stats.csv" && head -12 "$OUT/kernel_stats.csv" | cut -c1-200 | tee -a "$OUT/log.txt"
+
+if [ "$MODE" != "quick" ]; then
+  echo "== PMC passes (separate runs per counter, no tracing domains besides kernel-trace) ==" | tee -a "$OUT/log.txt"
+  for sched in fused passes; do
+    for ctr in FETCH_SIZE WRITE_SIZE; do
+      ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$OUT/pmc_${ctr}_${sched}" -o pmc -- \
+          python "$GRAFT_REPO_ROOT/bench.py" --steps 5 --warmup 0 --cpu-budget 0 --no-profile-pass --schedule $sched >/dev/null 2>>"$OUT/rocprof.err" )
+      F=$(find "$OUT/pmc_${ctr}_${sched}" -name '*counter_collection.csv' | head -1)
+      [ -n "$F" ] && cp "$F" "$OUT/pmc_${ctr}_${sched}.csv"
+      rm -rf "$OUT/pmc_${ctr}_${sched}"
+    done
+  done
+  python tools/pmc_traffic.py "$OUT/pmc_FETCH_SIZE_fused.csv" "$OUT/pmc_WRITE_SIZE_fused.csv" "$OUT/pmc_FETCH_SIZE_passes.csv" \
+      "$OUT/pmc_WRITE_SIZE_passes.csv" 4096 4096 "$OUT/traffic.json" >/dev/null 2>>"$OUT/log.txt"
+  python - "$OUT/traffic.json" <<'EOF' | tee -a "$OUT/log.txt"
+import json, sys
+t = json.load(open(sys.argv[1]))
+for k, v in t["kernels"].items():
+    print("%-28s %6.2f B/texel  (%d dispatches)" % (k, v["bytes_per_texel"], v["dispatches"]))
+EOF
+fi
+# keep the merged-back payload small
+rm -rf "$OUT/prof"
+echo "== done ==" | tee -a "$OUT/log.txt"
