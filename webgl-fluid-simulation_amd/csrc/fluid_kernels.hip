@@ -343,20 +343,27 @@ __host__ inline Axis make_axis(int lo, int hi, int dom, int T, int A)
 }
 
 // XCD-aware tile order (MI355X: 8 XCDs with private 4 MiB L2s; workgroup b is dispatched to XCD b % 8).
-// Vertically adjacent tiles share 2*apron rows, so each XCD is handed a CONTIGUOUS run of the column-major
-// tile sequence: the ~64 workgroups resident on an XCD at any time are then vertical neighbours and the
-// shared apron rows hit that XCD's L2 instead of being fetched once per tile.  Bijective for any tile count;
-// placement only affects speed, never results.  remap == 0: plain column-major order.
+// Adjacent tiles share their aprons, so each XCD is handed a CONTIGUOUS run of the tile sequence (remap bit 0): the
+// ~64 workgroups resident on an XCD at any time are then neighbours and the shared apron texels hit that XCD's L2
+// instead of being fetched once per tile.  Bit 1 picks the sequence: row-major (the tiles in flight together span
+// whole rows of the field, i.e. long contiguous address runs — measured 7 % faster for the Jacobi kernel at 4096^2,
+// profiles/r01/jacobi_tile_order.txt) or column-major.  Bijective for any tile count; placement only affects
+// speed, never results.
 __device__ __forceinline__ void tile_of_block(int b, int nx, int ny, int remap, int& bx, int& by)
 {
     const int n = nx * ny;
     int t = b;
-    if (remap) {
+    if (remap & 1) {
         const int q = n >> 3, r = n & 7, xcd = b & 7, slot = b >> 3;
         t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
-    bx = t / ny;
-    by = t - bx * ny;
+    if (remap & 2) {  // row-major tile sequence: the tiles in flight together span whole rows of the field
+        by = t / nx;
+        bx = t - by * nx;
+    } else {
+        bx = t / ny;
+        by = t - bx * ny;
+    }
 }
 
 // exact (storable) global range [a, b) of the tile starting at t0, intersected with [lo, hi)
@@ -387,114 +394,172 @@ __device__ __forceinline__ void tile_exact(int t0, int T, int A, int dom, int lo
 //
 // Domain edges: CLAMP_TO_EDGE means an off-domain neighbour equals the centre texel; handled by
 // selects in the EDGE instantiation, which only workgroups touching the domain border run.
-template <int NW, int RY, int HALO>
+template <int NW, int RY, int HX, int HY>
 struct JacobiTB {
     static constexpr int TX = 256;          // columns per tile (64 lanes x float4)
     static constexpr int TY = NW * RY;      // rows per tile
-    static constexpr int VX = TX - 2 * HALO;
-    static constexpr int VY = TY - 2 * HALO;
-    static_assert(HALO % 4 == 0, "apron must keep float4 alignment");
+    static constexpr int VX = TX - 2 * HX;  // HX-column / HY-row apron: up to min(HX, HY) iterations per launch
+    static constexpr int VY = TY - 2 * HY;
+    static_assert(HX % 4 == 0, "column apron must keep float4 alignment");
+    static_assert(HX >= HY, "iterations per launch are bounded by the row apron");
     static_assert(VX > 0 && VY > 0, "tile smaller than its apron");
 };
 
-__device__ __forceinline__ float from_left_lane(float v)  // value held by lane-1 (garbage in lane 0)
+// Undefined `old` operand (mov_dpp, not update_dpp with a zero): the lane without a source gets an unspecified value
+// — every caller either overrides it (EDGE) or only feeds the stale apron with it — and the DPP-combine pass is then
+// free to fold the shift into the consuming v_add_f32 (v_add_f32_dpp: no extra instruction, no zero-initialisation).
+__device__ __forceinline__ float from_left_lane(float v)  // value held by lane-1 (unspecified in lane 0)
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, true));
 }
-__device__ __forceinline__ float from_right_lane(float v)  // value held by lane+1 (garbage in lane 63)
+__device__ __forceinline__ float from_right_lane(float v)  // value held by lane+1 (unspecified in lane 63)
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, true));
 }
 
-template <int NW, int RY, int HALO, bool EDGE>
+// Two texels as one 64-bit register pair: arithmetic on it is v_pk_add_f32 / v_pk_mul_f32 (full rate on gfx950:
+// two IEEE fp32 results per lane per instruction — the same bits as two scalar operations).
+typedef float v2f __attribute__((ext_vector_type(2)));
+// A lane's four consecutive texels (c0 c1 c2 c3) of one row, held as the OUTER pair (c0, c3) and the INNER pair
+// (c1, c2).  With this pairing the horizontal sums need no register shuffling:
+//   inner: (c0 + c2, c3 + c1) = outer + swap(inner)            one v_pk_add_f32 with op_sel
+//   outer: (left + c1, c2 + right)                             two v_add_f32_dpp (lane shift folded in)
+// and everything vertical is pair-wise on (outer, inner) of the rows above / below.
+struct Quad {
+    v2f o, i;
+};
+__device__ __forceinline__ Quad quad_of(float4 v)
+{
+    Quad q;
+    q.o = v2f{ v.x, v.w };
+    q.i = v2f{ v.y, v.z };
+    return q;
+}
+__device__ __forceinline__ float4 float4_of(Quad q) { return make_float4(q.o.x, q.i.x, q.i.y, q.o.y); }
+// mailbox rows travel in register order (no permutation on the way through LDS)
+__device__ __forceinline__ float4 raw_of(Quad q) { return make_float4(q.o.x, q.o.y, q.i.x, q.i.y); }
+__device__ __forceinline__ Quad quad_of_raw(float4 v)
+{
+    Quad q;
+    q.o = v2f{ v.x, v.y };
+    q.i = v2f{ v.z, v.w };
+    return q;
+}
+
+// One Jacobi iteration over the wave's RY rows (pressureShader script.js:881-888, operand order of line 887:
+// ((L + R) + B) + T - div) * 0.25).  11 VALU instructions per row of four texels.  `box` is this iteration's
+// mailbox slot.
+template <int NW, int RY, bool EDGE>
+__device__ __forceinline__ void jacobi_sweep(Quad (&P)[RY], const Quad (&D)[RY], float4 (*box)[2][64], int wv, int lane, int gy,
+                                             int H, bool at_left, bool at_right)
+{
+    // publish this wave's first and last row, fetch the neighbours' adjacent rows
+    box[wv][0][lane] = raw_of(P[0]);
+    box[wv][1][lane] = raw_of(P[RY - 1]);
+    __syncthreads();
+    // unconditional b128 reads: the first/last wave reads its own mailbox, which only feeds the stale apron
+    Quad below = quad_of_raw(box[wv > 0 ? wv - 1 : 0][1][lane]);
+    const Quad above = quad_of_raw(box[wv < NW - 1 ? wv + 1 : NW - 1][0][lane]);
+    const v2f quarter = v2f{ 0.25f, 0.25f };
+#pragma unroll
+    for (int r = 0; r < RY; r++) {
+        const Quad C = P[r];
+        Quad T = (r < RY - 1) ? P[r + 1] : above;
+        Quad B = below;
+        float L = from_left_lane(C.o.y);   // column 4*lane - 1 = the left lane's c3
+        float R = from_right_lane(C.o.x);  // column 4*lane + 4 = the right lane's c0
+        if (EDGE) {  // CLAMP_TO_EDGE: an off-domain neighbour is the centre texel
+            const int gj = gy + r;
+            if (at_left) L = C.o.x;
+            if (at_right) R = C.o.y;
+            if (gj == 0) B = C;
+            if (gj == H - 1) T = C;
+        }
+        v2f h_o;
+        h_o.x = L + C.i.x;                                               // texel 0: left + c1
+        h_o.y = C.i.y + R;                                               // texel 3: c2 + right
+        const v2f h_i = C.o + __builtin_shufflevector(C.i, C.i, 1, 0);   // texels 1, 2: c0 + c2, c3 + c1
+        Quad n;
+        n.o = (h_o + B.o + T.o - D[r].o) * quarter;
+        n.i = (h_i + B.i + T.i - D[r].i) * quarter;
+        below = C;
+        P[r] = n;
+    }
+}
+
+template <int NW, int RY, int HX, int HY, bool EDGE>
 __device__ __forceinline__ void jacobi_tb_body(const Win& w, const float* __restrict__ p, const float* __restrict__ div,
                                                float* __restrict__ p_out, float pscale, int iters, int ga, int gb, int x0,
                                                int y0, float4 (*mail)[NW][2][64])
 {
-    using G = JacobiTB<NW, RY, HALO>;
+    using G = JacobiTB<NW, RY, HX, HY>;
     const int lane = threadIdx.x;
-    const int wv = threadIdx.y;
+    // the block is (64, NW): threadIdx.y is the wave index — tell the compiler it is wave-uniform so that all
+    // per-row address arithmetic lands on the scalar unit and the loads use SGPR-base + lane-offset addressing
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
     const int cx = x0 + 4 * lane;     // first of this lane's 4 columns
     const int gy = y0 + wv * RY;      // global row of this wave's row 0
 
     // Load the whole tile with UNCONDITIONAL loads from clamped addresses (no per-row branch, so the 2*RY
     // 1 KiB wave loads are all in flight together).  Apron texels outside the domain or outside the
     // stripe's window then hold some other texel's finite value; that is fine: they are never stored,
-    // and no in-domain texel reads an off-domain neighbour (EDGE selects below) or a texel deeper in
+    // and no in-domain texel reads an off-domain neighbour (EDGE selects) or a texel deeper in
     // the apron than `iters`.
-    float4 P[RY], D[RY];
-    const int cxs = min(max(cx, 0), w.W - 4);
+    Quad P[RY], D[RY];
+    const unsigned cxs = (unsigned)min(max(cx, 0), w.W - 4);
+    const v2f ps = v2f{ pscale, pscale };
 #pragma unroll
     for (int r = 0; r < RY; r++) {
         const int lr = min(max(gy + r - w.g0, 0), w.rows - 1);
-        const long c = (long)lr * w.W + cxs;
-        P[r] = *reinterpret_cast<const float4*>(p + c);
-        D[r] = *reinterpret_cast<const float4*>(div + c);
+        const size_t row = (size_t)lr * (size_t)w.W;  // wave-uniform
+        P[r] = quad_of(*reinterpret_cast<const float4*>(p + row + cxs));
+        D[r] = quad_of(*reinterpret_cast<const float4*>(div + row + cxs));
     }
 #pragma unroll
-    for (int r = 0; r < RY; r++) P[r] = make_float4(pscale * P[r].x, pscale * P[r].y, pscale * P[r].z, pscale * P[r].w);
+    for (int r = 0; r < RY; r++) {  // clearShader folded in: value * p, same rounding as the separate pass
+        P[r].o = ps * P[r].o;
+        P[r].i = ps * P[r].i;
+    }
 
     const bool at_left = (cx == 0), at_right = (cx + 3 == w.W - 1);
 
-    for (int it = 0; it < iters; it++) {
-        // publish this wave's first and last row, fetch the neighbours' adjacent rows
-        mail[it & 1][wv][0][lane] = P[0];
-        mail[it & 1][wv][1][lane] = P[RY - 1];
-        __syncthreads();
-        // unconditional b128 reads: the first/last wave reads its own mailbox, which only feeds the stale apron
-        float4 below = mail[it & 1][wv > 0 ? wv - 1 : 0][1][lane];
-        const float4 above = mail[it & 1][wv < NW - 1 ? wv + 1 : NW - 1][0][lane];
-
-#pragma unroll
-        for (int r = 0; r < RY; r++) {
-            const float4 C = P[r];
-            float4 T = (r < RY - 1) ? P[r + 1] : above;
-            float4 B = below;
-            float Lx = from_left_lane(C.w);
-            float Rw = from_right_lane(C.x);
-            if (EDGE) {
-                const int gj = gy + r;
-                if (at_left) Lx = C.x;
-                if (at_right) Rw = C.w;
-                if (gj == 0) B = C;
-                if (gj == w.H - 1) T = C;
-            }
-            float4 n;
-            n.x = (Lx + C.y + B.x + T.x - D[r].x) * 0.25f;
-            n.y = (C.x + C.z + B.y + T.y - D[r].y) * 0.25f;
-            n.z = (C.y + C.w + B.z + T.z - D[r].z) * 0.25f;
-            n.w = (C.z + Rw + B.w + T.w - D[r].w) * 0.25f;
-            below = C;
-            P[r] = n;
-        }
+    // two iterations per trip: the mailbox slot is a compile-time constant and the register allocator can hand the
+    // second sweep's results back to the registers the first one read (no copies on the loop back-edge)
+    int it = 0;
+    for (; it + 2 <= iters; it += 2) {
+        jacobi_sweep<NW, RY, EDGE>(P, D, mail[0], wv, lane, gy, w.H, at_left, at_right);
+        jacobi_sweep<NW, RY, EDGE>(P, D, mail[1], wv, lane, gy, w.H, at_left, at_right);
     }
+    if (it < iters) jacobi_sweep<NW, RY, EDGE>(P, D, mail[0], wv, lane, gy, w.H, at_left, at_right);
 
     // store the texels the apron kept exact
     int xa, xb, out_lo, out_hi;
-    tile_exact(x0, G::TX, HALO, w.W, 0, w.W, xa, xb);
-    tile_exact(y0, G::TY, HALO, w.H, ga, gb, out_lo, out_hi);
+    tile_exact(x0, G::TX, HX, w.W, 0, w.W, xa, xb);
+    tile_exact(y0, G::TY, HY, w.H, ga, gb, out_lo, out_hi);
     const bool col_store = (cx >= xa) && (cx < xb);
 #pragma unroll
     for (int r = 0; r < RY; r++) {
         const int gj = gy + r;
         if (col_store && gj >= out_lo && gj < out_hi)
-            *reinterpret_cast<float4*>(p_out + (long)(gj - w.g0) * w.W + cx) = P[r];
+            *reinterpret_cast<float4*>(p_out + (size_t)(gj - w.g0) * (size_t)w.W + (unsigned)cx) = float4_of(P[r]);
     }
 }
 
-template <int NW, int RY, int HALO>
-__global__ void __launch_bounds__(64 * NW) k_jacobi_tb(Win w, const float* __restrict__ p, const float* __restrict__ div,
+// BPC = workgroups that must fit on a CU together (their load / compute / store phases overlap each other):
+// the second __launch_bounds__ argument is waves per SIMD, i.e. the VGPR budget the compiler has to meet.
+template <int NW, int RY, int HX, int HY, int BPC>
+__global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb(Win w, const float* __restrict__ p, const float* __restrict__ div,
                                                         float* __restrict__ p_out, float pscale, int iters, int ga, int gb,
                                                         int ys, int nx, int ny, int remap)
 {
-    using G = JacobiTB<NW, RY, HALO>;
+    using G = JacobiTB<NW, RY, HX, HY>;
     __shared__ float4 mail[2][NW][2][64];
     int bx, by;
     tile_of_block((int)blockIdx.x, nx, ny, remap, bx, by);
     const int x0 = bx * G::VX, y0 = ys + by * G::VY;
     const bool edge = (x0 <= 0) || (x0 + G::TX >= w.W) || (y0 <= 0) || (y0 + G::TY >= w.H);
-    if (edge) jacobi_tb_body<NW, RY, HALO, true>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
-    else jacobi_tb_body<NW, RY, HALO, false>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
+    if (edge) jacobi_tb_body<NW, RY, HX, HY, true>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
+    else jacobi_tb_body<NW, RY, HX, HY, false>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -666,18 +731,24 @@ __global__ void __launch_bounds__(64 * NW) k_curl_vort_div(Win w, const float2* 
 
 constexpr int VD_NW = 8, VD_RY = 8;
 
-// tile-shape variants (NW waves x RY rows per wave, apron HALO); FLUID_TB_VARIANT picks one (tuning knob,
+// tile-shape variants (NW waves x RY rows per wave, apron HX columns x HY rows, BPC workgroups per CU); FLUID_TB_VARIANT picks one (tuning knob,
 // read once); the default is the shape that measured best on MI355X at 4096^2 (profiles/)
-struct TBVariant { int nw, ry, halo; };
-constexpr TBVariant kTB[] = { {4, 16, 8}, {8, 8, 8}, {8, 16, 8}, {4, 24, 8}, {8, 12, 12}, {8, 16, 16}, {4, 16, 4}, {8, 8, 4} };
+struct TBVariant { int nw, ry, hx, hy, bpc; };
+constexpr TBVariant kTB[] = {
+    {4, 16, 8, 8, 1},   {8, 8, 8, 8, 2},    {8, 16, 8, 8, 1},   {4, 24, 8, 8, 2},   {8, 12, 12, 12, 2}, {8, 16, 16, 16, 1},
+    {4, 16, 4, 4, 1},   {8, 8, 4, 4, 2},    {8, 10, 12, 10, 2}, {6, 16, 16, 13, 2}, {4, 24, 16, 13, 2}, {8, 16, 20, 17, 1},
+    {8, 11, 12, 10, 2}, {6, 14, 12, 10, 2}, {8, 12, 12, 10, 2}, {7, 12, 8, 8, 2},   {8, 10, 16, 13, 2}, {8, 12, 16, 13, 2},
+    {16, 8, 12, 10, 1}, {16, 12, 16, 13, 1}, {16, 12, 20, 17, 1}, {16, 10, 16, 13, 1}, {16, 12, 28, 25, 1},
+};
 constexpr int kNumTB = sizeof(kTB) / sizeof(kTB[0]);
-constexpr int kDefaultTB = 1;  // 8 waves x 8 rows, apron 8: 110 VGPRs, best of the table at 4096^2 (profiles/r01)
+constexpr int kDefaultTB = 8;  // 8 waves x 10 rows, apron 12 x 10: 120 VGPRs (two workgroups per CU), 50 iterations in 5
+                               // launches; best of the table at 4096^2 (profiles/r01/jacobi_variants.txt)
 
-int xcd_remap()  // FLUID_XCD_REMAP=0 switches the XCD-aware tile order off (A/B knob)
+int xcd_remap()  // FLUID_XCD_REMAP: tile order of the Jacobi kernel (A/B knob); bit 0 = XCD-contiguous runs, bit 1 = row-major
 {
     static const int v = [] {
         const char* e = getenv("FLUID_XCD_REMAP");
-        return e ? atoi(e) : 1;
+        return (e ? atoi(e) : 3) & 3;
     }();
     return v;
 }
@@ -692,12 +763,12 @@ int tb_variant()
     return v;
 }
 
-template <int NW, int RY, int HALO>
+template <int NW, int RY, int HX, int HY, int BPC>
 hipError_t launch_tb(hipStream_t s, Win w, const float* p, const float* div, float* p_out, float pscale, int iters, int ga, int gb)
 {
-    using G = JacobiTB<NW, RY, HALO>;
-    const Axis ax = make_axis(0, w.W, w.W, G::TX, HALO), ay = make_axis(ga, gb, w.H, G::TY, HALO);
-    k_jacobi_tb<NW, RY, HALO><<<dim3(ax.n * ay.n, 1, 1), dim3(64, NW, 1), 0, s>>>(w, p, div, p_out, pscale, iters, ga, gb, ay.S, ax.n,
+    using G = JacobiTB<NW, RY, HX, HY>;
+    const Axis ax = make_axis(0, w.W, w.W, G::TX, HX), ay = make_axis(ga, gb, w.H, G::TY, HY);
+    k_jacobi_tb<NW, RY, HX, HY, BPC><<<dim3(ax.n * ay.n, 1, 1), dim3(64, NW, 1), 0, s>>>(w, p, div, p_out, pscale, iters, ga, gb, ay.S, ax.n,
                                                                                  ay.n, xcd_remap());
     return hipGetLastError();
 }
@@ -833,7 +904,7 @@ hipError_t launch_curl_vort_div(hipStream_t s, Win w, const float2* vel, float* 
     return hipGetLastError();
 }
 
-int jacobi_tb_max_iters() { return kTB[tb_variant()].halo; }
+int jacobi_tb_max_iters() { return kTB[tb_variant()].hy; }
 
 bool jacobi_tb_supported(Win w) { return w.W % 4 == 0 && w.W >= 4; }
 
@@ -843,14 +914,35 @@ hipError_t launch_jacobi_tb(hipStream_t s, Win w, const float* p, const float* d
     ROWS_OR_RETURN();
     if (iters < 1 || iters > jacobi_tb_max_iters() || !jacobi_tb_supported(w)) return hipErrorInvalidValue;
     switch (tb_variant()) {
-    case 1: return launch_tb<8, 8, 8>(s, w, p, div, p_out, pscale, iters, ga, gb);
-    case 2: return launch_tb<8, 16, 8>(s, w, p, div, p_out, pscale, iters, ga, gb);
-    case 3: return launch_tb<4, 24, 8>(s, w, p, div, p_out, pscale, iters, ga, gb);
-    case 4: return launch_tb<8, 12, 12>(s, w, p, div, p_out, pscale, iters, ga, gb);
-    case 5: return launch_tb<8, 16, 16>(s, w, p, div, p_out, pscale, iters, ga, gb);
-    case 6: return launch_tb<4, 16, 4>(s, w, p, div, p_out, pscale, iters, ga, gb);
-    case 7: return launch_tb<8, 8, 4>(s, w, p, div, p_out, pscale, iters, ga, gb);
-    default: return launch_tb<4, 16, 8>(s, w, p, div, p_out, pscale, iters, ga, gb);
+#define TB_CASE(k, NW, RY, HX, HY, BPC)                                                                                         \
+    case k:                                                                                                                     \
+        static_assert(kTB[k].nw == NW && kTB[k].ry == RY && kTB[k].hx == HX && kTB[k].hy == HY && kTB[k].bpc == BPC, "table"); \
+        return launch_tb<NW, RY, HX, HY, BPC>(s, w, p, div, p_out, pscale, iters, ga, gb)
+    TB_CASE(0, 4, 16, 8, 8, 1);
+    TB_CASE(1, 8, 8, 8, 8, 2);
+    TB_CASE(2, 8, 16, 8, 8, 1);
+    TB_CASE(3, 4, 24, 8, 8, 2);
+    TB_CASE(4, 8, 12, 12, 12, 2);
+    TB_CASE(5, 8, 16, 16, 16, 1);
+    TB_CASE(6, 4, 16, 4, 4, 1);
+    TB_CASE(7, 8, 8, 4, 4, 2);
+    TB_CASE(8, 8, 10, 12, 10, 2);
+    TB_CASE(9, 6, 16, 16, 13, 2);
+    TB_CASE(10, 4, 24, 16, 13, 2);
+    TB_CASE(11, 8, 16, 20, 17, 1);
+    TB_CASE(12, 8, 11, 12, 10, 2);
+    TB_CASE(13, 6, 14, 12, 10, 2);
+    TB_CASE(14, 8, 12, 12, 10, 2);
+    TB_CASE(15, 7, 12, 8, 8, 2);
+    TB_CASE(16, 8, 10, 16, 13, 2);
+    TB_CASE(17, 8, 12, 16, 13, 2);
+    TB_CASE(18, 16, 8, 12, 10, 1);
+    TB_CASE(19, 16, 12, 16, 13, 1);
+    TB_CASE(20, 16, 12, 20, 17, 1);
+    TB_CASE(21, 16, 10, 16, 13, 1);
+    TB_CASE(22, 16, 12, 28, 25, 1);
+#undef TB_CASE
+    default: return hipErrorInvalidValue;
     }
 }
 

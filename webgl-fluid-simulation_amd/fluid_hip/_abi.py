@@ -9,7 +9,8 @@ import os
 import subprocess
 
 PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(PKG_DIR, "libfluid_hip.so")
+# FLUID_HIP_LIB: load another build of the same library (kernel A/B experiments); the default is the in-tree build
+LIB_PATH = os.environ.get("FLUID_HIP_LIB") or os.path.join(PKG_DIR, "libfluid_hip.so")
 
 FLUID_OK = 0
 ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_OOM, ERR_HALO, ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6
