@@ -10,8 +10,9 @@ enqueued back to back, bracketed by barrier + device sync on both sides, max ove
 
   N = 1 : one whole-domain context, 4096 x 4096.
   N > 1 : weak scaling — N row stripes of 4096 x 4096 each (global grid 4096 x 4096*N), one process
-          per GPU, ghost rows exchanged with torch.distributed (RCCL) send/recv.  No collective
-          on the data path other than neighbour exchange.
+          per GPU, ghost rows exchanged with ncclSend/ncclRecv (RCCL over xGMI) issued by libfluid_hip.so
+          itself; torch.distributed carries the ncclUniqueId, the barrier and the max-over-ranks time.
+          No collective on the data path other than neighbour exchange.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
 """
@@ -140,8 +141,7 @@ def main():
         sim.multipleSplats(20)
 
         def run(k):
-            for _ in range(k):
-                sim.step(DT)
+            sim.step(DT, k)   # native driver: the plan and its RCCL exchanges run inside libfluid_hip.so
 
         def sync():
             sim.sync()

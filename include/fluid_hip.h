@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FLUID_ABI_VERSION 1
+#define FLUID_ABI_VERSION 2
 
 typedef enum fluid_status {
     FLUID_OK = 0,
@@ -42,7 +42,8 @@ typedef enum fluid_status {
     FLUID_ERR_NO_DEVICE = -3,     /* no gfx950-capable device visible             */
     FLUID_ERR_OOM = -4,           /* device allocation failed                     */
     FLUID_ERR_HALO = -5,          /* an advection back-trace left the ghost rows  */
-    FLUID_ERR_UNSUPPORTED = -6
+    FLUID_ERR_UNSUPPORTED = -6,
+    FLUID_ERR_COMM = -7           /* RCCL missing / failed, or a stripe without communicator */
 } fluid_status;
 
 /* the reference's five simulation fields: `let dye; let velocity; ...` script.js:950-954 */
@@ -121,7 +122,7 @@ int fluid_set_stream(fluid_ctx *ctx, void *hip_stream, int external);
 int fluid_splat(fluid_ctx *ctx, float x, float y, float dx, float dy, float r, float g, float b,
                 float aspect, float radius);
 
-/* step(dt), script.js:1231-1294 */
+/* step(dt), script.js:1231-1294.  On a stripe context (parts > 1): this rank's share, see the multi-GPU block below */
 int fluid_step(fluid_ctx *ctx, float dt, const fluid_params *params);
 /* n consecutive step(dt) without returning to the host (the benchmark loop) */
 int fluid_step_n(fluid_ctx *ctx, int n, float dt, const fluid_params *params);
@@ -172,6 +173,52 @@ int fluid_halo_unpack(fluid_ctx *ctx, int field, int side, int nrows, const void
 int fluid_field_device_ptr(fluid_ctx *ctx, int field, void **dev_ptr);
 /* synchronises, then returns FLUID_ERR_HALO if any advection tap since the last check fell outside the stripe's rows */
 int fluid_halo_check(fluid_ctx *ctx);
+
+/* ---- multi-GPU: one stripe context per GPU, one process per GPU, ghost rows over RCCL (xGMI) ----
+ * The reference is single-GPU, so nothing in script.js corresponds to this block; it is how step() (1231-1294)
+ * runs when `parts` > 1.  fluid_step / fluid_step_n on a stripe context execute the plan below: pass groups on the
+ * stripe's window with neighbour ncclSend / ncclRecv (one ncclGroup per exchange, in place on the ghost rows)
+ * between them, all on the context stream.  No global collective is on the data path. */
+typedef enum fluid_stripe_op_kind {
+    FLUID_OP_EXCHANGE = 0,       /* refresh n_items fields' ghost rows from both neighbours                  */
+    FLUID_OP_CURL_VORT_DIV = 1,  /* script.js:1234-1251, ghost rows out to `ext`                               */
+    FLUID_OP_CLEAR = 2,          /* 1253-1257                                                                  */
+    FLUID_OP_CLEAR_JACOBI = 3,   /* 1253-1266: clear, then `iters` Jacobi iterations leaving `ext` ghost rows  */
+    FLUID_OP_JACOBI = 4,         /* `iters` more iterations                                                    */
+    FLUID_OP_GRADSUB = 5,        /* 1268-1273                                                                  */
+    FLUID_OP_ADVECT = 6          /* 1275-1293                                                                  */
+} fluid_stripe_op_kind;
+
+typedef struct fluid_stripe_op {
+    int kind;        /* fluid_stripe_op_kind                        */
+    int iters, ext;  /* pass operands                               */
+    int n_items;     /* EXCHANGE: how many (field, rows) pairs      */
+    int field[2];    /* fluid_field                                 */
+    int rows[2];     /* rows of that field to refresh on each side  */
+} fluid_stripe_op;
+
+/* the per-step plan for a stripe with `halo` sim ghost rows, `dye_halo` dye ghost rows and `iterations` Jacobi
+ * iterations (pure host logic, no device needed).  ops may be NULL to query *n_ops. */
+int fluid_stripe_plan(int halo, int dye_halo, int iterations, fluid_stripe_op *ops, int max_ops, int *n_ops);
+
+typedef struct fluid_comm_id {
+    char bytes[128]; /* an ncclUniqueId */
+} fluid_comm_id;
+
+/* which RCCL to dlopen (default: FLUID_RCCL_LIB, then librccl.so.1).  A process that already holds an RCCL — PyTorch
+ * bundles one — passes that file so both share one library and one HIP runtime.  Before the first comm call. */
+int fluid_comm_set_library(const char *path);
+/* rank 0 creates the id (ncclGetUniqueId) and hands it to every rank out of band (any launcher transport) */
+int fluid_comm_unique_id(fluid_comm_id *id);
+/* collective over the stripe set: ncclCommInitRank(parts, id, part) on the context's device */
+int fluid_comm_init(fluid_ctx *ctx, const fluid_comm_id *id);
+/* loops `nfloats` floats through ncclSend/ncclRecv to this very rank, stream-ordered between two kernels */
+int fluid_comm_selftest(fluid_ctx *ctx, int nfloats);
+/* neighbour exchanges issued so far by this context */
+long fluid_exchange_count(const fluid_ctx *ctx);
+/* the SAME plan for a whole stripe set living in one process (contexts 0..parts-1 in order, any devices): ghost
+ * rows move by device-to-device copies instead of RCCL.  Validation path on a single-GPU box. */
+int fluid_group_step_n(fluid_ctx **ctxs, int n_ctx, int steps, float dt, const fluid_params *params);
 
 int fluid_set_timing(fluid_ctx *ctx, int enabled);
 int fluid_get_timings(fluid_ctx *ctx, fluid_timings *out);

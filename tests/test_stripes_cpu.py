@@ -114,3 +114,78 @@ def test_gloo_world2_bitwise(oracle, tmp_path):
     got = np.load(os.path.join(str(tmp_path), "stripes.npz"))
     for k in S.FIELDS:
         assert np.array_equal(got[k], want[k]), k
+
+
+# ---- the NATIVE plan (csrc/fluid_stripes.cpp, what bench.py --gpus N executes over RCCL) is the schedule above ----
+class _RecordingEngine:
+    """interface of a stripe engine that only writes down what StripeSim asks for"""
+
+    def __init__(self, sim_wh, dye_wh, part, parts, halo, schedule, device):
+        self.log = []
+        self.halo = halo
+        self.dye_halo = (halo * dye_wh[1] + sim_wh[1] - 1) // sim_wh[1]
+        self.rows, self.drows = sim_wh[1] // parts, dye_wh[1] // parts
+        self.W, self.DW = sim_wh[0], dye_wh[0]
+
+    def info(self, name):
+        from oracle_engine import _Info
+        if name == "dye":
+            return _Info(self.DW, 0, 4, 0, self.drows, self.dye_halo)
+        return _Info(self.W, 0, 2 if name == "velocity" else 1, 0, self.rows, self.halo)
+
+    def view(self, name):
+        import torch
+        fi = self.info(name)
+        return torch.zeros((fi.rows + 2 * fi.halo, 1, 1))
+
+    def stream_ctx(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def close(self): pass
+    def curl_vorticity_divergence(self, curl, dt, ext): self.log.append(("curl_vorticity_divergence", 0, ext))
+    def clear(self, value, ext): self.log.append(("clear", 0, ext))
+    def clear_jacobi(self, value, iters, ext): self.log.append(("clear_jacobi", iters, ext))
+    def jacobi(self, iters, ext): self.log.append(("jacobi", iters, ext))
+    def gradsub(self, ext): self.log.append(("gradsub", 0, ext))
+    def advect(self, dt, a, b): self.log.append(("advect", 0, 0))
+
+
+class _RecordingComm:
+    rank, world = 0, 2
+
+    def __init__(self):
+        self.engine = None
+
+    def exchange(self, send_lo, send_hi, recv_lo, recv_hi):
+        pass
+
+
+@pytest.mark.parametrize("halo,iters,sim,dye", [(32, 50, 256, 256), (56, 50, 256, 256), (8, 20, 64, 128), (12, 50, 96, 96),
+                                                (16, 0, 64, 64), (4, 3, 64, 64), (32, 200, 256, 512), (10, 7, 64, 32)])
+def test_native_plan_is_the_hosted_schedule(halo, iters, sim, dye):
+    from fluid_hip import _abi
+    from fluid_hip.stripes import StripeSim
+    comm = _RecordingComm()
+    s = StripeSim(canvas=(256, 256), config={"SIM_RESOLUTION": sim, "DYE_RESOLUTION": dye, "PRESSURE_ITERATIONS": iters},
+                  halo=halo, comm=comm, engine_factory=_RecordingEngine)
+    log = s.engine.log
+    real_exchange = s.exchange
+
+    def exchange(*items):   # record what is asked for, in plan form
+        items = [(n, k) for n, k in items if k > 0]
+        if items:
+            log.append(("exchange", items))
+        real_exchange(*items)
+    s.exchange = exchange
+    s.step(0.016666)
+    native = _abi.stripe_plan(halo, s.engine.dye_halo, iters)
+    assert native == log
+
+
+def test_native_plan_rejects_bad_arguments():
+    from fluid_hip import _abi
+    with pytest.raises(_abi.FluidError):
+        _abi.stripe_plan(3, 3, 10)     # halo < 4
+    with pytest.raises(_abi.FluidError):
+        _abi.stripe_plan(8, 8, -1)

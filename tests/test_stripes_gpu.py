@@ -57,3 +57,79 @@ def test_hip_halo_overflow_raises():
     with pytest.raises(fluid_hip.FluidError) as e:
         run_local_stripes(2, body, canvas=(256, 256), config=cfg, halo=4, device=0)
     assert e.value.status == -5
+
+
+# ---- the NATIVE driver: libfluid_hip.so runs the plan itself (csrc/fluid_stripes.cpp) ------------------------------
+GROUP_CASES = CASES + [
+    ((512, 512), {"SIM_RESOLUTION": 512, "DYE_RESOLUTION": 512, "PRESSURE_ITERATIONS": 50}, 56, 2, 2, "fused"),   # 2 exchanges per step
+    ((512, 512), {"SIM_RESOLUTION": 256, "DYE_RESOLUTION": 256, "PRESSURE_ITERATIONS": 0, "CURL": 0}, 8, 4, 2, "fused"),
+]
+
+
+@pytest.mark.parametrize("canvas,cfg,halo,world,steps,schedule", GROUP_CASES)
+def test_native_group_equals_single_domain_bitwise(canvas, cfg, halo, world, steps, schedule):
+    """fluid_group_step_n: the same plan, windowed kernels and ghost-row addressing as the RCCL driver, the whole stripe
+    set in this process with device-to-device copies for the exchanges — bitwise equal to the single-domain run"""
+    import fluid_hip
+    from fluid_hip.stripes import StripeGroup
+    with fluid_hip.FluidSim(canvas=canvas, config=cfg, schedule=schedule, random=fluid_hip.mulberry32(9)) as one:
+        one.multipleSplats(6)
+        one.step(0.016666, steps)
+        want = one.fields()
+    g = StripeGroup(world, canvas=canvas, config=cfg, halo=halo, schedule=schedule, random=fluid_hip.mulberry32(9))
+    try:
+        g.multipleSplats(6)
+        g.step(0.016666, steps)
+        g.sync()
+        g.check_halo()
+        for k in S.FIELDS:
+            got = g.read(k)
+            assert got.shape == want[k].shape
+            assert np.array_equal(got, want[k]), k
+        plan = fluid_hip._abi.stripe_plan(halo, g.engines[0].info("dye").halo, cfg["PRESSURE_ITERATIONS"])
+        assert g.exchanges == steps * sum(1 for op in plan if op[0] == "exchange")
+    finally:
+        g.close()
+
+
+def test_native_group_halo_overflow_raises():
+    import fluid_hip
+    from fluid_hip.stripes import StripeGroup
+    g = StripeGroup(2, canvas=(256, 256), config={"SIM_RESOLUTION": 64, "DYE_RESOLUTION": 64, "PRESSURE_ITERATIONS": 4}, halo=4)
+    try:
+        g.splat(0.5, 0.5, 0.0, 90000.0, (1, 1, 1))
+        g.step(0.016666)
+        with pytest.raises(fluid_hip.FluidError) as e:
+            g.check_halo()
+        assert e.value.status == -5
+    finally:
+        g.close()
+
+
+def test_stripe_without_communicator_fails_loudly():
+    import fluid_hip
+    from fluid_hip.stripes import StripeGroup
+    g = StripeGroup(2, canvas=(256, 256), config={"SIM_RESOLUTION": 64, "DYE_RESOLUTION": 64}, halo=8)
+    try:
+        with pytest.raises(fluid_hip.FluidError) as e:
+            g.engines[0].step_n(1, 0.016666, g.config)     # a lone stripe cannot step: no RCCL communicator
+        assert e.value.status == -7
+    finally:
+        g.close()
+
+
+def test_rccl_communicator_and_stream_ordered_self_exchange():
+    """RCCL resolved at run time, ncclCommInitRank, and a grouped ncclSend/ncclRecv pair ordered on the context
+    stream between two kernels.  One rank is all a single-GPU box can host; the N-rank run is bench.py --gpus N."""
+    import fluid_hip
+    from fluid_hip.stripes import HipStripeEngine, new_comm_id
+    from fluid_hip import _abi
+    e = HipStripeEngine((64, 64), (64, 64), 0, 1, 0, _abi.SCHED_FUSED, 0)
+    try:
+        e.use_own_stream()
+        e.comm_init(new_comm_id())
+        e.comm_selftest(1 << 18)
+        e.step_n(2, 0.016666, fluid_hip.DEFAULT_CONFIG)   # parts == 1: the whole-domain step, unaffected by the communicator
+        e.sync()
+    finally:
+        e.close()

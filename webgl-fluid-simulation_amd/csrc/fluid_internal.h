@@ -1,0 +1,106 @@
+// fluid_internal.h — what fluid_solver.cpp (fields, passes, whole-domain step) and fluid_stripes.cpp (the
+// multi-GPU stripe plan, RCCL ghost-row exchange) share.  Internal; the public boundary is include/fluid_hip.h.
+#pragma once
+#include "../../include/fluid_hip.h"
+#include "fluid_kernels.h"
+
+#include <string>
+
+enum PassId { P_CURL, P_VORT, P_DIV, P_CLEAR, P_JACOBI, P_GRADSUB, P_ADVV, P_ADVD, P_COUNT };
+
+struct fluid_ctx {
+    fluid_desc desc{};
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // local windows (sim grid, dye grid); rows include the ghost rows of a stripe
+    fluid::Win sim{}, dye{};
+    int sim_row0 = 0, sim_rows = 0, dye_row0 = 0, dye_rows = 0, dye_halo = 0;
+
+    float2* vel[2] = { nullptr, nullptr };   // velocity.read / velocity.write
+    float* prs[2] = { nullptr, nullptr };    // pressure.read / pressure.write
+    float4* dyeb[2] = { nullptr, nullptr };  // dye.read / dye.write
+    float* div = nullptr;
+    float* curl = nullptr;
+    unsigned int* miss = nullptr;  // advection taps that fell outside the window
+
+    bool timing = false;
+    hipEvent_t ev[P_COUNT + 1] = {};
+    double acc_ms[P_COUNT] = {};
+    double acc_total = 0;
+    int acc_steps = 0, acc_jacobi_launches = 0;
+
+    // stripe driver (fluid_stripes.cpp): RCCL communicator of the stripe set, exchange bookkeeping
+    void* comm = nullptr;          // ncclComm_t, rank == desc.part, nranks == desc.parts
+    hipEvent_t ev_group[2] = { nullptr, nullptr };  // in-process stripe group: rows ready / copies landed
+    long exchanges = 0;
+
+    int fail(int code, const std::string& what)
+    {
+        err = what;
+        return code;
+    }
+    int hip(hipError_t e, const char* what)
+    {
+        if (e == hipSuccess) return FLUID_OK;
+        err = std::string(what) + ": " + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? FLUID_ERR_OOM : FLUID_ERR_HIP;
+    }
+};
+
+#define CK(expr)                                   \
+    do {                                           \
+        int _rc = (expr);                          \
+        if (_rc != FLUID_OK) return _rc;           \
+    } while (0)
+#define HIPCK(ctx, expr) CK((ctx)->hip((expr), #expr))
+
+namespace fluid_impl {
+
+struct FieldRef {
+    void* ptr;
+    const fluid::Win* win;
+    int row0, rows, halo, nc;
+};
+int field_ref(fluid_ctx* c, int field, FieldRef* f);
+
+// per-pass device time (fluid_set_timing): events on the context stream around each pass group
+struct Timer {
+    fluid_ctx* c;
+    int idx = 0;
+    explicit Timer(fluid_ctx* ctx) : c(ctx)
+    {
+        if (c->timing) (void)hipEventRecord(c->ev[0], c->stream);
+    }
+    void mark(int pass)  // closes `pass`: time since the previous mark is charged to it
+    {
+        if (!c->timing) return;
+        (void)hipEventRecord(c->ev[1], c->stream);
+        (void)hipEventSynchronize(c->ev[1]);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
+        c->acc_ms[pass] += ms;
+        c->acc_total += ms;
+        (void)hipEventRecord(c->ev[0], c->stream);
+    }
+};
+
+int pass_curl(fluid_ctx* c, int ext);
+int pass_vorticity(fluid_ctx* c, float curl, float dt, int ext);
+int pass_divergence(fluid_ctx* c, int ext);
+int pass_curl_vort_div(fluid_ctx* c, float curl, float dt, int ext, Timer* t);
+int pass_clear(fluid_ctx* c, float value, int ext);
+int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launches);
+int pass_clear_jacobi(fluid_ctx* c, float value, int iters, int ext_out, int* launches);
+int pass_gradsub(fluid_ctx* c, int ext);
+int pass_advect_velocity(fluid_ctx* c, float dt, float dissipation, int ext);
+int pass_advect_dye(fluid_ctx* c, float dt, float dissipation);
+int pass_advect(fluid_ctx* c, float dt, float vel_diss, float dye_diss, Timer* t);
+
+// fluid_stripes.cpp
+int stripe_step_n(fluid_ctx* c, int n, float dt, const fluid_params* P);  // this rank's stripe, exchanges over RCCL
+void stripes_release(fluid_ctx* c);                                       // frees the communicator (fluid_destroy)
+
+}  // namespace fluid_impl

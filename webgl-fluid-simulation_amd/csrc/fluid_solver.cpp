@@ -6,7 +6,7 @@
 // (script.js:1441-1455), and the row-stripe window used by the multi-GPU driver.
 // There is NO CPU path here: without a HIP device fluid_create() fails.
 #include "../../include/fluid_hip.h"
-#include "fluid_kernels.h"
+#include "fluid_internal.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -16,59 +16,11 @@
 #include <vector>
 
 using namespace fluid;
+using namespace fluid_impl;
 
 namespace {
-
 thread_local std::string g_create_error;
-
-
-enum PassId { P_CURL, P_VORT, P_DIV, P_CLEAR, P_JACOBI, P_GRADSUB, P_ADVV, P_ADVD, P_COUNT };
-
 }  // namespace
-
-struct fluid_ctx {
-    fluid_desc desc{};
-    int device = 0;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    std::string err;
-
-    // local windows (sim grid, dye grid); rows include the ghost rows of a stripe
-    Win sim{}, dye{};
-    int sim_row0 = 0, sim_rows = 0, dye_row0 = 0, dye_rows = 0, dye_halo = 0;
-
-    float2* vel[2] = { nullptr, nullptr };   // velocity.read / velocity.write
-    float* prs[2] = { nullptr, nullptr };    // pressure.read / pressure.write
-    float4* dyeb[2] = { nullptr, nullptr };  // dye.read / dye.write
-    float* div = nullptr;
-    float* curl = nullptr;
-    unsigned int* miss = nullptr;  // advection taps that fell outside the window
-
-    bool timing = false;
-    hipEvent_t ev[P_COUNT + 1] = {};
-    double acc_ms[P_COUNT] = {};
-    double acc_total = 0;
-    int acc_steps = 0, acc_jacobi_launches = 0;
-
-    int fail(int code, const std::string& what)
-    {
-        err = what;
-        return code;
-    }
-    int hip(hipError_t e, const char* what)
-    {
-        if (e == hipSuccess) return FLUID_OK;
-        err = std::string(what) + ": " + hipGetErrorString(e);
-        return e == hipErrorOutOfMemory ? FLUID_ERR_OOM : FLUID_ERR_HIP;
-    }
-};
-
-#define CK(expr)                                   \
-    do {                                           \
-        int _rc = (expr);                          \
-        if (_rc != FLUID_OK) return _rc;           \
-    } while (0)
-#define HIPCK(ctx, expr) CK((ctx)->hip((expr), #expr))
 
 namespace {
 
@@ -156,25 +108,9 @@ int check_ext(fluid_ctx* c, int ext, int need_in)
     return FLUID_OK;
 }
 
-struct Timer {
-    fluid_ctx* c;
-    int idx = 0;
-    explicit Timer(fluid_ctx* ctx) : c(ctx)
-    {
-        if (c->timing) (void)hipEventRecord(c->ev[0], c->stream);
-    }
-    void mark(int pass)  // closes `pass`: time since the previous mark is charged to it
-    {
-        if (!c->timing) return;
-        (void)hipEventRecord(c->ev[1], c->stream);
-        (void)hipEventSynchronize(c->ev[1]);
-        float ms = 0;
-        (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
-        c->acc_ms[pass] += ms;
-        c->acc_total += ms;
-        (void)hipEventRecord(c->ev[0], c->stream);
-    }
-};
+}  // namespace
+
+namespace fluid_impl {
 
 // ---- passes -------------------------------------------------------------------------------------
 int pass_curl(fluid_ctx* c, int ext)
@@ -327,8 +263,12 @@ int pass_advect(fluid_ctx* c, float dt, float vel_diss, float dye_diss, Timer* t
     return FLUID_OK;
 }
 
-// step(dt), script.js:1231-1294 — whole-domain contexts (a stripe is driven pass by pass from the host,
-// with ghost-row exchanges in between)
+}  // namespace fluid_impl
+
+namespace {
+
+// step(dt), script.js:1231-1294 — whole-domain contexts (a stripe runs the plan of fluid_stripes.cpp, with
+// ghost-row exchanges between the pass groups)
 int step_once(fluid_ctx* c, float dt, const fluid_params* P)
 {
     Timer t(c);
@@ -351,11 +291,9 @@ int step_once(fluid_ctx* c, float dt, const fluid_params* P)
     return FLUID_OK;
 }
 
-struct FieldRef {
-    void* ptr;
-    const Win* win;
-    int row0, rows, halo, nc;
-};
+}  // namespace
+
+namespace fluid_impl {
 
 int field_ref(fluid_ctx* c, int field, FieldRef* f)
 {
@@ -371,7 +309,7 @@ int field_ref(fluid_ctx* c, int field, FieldRef* f)
     return FLUID_OK;
 }
 
-}  // namespace
+}  // namespace fluid_impl
 
 // ================================================================================================
 extern "C" {
@@ -388,6 +326,7 @@ const char* fluid_error_string(int status)
     case FLUID_ERR_OOM: return "out of device memory";
     case FLUID_ERR_HALO: return "advection back-trace left the stripe's ghost rows";
     case FLUID_ERR_UNSUPPORTED: return "unsupported";
+    case FLUID_ERR_COMM: return "RCCL unavailable / failed, or stripe without communicator";
     default: return "unknown status";
     }
 }
@@ -454,6 +393,7 @@ int fluid_destroy(fluid_ctx* c)
     if (!c) return FLUID_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    stripes_release(c);
     free_fields(c);
     if (c->miss) (void)hipFree(c->miss);
     for (auto& e : c->ev)
@@ -564,9 +504,9 @@ int fluid_step_n(fluid_ctx* c, int n, float dt, const fluid_params* P)
 {
     if (!c || !P) return FLUID_ERR_INVALID;
     if (n < 0) return c->fail(FLUID_ERR_INVALID, "negative step count");
-    if (c->desc.parts != 1) return c->fail(FLUID_ERR_UNSUPPORTED, "a stripe context is stepped pass by pass by the host driver");
     if (P->iterations < 0) return c->fail(FLUID_ERR_INVALID, "negative PRESSURE_ITERATIONS");
     HIPCK(c, hipSetDevice(c->device));
+    if (c->desc.parts != 1) return stripe_step_n(c, n, dt, P);  // ghost-row exchanges over RCCL (fluid_stripes.cpp)
     for (int k = 0; k < n; k++) CK(step_once(c, dt, P));
     return FLUID_OK;
 }

@@ -13,7 +13,7 @@ PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("FLUID_HIP_LIB") or os.path.join(PKG_DIR, "libfluid_hip.so")
 
 FLUID_OK = 0
-ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_OOM, ERR_HALO, ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6
+ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_OOM, ERR_HALO, ERR_UNSUPPORTED, ERR_COMM = -1, -2, -3, -4, -5, -6, -7
 VELOCITY, PRESSURE, DIVERGENCE, CURL, DYE = 0, 1, 2, 3, 4
 FIELD_IDS = {"velocity": VELOCITY, "pressure": PRESSURE, "divergence": DIVERGENCE, "curl": CURL, "dye": DYE}
 FIELD_CHANNELS = {VELOCITY: 2, PRESSURE: 1, DIVERGENCE: 1, CURL: 1, DYE: 4}
@@ -44,6 +44,16 @@ class Timings(C.Structure):
                                          "advect_velocity_ms", "advect_dye_ms", "total_ms")] + \
                [("jacobi_launches", C.c_int), ("steps", C.c_int)]
 
+
+class StripeOp(C.Structure):
+    _fields_ = [("kind", C.c_int), ("iters", C.c_int), ("ext", C.c_int), ("n_items", C.c_int), ("field", C.c_int * 2), ("rows", C.c_int * 2)]
+
+
+class CommId(C.Structure):
+    _fields_ = [("bytes", C.c_char * 128)]
+
+
+OP_EXCHANGE, OP_CURL_VORT_DIV, OP_CLEAR, OP_CLEAR_JACOBI, OP_JACOBI, OP_GRADSUB, OP_ADVECT = range(7)
 
 # every symbol include/fluid_hip.h declares: name -> (restype, argtypes)
 _CTX = C.c_void_p
@@ -82,6 +92,13 @@ SYMBOLS = {
     "fluid_halo_unpack": (_I, [_CTX, _I, _I, _I, C.c_void_p]),
     "fluid_field_device_ptr": (_I, [_CTX, _I, C.POINTER(C.c_void_p)]),
     "fluid_halo_check": (_I, [_CTX]),
+    "fluid_stripe_plan": (_I, [_I, _I, _I, C.POINTER(StripeOp), _I, C.POINTER(_I)]),
+    "fluid_comm_set_library": (_I, [C.c_char_p]),
+    "fluid_comm_unique_id": (_I, [C.POINTER(CommId)]),
+    "fluid_comm_init": (_I, [_CTX, C.POINTER(CommId)]),
+    "fluid_comm_selftest": (_I, [_CTX, _I]),
+    "fluid_exchange_count": (C.c_long, [_CTX]),
+    "fluid_group_step_n": (_I, [C.POINTER(_CTX), _I, _I, _F, C.POINTER(Params)]),
     "fluid_set_timing": (_I, [_CTX, _I]),
     "fluid_get_timings": (_I, [_CTX, C.POINTER(Timings)]),
 }
@@ -124,10 +141,42 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the header and the library disagree
             fn.restype = res
             fn.argtypes = args
-        if L.fluid_abi_version() != 1:
+        if L.fluid_abi_version() != 2:
             raise FluidError(ERR_UNSUPPORTED, "ABI version mismatch")
         _lib = L
+        _point_at_torch_rccl(L)
     return _lib
+
+
+def _point_at_torch_rccl(L):
+    """If torch is in the process, its bundled librccl.so is (or will be) mapped next to its bundled HIP runtime:
+    hand that file to libfluid_hip so both use ONE RCCL on ONE runtime.  Otherwise the system librccl.so.1."""
+    import sys
+    t = sys.modules.get("torch")
+    if t is None or os.environ.get("FLUID_RCCL_LIB"):
+        return
+    cand = os.path.join(os.path.dirname(t.__file__), "lib", "librccl.so")
+    if os.path.exists(cand):
+        L.fluid_comm_set_library(cand.encode())
+
+
+def stripe_plan(halo: int, dye_halo: int, iterations: int):
+    """the native per-step plan as a list of tuples: ("exchange", [(field, rows), ...]) or (kind, iters, ext)"""
+    L = lib()
+    n = C.c_int(0)
+    check(None, L.fluid_stripe_plan(halo, dye_halo, iterations, None, 0, C.byref(n)))
+    ops = (StripeOp * n.value)()
+    check(None, L.fluid_stripe_plan(halo, dye_halo, iterations, ops, n.value, C.byref(n)))
+    names = {OP_CURL_VORT_DIV: "curl_vorticity_divergence", OP_CLEAR: "clear", OP_CLEAR_JACOBI: "clear_jacobi",
+             OP_JACOBI: "jacobi", OP_GRADSUB: "gradsub", OP_ADVECT: "advect"}
+    fields = {v: k for k, v in FIELD_IDS.items()}
+    out = []
+    for op in ops:
+        if op.kind == OP_EXCHANGE:
+            out.append(("exchange", [(fields[op.field[i]], op.rows[i]) for i in range(op.n_items)]))
+        else:
+            out.append((names[op.kind], op.iters, op.ext))
+    return out
 
 
 def check(ctx, status: int):

@@ -30,6 +30,14 @@ raises instead of returning a wrong field.
 
 The compute engine is injectable (`engine_factory`) so the host logic here can be exercised on CPU
 by the tests with the oracle as the engine; the default engine is the HIP C ABI and nothing else.
+
+Two drivers run this schedule on the HIP engine:
+  * NATIVE (default under torch.distributed's nccl backend): libfluid_hip.so executes the whole plan itself —
+    `fluid_step_n` on the stripe context, ncclSend/ncclRecv issued from C++ on the context stream (csrc/
+    fluid_stripes.cpp, `fluid_stripe_plan` is the same schedule as `StripeSim.step` below and is held to it by
+    tests/test_stripes_cpu.py).  torch.distributed only carries the 128-byte ncclUniqueId at start-up.
+  * HOSTED (`native=False`, and always for the CPU/oracle engine): this module calls the passes one by one and
+    exchanges through `comm.exchange` (torch.distributed batch_isend_irecv, or LocalComm mailboxes).
 """
 from __future__ import annotations
 
@@ -136,6 +144,35 @@ class HipStripeEngine:
     def sync(self): self._ck(self.lib.fluid_sync(self.ctx))
     def check_halo(self): self._ck(self.lib.fluid_halo_check(self.ctx))
 
+    # -- native driver: the library runs the plan and the RCCL exchanges itself ---------------------------------
+    def use_own_stream(self):
+        """back to the context's own HIP stream (the native driver does not involve torch streams)"""
+        self._ck(self.lib.fluid_set_stream(self.ctx, None, 0))
+        self._views.clear()
+
+    def comm_init(self, id_bytes: bytes):
+        cid = _abi.CommId()
+        C.memmove(C.byref(cid), id_bytes, 128)
+        self._ck(self.lib.fluid_comm_init(self.ctx, C.byref(cid)))
+
+    def comm_selftest(self, nfloats=1 << 16):
+        self._ck(self.lib.fluid_comm_selftest(self.ctx, nfloats))
+
+    def step_n(self, n, dt, config):
+        p = _abi.Params(float(config["CURL"]), float(config["PRESSURE"]), int(config["PRESSURE_ITERATIONS"]),
+                        float(config["VELOCITY_DISSIPATION"]), float(config["DENSITY_DISSIPATION"]))
+        self._ck(self.lib.fluid_step_n(self.ctx, int(n), float(dt), C.byref(p)))
+
+    def exchange_count(self):
+        return int(self.lib.fluid_exchange_count(self.ctx))
+
+
+def new_comm_id() -> bytes:
+    """ncclGetUniqueId through libfluid_hip (rank 0 calls this and ships the 128 bytes to the other ranks)"""
+    cid = _abi.CommId()
+    _abi.check(None, _abi.lib().fluid_comm_unique_id(C.byref(cid)))
+    return C.string_at(C.byref(cid), 128)
+
 
 # ---------------------------------------------------------------------------------------------------
 class TorchDistComm:
@@ -148,6 +185,13 @@ class TorchDistComm:
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        self.backend = str(dist.get_backend(group))
+
+    def broadcast_bytes(self, payload: Optional[bytes]) -> bytes:
+        """rank 0's bytes on every rank (start-up only: carries the ncclUniqueId of the native driver)"""
+        box = [payload]
+        self.dist.broadcast_object_list(box, src=0, group=self.group)
+        return box[0]
 
     def exchange(self, send_lo, send_hi, recv_lo, recv_hi):
         """lists of tensors: send_lo[i] -> rank-1 (lands in its recv_hi[i]); send_hi[i] -> rank+1 (its recv_lo[i])"""
@@ -218,7 +262,7 @@ class StripeSim:
 
     def __init__(self, canvas=(512, 512), config: Optional[dict] = None, halo: int = 32, schedule: str = "fused",
                  random: Optional[Callable[[], float]] = None, device: int = 0, comm=None,
-                 engine_factory: Optional[Callable] = None):
+                 engine_factory: Optional[Callable] = None, native: Optional[bool] = None):
         self.canvas = canvas if isinstance(canvas, Canvas) else Canvas(*canvas)
         self.config = dict(DEFAULT_CONFIG)
         if config:
@@ -239,7 +283,18 @@ class StripeSim:
         factory = engine_factory or HipStripeEngine
         self.engine = factory(self.sim_wh, self.dye_wh, self.rank, self.world, self.halo, sched, device)
         self.same_res = self.sim_wh == self.dye_wh
-        self.exchanges = 0
+        self._hosted_exchanges = 0
+        # native driver: default whenever the ranks are connected by RCCL (torch.distributed backend nccl)
+        if native is None:
+            native = (engine_factory is None and isinstance(self.comm, TorchDistComm) and self.comm.backend == "nccl")
+        self.native = bool(native)
+        if self.native:
+            self.engine.use_own_stream()
+            self.engine.comm_init(self.comm.broadcast_bytes(new_comm_id() if self.rank == 0 else None))
+
+    @property
+    def exchanges(self):
+        return self.engine.exchange_count() if self.native else self._hosted_exchanges
 
     def close(self):
         self.engine.close()
@@ -263,7 +318,7 @@ class StripeSim:
             recv_hi.append(t[h + r:h + r + n])
         with e.stream_ctx():
             self.comm.exchange(send_lo, send_hi, recv_lo, recv_hi)
-        self.exchanges += 1
+        self._hosted_exchanges += 1
 
     # -- splat / multipleSplats: script.js:1441-1462, 1427-1439 (every rank evaluates its own rows) ----
     def splat(self, x, y, dx, dy, color):
@@ -288,7 +343,14 @@ class StripeSim:
         return issued
 
     # -- step(dt): script.js:1231-1294 with ghost-row exchanges between pass groups ---------------------
-    def step(self, dt: float):
+    def step(self, dt: float, n: int = 1):
+        if self.native:
+            self.engine.step_n(n, dt, self.config)   # the whole plan, exchanges included, inside libfluid_hip.so
+            return
+        for _ in range(n):
+            self._step_hosted(dt)
+
+    def _step_hosted(self, dt: float):
         c, e, H = self.config, self.engine, self.halo
         iters = int(c["PRESSURE_ITERATIONS"])
         if self.world == 1:
@@ -336,6 +398,79 @@ class StripeSim:
     def write(self, name: str, global_arr: np.ndarray):
         fi = self.engine.info(name)
         self.engine.write(name, np.ascontiguousarray(global_arr[fi.row0:fi.row0 + fi.rows]))
+
+
+class StripeGroup:
+    """The WHOLE stripe set in one process, stepped by libfluid_hip's own plan (`fluid_group_step_n`: the same plan
+    and kernels as the RCCL driver, ghost rows moved by device-to-device copies).  Validation on a single-GPU box."""
+
+    def __init__(self, world: int, canvas=(512, 512), config: Optional[dict] = None, halo: int = 32, schedule: str = "fused",
+                 random: Optional[Callable[[], float]] = None, device: int = 0):
+        self.canvas = canvas if isinstance(canvas, Canvas) else Canvas(*canvas)
+        self.config = dict(DEFAULT_CONFIG)
+        if config:
+            self.config.update(config)
+        self.random = random or _random.random
+        self.world = world
+        sim = getResolution(self.config["SIM_RESOLUTION"], self.canvas.width, self.canvas.height)
+        dye = getResolution(self.config["DYE_RESOLUTION"], self.canvas.width, self.canvas.height)
+        sched = {"passes": _abi.SCHED_PASSES, "fused": _abi.SCHED_FUSED}[schedule]
+        self.engines = [HipStripeEngine((sim["width"], sim["height"]), (dye["width"], dye["height"]), r, world,
+                                        halo if world > 1 else 0, sched, device) for r in range(world)]
+        for e in self.engines:
+            e.use_own_stream()
+        self.lib = _abi.lib()
+
+    def close(self):
+        for e in self.engines:
+            e.close()
+
+    def splat(self, x, y, dx, dy, color):
+        r, g, b = (color["r"], color["g"], color["b"]) if isinstance(color, dict) else color
+        aspect = self.canvas.width / self.canvas.height
+        radius = self.config["SPLAT_RADIUS"] / 100.0
+        if aspect > 1:
+            radius *= aspect
+        for e in self.engines:
+            e.splat(x, y, dx, dy, r, g, b, aspect, radius)
+
+    def multipleSplats(self, amount: int):
+        for _ in range(int(amount)):
+            c = HSVtoRGB(self.random(), 1.0, 1.0)
+            color = {k: v * 0.15 * 10.0 for k, v in c.items()}
+            x = self.random()
+            y = self.random()
+            dx = 1000 * (self.random() - 0.5)
+            dy = 1000 * (self.random() - 0.5)
+            self.splat(x, y, dx, dy, color)
+
+    def step(self, dt: float, n: int = 1):
+        c = self.config
+        p = _abi.Params(float(c["CURL"]), float(c["PRESSURE"]), int(c["PRESSURE_ITERATIONS"]),
+                        float(c["VELOCITY_DISSIPATION"]), float(c["DENSITY_DISSIPATION"]))
+        arr = (C.c_void_p * self.world)(*[e.ctx.value for e in self.engines])
+        rc = self.lib.fluid_group_step_n(arr, self.world, int(n), float(dt), C.byref(p))
+        if rc != _abi.FLUID_OK:
+            for e in self.engines:   # the failing context carries the message
+                msg = self.lib.fluid_last_error(e.ctx)
+                if msg:
+                    raise _abi.FluidError(rc, msg.decode())
+            _abi.check(None, rc)
+
+    def sync(self):
+        for e in self.engines:
+            e.sync()
+
+    def check_halo(self):
+        for e in self.engines:
+            e.check_halo()
+
+    def read(self, name: str) -> np.ndarray:
+        return np.concatenate([e.read(name) for e in self.engines], axis=0)
+
+    @property
+    def exchanges(self):
+        return self.engines[0].exchange_count()
 
 
 def run_local_stripes(world: int, body: Callable[["StripeSim"], object], **kw) -> List[object]:
