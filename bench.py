@@ -85,7 +85,8 @@ def main():
     ap.add_argument("--size", type=int, default=4096, help="grid edge per GPU (BASELINE config: 4096)")
     ap.add_argument("--iters", type=int, default=50, help="PRESSURE_ITERATIONS (BASELINE config: 50)")
     ap.add_argument("--schedule", default="fused", choices=["fused", "passes"])
-    ap.add_argument("--halo", type=int, default=32, help="ghost rows per stripe side (N > 1)")
+    ap.add_argument("--halo", type=int, default=56, help="ghost rows per stripe side (N > 1); >= 54 keeps 50 Jacobi iterations in one "
+                                                        "block: 2 exchanges per step (profiles/r01/stripe_overhead_one_gpu.txt)")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-oracle work for cpu_baseline (0 = skip)")
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the HIP-event instrumented pass")
     ap.add_argument("--stripes", action="store_true", help="use the multi-GPU stripe driver even at N = 1 (exercises that code path)")

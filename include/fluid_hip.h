@@ -198,8 +198,17 @@ typedef struct fluid_stripe_op {
 } fluid_stripe_op;
 
 /* the per-step plan for a stripe with `halo` sim ghost rows, `dye_halo` dye ghost rows and `iterations` Jacobi
- * iterations (pure host logic, no device needed).  ops may be NULL to query *n_ops. */
-int fluid_stripe_plan(int halo, int dye_halo, int iterations, fluid_stripe_op *ops, int max_ops, int *n_ops);
+ * iterations; advect_rows / advect_dye_rows = velocity / dye rows refreshed in front of the advection (pure host
+ * logic, no device needed).  ops may be NULL to query *n_ops. */
+int fluid_stripe_plan(int halo, int dye_halo, int iterations, int advect_rows, int advect_dye_rows,
+                      fluid_stripe_op *ops, int max_ops, int *n_ops);
+/* rows an advection back-trace may span: dt * max|v| + 2 (default 20: dt <= 1/60, script.js:1191, and |v| <= 1000,
+ * script.js:864).  Only that many velocity / dye ghost rows are refreshed before the advection; a longer back-trace
+ * is counted and reported by fluid_halo_check (FLUID_ERR_HALO), never silently served from a stale row. */
+int fluid_set_reach(fluid_ctx *ctx, int rows);
+int fluid_advect_exchange_rows(const fluid_ctx *ctx, int *velocity_rows, int *dye_rows);
+/* interior-first overlap of the exchanges with the curl/vorticity/divergence and advection kernels (default on) */
+int fluid_set_overlap(fluid_ctx *ctx, int enabled);
 
 typedef struct fluid_comm_id {
     char bytes[128]; /* an ncclUniqueId */

@@ -66,8 +66,9 @@ GROUP_CASES = CASES + [
 ]
 
 
+@pytest.mark.parametrize("overlap", [True, False])
 @pytest.mark.parametrize("canvas,cfg,halo,world,steps,schedule", GROUP_CASES)
-def test_native_group_equals_single_domain_bitwise(canvas, cfg, halo, world, steps, schedule):
+def test_native_group_equals_single_domain_bitwise(canvas, cfg, halo, world, steps, schedule, overlap):
     """fluid_group_step_n: the same plan, windowed kernels and ghost-row addressing as the RCCL driver, the whole stripe
     set in this process with device-to-device copies for the exchanges — bitwise equal to the single-domain run"""
     import fluid_hip
@@ -76,7 +77,7 @@ def test_native_group_equals_single_domain_bitwise(canvas, cfg, halo, world, ste
         one.multipleSplats(6)
         one.step(0.016666, steps)
         want = one.fields()
-    g = StripeGroup(world, canvas=canvas, config=cfg, halo=halo, schedule=schedule, random=fluid_hip.mulberry32(9))
+    g = StripeGroup(world, canvas=canvas, config=cfg, halo=halo, schedule=schedule, random=fluid_hip.mulberry32(9), overlap=overlap)
     try:
         g.multipleSplats(6)
         g.step(0.016666, steps)
@@ -102,6 +103,45 @@ def test_native_group_halo_overflow_raises():
         with pytest.raises(fluid_hip.FluidError) as e:
             g.check_halo()
         assert e.value.status == -5
+    finally:
+        g.close()
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_native_group_back_trace_beyond_reach_is_reported(overlap):
+    """only `reach` ghost rows are refreshed before the advection: a longer back-trace must not be served from a stale
+    (or in-flight) row — it is counted, and check_halo raises"""
+    import fluid_hip
+    from fluid_hip.stripes import StripeGroup
+    cfg = {"SIM_RESOLUTION": 256, "DYE_RESOLUTION": 256, "PRESSURE_ITERATIONS": 10}
+    g = StripeGroup(2, canvas=(256, 256), config=cfg, halo=32, reach=3, overlap=overlap)
+    try:
+        assert g.engines[0].advect_exchange_rows() == (3, 3)
+        g.splat(0.5, 0.5, 0.0, 800.0, (1, 1, 1))      # dt * |v| = 13 rows > reach 3, < halo 32
+        g.step(0.016666)
+        with pytest.raises(fluid_hip.FluidError) as e:
+            g.check_halo()
+        assert e.value.status == -5
+    finally:
+        g.close()
+
+
+def test_native_group_default_reach_covers_the_velocity_clamp():
+    """|v| <= 1000 (script.js:864) and dt <= 1/60 (script.js:1191): 16.7 rows + the bilinear footprint < 20"""
+    import fluid_hip
+    from fluid_hip.stripes import StripeGroup
+    cfg = {"SIM_RESOLUTION": 256, "DYE_RESOLUTION": 256, "PRESSURE_ITERATIONS": 10, "CURL": 0}
+    with fluid_hip.FluidSim(canvas=(256, 256), config=cfg) as one:
+        one.splat(0.5, 0.5, 0.0, 5000.0, (1, 1, 1)); one.splat(0.5, 0.5, 3000.0, -5000.0, (1, 0, 1))
+        one.step(0.016666, 2)
+        want = one.fields()
+    g = StripeGroup(2, canvas=(256, 256), config=cfg, halo=32)
+    try:
+        g.splat(0.5, 0.5, 0.0, 5000.0, (1, 1, 1)); g.splat(0.5, 0.5, 3000.0, -5000.0, (1, 0, 1))
+        g.step(0.016666, 2)
+        g.check_halo()
+        for k in S.FIELDS:
+            assert np.array_equal(g.read(k), want[k]), k
     finally:
         g.close()
 

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Overhead of the stripe decomposition measured on ONE GPU: the same 4096 x 4096 grid as a single domain and as an
+in-process stripe group (fluid_group_step_n: the native plan, ghost-row copies device-to-device) of 2 / 4 / 8
+stripes, overlap on and off.  Same total work on the same device, so time ratio = redundant ghost rows + strip
+launches + exchange bookkeeping (everything except the xGMI link itself).  Usage: tools/bench_group.py [N] [iters] [halo] [tall]"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "webgl-fluid-simulation_amd"))
+
+
+def main():
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    iters = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+    halo = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+    tall = int(sys.argv[4]) if len(sys.argv) > 4 else 1     # grid = N x (N * tall): `tall` stripes of N x N each
+    import fluid_hip
+    from fluid_hip.stripes import StripeGroup
+    cfg = {"SIM_RESOLUTION": N, "DYE_RESOLUTION": N, "PRESSURE_ITERATIONS": iters}
+    steps, warm = 50, 5
+    out = {"grid": [N, N * tall], "halo": halo}
+    canvas = (N, N * tall)
+    with fluid_hip.FluidSim(canvas=canvas, config=cfg, random=fluid_hip.mulberry32(1234)) as one:
+        one.multipleSplats(20)
+        one.step(0.016666, warm); one.sync()
+        t0 = time.perf_counter(); one.step(0.016666, steps); one.sync()
+        out["single_ms"] = round((time.perf_counter() - t0) / steps * 1e3, 4)
+    for world in ((tall,) if tall > 1 else (2, 4, 8)):
+        for overlap in (True, False):
+            g = StripeGroup(world, canvas=canvas, config=cfg, halo=halo, random=fluid_hip.mulberry32(1234), overlap=overlap)
+            try:
+                g.multipleSplats(20)
+                g.step(0.016666, warm); g.sync()
+                t0 = time.perf_counter(); g.step(0.016666, steps); g.sync()
+                ms = (time.perf_counter() - t0) / steps * 1e3
+                g.check_halo()
+                out["group%d_%s_ms" % (world, "overlap" if overlap else "sync")] = round(ms, 4)
+            finally:
+                g.close()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

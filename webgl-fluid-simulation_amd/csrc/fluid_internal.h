@@ -33,9 +33,13 @@ struct fluid_ctx {
     int acc_steps = 0, acc_jacobi_launches = 0;
 
     // stripe driver (fluid_stripes.cpp): RCCL communicator of the stripe set, exchange bookkeeping
-    void* comm = nullptr;          // ncclComm_t, rank == desc.part, nranks == desc.parts
-    hipEvent_t ev_group[2] = { nullptr, nullptr };  // in-process stripe group: rows ready / copies landed
+    void* comm = nullptr;                // ncclComm_t, rank == desc.part, nranks == desc.parts
+    hipStream_t comm_stream = nullptr;   // ghost rows travel here while the interior rows of the next pass compute
+    hipEvent_t ev_ready = nullptr;       // context stream -> comm stream: the rows to send exist
+    hipEvent_t ev_landed = nullptr;      // comm stream -> context stream: the ghost rows have arrived
     long exchanges = 0;
+    int reach = 20;                      // rows an advection back-trace may span (dt*|v| + 2); see fluid_set_reach
+    int overlap = 1;                     // interior-first overlap of exchanges (FLUID_STRIPE_OVERLAP=0 turns it off)
 
     int fail(int code, const std::string& what)
     {
@@ -98,6 +102,15 @@ int pass_gradsub(fluid_ctx* c, int ext);
 int pass_advect_velocity(fluid_ctx* c, float dt, float dissipation, int ext);
 int pass_advect_dye(fluid_ctx* c, float dt, float dissipation);
 int pass_advect(fluid_ctx* c, float dt, float vel_diss, float dye_diss, Timer* t);
+
+// band forms (no ping-pong swap) of the single-kernel passes, for interior-first overlap in the stripe driver
+bool fused_cvd_applies(const fluid_ctx* c);
+bool fused_advect_applies(const fluid_ctx* c);
+void sim_band(const fluid_ctx* c, int ext, int& ga, int& gb);  // owned rows +- ext, clipped to domain and window
+int cvd_band(fluid_ctx* c, float curl, float dt, int ga, int gb);
+void cvd_swap(fluid_ctx* c);
+int advect_both_band(fluid_ctx* c, float dt, float vel_diss, float dye_diss, int ga, int gb, int v0, int v1);
+void advect_both_swap(fluid_ctx* c);
 
 // fluid_stripes.cpp
 int stripe_step_n(fluid_ctx* c, int n, float dt, const fluid_params* P);  // this rank's stripe, exchanges over RCCL

@@ -12,7 +12,12 @@ struct Win {
     int W, H;
     int g0;
     int rows;
+    // Global rows [v0, v1) hold data a GATHER (bilinear fetch) may use: the advection / resample kernels count every
+    // tap outside as a miss.  Normally the whole window; the stripe driver narrows it to the rows that are fresh at
+    // that moment (owned rows while an exchange is in flight, owned + exchanged rows afterwards).
+    int v0, v1;
 };
+inline Win make_win(int W, int H, int g0, int rows) { return Win{ W, H, g0, rows, g0, g0 + rows }; }
 
 // All launchers enqueue on `s` and return hipGetLastError().  Row ranges [ga, gb) are GLOBAL rows.
 hipError_t launch_curl(hipStream_t s, Win w, const float2* vel, float* curl, int ga, int gb);

@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(BX) k_gradsub(Win w, const float* __restrict__
 struct Taps {
     long a, b, c, d;  // array indices of the four taps
     float fx, fy;
-    int miss;  // taps whose row is outside the window (stripe ghost rows exhausted)
+    int miss;  // taps whose row is outside the window's valid rows (stripe ghost rows exhausted)
 };
 
 __device__ __forceinline__ Taps bil_taps(const Win& w, float u, float v)
@@ -158,10 +158,9 @@ __device__ __forceinline__ Taps bil_taps(const Win& w, float u, float v)
     t.fy = y - fj;
     const int i0 = (int)fi, j0 = (int)fj;
     const int ia = clampi(i0, 0, w.W - 1), ib = clampi(i0 + 1, 0, w.W - 1);
-    int la = clampi(j0, 0, w.H - 1) - w.g0, lb = clampi(j0 + 1, 0, w.H - 1) - w.g0;
-    t.miss = 0;
-    if (la < 0 || la >= w.rows) { t.miss++; la = clampi(la, 0, w.rows - 1); }
-    if (lb < 0 || lb >= w.rows) { t.miss++; lb = clampi(lb, 0, w.rows - 1); }
+    const int ja = clampi(j0, 0, w.H - 1), jb = clampi(j0 + 1, 0, w.H - 1);  // CLAMP_TO_EDGE first, in global rows
+    t.miss = (ja < w.v0 || ja >= w.v1) + (jb < w.v0 || jb >= w.v1);         // then: is that row fresh in this window?
+    const int la = clampi(ja - w.g0, 0, w.rows - 1), lb = clampi(jb - w.g0, 0, w.rows - 1);
     t.a = (long)la * w.W + ia;
     t.b = (long)la * w.W + ib;
     t.c = (long)lb * w.W + ia;

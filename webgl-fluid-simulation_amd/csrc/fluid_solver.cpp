@@ -59,8 +59,8 @@ int set_geometry(fluid_ctx* c, int sw, int sh, int dw, int dh)
     c->dye_row0 = d.part * c->dye_rows;
     c->dye_halo = d.parts > 1 ? (int)(((long)d.halo * dh + sh - 1) / sh) : 0;
     const int sh_halo = d.parts > 1 ? d.halo : 0;
-    c->sim = Win{ sw, sh, c->sim_row0 - sh_halo, c->sim_rows + 2 * sh_halo };
-    c->dye = Win{ dw, dh, c->dye_row0 - c->dye_halo, c->dye_rows + 2 * c->dye_halo };
+    c->sim = make_win(sw, sh, c->sim_row0 - sh_halo, c->sim_rows + 2 * sh_halo);
+    c->dye = make_win(dw, dh, c->dye_row0 - c->dye_halo, c->dye_rows + 2 * c->dye_halo);
     return FLUID_OK;
 }
 
@@ -263,6 +263,39 @@ int pass_advect(fluid_ctx* c, float dt, float vel_diss, float dye_diss, Timer* t
     return FLUID_OK;
 }
 
+// ---- band forms for the stripe driver: one row band of a single-kernel pass, WITHOUT the ping-pong swap, so that a
+//      pass can run as "interior rows while the ghost rows are in flight, then the strips next to them" ----
+bool fused_cvd_applies(const fluid_ctx* c) { return c->desc.schedule == FLUID_SCHED_FUSED && fused_supported(c->sim); }
+
+bool fused_advect_applies(const fluid_ctx* c)
+{
+    return c->desc.schedule == FLUID_SCHED_FUSED && c->sim.W == c->dye.W && c->sim.H == c->dye.H;
+}
+
+void sim_band(const fluid_ctx* c, int ext, int& ga, int& gb) { row_range(c->sim, c->sim_row0, c->sim_rows, ext, ga, gb); }
+
+int cvd_band(fluid_ctx* c, float curl, float dt, int ga, int gb)
+{
+    return c->hip(launch_curl_vort_div(c->stream, c->sim, c->vel[0], c->curl, c->vel[1], c->div, curl, dt, ga, gb), "curl_vort_div");
+}
+
+void cvd_swap(fluid_ctx* c) { std::swap(c->vel[0], c->vel[1]); }
+
+int advect_both_band(fluid_ctx* c, float dt, float vel_diss, float dye_diss, int ga, int gb, int v0, int v1)
+{
+    Win w = c->sim;  // dye grid == sim grid: one window serves both gathers
+    w.v0 = v0;
+    w.v1 = v1;
+    return c->hip(launch_advect_both(c->stream, w, c->vel[0], c->vel[1], c->dyeb[0], c->dyeb[1], dt, vel_diss, dye_diss, ga, gb, c->miss),
+                  "advect");
+}
+
+void advect_both_swap(fluid_ctx* c)
+{
+    std::swap(c->vel[0], c->vel[1]);
+    std::swap(c->dyeb[0], c->dyeb[1]);
+}
+
 }  // namespace fluid_impl
 
 namespace {
@@ -413,7 +446,7 @@ int fluid_resize(fluid_ctx* c, int sw, int sh, int dw, int dh)
     const bool sim_changed = (sw != osim.W || sh != osim.H), dye_changed = (dw != odye.W || dh != odye.H);
     // resizeDoubleFBO (script.js:1116-1126): read <- bilinear copy of the old read, write <- fresh zero texture
     if (dye_changed) {
-        const Win nd{ dw, dh, 0, dh };
+        const Win nd = make_win(dw, dh, 0, dh);
         float4 *nr = nullptr, *nw = nullptr;
         HIPCK(c, hipMalloc((void**)&nr, cells(nd) * sizeof(float4)));
         HIPCK(c, hipMalloc((void**)&nw, cells(nd) * sizeof(float4)));
@@ -426,7 +459,7 @@ int fluid_resize(fluid_ctx* c, int sw, int sh, int dw, int dh)
         c->dyeb[1] = nw;
     }
     if (sim_changed) {
-        const Win ns{ sw, sh, 0, sh };
+        const Win ns = make_win(sw, sh, 0, sh);
         float2 *nr = nullptr, *nw = nullptr;
         HIPCK(c, hipMalloc((void**)&nr, cells(ns) * sizeof(float2)));
         HIPCK(c, hipMalloc((void**)&nw, cells(ns) * sizeof(float2)));

@@ -14,11 +14,17 @@
 //     curl -> vorticity -> divergence      (ghost rows out to H - 3)
 //     clear + D0 Jacobi iterations; while iterations remain: exchange pressure, next block (D <= H - 3 each)
 //     gradient subtract
-//     exchange { velocity H rows, dye Hd rows }
+//     exchange { velocity A rows, dye Ad rows }     (A = the rows an advection back-trace may span, fluid_set_reach)
 //     advect velocity + dye
 //
 // With H = 32 and 50 iterations: 3 exchanges per step; H >= 54: 2.  Every recomputed ghost row is the same
 // arithmetic on the same inputs as its owner's, so the decomposed result is BITWISE equal to the single-domain run.
+//
+// Overlap: the exchanges in front of the two single-kernel pass groups (curl/vorticity/divergence, advection) run on
+// a second HIP stream while the context stream computes the INTERIOR rows of that pass — the rows whose inputs are
+// all owned — and only the thin strips next to the ghost rows wait for the transfer (events both ways).  The
+// advection kernels count every tap outside the rows that are fresh for that launch, so a back-trace longer than
+// the reach is reported (FLUID_ERR_HALO) instead of reading a row that is still in flight.
 //
 // RCCL is loaded at run time (dlopen): the single-GPU path does not depend on it, and a process that already
 // holds an RCCL (PyTorch bundles one) shares that copy instead of pulling in a second HIP runtime.
@@ -64,9 +70,10 @@ void push_pass(std::vector<fluid_stripe_op>& ops, int kind, int iters, int ext)
     ops.push_back(op);
 }
 
-int build_plan(int halo, int dye_halo, int iterations, std::vector<fluid_stripe_op>& ops)
+int build_plan(int halo, int dye_halo, int iterations, int advect_rows, int advect_dye_rows, std::vector<fluid_stripe_op>& ops)
 {
     if (halo < 4 || dye_halo < 1 || iterations < 0) return FLUID_ERR_INVALID;
+    if (advect_rows < 1 || advect_rows > halo || advect_dye_rows < 1 || advect_dye_rows > dye_halo) return FLUID_ERR_INVALID;
     const int H = halo;
     // pressure blocks: divergence is valid H-3 rows out and iteration k of a block of d needs it d-k+e rows out
     // -> d <= H-3; the last block also leaves e = 1 valid ghost row (gradient subtract reads pressure one row out)
@@ -90,9 +97,25 @@ int build_plan(int halo, int dye_halo, int iterations, std::vector<fluid_stripe_
         }
     }
     push_pass(ops, FLUID_OP_GRADSUB, 0, 0);
-    push_exchange(ops, FLUID_VELOCITY, H, FLUID_DYE, dye_halo);
+    push_exchange(ops, FLUID_VELOCITY, advect_rows, FLUID_DYE, advect_dye_rows);
     push_pass(ops, FLUID_OP_ADVECT, 0, 0);
     return FLUID_OK;
+}
+
+// rows refreshed in front of the advection: the reach of a back-trace (one more when the dye grid differs from the
+// sim grid: the dye pass samples the NEW velocity bilinearly, so that is advected one ghost row out), and the same
+// distance in dye rows
+void advect_rows(const fluid_ctx* c, int* vel_rows, int* dye_rows)
+{
+    const bool same = c->sim.W == c->dye.W && c->sim.H == c->dye.H;
+    int va = c->reach + (same ? 0 : 1);
+    if (va > c->desc.halo) va = c->desc.halo;
+    long vd = same ? va : ((long)c->reach * c->dye.H + c->sim.H - 1) / c->sim.H + 1;
+    if (vd > c->dye_halo) vd = c->dye_halo;
+    if (vd < 1) vd = 1;
+    if (va < 1) va = 1;
+    *vel_rows = va;
+    *dye_rows = (int)vd;
 }
 
 int run_pass(fluid_ctx* c, const fluid_stripe_op& op, float dt, const fluid_params* P)
@@ -203,9 +226,22 @@ int nccl_fail(fluid_ctx* c, const Rccl* R, ncclResult_t e, const char* what)
         if (_e != ncclSuccess) return nccl_fail(c, R, _e, #expr); \
     } while (0)
 
-// one batched neighbour exchange on the context stream: kernels before it have produced the owned rows it sends,
-// kernels after it read the ghost rows it fills (stream order)
-int rccl_exchange(fluid_ctx* c, const fluid_stripe_op& op)
+// ---- exchanges -------------------------------------------------------------------------------------------------
+// An exchange is begun (transfers enqueued on the comm stream, after everything the context stream has produced so
+// far) and ended (the context stream waits for the ghost rows).  Between the two the context stream may compute
+// whatever does not read the ghost rows in flight.  begin + end back to back is the plain synchronous exchange.
+int ensure_comm_stream(fluid_ctx* c)
+{
+    if (c->comm_stream) return FLUID_OK;
+    HIPCK(c, hipSetDevice(c->device));
+    HIPCK(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    HIPCK(c, hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+    HIPCK(c, hipEventCreateWithFlags(&c->ev_landed, hipEventDisableTiming));
+    if (const char* e = getenv("FLUID_STRIPE_OVERLAP")) c->overlap = atoi(e) != 0;
+    return FLUID_OK;
+}
+
+int rccl_exchange_begin(fluid_ctx* c, const fluid_stripe_op& op)
 {
     const Rccl* R = rccl(nullptr);
     if (!R || !c->comm) return c->fail(FLUID_ERR_COMM, "stripe context has no communicator (fluid_comm_init)");
@@ -213,66 +249,165 @@ int rccl_exchange(fluid_ctx* c, const fluid_stripe_op& op)
     const int rank = c->desc.part, world = c->desc.parts;
     Rows rows[2];
     for (int i = 0; i < op.n_items; i++) CK(rows_of(c, op.field[i], op.rows[i], &rows[i]));
+    HIPCK(c, hipEventRecord(c->ev_ready, c->stream));
+    HIPCK(c, hipStreamWaitEvent(c->comm_stream, c->ev_ready, 0));
     NCCLCK(c, R, R->GroupStart());
     // per peer, sends and receives are issued in item order on both sides, so they pair up
     if (rank > 0)
         for (int i = 0; i < op.n_items; i++) {
-            NCCLCK(c, R, R->Send(rows[i].send_lo, rows[i].count, ncclFloat, rank - 1, comm, c->stream));
-            NCCLCK(c, R, R->Recv(rows[i].recv_lo, rows[i].count, ncclFloat, rank - 1, comm, c->stream));
+            NCCLCK(c, R, R->Send(rows[i].send_lo, rows[i].count, ncclFloat, rank - 1, comm, c->comm_stream));
+            NCCLCK(c, R, R->Recv(rows[i].recv_lo, rows[i].count, ncclFloat, rank - 1, comm, c->comm_stream));
         }
     if (rank < world - 1)
         for (int i = 0; i < op.n_items; i++) {
-            NCCLCK(c, R, R->Send(rows[i].send_hi, rows[i].count, ncclFloat, rank + 1, comm, c->stream));
-            NCCLCK(c, R, R->Recv(rows[i].recv_hi, rows[i].count, ncclFloat, rank + 1, comm, c->stream));
+            NCCLCK(c, R, R->Send(rows[i].send_hi, rows[i].count, ncclFloat, rank + 1, comm, c->comm_stream));
+            NCCLCK(c, R, R->Recv(rows[i].recv_hi, rows[i].count, ncclFloat, rank + 1, comm, c->comm_stream));
         }
     NCCLCK(c, R, R->GroupEnd());
+    HIPCK(c, hipEventRecord(c->ev_landed, c->comm_stream));
     c->exchanges++;
     return FLUID_OK;
 }
 
-// the same exchange between stripe contexts that live in ONE process (the whole stripe set on one or several
-// devices, driven by one host thread): device-to-device copies ordered with events.  This is how the plan and the
-// windowed kernels are validated bit for bit on a single-GPU box; bench.py --gpus N uses the RCCL path.
-int group_exchange(fluid_ctx** cs, int n, const fluid_stripe_op& op)
+int rccl_exchange_end(fluid_ctx* c)
 {
-    // 1. every stripe's producers are done before anyone copies from it
+    HIPCK(c, hipStreamWaitEvent(c->stream, c->ev_landed, 0));
+    return FLUID_OK;
+}
+
+// The same exchange between stripe contexts that live in ONE process (the whole stripe set, driven by one host
+// thread): device-to-device copies on each context's comm stream, ordered with the same two events per context.
+// This is how the plan, the interior / strip split and the windowed kernels are validated bit for bit on a
+// single-GPU box; bench.py --gpus N uses the RCCL path.
+int group_exchange_begin(fluid_ctx** cs, int n, const fluid_stripe_op& op)
+{
     for (int r = 0; r < n; r++) {
         HIPCK(cs[r], hipSetDevice(cs[r]->device));
-        HIPCK(cs[r], hipEventRecord(cs[r]->ev_group[0], cs[r]->stream));
+        HIPCK(cs[r], hipEventRecord(cs[r]->ev_ready, cs[r]->stream));
     }
     for (int r = 0; r < n; r++) {
         fluid_ctx* c = cs[r];
         HIPCK(c, hipSetDevice(c->device));
-        if (r > 0) HIPCK(c, hipStreamWaitEvent(c->stream, cs[r - 1]->ev_group[0], 0));
-        if (r < n - 1) HIPCK(c, hipStreamWaitEvent(c->stream, cs[r + 1]->ev_group[0], 0));
+        HIPCK(c, hipStreamWaitEvent(c->comm_stream, c->ev_ready, 0));
+        if (r > 0) HIPCK(c, hipStreamWaitEvent(c->comm_stream, cs[r - 1]->ev_ready, 0));
+        if (r < n - 1) HIPCK(c, hipStreamWaitEvent(c->comm_stream, cs[r + 1]->ev_ready, 0));
         for (int i = 0; i < op.n_items; i++) {
             Rows me, lo, hi;
             CK(rows_of(c, op.field[i], op.rows[i], &me));
             if (r > 0) {
                 CK(rows_of(cs[r - 1], op.field[i], op.rows[i], &lo));
-                HIPCK(c, hipMemcpyAsync(me.recv_lo, lo.send_hi, me.count * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+                HIPCK(c, hipMemcpyAsync(me.recv_lo, lo.send_hi, me.count * sizeof(float), hipMemcpyDeviceToDevice, c->comm_stream));
             }
             if (r < n - 1) {
                 CK(rows_of(cs[r + 1], op.field[i], op.rows[i], &hi));
-                HIPCK(c, hipMemcpyAsync(me.recv_hi, hi.send_lo, me.count * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+                HIPCK(c, hipMemcpyAsync(me.recv_hi, hi.send_lo, me.count * sizeof(float), hipMemcpyDeviceToDevice, c->comm_stream));
             }
         }
-        HIPCK(c, hipEventRecord(c->ev_group[1], c->stream));
+        HIPCK(c, hipEventRecord(c->ev_landed, c->comm_stream));
         c->exchanges++;
-    }
-    // 2. nobody overwrites rows a neighbour is still copying from
-    for (int r = 0; r < n; r++) {
-        fluid_ctx* c = cs[r];
-        HIPCK(c, hipSetDevice(c->device));
-        if (r > 0) HIPCK(c, hipStreamWaitEvent(c->stream, cs[r - 1]->ev_group[1], 0));
-        if (r < n - 1) HIPCK(c, hipStreamWaitEvent(c->stream, cs[r + 1]->ev_group[1], 0));
     }
     return FLUID_OK;
 }
 
+int group_exchange_end(fluid_ctx** cs, int n)
+{
+    // own ghost rows have landed, and no neighbour is still copying out of rows this stripe may overwrite next
+    for (int r = 0; r < n; r++) {
+        fluid_ctx* c = cs[r];
+        HIPCK(c, hipSetDevice(c->device));
+        HIPCK(c, hipStreamWaitEvent(c->stream, c->ev_landed, 0));
+        if (r > 0) HIPCK(c, hipStreamWaitEvent(c->stream, cs[r - 1]->ev_landed, 0));
+        if (r < n - 1) HIPCK(c, hipStreamWaitEvent(c->stream, cs[r + 1]->ev_landed, 0));
+    }
+    return FLUID_OK;
+}
+
+// ---- interior-first forms of the two single-kernel pass groups ----------------------------------------------------
+// rows of the band [ga, gb) that do not depend on ghost rows when every output row reads `dep` rows on each side
+struct Split {
+    int ga, gb;  // whole band
+    int ia, ib;  // interior
+};
+
+Split split_band(const fluid_ctx* c, int ext, int dep)
+{
+    Split s;
+    sim_band(c, ext, s.ga, s.gb);
+    const int r0 = c->sim_row0, r1 = c->sim_row0 + c->sim_rows;
+    s.ia = c->desc.part > 0 ? r0 + dep : s.ga;                   // rank 0 has no lower neighbour: its low rows are interior
+    s.ib = c->desc.part < c->desc.parts - 1 ? r1 - dep : s.gb;
+    if (s.ia > s.ib) s.ia = s.ib = s.ga;                         // stripe thinner than 2 * dep: no interior
+    return s;
+}
+
+int exchanged_reach(const fluid_ctx* c)  // velocity rows the exchange in front of the advection refreshes
+{
+    int va, vd;
+    advect_rows(c, &va, &vd);
+    return va;
+}
+
+bool overlap_ok(const fluid_ctx* c, const fluid_stripe_op& pass)
+{
+    if (!c->overlap) return false;
+    if (pass.kind == FLUID_OP_CURL_VORT_DIV) return fused_cvd_applies(c) && c->sim_rows > 6;
+    if (pass.kind == FLUID_OP_ADVECT) return fused_advect_applies(c) && c->sim_rows > 2 * exchanged_reach(c);
+    return false;
+}
+
+int pass_interior(fluid_ctx* c, const fluid_stripe_op& op, float dt, const fluid_params* P)
+{
+    if (op.kind == FLUID_OP_CURL_VORT_DIV) {
+        const Split s = split_band(c, op.ext, 3);  // a divergence row reads velocity 3 rows up and down
+        return s.ib > s.ia ? cvd_band(c, P->curl, dt, s.ia, s.ib) : FLUID_OK;
+    }
+    const Split s = split_band(c, 0, exchanged_reach(c));  // an advected row gathers from at most `reach` rows away ...
+    const int r0 = c->sim_row0, r1 = c->sim_row0 + c->sim_rows;
+    // ... and is held to it: only the owned rows count as fresh for this launch
+    return s.ib > s.ia ? advect_both_band(c, dt, P->velocity_dissipation, P->density_dissipation, s.ia, s.ib, r0, r1) : FLUID_OK;
+}
+
+int pass_strips(fluid_ctx* c, const fluid_stripe_op& op, float dt, const fluid_params* P)
+{
+    if (op.kind == FLUID_OP_CURL_VORT_DIV) {
+        const Split s = split_band(c, op.ext, 3);
+        if (s.ia > s.ga) CK(cvd_band(c, P->curl, dt, s.ga, s.ia));
+        if (s.gb > s.ib) CK(cvd_band(c, P->curl, dt, s.ib, s.gb));
+        cvd_swap(c);
+        return FLUID_OK;
+    }
+    const int A = exchanged_reach(c);
+    const Split s = split_band(c, 0, A);
+    const int v0 = c->sim_row0 - A, v1 = c->sim_row0 + c->sim_rows + A;  // owned + the rows just exchanged
+    if (s.ia > s.ga) CK(advect_both_band(c, dt, P->velocity_dissipation, P->density_dissipation, s.ga, s.ia, v0, v1));
+    if (s.gb > s.ib) CK(advect_both_band(c, dt, P->velocity_dissipation, P->density_dissipation, s.ib, s.gb, v0, v1));
+    advect_both_swap(c);
+    return FLUID_OK;
+}
+
+// whole pass after a synchronous exchange; the advection windows are narrowed to the rows that were refreshed
+int pass_whole(fluid_ctx* c, const fluid_stripe_op& op, float dt, const fluid_params* P)
+{
+    if (op.kind != FLUID_OP_ADVECT) return run_pass(c, op, dt, P);
+    const Win sim = c->sim, dye = c->dye;
+    int va, vd;
+    advect_rows(c, &va, &vd);
+    c->sim.v0 = c->sim_row0 - va;
+    c->sim.v1 = c->sim_row0 + c->sim_rows + va;
+    c->dye.v0 = c->dye_row0 - vd;
+    c->dye.v1 = c->dye_row0 + c->dye_rows + vd;
+    const int rc = run_pass(c, op, dt, P);
+    c->sim.v0 = sim.v0; c->sim.v1 = sim.v1;
+    c->dye.v0 = dye.v0; c->dye.v1 = dye.v1;
+    return rc;
+}
+
 int plan_for(fluid_ctx* c, const fluid_params* P, std::vector<fluid_stripe_op>& ops)
 {
-    if (build_plan(c->desc.halo, c->dye_halo, P->iterations, ops) != FLUID_OK) return c->fail(FLUID_ERR_INVALID, "stripe plan: bad halo / iterations");
+    int va, vd;
+    advect_rows(c, &va, &vd);
+    if (build_plan(c->desc.halo, c->dye_halo, P->iterations, va, vd, ops) != FLUID_OK)
+        return c->fail(FLUID_ERR_INVALID, "stripe plan: bad halo / iterations / reach");
     return FLUID_OK;
 }
 
@@ -284,12 +419,25 @@ int stripe_step_n(fluid_ctx* c, int n, float dt, const fluid_params* P)
 {
     if (!c->comm) return c->fail(FLUID_ERR_COMM, "a stripe context steps with its communicator: call fluid_comm_init first (or drive the "
                                                   "passes and exchanges yourself through fluid_pass_* / fluid_field_device_ptr)");
+    CK(ensure_comm_stream(c));
     std::vector<fluid_stripe_op> ops;
     CK(plan_for(c, P, ops));
     for (int k = 0; k < n; k++)
-        for (const fluid_stripe_op& op : ops) {
-            if (op.kind == FLUID_OP_EXCHANGE) CK(rccl_exchange(c, op));
-            else CK(run_pass(c, op, dt, P));
+        for (size_t i = 0; i < ops.size(); i++) {
+            const fluid_stripe_op& op = ops[i];
+            if (op.kind != FLUID_OP_EXCHANGE) {
+                CK(pass_whole(c, op, dt, P));
+                continue;
+            }
+            CK(rccl_exchange_begin(c, op));
+            if (i + 1 < ops.size() && overlap_ok(c, ops[i + 1])) {
+                CK(pass_interior(c, ops[i + 1], dt, P));  // computes while the ghost rows travel
+                CK(rccl_exchange_end(c));
+                CK(pass_strips(c, ops[i + 1], dt, P));
+                i++;
+            } else {
+                CK(rccl_exchange_end(c));
+            }
         }
     return FLUID_OK;
 }
@@ -301,11 +449,14 @@ void stripes_release(fluid_ctx* c)
         if (R) (void)R->CommDestroy((ncclComm_t)c->comm);
         c->comm = nullptr;
     }
-    for (auto& e : c->ev_group)
-        if (e) {
-            (void)hipEventDestroy(e);
-            e = nullptr;
-        }
+    if (c->comm_stream) {
+        (void)hipStreamSynchronize(c->comm_stream);
+        (void)hipStreamDestroy(c->comm_stream);
+        c->comm_stream = nullptr;
+    }
+    if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
+    if (c->ev_landed) (void)hipEventDestroy(c->ev_landed);
+    c->ev_ready = c->ev_landed = nullptr;
 }
 
 }  // namespace fluid_impl
@@ -313,17 +464,41 @@ void stripes_release(fluid_ctx* c)
 // ================================================================================================================
 extern "C" {
 
-int fluid_stripe_plan(int halo, int dye_halo, int iterations, fluid_stripe_op* ops, int max_ops, int* n_ops)
+int fluid_stripe_plan(int halo, int dye_halo, int iterations, int advect_rows, int advect_dye_rows, fluid_stripe_op* ops, int max_ops,
+                      int* n_ops)
 {
     if (!n_ops) return FLUID_ERR_INVALID;
     std::vector<fluid_stripe_op> v;
-    const int rc = build_plan(halo, dye_halo, iterations, v);
+    const int rc = build_plan(halo, dye_halo, iterations, advect_rows, advect_dye_rows, v);
     if (rc != FLUID_OK) return rc;
     *n_ops = (int)v.size();
     if (ops) {
         if (max_ops < (int)v.size()) return FLUID_ERR_INVALID;
         std::memcpy(ops, v.data(), v.size() * sizeof(fluid_stripe_op));
     }
+    return FLUID_OK;
+}
+
+int fluid_set_reach(fluid_ctx* c, int rows)
+{
+    if (!c) return FLUID_ERR_INVALID;
+    if (rows < 1) return c->fail(FLUID_ERR_INVALID, "reach must be >= 1 row");
+    c->reach = rows;
+    return FLUID_OK;
+}
+
+int fluid_set_overlap(fluid_ctx* c, int enabled)
+{
+    if (!c) return FLUID_ERR_INVALID;
+    CK(ensure_comm_stream(c));
+    c->overlap = enabled != 0;
+    return FLUID_OK;
+}
+
+int fluid_advect_exchange_rows(const fluid_ctx* c, int* velocity_rows, int* dye_rows)
+{
+    if (!c || !velocity_rows || !dye_rows) return FLUID_ERR_INVALID;
+    advect_rows(c, velocity_rows, dye_rows);
     return FLUID_OK;
 }
 
@@ -369,11 +544,12 @@ int fluid_comm_init(fluid_ctx* c, const fluid_comm_id* id)
 
 int fluid_comm_selftest(fluid_ctx* c, int nfloats)
 {
-    // loop a buffer through ncclSend / ncclRecv to THIS rank inside one group, on the context stream, between two
-    // kernels: checks that the library resolves, the communicator works and the transfers are stream-ordered
+    // loop a buffer through ncclSend / ncclRecv to THIS rank inside one group, on the comm stream, fenced by the
+    // same two events as a real exchange, between two kernels of the context stream
     if (!c || nfloats < 1) return FLUID_ERR_INVALID;
     const Rccl* R = rccl(nullptr);
     if (!R || !c->comm) return c->fail(FLUID_ERR_COMM, "no communicator");
+    CK(ensure_comm_stream(c));
     HIPCK(c, hipSetDevice(c->device));
     float *a = nullptr, *b = nullptr;
     HIPCK(c, hipMalloc((void**)&a, nfloats * sizeof(float)));
@@ -382,14 +558,18 @@ int fluid_comm_selftest(fluid_ctx* c, int nfloats)
     do {
         if ((rc = c->hip(launch_fill(c->stream, a, (size_t)nfloats, 1, 3.25f, 0, 0, 0), "fill"))) break;
         if ((rc = c->hip(launch_fill(c->stream, b, (size_t)nfloats, 1, -1.0f, 0, 0, 0), "fill"))) break;
+        if ((rc = c->hip(hipEventRecord(c->ev_ready, c->stream), "record"))) break;
+        if ((rc = c->hip(hipStreamWaitEvent(c->comm_stream, c->ev_ready, 0), "wait"))) break;
         ncclComm_t comm = (ncclComm_t)c->comm;
         const int me = c->desc.part;
         ncclResult_t e;
-        if ((e = R->GroupStart()) != ncclSuccess || (e = R->Send(a, nfloats, ncclFloat, me, comm, c->stream)) != ncclSuccess ||
-            (e = R->Recv(b, nfloats, ncclFloat, me, comm, c->stream)) != ncclSuccess || (e = R->GroupEnd()) != ncclSuccess) {
+        if ((e = R->GroupStart()) != ncclSuccess || (e = R->Send(a, nfloats, ncclFloat, me, comm, c->comm_stream)) != ncclSuccess ||
+            (e = R->Recv(b, nfloats, ncclFloat, me, comm, c->comm_stream)) != ncclSuccess || (e = R->GroupEnd()) != ncclSuccess) {
             rc = nccl_fail(c, R, e, "self send/recv");
             break;
         }
+        if ((rc = c->hip(hipEventRecord(c->ev_landed, c->comm_stream), "record"))) break;
+        if ((rc = c->hip(hipStreamWaitEvent(c->stream, c->ev_landed, 0), "wait"))) break;
         std::vector<float> host(nfloats);
         if ((rc = c->hip(hipMemcpyAsync(host.data(), b, nfloats * sizeof(float), hipMemcpyDeviceToHost, c->stream), "copy"))) break;
         if ((rc = c->hip(hipStreamSynchronize(c->stream), "sync"))) break;
@@ -410,27 +590,38 @@ int fluid_group_step_n(fluid_ctx** cs, int n_ctx, int steps, float dt, const flu
     for (int r = 0; r < n_ctx; r++) {
         if (!cs[r]) return FLUID_ERR_INVALID;
         if (cs[r]->desc.parts != n_ctx || cs[r]->desc.part != r) return cs[r]->fail(FLUID_ERR_INVALID, "group must hold stripes 0..parts-1 in order");
-        if (cs[r]->desc.halo != cs[0]->desc.halo) return cs[r]->fail(FLUID_ERR_INVALID, "stripes of a group share one halo");
+        if (cs[r]->desc.halo != cs[0]->desc.halo || cs[r]->reach != cs[0]->reach || cs[r]->desc.schedule != cs[0]->desc.schedule)
+            return cs[r]->fail(FLUID_ERR_INVALID, "stripes of a group share halo, reach and schedule");
     }
     if (n_ctx == 1) return fluid_step_n(cs[0], steps, dt, P);
-    for (int r = 0; r < n_ctx; r++)
-        for (auto& e : cs[r]->ev_group)
-            if (!e) {
-                HIPCK(cs[r], hipSetDevice(cs[r]->device));
-                HIPCK(cs[r], hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            }
+    for (int r = 0; r < n_ctx; r++) CK(ensure_comm_stream(cs[r]));
     std::vector<fluid_stripe_op> ops;
     CK(plan_for(cs[0], P, ops));
+    auto each = [&](auto&& fn) {
+        for (int r = 0; r < n_ctx; r++) {
+            const int rc_dev = cs[r]->hip(hipSetDevice(cs[r]->device), "hipSetDevice");
+            if (rc_dev != FLUID_OK) return rc_dev;
+            const int rc = fn(cs[r]);
+            if (rc != FLUID_OK) return rc;
+        }
+        return (int)FLUID_OK;
+    };
     for (int k = 0; k < steps; k++)
-        for (const fluid_stripe_op& op : ops) {
-            if (op.kind == FLUID_OP_EXCHANGE) {
-                const int rc = group_exchange(cs, n_ctx, op);
-                if (rc != FLUID_OK) return rc;
+        for (size_t i = 0; i < ops.size(); i++) {
+            const fluid_stripe_op& op = ops[i];
+            if (op.kind != FLUID_OP_EXCHANGE) {
+                CK(each([&](fluid_ctx* c) { return pass_whole(c, op, dt, P); }));
+                continue;
+            }
+            CK(group_exchange_begin(cs, n_ctx, op));
+            if (i + 1 < ops.size() && overlap_ok(cs[0], ops[i + 1])) {
+                const fluid_stripe_op& next = ops[i + 1];
+                CK(each([&](fluid_ctx* c) { return pass_interior(c, next, dt, P); }));
+                CK(group_exchange_end(cs, n_ctx));
+                CK(each([&](fluid_ctx* c) { return pass_strips(c, next, dt, P); }));
+                i++;
             } else {
-                for (int r = 0; r < n_ctx; r++) {
-                    HIPCK(cs[r], hipSetDevice(cs[r]->device));
-                    CK(run_pass(cs[r], op, dt, P));
-                }
+                CK(group_exchange_end(cs, n_ctx));
             }
         }
     return FLUID_OK;

@@ -92,7 +92,10 @@ SYMBOLS = {
     "fluid_halo_unpack": (_I, [_CTX, _I, _I, _I, C.c_void_p]),
     "fluid_field_device_ptr": (_I, [_CTX, _I, C.POINTER(C.c_void_p)]),
     "fluid_halo_check": (_I, [_CTX]),
-    "fluid_stripe_plan": (_I, [_I, _I, _I, C.POINTER(StripeOp), _I, C.POINTER(_I)]),
+    "fluid_stripe_plan": (_I, [_I, _I, _I, _I, _I, C.POINTER(StripeOp), _I, C.POINTER(_I)]),
+    "fluid_set_reach": (_I, [_CTX, _I]),
+    "fluid_advect_exchange_rows": (_I, [_CTX, C.POINTER(_I), C.POINTER(_I)]),
+    "fluid_set_overlap": (_I, [_CTX, _I]),
     "fluid_comm_set_library": (_I, [C.c_char_p]),
     "fluid_comm_unique_id": (_I, [C.POINTER(CommId)]),
     "fluid_comm_init": (_I, [_CTX, C.POINTER(CommId)]),
@@ -160,13 +163,16 @@ def _point_at_torch_rccl(L):
         L.fluid_comm_set_library(cand.encode())
 
 
-def stripe_plan(halo: int, dye_halo: int, iterations: int):
-    """the native per-step plan as a list of tuples: ("exchange", [(field, rows), ...]) or (kind, iters, ext)"""
+def stripe_plan(halo: int, dye_halo: int, iterations: int, advect_rows: int = None, advect_dye_rows: int = None):
+    """the native per-step plan as a list of tuples: ("exchange", [(field, rows), ...]) or (kind, iters, ext);
+    advect_rows / advect_dye_rows default to the full ghost depth (what the hosted driver exchanges)"""
     L = lib()
     n = C.c_int(0)
-    check(None, L.fluid_stripe_plan(halo, dye_halo, iterations, None, 0, C.byref(n)))
+    va = halo if advect_rows is None else advect_rows
+    vd = dye_halo if advect_dye_rows is None else advect_dye_rows
+    check(None, L.fluid_stripe_plan(halo, dye_halo, iterations, va, vd, None, 0, C.byref(n)))
     ops = (StripeOp * n.value)()
-    check(None, L.fluid_stripe_plan(halo, dye_halo, iterations, ops, n.value, C.byref(n)))
+    check(None, L.fluid_stripe_plan(halo, dye_halo, iterations, va, vd, ops, n.value, C.byref(n)))
     names = {OP_CURL_VORT_DIV: "curl_vorticity_divergence", OP_CLEAR: "clear", OP_CLEAR_JACOBI: "clear_jacobi",
              OP_JACOBI: "jacobi", OP_GRADSUB: "gradsub", OP_ADVECT: "advect"}
     fields = {v: k for k, v in FIELD_IDS.items()}

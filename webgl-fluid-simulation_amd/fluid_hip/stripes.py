@@ -166,6 +166,14 @@ class HipStripeEngine:
     def exchange_count(self):
         return int(self.lib.fluid_exchange_count(self.ctx))
 
+    def set_reach(self, rows): self._ck(self.lib.fluid_set_reach(self.ctx, int(rows)))
+    def set_overlap(self, on): self._ck(self.lib.fluid_set_overlap(self.ctx, 1 if on else 0))
+
+    def advect_exchange_rows(self):
+        a, b = C.c_int(0), C.c_int(0)
+        self._ck(self.lib.fluid_advect_exchange_rows(self.ctx, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
 
 def new_comm_id() -> bytes:
     """ncclGetUniqueId through libfluid_hip (rank 0 calls this and ships the 128 bytes to the other ranks)"""
@@ -262,7 +270,8 @@ class StripeSim:
 
     def __init__(self, canvas=(512, 512), config: Optional[dict] = None, halo: int = 32, schedule: str = "fused",
                  random: Optional[Callable[[], float]] = None, device: int = 0, comm=None,
-                 engine_factory: Optional[Callable] = None, native: Optional[bool] = None):
+                 engine_factory: Optional[Callable] = None, native: Optional[bool] = None, reach: Optional[int] = None,
+                 overlap: Optional[bool] = None):
         self.canvas = canvas if isinstance(canvas, Canvas) else Canvas(*canvas)
         self.config = dict(DEFAULT_CONFIG)
         if config:
@@ -290,6 +299,10 @@ class StripeSim:
         self.native = bool(native)
         if self.native:
             self.engine.use_own_stream()
+            if reach is not None:
+                self.engine.set_reach(reach)
+            if overlap is not None:
+                self.engine.set_overlap(overlap)
             self.engine.comm_init(self.comm.broadcast_bytes(new_comm_id() if self.rank == 0 else None))
 
     @property
@@ -405,7 +418,8 @@ class StripeGroup:
     and kernels as the RCCL driver, ghost rows moved by device-to-device copies).  Validation on a single-GPU box."""
 
     def __init__(self, world: int, canvas=(512, 512), config: Optional[dict] = None, halo: int = 32, schedule: str = "fused",
-                 random: Optional[Callable[[], float]] = None, device: int = 0):
+                 random: Optional[Callable[[], float]] = None, device: int = 0, reach: Optional[int] = None,
+                 overlap: Optional[bool] = None):
         self.canvas = canvas if isinstance(canvas, Canvas) else Canvas(*canvas)
         self.config = dict(DEFAULT_CONFIG)
         if config:
@@ -419,6 +433,10 @@ class StripeGroup:
                                         halo if world > 1 else 0, sched, device) for r in range(world)]
         for e in self.engines:
             e.use_own_stream()
+            if reach is not None:
+                e.set_reach(reach)
+            if overlap is not None:
+                e.set_overlap(overlap)
         self.lib = _abi.lib()
 
     def close(self):
