@@ -445,45 +445,55 @@ __device__ __forceinline__ Quad quad_of_raw(float4 v)
     return q;
 }
 
-// One Jacobi iteration over the wave's RY rows (pressureShader script.js:881-888, operand order of line 887:
-// ((L + R) + B) + T - div) * 0.25).  11 VALU instructions per row of four texels.  `box` is this iteration's
-// mailbox slot.
+// One texel row of a Jacobi iteration (pressureShader script.js:881-888, operand order of line 887:
+// ((L + R) + B) + T - div) * 0.25): 11 VALU instructions for the lane's four texels.
+template <bool EDGE>
+__device__ __forceinline__ Quad jacobi_row(const Quad C, Quad T, Quad B, const Quad D, int gj, int H, bool at_left, bool at_right)
+{
+    float L = from_left_lane(C.o.y);   // column 4*lane - 1 = the left lane's c3
+    float R = from_right_lane(C.o.x);  // column 4*lane + 4 = the right lane's c0
+    if (EDGE) {  // CLAMP_TO_EDGE: an off-domain neighbour is the centre texel
+        if (at_left) L = C.o.x;
+        if (at_right) R = C.o.y;
+        if (gj == 0) B = C;
+        if (gj == H - 1) T = C;
+    }
+    const v2f quarter = v2f{ 0.25f, 0.25f };
+    v2f h_o;
+    h_o.x = L + C.i.x;                                               // texel 0: left + c1
+    h_o.y = C.i.y + R;                                               // texel 3: c2 + right
+    const v2f h_i = C.o + __builtin_shufflevector(C.i, C.i, 1, 0);   // texels 1, 2: c0 + c2, c3 + c1
+    Quad n;
+    n.o = (h_o + B.o + T.o - D.o) * quarter;
+    n.i = (h_i + B.i + T.i - D.i) * quarter;
+    return n;
+}
+
+// One Jacobi iteration over the wave's RY rows, updated in place.  The wave's first and last row need a row of the
+// neighbouring waves (LDS mailbox, `box` is this iteration's slot); every other row only needs the wave's own
+// registers.  So: publish, sweep the inner rows (one delay register carries the old row below), THEN meet the other
+// waves at the barrier and finish the two outer rows — the mailbox round trip hides behind RY - 2 rows of arithmetic.
 template <int NW, int RY, bool EDGE>
 __device__ __forceinline__ void jacobi_sweep(Quad (&P)[RY], const Quad (&D)[RY], float4 (*box)[2][64], int wv, int lane, int gy,
                                              int H, bool at_left, bool at_right)
 {
-    // publish this wave's first and last row, fetch the neighbours' adjacent rows
+    static_assert(RY >= 3, "a wave needs an inner row");
     box[wv][0][lane] = raw_of(P[0]);
     box[wv][1][lane] = raw_of(P[RY - 1]);
+    const Quad old0 = P[0], old1 = P[1];
+    Quad below = old0;
+#pragma unroll
+    for (int r = 1; r < RY - 1; r++) {
+        const Quad C = P[r];
+        P[r] = jacobi_row<EDGE>(C, P[r + 1], below, D[r], gy + r, H, at_left, at_right);
+        below = C;
+    }
     __syncthreads();
     // unconditional b128 reads: the first/last wave reads its own mailbox, which only feeds the stale apron
-    Quad below = quad_of_raw(box[wv > 0 ? wv - 1 : 0][1][lane]);
-    const Quad above = quad_of_raw(box[wv < NW - 1 ? wv + 1 : NW - 1][0][lane]);
-    const v2f quarter = v2f{ 0.25f, 0.25f };
-#pragma unroll
-    for (int r = 0; r < RY; r++) {
-        const Quad C = P[r];
-        Quad T = (r < RY - 1) ? P[r + 1] : above;
-        Quad B = below;
-        float L = from_left_lane(C.o.y);   // column 4*lane - 1 = the left lane's c3
-        float R = from_right_lane(C.o.x);  // column 4*lane + 4 = the right lane's c0
-        if (EDGE) {  // CLAMP_TO_EDGE: an off-domain neighbour is the centre texel
-            const int gj = gy + r;
-            if (at_left) L = C.o.x;
-            if (at_right) R = C.o.y;
-            if (gj == 0) B = C;
-            if (gj == H - 1) T = C;
-        }
-        v2f h_o;
-        h_o.x = L + C.i.x;                                               // texel 0: left + c1
-        h_o.y = C.i.y + R;                                               // texel 3: c2 + right
-        const v2f h_i = C.o + __builtin_shufflevector(C.i, C.i, 1, 0);   // texels 1, 2: c0 + c2, c3 + c1
-        Quad n;
-        n.o = (h_o + B.o + T.o - D[r].o) * quarter;
-        n.i = (h_i + B.i + T.i - D[r].i) * quarter;
-        below = C;
-        P[r] = n;
-    }
+    const Quad lo = quad_of_raw(box[wv > 0 ? wv - 1 : 0][1][lane]);
+    const Quad hi = quad_of_raw(box[wv < NW - 1 ? wv + 1 : NW - 1][0][lane]);
+    P[RY - 1] = jacobi_row<EDGE>(P[RY - 1], hi, below, D[RY - 1], gy + RY - 1, H, at_left, at_right);
+    P[0] = jacobi_row<EDGE>(old0, old1, lo, D[0], gy, H, at_left, at_right);
 }
 
 template <int NW, int RY, int HX, int HY, bool EDGE>
@@ -570,6 +580,9 @@ __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb(Win w
 // Each stage shrinks the exact region by one ring, so the tile carries a 3-row / 4-column apron
 // (4 keeps float4 alignment) and stores only its interior.  The per-texel arithmetic is the same
 // device code as the single-pass kernels, so the result is bit-identical to running them in turn.
+#ifndef VD_WAVES_PER_EU
+#define VD_WAVES_PER_EU 2
+#endif
 template <int NW, int RY>
 struct VortDiv {
     static constexpr int TX = 256, TY = NW * RY, AX = 4, AY = 3;
@@ -713,7 +726,7 @@ __device__ __forceinline__ void vort_div_body(const Win& w, const float2* __rest
 }
 
 template <int NW, int RY>
-__global__ void __launch_bounds__(64 * NW) k_curl_vort_div(Win w, const float2* __restrict__ vel, float* __restrict__ curl_out,
+__global__ void __launch_bounds__(64 * NW, VD_WAVES_PER_EU) k_curl_vort_div(Win w, const float2* __restrict__ vel, float* __restrict__ curl_out,
                                                             float2* __restrict__ vel_out, float* __restrict__ div_out,
                                                             float curl_strength, float dt, int ga, int gb, int ys, int nx, int ny,
                                                             int remap)
