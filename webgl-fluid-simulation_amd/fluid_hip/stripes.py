@@ -303,7 +303,16 @@ class StripeSim:
                 self.engine.set_reach(reach)
             if overlap is not None:
                 self.engine.set_overlap(overlap)
-            self.engine.comm_init(self.comm.broadcast_bytes(new_comm_id() if self.rank == 0 else None))
+            payload = None
+            if self.rank == 0:   # a failure on rank 0 must reach every rank, or they would wait in the broadcast forever
+                try:
+                    payload = new_comm_id()
+                except _abi.FluidError as ex:
+                    payload = b"ERR:" + str(ex).encode()
+            payload = self.comm.broadcast_bytes(payload)
+            if payload[:4] == b"ERR:":
+                raise _abi.FluidError(_abi.ERR_COMM, payload[4:].decode())
+            self.engine.comm_init(payload)
 
     @property
     def exchanges(self):
