@@ -17,6 +17,9 @@
 //   passes             ["curl","vorticity",...] run single passes instead of step()
 //   resizeTo           {SIM_RESOLUTION, DYE_RESOLUTION} -> initFramebuffers() again after the steps
 //   steps, dt, timing, noDump
+//   frames             [{dt, events: [{type, offsetX, offsetY, touches: [{identifier, pageX, pageY}], code, key}]}]:
+//                      per frame the events go through the reference's OWN listeners (script.js:1464-1530) and then
+//                      the body of its update() runs with that dt (updateColors, applyInputs, step unless PAUSED)
 (function () {
   function load(src) {
     return new Promise(function (ok, no) {
@@ -175,6 +178,30 @@
       for (var i = 0; i < (P.steps || 0); i++) {
         var t0 = performance.now(); step(dt);
         if (P.timing) { sync(); ms.push(performance.now() - t0); }
+      }
+      // input replay: synthetic events carry exactly the properties the reference's handlers read
+      function fire(ev) {
+        var e = new Event(ev.type, { bubbles: true, cancelable: true });
+        ['offsetX', 'offsetY', 'code', 'key'].forEach(function (n) { if (ev[n] !== undefined) Object.defineProperty(e, n, { value: ev[n] }); });
+        if (ev.touches) {
+          Object.defineProperty(e, 'targetTouches', { value: ev.touches });
+          Object.defineProperty(e, 'changedTouches', { value: ev.touches });
+        }
+        var onWindow = ev.type === 'mouseup' || ev.type === 'touchend' || ev.type === 'keydown';
+        (onWindow ? window : canvas).dispatchEvent(e);
+      }
+      if (P.frames) {
+        colorUpdateTimer = 0.0;
+        pointers.length = 0; pointers.push(new pointerPrototype());
+        splatStack.length = 0;
+        out.frameLog = [];
+        P.frames.forEach(function (f) {
+          (f.events || []).forEach(fire);
+          var n0 = splatLog.length;
+          updateColors(f.dt); applyInputs();                 // update(), script.js:1176-1186, with a prescribed dt
+          if (!config.PAUSED) step(f.dt);
+          out.frameLog.push({ splats: splatLog.length - n0, paused: !!config.PAUSED, pointers: pointers.length, draws: draws.length });
+        });
       }
       if (P.resizeTo) {
         for (k in P.resizeTo) config[k] = P.resizeTo[k];

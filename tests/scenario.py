@@ -14,7 +14,9 @@ FIELDS = ("velocity", "pressure", "divergence", "curl", "dye")
 
 
 def golden_names(prefix=""):
-    return sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
+    """driver / single-pass scenarios (the input-replay fixture has its own test: tests/test_input_replay.py)"""
+    names = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
+    return [n for n in names if not n.startswith("input_")]
 
 
 def load(name):

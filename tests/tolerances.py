@@ -38,3 +38,6 @@ HIP_VS_ORACLE_ULP_PASSES = 4e-7
 # where grad|curl| ~ 0 (script.js:856-857), so the 1-ulp exp() difference between ocml and glibc in the splats
 # is amplified locally (measured <= 7.7e-6 at 1024^2); with CURL = 0 the step agrees to ~1e-7.
 HIP_VS_ORACLE_STEP = 3e-5
+
+# input replay (tests/test_input_replay.py): 16 frames, 14 of them stepped, CURL = 30 -> the 10-step regime above
+INPUT_REPLAY = 1e-3

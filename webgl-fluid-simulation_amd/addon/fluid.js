@@ -20,6 +20,11 @@
 //   multipleSplats(amount)       1427-1439     sim.multipleSplats(amount)
 //   splat(x, y, dx, dy, color)   1441-1455     sim.splat(x, y, dx, dy, color)
 //   correctRadius(radius)        1457-1462     sim.correctRadius(radius)
+//   updateColors(dt)             1207-1217     sim.updateColors(dt)
+//   mouse / touch / key listeners 1464-1530    sim.dispatch(event)   (headless: events are plain objects)
+//   updatePointerDown/Move/UpData 1532-1558    sim.updatePointerDownData / MoveData / UpData
+//   correctDeltaX/Y              1560-1570     sim.correctDeltaX / sim.correctDeltaY
+//   scaleByPixelRatio(input)     1626-1629     sim.scaleByPixelRatio(input)   (options.pixelRatio, default 1)
 //   generateColor()              1565-1571     sim.generateColor()
 //   HSVtoRGB(h, s, v)            1573-1595     HSVtoRGB(h, s, v)
 //   framebufferToTexture(target) 301-307       sim.framebufferToTexture(target)
@@ -207,6 +212,117 @@ function createFluid (options) {
             colorUpdateTimer = wrap(colorUpdateTimer, 0, 1);
             sim.pointers.forEach(p => { p.color = sim.generateColor(); });
         }
+    };
+
+    // ---- input path (SURVEY §8f N2): the reference's DOM listeners, headless --------------------------------
+    const pixelRatio = options.pixelRatio || 1;
+    sim.scaleByPixelRatio = function (input) { return Math.floor(input * pixelRatio); };
+
+    sim.correctDeltaX = function (delta) {
+        const aspectRatio = sim.canvas.width / sim.canvas.height;
+        if (aspectRatio < 1) delta *= aspectRatio;
+        return delta;
+    };
+
+    sim.correctDeltaY = function (delta) {
+        const aspectRatio = sim.canvas.width / sim.canvas.height;
+        if (aspectRatio > 1) delta /= aspectRatio;
+        return delta;
+    };
+
+    sim.updatePointerDownData = function (pointer, id, posX, posY) {
+        pointer.id = id;
+        pointer.down = true;
+        pointer.moved = false;
+        pointer.texcoordX = posX / sim.canvas.width;
+        pointer.texcoordY = 1.0 - posY / sim.canvas.height;
+        pointer.prevTexcoordX = pointer.texcoordX;
+        pointer.prevTexcoordY = pointer.texcoordY;
+        pointer.deltaX = 0;
+        pointer.deltaY = 0;
+        pointer.color = sim.generateColor();
+    };
+
+    sim.updatePointerMoveData = function (pointer, posX, posY) {
+        pointer.prevTexcoordX = pointer.texcoordX;
+        pointer.prevTexcoordY = pointer.texcoordY;
+        pointer.texcoordX = posX / sim.canvas.width;
+        pointer.texcoordY = 1.0 - posY / sim.canvas.height;
+        pointer.deltaX = sim.correctDeltaX(pointer.texcoordX - pointer.prevTexcoordX);
+        pointer.deltaY = sim.correctDeltaY(pointer.texcoordY - pointer.prevTexcoordY);
+        pointer.moved = Math.abs(pointer.deltaX) > 0 || Math.abs(pointer.deltaY) > 0;
+    };
+
+    sim.updatePointerUpData = function (pointer) {
+        pointer.down = false;
+    };
+
+    // One recorded DOM event: { type, offsetX, offsetY } (mouse), { type, touches: [{identifier, pageX, pageY}] }
+    // (touchstart / touchmove: targetTouches; touchend: changedTouches), { type: 'keydown', code, key }.
+    // Same bodies as the listeners of script.js:1464-1530.
+    sim.dispatch = function (e) {
+        const pointers = sim.pointers;
+        switch (e.type) {
+        case 'mousedown': {
+            const posX = sim.scaleByPixelRatio(e.offsetX);
+            const posY = sim.scaleByPixelRatio(e.offsetY);
+            let pointer = pointers.find(p => p.id == -1);
+            if (pointer == null) pointer = new pointerPrototype();
+            sim.updatePointerDownData(pointer, -1, posX, posY);
+            break;
+        }
+        case 'mousemove': {
+            const pointer = pointers[0];
+            if (!pointer.down) return;
+            sim.updatePointerMoveData(pointer, sim.scaleByPixelRatio(e.offsetX), sim.scaleByPixelRatio(e.offsetY));
+            break;
+        }
+        case 'mouseup':
+            sim.updatePointerUpData(pointers[0]);
+            break;
+        case 'touchstart': {
+            const touches = e.touches;
+            while (touches.length >= pointers.length) pointers.push(new pointerPrototype());
+            for (let i = 0; i < touches.length; i++) {
+                sim.updatePointerDownData(pointers[i + 1], touches[i].identifier,
+                    sim.scaleByPixelRatio(touches[i].pageX), sim.scaleByPixelRatio(touches[i].pageY));
+            }
+            break;
+        }
+        case 'touchmove': {
+            const touches = e.touches;
+            for (let i = 0; i < touches.length; i++) {
+                const pointer = pointers[i + 1];
+                if (!pointer.down) continue;
+                sim.updatePointerMoveData(pointer, sim.scaleByPixelRatio(touches[i].pageX), sim.scaleByPixelRatio(touches[i].pageY));
+            }
+            break;
+        }
+        case 'touchend': {
+            const touches = e.touches;
+            for (let i = 0; i < touches.length; i++) {
+                const pointer = pointers.find(p => p.id == touches[i].identifier);
+                if (pointer == null) continue;
+                sim.updatePointerUpData(pointer);
+            }
+            break;
+        }
+        case 'keydown':
+            if (e.code === 'KeyP') sim.config.PAUSED = !sim.config.PAUSED;
+            if (e.key === ' ') sim.splatStack.push(parseInt(random() * 20) + 5);
+            break;
+        default:
+            throw new Error('fluid.js: unknown event type ' + e.type);
+        }
+    };
+
+    // replay a recorded session: frames = [{ dt, events: [...] }]; per frame the events are dispatched and one
+    // update() runs with that frame's dt (clamped like calcDeltaTime)
+    sim.replay = function (frames) {
+        frames.forEach(f => {
+            (f.events || []).forEach(sim.dispatch);
+            sim.update(f.dt);
+        });
     };
 
     sim.calcDeltaTime = function () {

@@ -33,6 +33,8 @@ DEFAULT_CONFIG = {
     "CURL": 30,
     "SPLAT_RADIUS": 0.25,
     "SPLAT_FORCE": 6000,
+    "COLORFUL": True,
+    "COLOR_UPDATE_SPEED": 10,
     "PAUSED": False,
 }
 
@@ -122,6 +124,17 @@ class FieldView:
         return self
 
 
+class Pointer:
+    """pointerPrototype, script.js:87-98"""
+
+    def __init__(self):
+        self.id = -1
+        self.texcoordX = self.texcoordY = self.prevTexcoordX = self.prevTexcoordY = 0.0
+        self.deltaX = self.deltaY = 0.0
+        self.down = self.moved = False
+        self.color = {"r": 30, "g": 0, "b": 300}
+
+
 class FluidSim:
     def __init__(self, canvas: Union[Canvas, Tuple[int, int]] = (512, 512), config: Optional[dict] = None,
                  device: int = 0, schedule: str = "fused", random: Optional[Callable[[], float]] = None):
@@ -132,6 +145,9 @@ class FluidSim:
             self.config.update(config)
         self.random = random or _random.random  # Math.random
         self.splatStack = []
+        self.pointers = [Pointer()]          # script.js:100-102
+        self.pixelRatio = 1.0
+        self._colorUpdateTimer = 0.0
         self._device = device
         self._schedule = SCHEDULES[schedule]
         self._ctx = None
@@ -235,14 +251,110 @@ class FluidSim:
         P = self.params()
         self._check(self._lib.fluid_step_n(self._ctx, int(n), dt, C.byref(P)))
 
-    # -- update(), script.js:1176-1186, without the render: dt clamp (1191), inputs, PAUSED gate ----
+    # -- update(), script.js:1176-1186, without the render: dt clamp (1191), colours, inputs, PAUSED gate ----
     def update(self, wall_dt: float):
         dt = min(wall_dt, 0.016666)
-        if self.splatStack:
-            self.multipleSplats(self.splatStack.pop())
+        self.updateColors(dt)
+        self.applyInputs()
         if not self.config["PAUSED"]:
             self.step(dt)
         return dt
+
+    # -- input path: the reference's listeners, headless ---------------------------------------
+    def updateColors(self, dt: float):                       # script.js:1207-1217
+        if not self.config["COLORFUL"]:
+            return
+        self._colorUpdateTimer += dt * self.config["COLOR_UPDATE_SPEED"]
+        if self._colorUpdateTimer >= 1:
+            self._colorUpdateTimer = math.fmod(self._colorUpdateTimer, 1.0)   # wrap(value, 0, 1), script.js:1603-1607
+            for p in self.pointers:
+                p.color = self.generateColor()
+
+    def applyInputs(self):                                   # script.js:1219-1229
+        if self.splatStack:
+            self.multipleSplats(self.splatStack.pop())
+        for p in self.pointers:
+            if p.moved:
+                p.moved = False
+                self.splatPointer(p)
+
+    def splatPointer(self, pointer):                         # script.js:1421-1425
+        dx = pointer.deltaX * self.config["SPLAT_FORCE"]
+        dy = pointer.deltaY * self.config["SPLAT_FORCE"]
+        self.splat(pointer.texcoordX, pointer.texcoordY, dx, dy, pointer.color)
+
+    def scaleByPixelRatio(self, value: float) -> int:        # script.js:1626-1629
+        return math.floor(value * self.pixelRatio)
+
+    def correctDeltaX(self, delta: float) -> float:          # script.js:1560-1564
+        aspect = self.canvas.width / self.canvas.height
+        return delta * aspect if aspect < 1 else delta
+
+    def correctDeltaY(self, delta: float) -> float:          # script.js:1566-1570
+        aspect = self.canvas.width / self.canvas.height
+        return delta / aspect if aspect > 1 else delta
+
+    def updatePointerDownData(self, pointer, pid, posX, posY):   # script.js:1532-1543
+        pointer.id = pid
+        pointer.down = True
+        pointer.moved = False
+        pointer.texcoordX = posX / self.canvas.width
+        pointer.texcoordY = 1.0 - posY / self.canvas.height
+        pointer.prevTexcoordX = pointer.texcoordX
+        pointer.prevTexcoordY = pointer.texcoordY
+        pointer.deltaX = 0
+        pointer.deltaY = 0
+        pointer.color = self.generateColor()
+
+    def updatePointerMoveData(self, pointer, posX, posY):        # script.js:1545-1553
+        pointer.prevTexcoordX = pointer.texcoordX
+        pointer.prevTexcoordY = pointer.texcoordY
+        pointer.texcoordX = posX / self.canvas.width
+        pointer.texcoordY = 1.0 - posY / self.canvas.height
+        pointer.deltaX = self.correctDeltaX(pointer.texcoordX - pointer.prevTexcoordX)
+        pointer.deltaY = self.correctDeltaY(pointer.texcoordY - pointer.prevTexcoordY)
+        pointer.moved = abs(pointer.deltaX) > 0 or abs(pointer.deltaY) > 0
+
+    def dispatch(self, e: dict):
+        """one recorded DOM event, through the bodies of the reference's listeners (script.js:1464-1530)"""
+        t, ptrs = e["type"], self.pointers
+        if t == "mousedown":
+            pointer = next((p for p in ptrs if p.id == -1), None) or Pointer()
+            self.updatePointerDownData(pointer, -1, self.scaleByPixelRatio(e["offsetX"]), self.scaleByPixelRatio(e["offsetY"]))
+        elif t == "mousemove":
+            if ptrs[0].down:
+                self.updatePointerMoveData(ptrs[0], self.scaleByPixelRatio(e["offsetX"]), self.scaleByPixelRatio(e["offsetY"]))
+        elif t == "mouseup":
+            ptrs[0].down = False
+        elif t == "touchstart":
+            touches = e["touches"]
+            while len(touches) >= len(ptrs):
+                ptrs.append(Pointer())
+            for i, tc in enumerate(touches):
+                self.updatePointerDownData(ptrs[i + 1], tc["identifier"], self.scaleByPixelRatio(tc["pageX"]), self.scaleByPixelRatio(tc["pageY"]))
+        elif t == "touchmove":
+            for i, tc in enumerate(e["touches"]):
+                if ptrs[i + 1].down:
+                    self.updatePointerMoveData(ptrs[i + 1], self.scaleByPixelRatio(tc["pageX"]), self.scaleByPixelRatio(tc["pageY"]))
+        elif t == "touchend":
+            for tc in e["touches"]:
+                pointer = next((p for p in ptrs if p.id == tc["identifier"]), None)
+                if pointer is not None:
+                    pointer.down = False
+        elif t == "keydown":
+            if e.get("code") == "KeyP":
+                self.config["PAUSED"] = not self.config["PAUSED"]
+            if e.get("key") == " ":
+                self.splatStack.append(int(self.random() * 20) + 5)
+        else:
+            raise ValueError("unknown event type %r" % t)
+
+    def replay(self, frames):
+        """frames = [{dt, events}]: dispatch the frame's events, then one update() with its dt"""
+        for f in frames:
+            for e in f.get("events", []):
+                self.dispatch(e)
+            self.update(f["dt"])
 
     def sync(self):
         self._check(self._lib.fluid_sync(self._ctx))
