@@ -47,8 +47,7 @@ def main():
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 50
     if os.environ.get("_TB_CHILD"):
         return child(N, iters)
-    names = ["4x16 h8", "8x8 h8", "8x16 h8", "4x24 h8", "8x12 h12", "8x16 h16", "4x16 h4", "8x8 h4", "8x10 h12/10", "6x16 h16/13",
-             "4x24 h16/13", "8x16 h20/17", "8x11 h12/10", "6x14 h12/10", "8x12 h12/10", "7x12 h8", "8x10 h16/13", "8x12 h16/13", "16x8 h12/10", "16x12 h16/13", "16x12 h20/17", "16x10 h16/13", "16x12 h28/25"]
+    names = ["8x10 h12/10", "8x8 h8", "8x11 h12/10", "8x12 h12/10", "8x12 h16/13", "8x16 h20/17", "16x12 h20/17", "4x24 h16/13"]
     only = [int(x) for x in os.environ.get("TB_VARIANTS", "").split()] or list(range(len(names)))
     for v, name in enumerate(names):
         if v not in only:

@@ -27,6 +27,8 @@ hipError_t launch_divergence(hipStream_t s, Win w, const float2* vel, float* div
 hipError_t launch_clear(hipStream_t s, Win w, const float* p, float* p_out, float value, int ga, int gb);
 hipError_t launch_jacobi(hipStream_t s, Win w, const float* p, const float* div, float* p_out, int ga, int gb);
 hipError_t launch_gradsub(hipStream_t s, Win w, const float* p, const float2* vel, float2* vel_out, int ga, int gb);
+// the same pass, four texels per lane (needs W % 4 == 0: fused_supported)
+hipError_t launch_gradsub4(hipStream_t s, Win w, const float* p, const float2* vel, float2* vel_out, int ga, int gb);
 hipError_t launch_advect_velocity(hipStream_t s, Win w, const float2* vel, float2* out, float dt, float dissipation,
                                   int ga, int gb, unsigned int* miss);
 hipError_t launch_advect_dye(hipStream_t s, Win vw, const float2* vel, Win dw, const float4* dye, float4* out,

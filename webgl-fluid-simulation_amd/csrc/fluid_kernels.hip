@@ -238,26 +238,73 @@ __global__ void __launch_bounds__(BX) k_advect_dye(Win vw, const float2* __restr
 // (script.js:1289: uVelocity sampled at vUv), so one thread advects the velocity texel, stores it, and
 // advects the dye texel with it — the new velocity is not re-read from HBM (48 B/texel instead of 56).
 // Same per-texel arithmetic as the two kernels above, hence the same bits.
+// ROWS texels per thread (consecutive rows, same column), processed stage by stage so that the ROWS independent
+// gathers of a stage are all in flight together: the kernel is a chain of three dependent memory round trips
+// (velocity -> 4 velocity taps -> 4 dye taps) and is latency-bound at one texel per thread.
+struct Fetch2 {
+    float2 a, b, c, d;
+    float fx, fy;
+};
+struct Fetch4 {
+    float4 a, b, c, d;
+    float fx, fy;
+};
+
+template <int ROWS>
 __global__ void __launch_bounds__(BX) k_advect_both(Win w, const float2* __restrict__ vel, float2* __restrict__ vel_out,
                                                      const float4* __restrict__ dye, float4* __restrict__ dye_out, float dt,
-                                                     float vel_dissipation, float dye_dissipation, float tsx, float tsy, int ga,
+                                                     float vel_dissipation, float dye_dissipation, float tsx, float tsy, int ga, int gb,
                                                      unsigned int* __restrict__ miss_out)
 {
     const int i = blockIdx.x * BX + threadIdx.x;
-    const int gj = ga + blockIdx.y;
+    const int gj0 = ga + blockIdx.y * ROWS;
     if (i >= w.W) return;
     const float u = ((float)i + 0.5f) / (float)w.W;
-    const float v = ((float)gj + 0.5f) / (float)w.H;
-    const long c = (long)(gj - w.g0) * w.W + i;
+    const float vdecay = 1.0f + vel_dissipation * dt, ddecay = 1.0f + dye_dissipation * dt;
     int miss = 0;
-    const float2 vv = vel[c];
-    const float2 r = bil2(w, vel, u - dt * vv.x * tsx, v - dt * vv.y * tsy, miss);
-    const float vdecay = 1.0f + vel_dissipation * dt;
-    const float2 nv = make_float2(r.x / vdecay, r.y / vdecay);
-    vel_out[c] = nv;
-    const float4 d = bil4(w, dye, u - dt * nv.x * tsx, v - dt * nv.y * tsy, miss);
-    const float ddecay = 1.0f + dye_dissipation * dt;
-    dye_out[c] = make_float4(d.x / ddecay, d.y / ddecay, d.z / ddecay, d.w / ddecay);
+    bool on[ROWS];
+    long c[ROWS];
+    float v[ROWS];
+    float2 vv[ROWS], nv[ROWS];
+#pragma unroll
+    for (int k = 0; k < ROWS; k++) {
+        const int gj = gj0 + k;
+        on[k] = gj < gb;
+        const int gjc = on[k] ? gj : gb - 1;  // a row past the band repeats the last one (loads stay in bounds, nothing stored)
+        v[k] = ((float)gjc + 0.5f) / (float)w.H;
+        c[k] = (long)(gjc - w.g0) * w.W + i;
+        vv[k] = vel[c[k]];
+    }
+    Fetch2 f2[ROWS];
+#pragma unroll
+    for (int k = 0; k < ROWS; k++) {
+        const Taps t = bil_taps(w, u - dt * vv[k].x * tsx, v[k] - dt * vv[k].y * tsy);
+        if (on[k]) miss += t.miss;
+        f2[k].a = vel[t.a]; f2[k].b = vel[t.b]; f2[k].c = vel[t.c]; f2[k].d = vel[t.d];
+        f2[k].fx = t.fx; f2[k].fy = t.fy;
+    }
+    Fetch4 f4[ROWS];
+#pragma unroll
+    for (int k = 0; k < ROWS; k++) {
+        const Fetch2& f = f2[k];
+        const float rx = mixf(mixf(f.a.x, f.b.x, f.fx), mixf(f.c.x, f.d.x, f.fx), f.fy);
+        const float ry = mixf(mixf(f.a.y, f.b.y, f.fx), mixf(f.c.y, f.d.y, f.fx), f.fy);
+        nv[k] = make_float2(rx / vdecay, ry / vdecay);
+        if (on[k]) vel_out[c[k]] = nv[k];
+        const Taps t = bil_taps(w, u - dt * nv[k].x * tsx, v[k] - dt * nv[k].y * tsy);
+        if (on[k]) miss += t.miss;
+        f4[k].a = dye[t.a]; f4[k].b = dye[t.b]; f4[k].c = dye[t.c]; f4[k].d = dye[t.d];
+        f4[k].fx = t.fx; f4[k].fy = t.fy;
+    }
+#pragma unroll
+    for (int k = 0; k < ROWS; k++) {
+        const Fetch4& f = f4[k];
+        const float4 d = make_float4(mixf(mixf(f.a.x, f.b.x, f.fx), mixf(f.c.x, f.d.x, f.fx), f.fy),
+                                     mixf(mixf(f.a.y, f.b.y, f.fx), mixf(f.c.y, f.d.y, f.fx), f.fy),
+                                     mixf(mixf(f.a.z, f.b.z, f.fx), mixf(f.c.z, f.d.z, f.fx), f.fy),
+                                     mixf(mixf(f.a.w, f.b.w, f.fx), mixf(f.c.w, f.d.w, f.fx), f.fy));
+        if (on[k]) dye_out[c[k]] = make_float4(d.x / ddecay, d.y / ddecay, d.z / ddecay, d.w / ddecay);
+    }
     if (miss) atomicAdd(miss_out, (unsigned)miss);
 }
 
@@ -572,6 +619,42 @@ __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb(Win w
 }
 
 // ------------------------------------------------------------------------------------------------
+// K6 gradient subtract, four texels per lane (fused schedule): the per-texel kernel issues six memory instructions for
+// 20 bytes; here a wave moves one 256-texel row segment with five 16-byte loads and two 16-byte stores per lane, the
+// horizontal pressure neighbours come from the lane's own float4 and the adjacent lanes (DPP), and only the two
+// lanes at the segment ends fetch their outside neighbour.  Same subtraction per texel, hence the same bits.
+__global__ void __launch_bounds__(256) k_gradsub4(Win w, const float* __restrict__ p, const float2* __restrict__ vel,
+                                                   float2* __restrict__ vel_out, int ga, int gb)
+{
+    const int lane = threadIdx.x;
+    const int gj = ga + (int)blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int cx = (int)blockIdx.x * 256 + 4 * lane;
+    if (gj >= gb || cx >= w.W) return;  // W % 4 == 0: a lane is either fully inside or fully outside
+    const size_t rowC = (size_t)(gj - w.g0) * (size_t)w.W;
+    const size_t rowT = (size_t)(min(gj + 1, w.H - 1) - w.g0) * (size_t)w.W;
+    const size_t rowB = (size_t)(max(gj - 1, 0) - w.g0) * (size_t)w.W;
+    const float4 C = *reinterpret_cast<const float4*>(p + rowC + cx);
+    const float4 T = *reinterpret_cast<const float4*>(p + rowT + cx);
+    const float4 B = *reinterpret_cast<const float4*>(p + rowB + cx);
+    const float4 va = *reinterpret_cast<const float4*>(vel + rowC + cx);
+    const float4 vb = *reinterpret_cast<const float4*>(vel + rowC + cx + 2);
+    float L = from_left_lane(C.w), R = from_right_lane(C.x);
+    if (lane == 0) L = cx > 0 ? p[rowC + cx - 1] : C.x;                    // CLAMP_TO_EDGE at the domain border
+    if (lane == 63 || cx + 4 >= w.W) R = cx + 4 < w.W ? p[rowC + cx + 4] : C.w;
+    float4 oa, ob;
+    oa.x = va.x - (C.y - L);
+    oa.y = va.y - (T.x - B.x);
+    oa.z = va.z - (C.z - C.x);
+    oa.w = va.w - (T.y - B.y);
+    ob.x = vb.x - (C.w - C.y);
+    ob.y = vb.y - (T.z - B.z);
+    ob.z = vb.z - (R - C.z);
+    ob.w = vb.w - (T.w - B.w);
+    *reinterpret_cast<float4*>(vel_out + rowC + cx) = oa;
+    *reinterpret_cast<float4*>(vel_out + rowC + cx + 2) = ob;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Fused K1 + K2 + K3: curl -> vorticity confinement -> divergence in one trip through HBM
 // (reads velocity once: 8 B/texel; writes curl 4, velocity 8, divergence 4 = 24 B/texel instead of
 // 12 + 20 + 12 = 44).  Same register-tile layout as the Jacobi kernel: lane l of wave wv holds 4
@@ -747,14 +830,17 @@ constexpr int VD_NW = 8, VD_RY = 8;
 // read once); the default is the shape that measured best on MI355X at 4096^2 (profiles/)
 struct TBVariant { int nw, ry, hx, hy, bpc; };
 constexpr TBVariant kTB[] = {
-    {4, 16, 8, 8, 1},   {8, 8, 8, 8, 2},    {8, 16, 8, 8, 1},   {4, 24, 8, 8, 2},   {8, 12, 12, 12, 2}, {8, 16, 16, 16, 1},
-    {4, 16, 4, 4, 1},   {8, 8, 4, 4, 2},    {8, 10, 12, 10, 2}, {6, 16, 16, 13, 2}, {4, 24, 16, 13, 2}, {8, 16, 20, 17, 1},
-    {8, 11, 12, 10, 2}, {6, 14, 12, 10, 2}, {8, 12, 12, 10, 2}, {7, 12, 8, 8, 2},   {8, 10, 16, 13, 2}, {8, 12, 16, 13, 2},
-    {16, 8, 12, 10, 1}, {16, 12, 16, 13, 1}, {16, 12, 20, 17, 1}, {16, 10, 16, 13, 1}, {16, 12, 28, 25, 1},
+    {8, 10, 12, 10, 2},  // 0: default — 112 VGPRs, two workgroups per CU, 50 iterations in 5 launches
+    {8, 8, 8, 8, 2},     // 1: shallow apron, 7 launches (the round's first shape)
+    {8, 11, 12, 10, 2},  // 2
+    {8, 12, 12, 10, 2},  // 3
+    {8, 12, 16, 13, 2},  // 4: 4 launches, 128 VGPRs
+    {8, 16, 20, 17, 1},  // 5: 3 launches, one workgroup per CU
+    {16, 12, 20, 17, 1}, // 6: 3 launches, 16-wave workgroup
+    {4, 24, 16, 13, 2},  // 7: 4 waves x 24 rows
 };
 constexpr int kNumTB = sizeof(kTB) / sizeof(kTB[0]);
-constexpr int kDefaultTB = 8;  // 8 waves x 10 rows, apron 12 x 10: 120 VGPRs (two workgroups per CU), 50 iterations in 5
-                               // launches; best of the table at 4096^2 (profiles/r01/jacobi_variants.txt)
+constexpr int kDefaultTB = 0;  // measured best of the table at 4096^2 (profiles/r01/jacobi_variants.txt, there listed as "8x10 h12/10")
 
 int xcd_remap()  // FLUID_XCD_REMAP: tile order of the Jacobi kernel (A/B knob); bit 0 = XCD-contiguous runs, bit 1 = row-major
 {
@@ -836,6 +922,14 @@ hipError_t launch_gradsub(hipStream_t s, Win w, const float* p, const float2* ve
     return hipGetLastError();
 }
 
+hipError_t launch_gradsub4(hipStream_t s, Win w, const float* p, const float2* vel, float2* vel_out, int ga, int gb)
+{
+    ROWS_OR_RETURN();
+    if (!fused_supported(w)) return hipErrorInvalidValue;
+    k_gradsub4<<<dim3((w.W + 255) / 256, (gb - ga + 3) / 4, 1), dim3(64, 4, 1), 0, s>>>(w, p, vel, vel_out, ga, gb);
+    return hipGetLastError();
+}
+
 hipError_t launch_advect_velocity(hipStream_t s, Win w, const float2* vel, float2* out, float dt, float dissipation, int ga,
                                   int gb, unsigned int* miss)
 {
@@ -860,8 +954,16 @@ hipError_t launch_advect_both(hipStream_t s, Win w, const float2* vel, float2* v
                               float dt, float vel_dissipation, float dye_dissipation, int ga, int gb, unsigned int* miss)
 {
     ROWS_OR_RETURN();
-    k_advect_both<<<row_grid(w.W, ga, gb), BX, 0, s>>>(w, vel, vel_out, dye, dye_out, dt, vel_dissipation, dye_dissipation,
-                                                       (float)(1.0 / w.W), (float)(1.0 / w.H), ga, miss);
+    static const int rows_per_thread = [] {  // FLUID_ADVECT_ROWS: 1, 2 or 4 texels per thread (A/B knob)
+        const char* e = getenv("FLUID_ADVECT_ROWS");
+        const int k = e ? atoi(e) : 2;
+        return (k == 1 || k == 2 || k == 4) ? k : 2;
+    }();
+    const float tsx = (float)(1.0 / w.W), tsy = (float)(1.0 / w.H);
+    const dim3 g((w.W + BX - 1) / BX, (gb - ga + rows_per_thread - 1) / rows_per_thread, 1);
+    if (rows_per_thread == 1) k_advect_both<1><<<g, BX, 0, s>>>(w, vel, vel_out, dye, dye_out, dt, vel_dissipation, dye_dissipation, tsx, tsy, ga, gb, miss);
+    else if (rows_per_thread == 2) k_advect_both<2><<<g, BX, 0, s>>>(w, vel, vel_out, dye, dye_out, dt, vel_dissipation, dye_dissipation, tsx, tsy, ga, gb, miss);
+    else k_advect_both<4><<<g, BX, 0, s>>>(w, vel, vel_out, dye, dye_out, dt, vel_dissipation, dye_dissipation, tsx, tsy, ga, gb, miss);
     return hipGetLastError();
 }
 
@@ -930,29 +1032,14 @@ hipError_t launch_jacobi_tb(hipStream_t s, Win w, const float* p, const float* d
     case k:                                                                                                                     \
         static_assert(kTB[k].nw == NW && kTB[k].ry == RY && kTB[k].hx == HX && kTB[k].hy == HY && kTB[k].bpc == BPC, "table"); \
         return launch_tb<NW, RY, HX, HY, BPC>(s, w, p, div, p_out, pscale, iters, ga, gb)
-    TB_CASE(0, 4, 16, 8, 8, 1);
+    TB_CASE(0, 8, 10, 12, 10, 2);
     TB_CASE(1, 8, 8, 8, 8, 2);
-    TB_CASE(2, 8, 16, 8, 8, 1);
-    TB_CASE(3, 4, 24, 8, 8, 2);
-    TB_CASE(4, 8, 12, 12, 12, 2);
-    TB_CASE(5, 8, 16, 16, 16, 1);
-    TB_CASE(6, 4, 16, 4, 4, 1);
-    TB_CASE(7, 8, 8, 4, 4, 2);
-    TB_CASE(8, 8, 10, 12, 10, 2);
-    TB_CASE(9, 6, 16, 16, 13, 2);
-    TB_CASE(10, 4, 24, 16, 13, 2);
-    TB_CASE(11, 8, 16, 20, 17, 1);
-    TB_CASE(12, 8, 11, 12, 10, 2);
-    TB_CASE(13, 6, 14, 12, 10, 2);
-    TB_CASE(14, 8, 12, 12, 10, 2);
-    TB_CASE(15, 7, 12, 8, 8, 2);
-    TB_CASE(16, 8, 10, 16, 13, 2);
-    TB_CASE(17, 8, 12, 16, 13, 2);
-    TB_CASE(18, 16, 8, 12, 10, 1);
-    TB_CASE(19, 16, 12, 16, 13, 1);
-    TB_CASE(20, 16, 12, 20, 17, 1);
-    TB_CASE(21, 16, 10, 16, 13, 1);
-    TB_CASE(22, 16, 12, 28, 25, 1);
+    TB_CASE(2, 8, 11, 12, 10, 2);
+    TB_CASE(3, 8, 12, 12, 10, 2);
+    TB_CASE(4, 8, 12, 16, 13, 2);
+    TB_CASE(5, 8, 16, 20, 17, 1);
+    TB_CASE(6, 16, 12, 20, 17, 1);
+    TB_CASE(7, 4, 24, 16, 13, 2);
 #undef TB_CASE
     default: return hipErrorInvalidValue;
     }

@@ -215,7 +215,10 @@ int pass_gradsub(fluid_ctx* c, int ext)
     CK(check_ext(c, ext, 1));
     int ga, gb;
     row_range(c->sim, c->sim_row0, c->sim_rows, ext, ga, gb);
-    CK(c->hip(launch_gradsub(c->stream, c->sim, c->prs[0], c->vel[0], c->vel[1], ga, gb), "gradsub"));
+    if (c->desc.schedule == FLUID_SCHED_FUSED && fused_supported(c->sim))
+        CK(c->hip(launch_gradsub4(c->stream, c->sim, c->prs[0], c->vel[0], c->vel[1], ga, gb), "gradsub"));
+    else
+        CK(c->hip(launch_gradsub(c->stream, c->sim, c->prs[0], c->vel[0], c->vel[1], ga, gb), "gradsub"));
     std::swap(c->vel[0], c->vel[1]);
     return FLUID_OK;
 }
