@@ -663,8 +663,12 @@ __global__ void __launch_bounds__(256) k_gradsub4(Win w, const float* __restrict
 // Each stage shrinks the exact region by one ring, so the tile carries a 3-row / 4-column apron
 // (4 keeps float4 alignment) and stores only its interior.  The per-texel arithmetic is the same
 // device code as the single-pass kernels, so the result is bit-identical to running them in turn.
+// Tile shape of the fused curl/vorticity/divergence kernel: 8 waves x 5 rows at <= 128 VGPRs, so that TWO workgroups
+// share a CU and one's loads overlap the other's arithmetic (69 VALU instructions per texel: two IEEE divides and a
+// square root).  Measured 85 us at 4096^2 against 99 us for 8 x 8 rows at 229 VGPRs / one workgroup per CU, although
+// the smaller tile re-reads more apron rows (profiles/r01/cvd_tile_shapes.txt).
 #ifndef VD_WAVES_PER_EU
-#define VD_WAVES_PER_EU 2
+#define VD_WAVES_PER_EU 4
 #endif
 template <int NW, int RY>
 struct VortDiv {
@@ -682,7 +686,7 @@ __device__ __forceinline__ void vort_div_body(const Win& w, const float2* __rest
                                               float dt, int ga, int gb, int x0, int y0, float4 (*mail)[2][2][64])
 {
     using G = VortDiv<NW, RY>;
-    const int lane = threadIdx.x, wv = threadIdx.y;
+    const int lane = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(threadIdx.y);  // wave-uniform: row addressing on the SALU
     const int cx = x0 + 4 * lane;
     const int gy = y0 + wv * RY;
     const int cxs = min(max(cx, 0), w.W - 4);
@@ -824,7 +828,13 @@ __global__ void __launch_bounds__(64 * NW, VD_WAVES_PER_EU) k_curl_vort_div(Win 
     else vort_div_body<NW, RY, false>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
 }
 
-constexpr int VD_NW = 8, VD_RY = 8;
+#ifndef VD_NW_
+#define VD_NW_ 8
+#endif
+#ifndef VD_RY_
+#define VD_RY_ 5
+#endif
+constexpr int VD_NW = VD_NW_, VD_RY = VD_RY_;
 
 // tile-shape variants (NW waves x RY rows per wave, apron HX columns x HY rows, BPC workgroups per CU); FLUID_TB_VARIANT picks one (tuning knob,
 // read once); the default is the shape that measured best on MI355X at 4096^2 (profiles/)
