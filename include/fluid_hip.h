@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FLUID_ABI_VERSION 2
+#define FLUID_ABI_VERSION 3
 
 typedef enum fluid_status {
     FLUID_OK = 0,
@@ -228,6 +228,34 @@ long fluid_exchange_count(const fluid_ctx *ctx);
 /* the SAME plan for a whole stripe set living in one process (contexts 0..parts-1 in order, any devices): ghost
  * rows move by device-to-device copies instead of RCCL.  Validation path on a single-GPU box. */
 int fluid_group_step_n(fluid_ctx **ctxs, int n_ctx, int steps, float dt, const fluid_params *params);
+
+/* ---- display compositor: render(target), script.js:1296-1419 — the first consumer of dye.read ----
+ * bloom (applyBloom 1346-1389), sunrays (applySunrays 1391-1403 + blur 1405-1419), then drawColor(BACK_COLOR) and
+ * drawDisplay (shading, bloom, sunrays, dithering, gamma; shader 549-612) with the target != null blend state
+ * (ONE, ONE_MINUS_SRC_ALPHA; blending off when TRANSPARENT).  Whole-domain contexts only. */
+typedef struct fluid_display_params {
+    int shading, bloom, sunrays, transparent;       /* config.SHADING / BLOOM / SUNRAYS / TRANSPARENT              */
+    float back_r, back_g, back_b;                   /* normalizeColor(config.BACK_COLOR): components / 255          */
+    int bloom_w, bloom_h;                           /* getResolution(config.BLOOM_RESOLUTION)                       */
+    int bloom_iterations;                           /* config.BLOOM_ITERATIONS                                      */
+    double bloom_intensity, bloom_threshold, bloom_soft_knee; /* doubles: the knee curve is computed in JS doubles (1354-1358) */
+    int sunrays_w, sunrays_h;                       /* getResolution(config.SUNRAYS_RESOLUTION)                     */
+    double sunrays_weight;                          /* config.SUNRAYS_WEIGHT                                        */
+} fluid_display_params;
+
+enum { FLUID_DISPLAY_BLOOM = 0, FLUID_DISPLAY_SUNRAYS = 1 };
+
+/* the dithering texture (script.js:958, createTextureAsync 1128-1158): R channel in [0, 1], sampled LINEAR + REPEAT.
+ * Default: the reference's 1 x 1 white placeholder (1135) — the blue-noise PNG is an asset of the page, not shipped. */
+int fluid_set_dither(fluid_ctx *ctx, const float *host_r, int width, int height);
+/* render(target) into the context's width x height float RGBA frame (captureScreenshot's target, script.js:287-290) */
+int fluid_render(fluid_ctx *ctx, int width, int height, const fluid_display_params *params);
+/* framebufferToTexture(target), script.js:301-307: RGBA floats, row 0 = bottom */
+int fluid_read_frame(fluid_ctx *ctx, float *host_rgba, size_t bytes);
+/* normalizeTexture(texture, w, h), script.js:309-323: clamp01 * 255 truncated to bytes, rows flipped (top row first) */
+int fluid_read_frame_rgba8(fluid_ctx *ctx, unsigned char *host_rgba8, size_t bytes);
+/* the bloom (RGBA) or blurred sunrays (R) buffer of the last render; host may be NULL to query the size */
+int fluid_read_display_buffer(fluid_ctx *ctx, int which, float *host, size_t bytes, int *width, int *height);
 
 int fluid_set_timing(fluid_ctx *ctx, int enabled);
 int fluid_get_timings(fluid_ctx *ctx, fluid_timings *out);

@@ -82,6 +82,16 @@ def run(scenario: Dict[str, Any], timeout: float = 1800.0) -> Dict[str, Any]:
             w, h = (dw, dh) if name == "dye" else (sw, sh)
             dec[name] = np.frombuffer(base64.b64decode(s), np.float32).reshape(h, w, 4).copy()
         res["fields"] = dec
+    if "frame" in res:   # render scenario: float frame, 8-bit frame (already flipped by normalizeTexture), bloom, sunrays, mask
+        fw, fh = res["frameSize"]
+        res["frame"] = np.frombuffer(base64.b64decode(res["frame"]), np.float32).reshape(fh, fw, 4).copy()
+        res["frame8"] = np.frombuffer(base64.b64decode(res["frame8"]), np.uint8).reshape(fh, fw, 4).copy()
+        bw, bh = res["bloomSize"]
+        res["bloom"] = np.frombuffer(base64.b64decode(res["bloom"]), np.float32).reshape(bh, bw, 4).copy()
+        sw_, sh_ = res["sunraysSize"]
+        res["sunrays"] = np.frombuffer(base64.b64decode(res["sunrays"]), np.float32).reshape(sh_, sw_, 4)[..., 0].copy()
+        dw_, dh_ = res["dye"]
+        res["mask"] = np.frombuffer(base64.b64decode(res["mask"]), np.float32).reshape(dh_, dw_, 4).copy()
     return res
 
 

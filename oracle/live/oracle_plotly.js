@@ -17,6 +17,11 @@
 //   passes             ["curl","vorticity",...] run single passes instead of step()
 //   resizeTo           {SIM_RESOLUTION, DYE_RESOLUTION} -> initFramebuffers() again after the steps
 //   steps, dt, timing, noDump
+//   render             {config: {SHADING, BLOOM, SUNRAYS, TRANSPARENT, BACK_COLOR, BLOOM_*, SUNRAYS_*, CAPTURE_RESOLUTION},
+//                       dither: {w, h, seed}} -> after the steps: the reference's captureScreenshot() up to the PNG
+//                      (render(target) into a float FBO of getResolution(CAPTURE_RESOLUTION), framebufferToTexture,
+//                      normalizeTexture); dumps the float frame, the 8-bit frame, and the bloom / sunrays buffers.
+//                      `dither` replaces the blue-noise PNG (an asset, not shipped) by a seeded R8 pattern.
 //   frames             [{dt, events: [{type, offsetX, offsetY, touches: [{identifier, pageX, pageY}], code, key}]}]:
 //                      per frame the events go through the reference's OWN listeners (script.js:1464-1530) and then
 //                      the body of its update() runs with that dt (updateColors, applyInputs, step unless PAUSED)
@@ -206,6 +211,44 @@
       if (P.resizeTo) {
         for (k in P.resizeTo) config[k] = P.resizeTo[k];
         initFramebuffers();
+      }
+      if (P.render) {
+        var R = P.render;
+        for (k in (R.config || {})) config[k] = R.config[k];
+        updateKeywords();
+        initBloomFramebuffers(); initSunraysFramebuffers();
+        if (R.dither) {
+          var dw = R.dither.w, dh = R.dither.h, ds = (R.dither.seed >>> 0), bytes = new Uint8Array(dw * dh * 3);
+          for (var q = 0; q < dw * dh; q++) {           // mulberry32 -> one byte per texel, replicated to RGB
+            ds |= 0; ds = ds + 0x6D2B79F5 | 0;
+            var tt = Math.imul(ds ^ ds >>> 15, 1 | ds); tt = tt + Math.imul(tt ^ tt >>> 7, 61 | tt) ^ tt;
+            var by = ((tt ^ tt >>> 14) >>> 0) >>> 24;
+            bytes[3 * q] = bytes[3 * q + 1] = bytes[3 * q + 2] = by;
+          }
+          var dtex = gl.createTexture();
+          gl.bindTexture(gl.TEXTURE_2D, dtex);
+          gl.texParameteri(gl.TEXTURE_2D, gl.TEXTURE_MIN_FILTER, gl.LINEAR);
+          gl.texParameteri(gl.TEXTURE_2D, gl.TEXTURE_MAG_FILTER, gl.LINEAR);
+          gl.texParameteri(gl.TEXTURE_2D, gl.TEXTURE_WRAP_S, gl.REPEAT);
+          gl.texParameteri(gl.TEXTURE_2D, gl.TEXTURE_WRAP_T, gl.REPEAT);
+          gl.pixelStorei(gl.UNPACK_ALIGNMENT, 1);
+          gl.texImage2D(gl.TEXTURE_2D, 0, gl.RGB, dw, dh, 0, gl.RGB, gl.UNSIGNED_BYTE, bytes);
+          ditheringTexture = { texture: dtex, width: dw, height: dh,
+            attach: function (id) { gl.activeTexture(gl.TEXTURE0 + id); gl.bindTexture(gl.TEXTURE_2D, dtex); return id; } };
+        }
+        var cres = getResolution(config.CAPTURE_RESOLUTION);
+        var target = createFBO(cres.width, cres.height, ext.formatRGBA.internalFormat, ext.formatRGBA.format, ext.halfFloatTexType, gl.NEAREST);
+        render(target);
+        var ftex = framebufferToTexture(target);
+        out.frame = b64(ftex); out.frameSize = [target.width, target.height];
+        var n8 = normalizeTexture(ftex, target.width, target.height), s8 = '';
+        for (var z = 0; z < n8.length; z += 32768) s8 += String.fromCharCode.apply(null, n8.subarray(z, z + 32768));
+        out.frame8 = btoa(s8);
+        out.bloom = b64(framebufferToTexture(bloom)); out.bloomSize = [bloom.width, bloom.height];
+        out.bloomLevels = bloomFramebuffers.map(function (f) { return [f.width, f.height]; });
+        out.sunrays = b64(framebufferToTexture(sunrays)); out.sunraysSize = [sunrays.width, sunrays.height];
+        out.mask = b64(framebufferToTexture(dye.write));
+        gl.disable(gl.BLEND);
       }
       out.ms = ms; out.sim = [velocity.width, velocity.height]; out.dye = [dye.width, dye.height];
       out.splats = splatLog; out.draws = draws.length;

@@ -1,0 +1,125 @@
+"""The display compositor: render(target) / captureScreenshot() of the reference
+(script.js:287-349, 1296-1419).  Goldens `display_*`: the UNMODIFIED reference's own render(target) on a state made by
+its own splat()/step() (oracle/live/make_golden_display.py): float frame, 8-bit frame, bloom, sunrays, mask.
+CPU: the numpy restatement (oracle/display.py) against the goldens.  GPU: the HIP kernels against the goldens and
+against the restatement, from the golden's dye."""
+import json
+
+import numpy as np
+import pytest
+
+import scenario as S
+
+NAMES = sorted(n for n in (__import__("glob").glob(S.GOLDEN_DIR + "/display_*.npz")))
+NAMES = [n.split("/")[-1][:-4] for n in NAMES]
+
+# relative to max|buffer|; measured oracle-vs-reference <= 7.8e-6 (texcoord jitter of the LINEAR fetches + SwiftShader's pow)
+FLOAT_TOL = 3e-5
+
+
+def load(name):
+    g = np.load(S.GOLDEN_DIR + "/" + name + ".npz")
+    sc = json.loads(str(g["scenario"]))
+    return g, sc, sc["render"]
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / max(float(np.abs(b).max()), 1e-30))
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_display_oracle_matches_live_reference(name):
+    from oracle import display as D
+    g, sc, R = load(name)
+    cfg = dict(D.DISPLAY_DEFAULTS, **R.get("config", {}))
+    dith = D.dither_pattern(**R["dither"]) if "dither" in R else None
+    out = D.capture(g["in_dye"], (int(g["canvas"][0]), int(g["canvas"][1])), cfg, dith)
+    if cfg["BLOOM"]:
+        assert rel(out["bloom"][..., :3], g["bloom"][..., :3]) <= FLOAT_TOL
+    if cfg["SUNRAYS"]:
+        assert rel(out["sunrays"], g["sunrays"]) <= FLOAT_TOL
+        assert rel(out["mask"], g["mask"]) <= FLOAT_TOL
+    assert out["frame"].shape == g["frame"].shape
+    assert rel(out["frame"], g["frame"]) <= FLOAT_TOL
+    assert np.array_equal(out["frame8"], g["frame8"])        # the 8-bit image the reference would encode: identical
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_hip_display_matches_live_reference_and_oracle(name):
+    import fluid_hip
+    from oracle import display as D
+    g, sc, R = load(name)
+    cfg = dict(sc["config"], **R.get("config", {}))
+    canvas = (int(g["canvas"][0]), int(g["canvas"][1]))
+    full = dict(D.DISPLAY_DEFAULTS, **R.get("config", {}))
+    dith = D.dither_pattern(**R["dither"]) if "dither" in R else None
+    want = D.capture(g["in_dye"], canvas, full, dith)
+    with fluid_hip.FluidSim(canvas=canvas, config=cfg) as sim:
+        assert [sim.dye.width, sim.dye.height] == [int(g["dye"][0]), int(g["dye"][1])]
+        sim.write("dye", g["in_dye"])
+        if dith is not None:
+            sim.setDitheringTexture(dith)
+        img = sim.captureScreenshot()
+        h, w = g["frame"].shape[:2]
+        frame = sim.render(w, h)
+        if full["BLOOM"]:
+            bloom = sim.display_buffer("bloom")
+            assert rel(bloom[..., :3], g["bloom"][..., :3]) <= FLOAT_TOL
+            assert rel(bloom, want["bloom"]) <= 2e-6
+        if full["SUNRAYS"]:
+            sun = sim.display_buffer("sunrays")
+            assert rel(sun, g["sunrays"]) <= FLOAT_TOL
+            assert rel(sun, want["sunrays"]) <= 2e-6
+    assert rel(frame, g["frame"]) <= FLOAT_TOL
+    assert rel(frame, want["frame"]) <= 4e-6                 # HIP vs restatement: same arithmetic, libm pow / sqrt ulps
+    d8 = np.abs(img.astype(np.int32) - g["frame8"].astype(np.int32))
+    assert d8.max() <= 1 and (d8 > 0).mean() <= 2e-3          # a 1-ulp pow difference may flip a byte at a x.0 boundary
+
+
+@pytest.mark.gpu
+def test_hip_display_defaults_full_size():
+    """shipping defaults (script.js:59-85): 1024^2 dye, 512 capture, 256 bloom x 8 iterations, 196 sunrays — runs and is finite"""
+    import fluid_hip
+    with fluid_hip.FluidSim(canvas=(1024, 768), config={"SIM_RESOLUTION": 128, "DYE_RESOLUTION": 1024},
+                            random=fluid_hip.mulberry32(3)) as sim:
+        sim.multipleSplats(8)
+        sim.step(0.016666, 5)
+        img = sim.captureScreenshot()
+        assert img.shape == (512, 683, 4) and img.dtype == np.uint8
+        assert (img[..., 3] == 255).all() and img[..., :3].max() > 0        # opaque over the black back colour
+        assert sim.display_buffer("bloom").shape == (256, 341, 4) and sim.display_buffer("sunrays").shape == (196, 261)
+
+
+
+
+@pytest.mark.gpu
+def test_node_and_python_hosts_capture_the_same_image(tmp_path):
+    """the JavaScript host (the reference's own language) and the Python host drive the same C ABI: same bytes"""
+    import os
+    import shutil
+    import subprocess
+    import fluid_hip
+    node = shutil.which("node")
+    if node is None:
+        pytest.skip("node not installed")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = {"SIM_RESOLUTION": 64, "DYE_RESOLUTION": 256, "CAPTURE_RESOLUTION": 120, "BLOOM_RESOLUTION": 64, "SUNRAYS_RESOLUTION": 50,
+           "BACK_COLOR": {"r": 10, "g": 40, "b": 90}, "PRESSURE_ITERATIONS": 20}
+    rng = np.random.default_rng(3)
+    dith = rng.random((8, 8)).astype(np.float32)
+    args = {"canvas": {"width": 640, "height": 360}, "config": cfg, "seed": 11, "randomSplats": 5, "steps": 4, "dt": 0.016666,
+            "dither": {"w": 8, "h": 8, "data": [float(x) for x in dith.ravel()]},
+            "out8": str(tmp_path / "shot.bin"), "outf": str(tmp_path / "frame.bin")}
+    r = subprocess.run([node, os.path.join(root, "tests", "node", "run_capture.js"), json.dumps(args)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    meta = json.loads(r.stdout.strip().splitlines()[-1])
+    with fluid_hip.FluidSim(canvas=(640, 360), config=cfg, random=fluid_hip.mulberry32(11)) as sim:
+        sim.multipleSplats(5)
+        sim.step(0.016666, 4)
+        sim.setDitheringTexture(dith)
+        img = sim.captureScreenshot()
+        frame = sim.render(img.shape[1], img.shape[0])
+    assert (meta["width"], meta["height"]) == (img.shape[1], img.shape[0]) == (213, 120)
+    assert np.array_equal(np.fromfile(args["out8"], np.uint8).reshape(img.shape), img)
+    assert np.array_equal(np.fromfile(args["outf"], np.float32).reshape(frame.shape), frame)

@@ -7,11 +7,8 @@ PKG=webgl-fluid-simulation_amd
 i=0
 for FL in "$@"; do
   i=$((i+1))
-  rm -rf /tmp/ab_$i && mkdir -p /tmp/ab_$i
-  ( cd $PKG && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math $FL -c csrc/fluid_kernels.hip -o /tmp/ab_$i/k.o \
-    && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -c csrc/fluid_solver.cpp -o /tmp/ab_$i/s.o \
-    && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -c csrc/fluid_stripes.cpp -o /tmp/ab_$i/t.o \
-    && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/ab_$i/libfluid_hip.so /tmp/ab_$i/k.o /tmp/ab_$i/s.o /tmp/ab_$i/t.o -ldl ) 2>&1 | tail -3
+  D=/tmp/ab_$i; rm -rf $D; mkdir -p $D; cp -r $PKG $D/pkg; cp -r include $D/include
+  make -C $D/pkg clean >/dev/null; make -C $D/pkg -j4 EXTRA="$FL" 2>&1 | grep -E "error" | head -3
   echo "=== build $i flags=[$FL] ===" | tee -a $OUT/ab.txt
-  FLUID_HIP_LIB=/tmp/ab_$i/libfluid_hip.so TB_VARIANTS="$VARS" python tools/bench_jacobi.py 4096 50 2>&1 | tee -a $OUT/ab.txt
+  FLUID_HIP_LIB=/tmp/ab_$i/pkg/libfluid_hip.so TB_VARIANTS="$VARS" python tools/bench_jacobi.py 4096 50 2>&1 | tee -a $OUT/ab.txt
 done

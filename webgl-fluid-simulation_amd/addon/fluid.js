@@ -28,6 +28,9 @@
 //   generateColor()              1565-1571     sim.generateColor()
 //   HSVtoRGB(h, s, v)            1573-1595     HSVtoRGB(h, s, v)
 //   framebufferToTexture(target) 301-307       sim.framebufferToTexture(target)
+//   render(target)               1296-1317     sim.render(target)    (target: {width, height}; bloom, sunrays, shading, blend)
+//   captureScreenshot()          287-299       sim.captureScreenshot() -> {width, height, data: Uint8Array RGBA8, top row first}
+//   normalizeColor(input)        1597-1604     normalizeColor(input)
 //   velocity, dye, pressure, divergence, curl  950-954   sim.velocity ... (width/height/texelSize views)
 //
 // There is no CPU path: without the addon / a HIP device, createFluid() throws.
@@ -55,6 +58,20 @@ function defaultConfig () {
         COLORFUL: true,
         COLOR_UPDATE_SPEED: 10,
         PAUSED: false,
+        // display compositor (script.js:61, 71-84)
+        CAPTURE_RESOLUTION: 512,
+        SHADING: true,
+        BACK_COLOR: { r: 0, g: 0, b: 0 },
+        TRANSPARENT: false,
+        BLOOM: true,
+        BLOOM_ITERATIONS: 8,
+        BLOOM_RESOLUTION: 256,
+        BLOOM_INTENSITY: 0.8,
+        BLOOM_THRESHOLD: 0.6,
+        BLOOM_SOFT_KNEE: 0.7,
+        SUNRAYS: true,
+        SUNRAYS_RESOLUTION: 196,
+        SUNRAYS_WEIGHT: 1.0,
     };
 }
 
@@ -91,6 +108,10 @@ function mulberry32 (seed) {
         t = t + Math.imul(t ^ t >>> 7, 61 | t) ^ t;
         return ((t ^ t >>> 14) >>> 0) / 4294967296;
     };
+}
+
+function normalizeColor (input) {
+    return { r: input.r / 255, g: input.g / 255, b: input.b / 255 };
 }
 
 function wrap (value, min, max) {
@@ -351,6 +372,7 @@ function createFluid (options) {
 
     // readPixels(RGBA, FLOAT): R and RG targets come back padded to (r, g, 0, 1); row 0 = bottom
     sim.framebufferToTexture = function (target) {
+        if (target && target.isFrame) return native.readFrame(handle, target.width, target.height);
         const name = typeof target === 'string' ? target : target.name;
         const info = native.fieldInfo(handle, FIELD[name]);
         const src = native.readField(handle, FIELD[name]);
@@ -363,6 +385,32 @@ function createFluid (options) {
         return out;
     };
 
+    // ---- display compositor (SURVEY §8f N3) ---------------------------------------------------------------------
+    // render(target), script.js:1296-1317: target = { width, height } stands for the float FBO captureScreenshot()
+    // creates; the frame stays on the device until framebufferToTexture(target) / captureScreenshot() read it
+    sim.render = function (target) {
+        const c = sim.config;
+        const bloomRes = sim.getResolution(c.BLOOM_RESOLUTION);
+        const sunRes = sim.getResolution(c.SUNRAYS_RESOLUTION);
+        const back = normalizeColor(c.BACK_COLOR);
+        native.render(handle, target.width, target.height, c.SHADING ? 1 : 0, c.BLOOM ? 1 : 0, c.SUNRAYS ? 1 : 0, c.TRANSPARENT ? 1 : 0,
+            back.r, back.g, back.b, bloomRes.width, bloomRes.height, c.BLOOM_ITERATIONS, c.BLOOM_INTENSITY, c.BLOOM_THRESHOLD,
+            c.BLOOM_SOFT_KNEE, sunRes.width, sunRes.height, c.SUNRAYS_WEIGHT);
+        target.isFrame = true;
+    };
+
+    // captureScreenshot(), script.js:287-299, up to the PNG encoder: render into a CAPTURE_RESOLUTION target,
+    // framebufferToTexture + normalizeTexture (clamp01 * 255, rows flipped: top row first)
+    sim.captureScreenshot = function () {
+        const res = sim.getResolution(sim.config.CAPTURE_RESOLUTION);
+        const target = { width: res.width, height: res.height };
+        sim.render(target);
+        return { width: res.width, height: res.height, data: native.readFrameRgba8(handle, res.width, res.height) };
+    };
+
+    // the dithering texture's R channel in [0, 1] (script.js:958; default = the 1 x 1 white placeholder of 1135)
+    sim.setDitheringTexture = function (r, width, height) { native.setDither(handle, r, width, height); };
+
     sim.readField = function (name) { return native.readField(handle, FIELD[name]); };
     sim.writeField = function (name, data) { native.writeField(handle, FIELD[name], data); };
     sim.sync = function () { native.sync(handle); };
@@ -374,4 +422,4 @@ function createFluid (options) {
     return sim;
 }
 
-module.exports = { createFluid, HSVtoRGB, mulberry32, pointerPrototype, defaultConfig, FIELD, SCHEDULE };
+module.exports = { createFluid, HSVtoRGB, normalizeColor, mulberry32, pointerPrototype, defaultConfig, FIELD, SCHEDULE };

@@ -242,6 +242,85 @@ static napi_value n_write_field(napi_env env, napi_callback_info info)
     return rc == FLUID_OK ? NULL : throw_status(env, c, rc);
 }
 
+static int get_d(napi_env env, napi_value v, double *out)
+{
+    if (napi_get_value_double(env, v, out) != napi_ok) {
+        napi_throw_type_error(env, NULL, "fluid_napi: expected a number");
+        return 0;
+    }
+    return 1;
+}
+
+/* setDither(h, Float32Array r, width, height): the dithering texture's R channel (script.js:958) */
+static napi_value n_set_dither(napi_env env, napi_callback_info info)
+{
+    napi_value a[4], ab;
+    fluid_ctx *c;
+    int w, h;
+    napi_typedarray_type t;
+    size_t len, off;
+    void *data;
+    if (!get_args(env, info, 4, a) || !get_ctx(env, a[0], &c) || !get_i(env, a[2], &w) || !get_i(env, a[3], &h)) return NULL;
+    if (napi_get_typedarray_info(env, a[1], &t, &len, &data, &ab, &off) != napi_ok || t != napi_float32_array || len != (size_t)w * h) {
+        napi_throw_type_error(env, NULL, "fluid_napi: setDither expects a Float32Array of width * height");
+        return NULL;
+    }
+    int rc = fluid_set_dither(c, (const float *)data, w, h);
+    return rc == FLUID_OK ? NULL : throw_status(env, c, rc);
+}
+
+/* render(h, width, height, shading, bloom, sunrays, transparent, backR, backG, backB, bloomW, bloomH, bloomIterations,
+ *        bloomIntensity, bloomThreshold, bloomSoftKnee, sunraysW, sunraysH, sunraysWeight): render(target), script.js:1296 */
+static napi_value n_render(napi_env env, napi_callback_info info)
+{
+    napi_value a[19];
+    fluid_ctx *c;
+    int w, h;
+    fluid_display_params P;
+    if (!get_args(env, info, 19, a) || !get_ctx(env, a[0], &c)) return NULL;
+    if (!get_i(env, a[1], &w) || !get_i(env, a[2], &h) || !get_i(env, a[3], &P.shading) || !get_i(env, a[4], &P.bloom) ||
+        !get_i(env, a[5], &P.sunrays) || !get_i(env, a[6], &P.transparent) || !get_f(env, a[7], &P.back_r) || !get_f(env, a[8], &P.back_g) ||
+        !get_f(env, a[9], &P.back_b) || !get_i(env, a[10], &P.bloom_w) || !get_i(env, a[11], &P.bloom_h) ||
+        !get_i(env, a[12], &P.bloom_iterations) || !get_d(env, a[13], &P.bloom_intensity) || !get_d(env, a[14], &P.bloom_threshold) ||
+        !get_d(env, a[15], &P.bloom_soft_knee) || !get_i(env, a[16], &P.sunrays_w) || !get_i(env, a[17], &P.sunrays_h) ||
+        !get_d(env, a[18], &P.sunrays_weight))
+        return NULL;
+    int rc = fluid_render(c, w, h, &P);
+    return rc == FLUID_OK ? NULL : throw_status(env, c, rc);
+}
+
+/* readFrame(h, width, height) -> Float32Array(width * height * 4): framebufferToTexture(target), row 0 = bottom */
+static napi_value n_read_frame(napi_env env, napi_callback_info info)
+{
+    napi_value a[3], buf, arr;
+    fluid_ctx *c;
+    int w, h;
+    if (!get_args(env, info, 3, a) || !get_ctx(env, a[0], &c) || !get_i(env, a[1], &w) || !get_i(env, a[2], &h)) return NULL;
+    size_t n = (size_t)w * h * 4;
+    void *data = NULL;
+    NAPI_OK(napi_create_arraybuffer(env, n * sizeof(float), &data, &buf));
+    int rc = fluid_read_frame(c, (float *)data, n * sizeof(float));
+    if (rc != FLUID_OK) return throw_status(env, c, rc);
+    NAPI_OK(napi_create_typedarray(env, napi_float32_array, n, buf, 0, &arr));
+    return arr;
+}
+
+/* readFrameRgba8(h, width, height) -> Uint8Array(width * height * 4): normalizeTexture, top row first */
+static napi_value n_read_frame_rgba8(napi_env env, napi_callback_info info)
+{
+    napi_value a[3], buf, arr;
+    fluid_ctx *c;
+    int w, h;
+    if (!get_args(env, info, 3, a) || !get_ctx(env, a[0], &c) || !get_i(env, a[1], &w) || !get_i(env, a[2], &h)) return NULL;
+    size_t n = (size_t)w * h * 4;
+    void *data = NULL;
+    NAPI_OK(napi_create_arraybuffer(env, n, &data, &buf));
+    int rc = fluid_read_frame_rgba8(c, (unsigned char *)data, n);
+    if (rc != FLUID_OK) return throw_status(env, c, rc);
+    NAPI_OK(napi_create_typedarray(env, napi_uint8_array, n, buf, 0, &arr));
+    return arr;
+}
+
 static napi_value n_device_count(napi_env env, napi_callback_info info)
 {
     napi_value v;
@@ -292,6 +371,7 @@ static napi_value init(napi_env env, napi_value exports)
         { "step", n_step }, { "sync", n_sync }, { "setSchedule", n_set_schedule }, { "fieldInfo", n_field_info },
         { "readField", n_read_field }, { "writeField", n_write_field }, { "deviceCount", n_device_count },
         { "setTiming", n_set_timing }, { "getTimings", n_get_timings },
+        { "setDither", n_set_dither }, { "render", n_render }, { "readFrame", n_read_frame }, { "readFrameRgba8", n_read_frame_rgba8 },
     };
     for (size_t k = 0; k < sizeof fns / sizeof fns[0]; k++) {
         napi_value f;

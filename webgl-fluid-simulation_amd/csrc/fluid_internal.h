@@ -6,6 +6,8 @@
 
 #include <string>
 
+struct fluid_display_state;  // fluid_display.cpp
+
 enum PassId { P_CURL, P_VORT, P_DIV, P_CLEAR, P_JACOBI, P_GRADSUB, P_ADVV, P_ADVD, P_COUNT };
 
 struct fluid_ctx {
@@ -40,6 +42,8 @@ struct fluid_ctx {
     long exchanges = 0;
     int reach = 20;                      // rows an advection back-trace may span (dt*|v| + 2); see fluid_set_reach
     int overlap = 1;                     // interior-first overlap of exchanges (FLUID_STRIPE_OVERLAP=0 turns it off)
+
+    fluid_display_state* display = nullptr;  // bloom pyramid, sunrays, dithering texture, frame (fluid_display.cpp)
 
     int fail(int code, const std::string& what)
     {
@@ -115,5 +119,7 @@ void advect_both_swap(fluid_ctx* c);
 // fluid_stripes.cpp
 int stripe_step_n(fluid_ctx* c, int n, float dt, const fluid_params* P);  // this rank's stripe, exchanges over RCCL
 void stripes_release(fluid_ctx* c);                                       // frees the communicator (fluid_destroy)
+// fluid_display.cpp
+void display_release(fluid_ctx* c);
 
 }  // namespace fluid_impl

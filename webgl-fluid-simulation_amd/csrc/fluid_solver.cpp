@@ -430,6 +430,7 @@ int fluid_destroy(fluid_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     stripes_release(c);
+    display_release(c);
     free_fields(c);
     if (c->miss) (void)hipFree(c->miss);
     for (auto& e : c->ev)

@@ -45,6 +45,17 @@ class Timings(C.Structure):
                [("jacobi_launches", C.c_int), ("steps", C.c_int)]
 
 
+class DisplayParams(C.Structure):
+    _fields_ = [("shading", C.c_int), ("bloom", C.c_int), ("sunrays", C.c_int), ("transparent", C.c_int),
+                ("back_r", C.c_float), ("back_g", C.c_float), ("back_b", C.c_float),
+                ("bloom_w", C.c_int), ("bloom_h", C.c_int), ("bloom_iterations", C.c_int),
+                ("bloom_intensity", C.c_double), ("bloom_threshold", C.c_double), ("bloom_soft_knee", C.c_double),
+                ("sunrays_w", C.c_int), ("sunrays_h", C.c_int), ("sunrays_weight", C.c_double)]
+
+
+DISPLAY_BLOOM, DISPLAY_SUNRAYS = 0, 1
+
+
 class StripeOp(C.Structure):
     _fields_ = [("kind", C.c_int), ("iters", C.c_int), ("ext", C.c_int), ("n_items", C.c_int), ("field", C.c_int * 2), ("rows", C.c_int * 2)]
 
@@ -102,6 +113,11 @@ SYMBOLS = {
     "fluid_comm_selftest": (_I, [_CTX, _I]),
     "fluid_exchange_count": (C.c_long, [_CTX]),
     "fluid_group_step_n": (_I, [C.POINTER(_CTX), _I, _I, _F, C.POINTER(Params)]),
+    "fluid_set_dither": (_I, [_CTX, C.c_void_p, _I, _I]),
+    "fluid_render": (_I, [_CTX, _I, _I, C.POINTER(DisplayParams)]),
+    "fluid_read_frame": (_I, [_CTX, C.c_void_p, C.c_size_t]),
+    "fluid_read_frame_rgba8": (_I, [_CTX, C.c_void_p, C.c_size_t]),
+    "fluid_read_display_buffer": (_I, [_CTX, _I, C.c_void_p, C.c_size_t, C.POINTER(_I), C.POINTER(_I)]),
     "fluid_set_timing": (_I, [_CTX, _I]),
     "fluid_get_timings": (_I, [_CTX, C.POINTER(Timings)]),
 }
@@ -144,7 +160,7 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the header and the library disagree
             fn.restype = res
             fn.argtypes = args
-        if L.fluid_abi_version() != 2:
+        if L.fluid_abi_version() != 3:
             raise FluidError(ERR_UNSUPPORTED, "ABI version mismatch")
         _lib = L
         _point_at_torch_rccl(L)

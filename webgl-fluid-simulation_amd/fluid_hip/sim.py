@@ -36,6 +36,20 @@ DEFAULT_CONFIG = {
     "COLORFUL": True,
     "COLOR_UPDATE_SPEED": 10,
     "PAUSED": False,
+    # display compositor (render / captureScreenshot, script.js:61, 71-84)
+    "CAPTURE_RESOLUTION": 512,
+    "SHADING": True,
+    "BACK_COLOR": {"r": 0, "g": 0, "b": 0},
+    "TRANSPARENT": False,
+    "BLOOM": True,
+    "BLOOM_ITERATIONS": 8,
+    "BLOOM_RESOLUTION": 256,
+    "BLOOM_INTENSITY": 0.8,
+    "BLOOM_THRESHOLD": 0.6,
+    "BLOOM_SOFT_KNEE": 0.7,
+    "SUNRAYS": True,
+    "SUNRAYS_RESOLUTION": 196,
+    "SUNRAYS_WEIGHT": 1.0,
 }
 
 SCHEDULES = {"passes": _abi.SCHED_PASSES, "fused": _abi.SCHED_FUSED}
@@ -358,6 +372,47 @@ class FluidSim:
 
     def sync(self):
         self._check(self._lib.fluid_sync(self._ctx))
+
+    # -- display compositor: render(target) / captureScreenshot(), script.js:287-349, 1296-1419 ------
+    def setDitheringTexture(self, r: np.ndarray):
+        """the R channel (0..1) of the dithering texture (script.js:958); default: the reference's 1 x 1 white placeholder"""
+        a = np.ascontiguousarray(r, np.float32)
+        self._check(self._lib.fluid_set_dither(self._ctx, a.ctypes.data_as(C.c_void_p), a.shape[1], a.shape[0]))
+
+    def _display_params(self) -> "_abi.DisplayParams":
+        c = self.config
+        bloom = getResolution(c["BLOOM_RESOLUTION"], self.canvas.width, self.canvas.height)
+        sun = getResolution(c["SUNRAYS_RESOLUTION"], self.canvas.width, self.canvas.height)
+        bc = c["BACK_COLOR"]                                     # normalizeColor, script.js:1597-1604
+        return _abi.DisplayParams(int(bool(c["SHADING"])), int(bool(c["BLOOM"])), int(bool(c["SUNRAYS"])), int(bool(c["TRANSPARENT"])),
+                                  bc["r"] / 255, bc["g"] / 255, bc["b"] / 255, bloom["width"], bloom["height"], int(c["BLOOM_ITERATIONS"]),
+                                  float(c["BLOOM_INTENSITY"]), float(c["BLOOM_THRESHOLD"]), float(c["BLOOM_SOFT_KNEE"]),
+                                  sun["width"], sun["height"], float(c["SUNRAYS_WEIGHT"]))
+
+    def render(self, width: int, height: int) -> np.ndarray:
+        """render(target) into a width x height float target; returns framebufferToTexture(target): [h, w, 4], row 0 = bottom"""
+        p = self._display_params()
+        self._check(self._lib.fluid_render(self._ctx, int(width), int(height), C.byref(p)))
+        out = np.empty((height, width, 4), np.float32)
+        self._check(self._lib.fluid_read_frame(self._ctx, out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out
+
+    def captureScreenshot(self) -> np.ndarray:
+        """captureScreenshot() up to the PNG encoder: the RGBA8 image [h, w, 4], top row first (normalizeTexture)"""
+        res = getResolution(self.config["CAPTURE_RESOLUTION"], self.canvas.width, self.canvas.height)
+        self.render(res["width"], res["height"])
+        out = np.empty((res["height"], res["width"], 4), np.uint8)
+        self._check(self._lib.fluid_read_frame_rgba8(self._ctx, out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out
+
+    def display_buffer(self, which: str) -> np.ndarray:
+        """the bloom ([h, w, 4]) or blurred sunrays ([h, w]) buffer of the last render"""
+        wid = {"bloom": _abi.DISPLAY_BLOOM, "sunrays": _abi.DISPLAY_SUNRAYS}[which]
+        w, h = C.c_int(0), C.c_int(0)
+        self._check(self._lib.fluid_read_display_buffer(self._ctx, wid, None, 0, C.byref(w), C.byref(h)))
+        out = np.empty((h.value, w.value, 4) if which == "bloom" else (h.value, w.value), np.float32)
+        self._check(self._lib.fluid_read_display_buffer(self._ctx, wid, out.ctypes.data_as(C.c_void_p), out.nbytes, None, None))
+        return out
 
     # -- field access ------------------------------------------------------------------------------
     def read(self, name: str) -> np.ndarray:
