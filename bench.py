@@ -98,6 +98,8 @@ def main():
     # else is routed to stderr and the JSON is written to the saved descriptor at the end
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    # before the HIP / HSA runtime initialises: the host driver only supports dmabuf IPC (RCCL across processes needs it)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import torch
     import fluid_hip
@@ -133,7 +135,6 @@ def main():
     else:
         import torch.distributed as dist
         from fluid_hip.stripes import StripeSim
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
