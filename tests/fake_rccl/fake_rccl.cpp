@@ -1,0 +1,203 @@
+// TEST INFRASTRUCTURE — an in-process stand-in for RCCL's point-to-point API, so that the multi-rank code path of
+// csrc/fluid_stripes.cpp (ncclCommInitRank, grouped ncclSend / ncclRecv to both neighbours on the comm stream) can run
+// with SEVERAL ranks on a single-GPU box: every "rank" is a host thread with its own stripe context on the same
+// device.  libfluid_hip.so dlopen()s this file instead of librccl.so when FLUID_RCCL_LIB points at it.
+//
+// Semantics kept from NCCL: CommInitRank blocks until all ranks of the id have arrived; sends and receives between a
+// pair of ranks match in issue order; a group issues all its operations together; a send is complete on the sender's
+// stream only after the receiver has copied the data; everything is ordered on the streams the caller passes.
+// Never shipped, never on a product path.
+#include <hip/hip_runtime.h>
+
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+extern "C" {
+
+typedef enum { ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclSystemError = 2, ncclInternalError = 3, ncclInvalidArgument = 4 } ncclResult_t;
+typedef enum { ncclFloat = 7 } ncclDataType_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef struct FakeComm* ncclComm_t;
+
+}  // extern "C"
+
+namespace {
+
+struct Parcel {          // one send waiting for its receive
+    const void* src;
+    size_t bytes;
+    hipEvent_t ready;    // recorded on the sender's stream: the data exists
+    hipEvent_t copied;   // recorded on the receiver's stream: the data has been copied out
+    bool taken = false;
+};
+
+struct World {
+    int nranks = 0, arrived = 0;
+    std::map<std::pair<int, int>, std::deque<Parcel*>> box;  // (src, dst) -> sends in issue order
+};
+
+std::mutex g_mu;
+std::condition_variable g_cv;
+std::map<std::string, World> g_worlds;
+int g_next_id = 1;
+
+}  // namespace
+
+struct FakeComm {
+    World* world;
+    int rank, nranks;
+};
+
+namespace {
+
+struct Op {
+    bool send;
+    void* ptr;
+    size_t bytes;
+    int peer;
+    FakeComm* comm;
+    hipStream_t stream;
+};
+thread_local int t_depth = 0;
+thread_local std::vector<Op> t_ops;
+
+ncclResult_t run(std::vector<Op>& ops)
+{
+    std::vector<Parcel*> mine;
+    // 1. post every send (never blocks)
+    for (Op& o : ops)
+        if (o.send) {
+            Parcel* p = new Parcel{ o.ptr, o.bytes, nullptr, nullptr };
+            if (hipEventCreateWithFlags(&p->ready, hipEventDisableTiming) != hipSuccess) return ncclUnhandledCudaError;
+            if (hipEventCreateWithFlags(&p->copied, hipEventDisableTiming) != hipSuccess) return ncclUnhandledCudaError;
+            if (hipEventRecord(p->ready, o.stream) != hipSuccess) return ncclUnhandledCudaError;
+            {
+                std::lock_guard<std::mutex> lk(g_mu);
+                o.comm->world->box[{ o.comm->rank, o.peer }].push_back(p);
+            }
+            g_cv.notify_all();
+            mine.push_back(p);
+        }
+    // 2. every receive takes the oldest unmatched send of its peer
+    for (Op& o : ops)
+        if (!o.send) {
+            Parcel* p = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(g_mu);
+                auto& q = o.comm->world->box[{ o.peer, o.comm->rank }];
+                g_cv.wait(lk, [&] { return !q.empty(); });
+                p = q.front();
+                q.pop_front();
+            }
+            if (p->bytes != o.bytes) return ncclInvalidArgument;  // count mismatch between the two sides
+            if (hipStreamWaitEvent(o.stream, p->ready, 0) != hipSuccess) return ncclUnhandledCudaError;
+            if (hipMemcpyAsync(o.ptr, p->src, o.bytes, hipMemcpyDeviceToDevice, o.stream) != hipSuccess) return ncclUnhandledCudaError;
+            if (hipEventRecord(p->copied, o.stream) != hipSuccess) return ncclUnhandledCudaError;
+            {
+                std::lock_guard<std::mutex> lk(g_mu);
+                p->taken = true;
+            }
+            g_cv.notify_all();
+        }
+    // 3. a send completes on the sender's stream once the receiver has copied
+    size_t k = 0;
+    for (Op& o : ops)
+        if (o.send) {
+            Parcel* p = mine[k++];
+            {
+                std::unique_lock<std::mutex> lk(g_mu);
+                g_cv.wait(lk, [&] { return p->taken; });
+            }
+            if (hipStreamWaitEvent(o.stream, p->copied, 0) != hipSuccess) return ncclUnhandledCudaError;
+            (void)hipEventDestroy(p->ready);   // destruction is deferred by the runtime until the recorded work is done
+            (void)hipEventDestroy(p->copied);
+            delete p;
+        }
+    return ncclSuccess;
+}
+
+}  // namespace
+
+extern "C" {
+
+ncclResult_t ncclGetUniqueId(ncclUniqueId* id)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    std::memset(id, 0, sizeof *id);
+    std::snprintf(id->internal, sizeof id->internal, "fake-rccl-%d", g_next_id++);
+    return ncclSuccess;
+}
+
+ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int rank)
+{
+    if (!comm || nranks < 1 || rank < 0 || rank >= nranks) return ncclInvalidArgument;
+    std::unique_lock<std::mutex> lk(g_mu);
+    World& w = g_worlds[std::string(id.internal)];
+    if (w.nranks == 0) w.nranks = nranks;
+    if (w.nranks != nranks) return ncclInvalidArgument;
+    w.arrived++;
+    g_cv.notify_all();
+    g_cv.wait(lk, [&] { return w.arrived >= w.nranks; });  // collective: returns when every rank is here
+    *comm = new FakeComm{ &w, rank, nranks };
+    return ncclSuccess;
+}
+
+ncclResult_t ncclCommDestroy(ncclComm_t comm)
+{
+    delete comm;
+    return ncclSuccess;
+}
+
+ncclResult_t ncclGroupStart()
+{
+    t_depth++;
+    return ncclSuccess;
+}
+
+ncclResult_t ncclGroupEnd()
+{
+    if (t_depth <= 0) return ncclInvalidArgument;
+    if (--t_depth > 0) return ncclSuccess;
+    std::vector<Op> ops;
+    ops.swap(t_ops);
+    return run(ops);
+}
+
+static ncclResult_t enqueue(bool send, void* ptr, size_t count, ncclDataType_t type, int peer, ncclComm_t comm, hipStream_t stream)
+{
+    if (!comm || type != ncclFloat || peer < 0 || peer >= comm->nranks) return ncclInvalidArgument;
+    t_ops.push_back(Op{ send, ptr, count * sizeof(float), peer, comm, stream });
+    if (t_depth == 0) {
+        std::vector<Op> ops;
+        ops.swap(t_ops);
+        return run(ops);
+    }
+    return ncclSuccess;
+}
+
+ncclResult_t ncclSend(const void* buf, size_t count, ncclDataType_t type, int peer, ncclComm_t comm, hipStream_t stream)
+{
+    return enqueue(true, const_cast<void*>(buf), count, type, peer, comm, stream);
+}
+
+ncclResult_t ncclRecv(void* buf, size_t count, ncclDataType_t type, int peer, ncclComm_t comm, hipStream_t stream)
+{
+    return enqueue(false, buf, count, type, peer, comm, stream);
+}
+
+const char* ncclGetErrorString(ncclResult_t r)
+{
+    switch (r) {
+    case ncclSuccess: return "success";
+    case ncclInvalidArgument: return "invalid argument (fake rccl: count / peer / type mismatch)";
+    default: return "fake rccl error";
+    }
+}
+
+}  // extern "C"

@@ -173,3 +173,38 @@ def test_rccl_communicator_and_stream_ordered_self_exchange():
         e.sync()
     finally:
         e.close()
+
+
+# ---- the RCCL leg with SEVERAL ranks: rank threads in a fresh process, the in-process stand-in loaded as librccl ----------
+@pytest.mark.parametrize("world,halo,overlap,cfg,canvas,steps", [
+    (2, 56, True, {"SIM_RESOLUTION": 512, "DYE_RESOLUTION": 512, "PRESSURE_ITERATIONS": 50}, (512, 512), 2),
+    (4, 32, True, {"SIM_RESOLUTION": 512, "DYE_RESOLUTION": 512, "PRESSURE_ITERATIONS": 50}, (512, 512), 2),
+    (4, 32, False, {"SIM_RESOLUTION": 256, "DYE_RESOLUTION": 256, "PRESSURE_ITERATIONS": 50}, (512, 512), 2),
+    (8, 12, True, {"SIM_RESOLUTION": 256, "DYE_RESOLUTION": 256, "PRESSURE_ITERATIONS": 30}, (256, 1024), 1),
+    (3, 16, True, {"SIM_RESOLUTION": 96, "DYE_RESOLUTION": 192, "PRESSURE_ITERATIONS": 20}, (512, 512), 2),     # dye grid != sim grid
+])
+def test_native_rccl_path_with_several_ranks_bitwise(world, halo, overlap, cfg, canvas, steps):
+    """fluid_step_n on stripe contexts with a communicator — stripe_step_n, rccl_exchange_begin / end, the interior-first
+    overlap — run by `world` rank threads against tests/fake_rccl (an in-process implementation of the nccl point-to-point
+    calls with NCCL's matching and ordering rules).  Assembled result bitwise equal to the single domain."""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = os.path.join(here, "fake_rccl", "libfake_rccl.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["bash", os.path.join(here, "fake_rccl", "build.sh")], stdout=subprocess.DEVNULL)
+    args = {"world": world, "halo": halo, "overlap": overlap, "config": cfg, "canvas": list(canvas), "steps": steps}
+    env = dict(os.environ, FLUID_RCCL_LIB=lib)
+    r = subprocess.run([sys.executable, os.path.join(here, "fake_rccl", "run_ranks.py"), json.dumps(args)], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["ok"], out
+    assert out["rccl"] == lib
+    import fluid_hip
+    dye_halo = -(-halo * cfg["DYE_RESOLUTION"] // cfg["SIM_RESOLUTION"])
+    va = min(20 + (0 if cfg["DYE_RESOLUTION"] == cfg["SIM_RESOLUTION"] else 1), halo)
+    plan = fluid_hip._abi.stripe_plan(halo, dye_halo, cfg["PRESSURE_ITERATIONS"], va, min(dye_halo, va if cfg["DYE_RESOLUTION"] == cfg["SIM_RESOLUTION"] else 41))
+    assert out["exchanges"] == steps * sum(1 for op in plan if op[0] == "exchange")
