@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-oracle work for cpu_baseline (0 = skip)")
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the HIP-event instrumented pass")
     ap.add_argument("--stripes", action="store_true", help="use the multi-GPU stripe driver even at N = 1 (exercises that code path)")
+    ap.add_argument("--tiles-x", type=int, default=1, help="N > 1: 2-D decomposition, N // tiles_x row stripes x tiles_x column tiles "
+                                                           "(global grid size*tiles_x x size*N/tiles_x); default 1 = row stripes")
     ap.add_argument("--hosted", action="store_true", help="N > 1: drive the passes from Python with torch.distributed send/recv "
                                                           "instead of the native plan + RCCL inside libfluid_hip.so")
     args = ap.parse_args()
@@ -140,16 +142,20 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29511")
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         # global grid: `size` columns x `size * N` rows -> canvas of the same aspect, SIM_RESOLUTION = short side
+        # (--tiles-x T: size * T columns x size * N / T rows, every rank still owns size x size texels)
+        tx = max(1, args.tiles_x)
+        gw, gh = size * tx, size * N // tx
+        cfg = dict(cfg, SIM_RESOLUTION=min(gw, gh), DYE_RESOLUTION=min(gw, gh))
         try:
-            sim = StripeSim(canvas=(size, size * N), config=cfg, halo=args.halo, schedule=args.schedule,
-                            random=fluid_hip.mulberry32(1234), device=local_rank, native=not args.hosted)
+            sim = StripeSim(canvas=(gw, gh), config=cfg, halo=args.halo, schedule=args.schedule,
+                            random=fluid_hip.mulberry32(1234), device=local_rank, native=not args.hosted, tiles_x=tx)
         except fluid_hip.FluidError as ex:
             # the native driver needs RCCL inside libfluid_hip.so (dlopen + ncclCommInitRank); if that cannot be set up,
             # say so loudly and drive the SAME kernels pass by pass with torch.distributed's RCCL send/recv instead
             if args.hosted:
                 raise
             print("bench.py: native RCCL driver unavailable (%s); using the hosted torch.distributed driver" % ex, file=sys.stderr)
-            sim = StripeSim(canvas=(size, size * N), config=cfg, halo=args.halo, schedule=args.schedule,
+            sim = StripeSim(canvas=(gw, gh), config=cfg, halo=args.halo, schedule=args.schedule,
                             random=fluid_hip.mulberry32(1234), device=local_rank, native=False)
         sim.multipleSplats(20)
 
@@ -160,7 +166,7 @@ def main():
             sim.sync()
             torch.cuda.synchronize()
         barrier = dist.barrier
-        grid_w, grid_h = size, size * N
+        grid_w, grid_h = gw, gh
 
     run(args.warmup)
     sync(); barrier(); sync()
@@ -188,7 +194,8 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "configs[2]: %dx%d sim = dye grid%s, %d Jacobi iters/step, dt=%.6f, 20 splats mulberry32(1234), defaults otherwise"
                                % (grid_w, grid_h, "" if N == 1 else " (%d row stripes of %dx%d, halo %d)" % (N, size, size, args.halo), iters, DT),
-                   "schedule": args.schedule, "parallelism": "single" if N == 1 else "stripes%d" % N},
+                   "schedule": args.schedule,
+                   "parallelism": "single" if N == 1 else ("stripes%d" % N if args.tiles_x <= 1 else "tiles%dx%d" % (N // args.tiles_x, args.tiles_x))},
         "step_algorithmic_GBps": round(alg_step_bytes * steps_per_s / 1e9, 1),
         "step_roofline_frac": round(alg_step_bytes * steps_per_s / 1e9 / (HBM_PEAK_GBPS * N), 4),
     }

@@ -19,10 +19,11 @@
  *     divergence / curl = 1.  All fp32 (what the SwiftShader reference stores).
  *   - Scalars arrive as float: the caller rounds its doubles exactly like gl.uniform1f does.
  *
- * Stripe decomposition (multi-GPU): a context may own `part` of `parts` equal row stripes of
- * the global grid plus `halo` ghost rows on each side.  part = 0, parts = 1, halo = 0 is the
- * whole domain.  The per-pass entry points take `ext`: how many ghost rows beyond the owned
- * rows are (re)computed, so a rank can trade halo exchanges for redundant rows.
+ * Domain decomposition (multi-GPU): a context may own `part` of `parts` equal row stripes of
+ * the global grid plus `halo` ghost rows on each side — and, for a 2-D tile set, column tile
+ * `part_x` of `parts_x` of that stripe plus `halo` ghost columns.  part = 0, parts = 1, halo = 0
+ * is the whole domain.  The per-pass entry points take `ext`: how many ghost rows (and columns)
+ * beyond the owned ones are (re)computed, so a rank can trade halo exchanges for redundant work.
  */
 #ifndef FLUID_HIP_H
 #define FLUID_HIP_H
@@ -33,7 +34,7 @@
 extern "C" {
 #endif
 
-#define FLUID_ABI_VERSION 3
+#define FLUID_ABI_VERSION 4
 
 typedef enum fluid_status {
     FLUID_OK = 0,
@@ -70,6 +71,8 @@ typedef struct fluid_desc {
     int part, parts;    /* row-stripe decomposition; 0, 1 for a whole-domain context                    */
     int halo;           /* ghost rows (in sim rows) on each side of the stripe; 0 for whole domain       */
     int schedule;       /* fluid_schedule for fluid_step()                                               */
+    int part_x, parts_x; /* 2-D tile decomposition: column tile part_x of parts_x (0, 1 or 0, 0: full width); the   */
+                        /* rank owns rows of stripe `part` x columns of tile `part_x`, ghost depth `halo` all round */
 } fluid_desc;
 
 /* the per-step uniforms step() reads from `config`, script.js:1243, 1255, 1262, 1283, 1291 */
@@ -86,6 +89,8 @@ typedef struct fluid_field_info {
     int channels;       /* floats per texel                              */
     int row0, rows;     /* owned global rows [row0, row0 + rows)         */
     int halo;           /* ghost rows each side, in this field's rows    */
+    int col0, cols;     /* owned global columns [col0, col0 + cols)      */
+    int halo_x;         /* ghost columns each side (0 unless parts_x > 1) */
 } fluid_field_info;
 
 /* per-pass device time of the last fluid_step*(), filled when timing is enabled */

@@ -20,6 +20,8 @@ def main():
     from fluid_hip.sim import getResolution
     from fluid_hip.stripes import HipStripeEngine, new_comm_id
     world, halo, steps, cfg, canvas = a["world"], a["halo"], a["steps"], a["config"], tuple(a["canvas"])
+    tx = a.get("tiles_x", 1)
+    ty = world // tx
     full = dict(fluid_hip.DEFAULT_CONFIG, **cfg)
     with fluid_hip.FluidSim(canvas=canvas, config=cfg, random=fluid_hip.mulberry32(9)) as one:
         splats = one.multipleSplats(6)
@@ -34,7 +36,8 @@ def main():
 
     def rank(r):
         try:
-            e = HipStripeEngine((sim["width"], sim["height"]), (dye["width"], dye["height"]), r, world, halo, _abi.SCHED_FUSED, 0)
+            e = HipStripeEngine((sim["width"], sim["height"]), (dye["width"], dye["height"]), r // tx, ty, halo, _abi.SCHED_FUSED, 0,
+                                part_x=r % tx, parts_x=tx)
             e.use_own_stream()
             if "overlap" in a:
                 e.set_overlap(a["overlap"])
@@ -57,7 +60,9 @@ def main():
     if errs or any(o is None for o in out):
         print(json.dumps({"ok": False, "errors": errs}))
         return
-    bad = [k for k in want if not np.array_equal(np.concatenate([o[0][k] for o in out], axis=0), want[k])]
+    def assemble(k):
+        return np.concatenate([np.concatenate([out[y * tx + x][0][k] for x in range(tx)], axis=1) for y in range(ty)], axis=0)
+    bad = [k for k in want if not np.array_equal(assemble(k), want[k])]
     print(json.dumps({"ok": not bad, "mismatch": bad, "exchanges": out[0][1], "rccl": os.environ.get("FLUID_RCCL_LIB")}))
 
 

@@ -77,3 +77,24 @@ def test_config4_16384_sq_200_iterations_eight_stripes_equal_single_domain_bitwi
             _free()
     finally:
         one.close(); g.close()
+
+
+def test_config3_8192_sq_two_by_two_tiles_equal_single_domain_bitwise():
+    """configs[3] as BASELINE.json words it: 8192^2, 2 x 2 domain decomposition (four tiles of 4096 x 4096), 50 iterations"""
+    import fluid_hip
+    from fluid_hip.stripes import StripeGroup
+    cfg = {"SIM_RESOLUTION": 8192, "DYE_RESOLUTION": 8192, "PRESSURE_ITERATIONS": 50}
+    one = fluid_hip.FluidSim(canvas=(8192, 8192), config=cfg, random=fluid_hip.mulberry32(21))
+    g = StripeGroup(4, canvas=(8192, 8192), config=cfg, halo=56, random=fluid_hip.mulberry32(21), tiles_x=2)
+    try:
+        one.multipleSplats(6); g.multipleSplats(6)
+        one.step(0.016666, 2); g.step(0.016666, 2)
+        g.check_halo()
+        assert [(e.info("velocity").col0, e.info("velocity").row0) for e in g.engines] == [(0, 0), (4096, 0), (0, 4096), (4096, 4096)]
+        for k in S.FIELDS:
+            a, b = one.read(k), g.read(k)
+            assert np.array_equal(a, b), k
+            del a, b
+            _free()
+    finally:
+        one.close(); g.close()

@@ -208,3 +208,77 @@ def test_native_rccl_path_with_several_ranks_bitwise(world, halo, overlap, cfg, 
     va = min(20 + (0 if cfg["DYE_RESOLUTION"] == cfg["SIM_RESOLUTION"] else 1), halo)
     plan = fluid_hip._abi.stripe_plan(halo, dye_halo, cfg["PRESSURE_ITERATIONS"], va, min(dye_halo, va if cfg["DYE_RESOLUTION"] == cfg["SIM_RESOLUTION"] else 41))
     assert out["exchanges"] == steps * sum(1 for op in plan if op[0] == "exchange")
+
+
+# ---- 2-D tile decomposition (BASELINE configs[3]: 2 x 2 on four GPUs): ghost columns as well -------------------------------
+TILE_CASES = [
+    # canvas, config, halo, tiles_y, tiles_x, steps
+    ((512, 512), {"SIM_RESOLUTION": 512, "DYE_RESOLUTION": 512, "PRESSURE_ITERATIONS": 50}, 56, 2, 2, 2),
+    ((512, 512), {"SIM_RESOLUTION": 256, "DYE_RESOLUTION": 256, "PRESSURE_ITERATIONS": 50}, 32, 2, 2, 2),
+    ((512, 512), {"SIM_RESOLUTION": 256, "DYE_RESOLUTION": 256, "PRESSURE_ITERATIONS": 20}, 16, 1, 4, 2),   # column tiles only
+    ((1024, 512), {"SIM_RESOLUTION": 256, "DYE_RESOLUTION": 256, "PRESSURE_ITERATIONS": 30}, 24, 2, 4, 1),  # 512 x 256 grid, 2 x 4 tiles
+    ((512, 512), {"SIM_RESOLUTION": 128, "DYE_RESOLUTION": 512, "PRESSURE_ITERATIONS": 20}, 16, 2, 2, 2),   # dye grid != sim grid
+    ((512, 512), {"SIM_RESOLUTION": 256, "DYE_RESOLUTION": 256, "PRESSURE_ITERATIONS": 0, "CURL": 0}, 8, 2, 2, 2),
+]
+
+
+@pytest.mark.parametrize("schedule", ["fused", "passes"])
+@pytest.mark.parametrize("canvas,cfg,halo,ty,tx,steps", TILE_CASES)
+def test_native_tile_group_equals_single_domain_bitwise(canvas, cfg, halo, ty, tx, steps, schedule):
+    """tiles_y x tiles_x contexts in one process (fluid_group_step_n): ghost columns between left / right neighbours, then
+    ghost rows including the fresh ghost columns (corners without diagonal messages) — bitwise equal to the single domain"""
+    import fluid_hip
+    from fluid_hip.stripes import StripeGroup
+    with fluid_hip.FluidSim(canvas=canvas, config=cfg, schedule=schedule, random=fluid_hip.mulberry32(9)) as one:
+        one.multipleSplats(6)
+        one.step(0.016666, steps)
+        want = one.fields()
+    g = StripeGroup(ty * tx, canvas=canvas, config=cfg, halo=halo, schedule=schedule, random=fluid_hip.mulberry32(9), tiles_x=tx)
+    try:
+        g.multipleSplats(6)
+        g.step(0.016666, steps)
+        g.sync()
+        g.check_halo()
+        for k in S.FIELDS:
+            got = g.read(k)
+            assert got.shape == want[k].shape
+            assert np.array_equal(got, want[k]), k
+    finally:
+        g.close()
+
+
+def test_native_tile_group_back_trace_beyond_reach_is_reported():
+    import fluid_hip
+    from fluid_hip.stripes import StripeGroup
+    cfg = {"SIM_RESOLUTION": 256, "DYE_RESOLUTION": 256, "PRESSURE_ITERATIONS": 10}
+    g = StripeGroup(2, canvas=(256, 256), config=cfg, halo=32, reach=3, tiles_x=2)     # 1 x 2: only ghost columns
+    try:
+        g.splat(0.5, 0.5, 800.0, 0.0, (1, 1, 1))       # a horizontal jet across the tile border: dt * |v| = 13 columns > 3
+        g.step(0.016666)
+        with pytest.raises(fluid_hip.FluidError) as e:
+            g.check_halo()
+        assert e.value.status == -5
+    finally:
+        g.close()
+
+
+@pytest.mark.parametrize("ty,tx,halo,cfg", [(2, 2, 56, {"SIM_RESOLUTION": 512, "DYE_RESOLUTION": 512, "PRESSURE_ITERATIONS": 50}),
+                                            (2, 2, 16, {"SIM_RESOLUTION": 128, "DYE_RESOLUTION": 256, "PRESSURE_ITERATIONS": 20}),
+                                            (1, 3, 16, {"SIM_RESOLUTION": 192, "DYE_RESOLUTION": 192, "PRESSURE_ITERATIONS": 20})])
+def test_native_rccl_path_2d_tiles_with_several_ranks_bitwise(ty, tx, halo, cfg):
+    """the RCCL leg of the 2-D decomposition (two grouped phases, staged column blocks, one message per neighbour) with
+    ty x tx rank threads against tests/fake_rccl"""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = os.path.join(here, "fake_rccl", "libfake_rccl.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["bash", os.path.join(here, "fake_rccl", "build.sh")], stdout=subprocess.DEVNULL)
+    args = {"world": ty * tx, "tiles_x": tx, "halo": halo, "config": cfg, "canvas": [512, 512], "steps": 2}
+    r = subprocess.run([sys.executable, os.path.join(here, "fake_rccl", "run_ranks.py"), json.dumps(args)], env=dict(os.environ, FLUID_RCCL_LIB=lib),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["ok"], out

@@ -215,7 +215,7 @@ static napi_value n_read_field(napi_env env, napi_callback_info info)
     if (!get_args(env, info, 2, a) || !get_ctx(env, a[0], &c) || !get_i(env, a[1], &field)) return NULL;
     int rc = fluid_field_info_get(c, field, &fi);
     if (rc != FLUID_OK) return throw_status(env, c, rc);
-    size_t n = (size_t)fi.width * fi.rows * fi.channels;
+    size_t n = (size_t)fi.cols * fi.rows * fi.channels; /* the owned block: the whole field for a whole-domain context */
     void *data = NULL;
     NAPI_OK(napi_create_arraybuffer(env, n * sizeof(float), &data, &buf));
     rc = fluid_read_field(c, field, (float *)data, n * sizeof(float));

@@ -20,6 +20,7 @@ struct fluid_ctx {
     // local windows (sim grid, dye grid); rows include the ghost rows of a stripe
     fluid::Win sim{}, dye{};
     int sim_row0 = 0, sim_rows = 0, dye_row0 = 0, dye_rows = 0, dye_halo = 0;
+    int sim_col0 = 0, sim_ncols = 0, dye_col0 = 0, dye_ncols = 0, dye_halo_x = 0;  // 2-D tiles: owned columns
 
     float2* vel[2] = { nullptr, nullptr };   // velocity.read / velocity.write
     float* prs[2] = { nullptr, nullptr };    // pressure.read / pressure.write
@@ -39,6 +40,9 @@ struct fluid_ctx {
     hipStream_t comm_stream = nullptr;   // ghost rows travel here while the interior rows of the next pass compute
     hipEvent_t ev_ready = nullptr;       // context stream -> comm stream: the rows to send exist
     hipEvent_t ev_landed = nullptr;      // comm stream -> context stream: the ghost rows have arrived
+    hipEvent_t ev_mid = nullptr;         // 2-D tiles: this tile's ghost columns are in (phase A), ghost rows may follow
+    void* stage[8] = {};                 // 2-D tiles: contiguous staging of the strided column / row blocks, per direction
+    size_t stage_bytes[8] = {};
     long exchanges = 0;
     int reach = 20;                      // rows an advection back-trace may span (dt*|v| + 2); see fluid_set_reach
     int overlap = 1;                     // interior-first overlap of exchanges (FLUID_STRIPE_OVERLAP=0 turns it off)
@@ -71,6 +75,7 @@ struct FieldRef {
     void* ptr;
     const fluid::Win* win;
     int row0, rows, halo, nc;
+    int col0, cols, halo_x;  // owned columns and ghost columns (2-D tiles; 0, W, 0 otherwise)
 };
 int field_ref(fluid_ctx* c, int field, FieldRef* f);
 
@@ -111,6 +116,8 @@ int pass_advect(fluid_ctx* c, float dt, float vel_diss, float dye_diss, Timer* t
 bool fused_cvd_applies(const fluid_ctx* c);
 bool fused_advect_applies(const fluid_ctx* c);
 void sim_band(const fluid_ctx* c, int ext, int& ga, int& gb);  // owned rows +- ext, clipped to domain and window
+fluid::Win sim_cols(const fluid_ctx* c, int ext);              // the window with this launch's column range (2-D tiles)
+fluid::Win dye_cols(const fluid_ctx* c, int ext);
 int cvd_band(fluid_ctx* c, float curl, float dt, int ga, int gb);
 void cvd_swap(fluid_ctx* c);
 int advect_both_band(fluid_ctx* c, float dt, float vel_diss, float dye_diss, int ga, int gb, int v0, int v1);

@@ -16,8 +16,12 @@ struct Win {
     // tap outside as a miss.  Normally the whole window; the stripe driver narrows it to the rows that are fresh at
     // that moment (owned rows while an exchange is in flight, owned + exchanged rows afterwards).
     int v0, v1;
+    // 2-D tile decomposition: the arrays always span the full width W (columns a rank does not own are simply never
+    // touched), a launch writes columns [x0, x1) only, and gathers may use columns [u0, u1).  Whole width: 0, W.
+    int x0, x1;
+    int u0, u1;
 };
-inline Win make_win(int W, int H, int g0, int rows) { return Win{ W, H, g0, rows, g0, g0 + rows }; }
+inline Win make_win(int W, int H, int g0, int rows) { return Win{ W, H, g0, rows, g0, g0 + rows, 0, W, 0, W }; }
 
 // All launchers enqueue on `s` and return hipGetLastError().  Row ranges [ga, gb) are GLOBAL rows.
 hipError_t launch_curl(hipStream_t s, Win w, const float2* vel, float* curl, int ga, int gb);

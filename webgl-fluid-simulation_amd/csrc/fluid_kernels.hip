@@ -35,9 +35,9 @@ __device__ __forceinline__ long widx(const Win& w, int gj, int gi)
 // K1 curl — curlShader script.js:814-833
 __global__ void __launch_bounds__(BX) k_curl(Win w, const float2* __restrict__ vel, float* __restrict__ curl, int ga)
 {
-    const int i = blockIdx.x * BX + threadIdx.x;
+    const int i = w.x0 + blockIdx.x * BX + threadIdx.x;
     const int gj = ga + blockIdx.y;
-    if (i >= w.W) return;
+    if (i >= w.x1) return;
     const float L = vel[widx(w, gj, i - 1)].y;
     const float R = vel[widx(w, gj, i + 1)].y;
     const float T = vel[widx(w, gj + 1, i)].x;
@@ -68,9 +68,9 @@ __device__ __forceinline__ float2 vorticity_cell(float L, float R, float T, floa
 __global__ void __launch_bounds__(BX) k_vorticity(Win w, const float2* __restrict__ vel, const float* __restrict__ curl,
                                                    float2* __restrict__ vel_out, float curl_strength, float dt, int ga)
 {
-    const int i = blockIdx.x * BX + threadIdx.x;
+    const int i = w.x0 + blockIdx.x * BX + threadIdx.x;
     const int gj = ga + blockIdx.y;
-    if (i >= w.W) return;
+    if (i >= w.x1) return;
     const long c = (long)(gj - w.g0) * w.W + i;
     const float L = curl[widx(w, gj, i - 1)];
     const float R = curl[widx(w, gj, i + 1)];
@@ -82,9 +82,9 @@ __global__ void __launch_bounds__(BX) k_vorticity(Win w, const float2* __restric
 // K3 divergence with the reflecting-wall rule — divergenceShader script.js:786-812
 __global__ void __launch_bounds__(BX) k_divergence(Win w, const float2* __restrict__ vel, float* __restrict__ div, int ga)
 {
-    const int i = blockIdx.x * BX + threadIdx.x;
+    const int i = w.x0 + blockIdx.x * BX + threadIdx.x;
     const int gj = ga + blockIdx.y;
-    if (i >= w.W) return;
+    if (i >= w.x1) return;
     const long c = (long)(gj - w.g0) * w.W + i;
     float L = vel[widx(w, gj, i - 1)].x;
     float R = vel[widx(w, gj, i + 1)].x;
@@ -101,9 +101,9 @@ __global__ void __launch_bounds__(BX) k_divergence(Win w, const float2* __restri
 // K4 clear — clearShader script.js:508-519
 __global__ void __launch_bounds__(BX) k_clear(Win w, const float* __restrict__ p, float* __restrict__ p_out, float value, int ga)
 {
-    const int i = blockIdx.x * BX + threadIdx.x;
+    const int i = w.x0 + blockIdx.x * BX + threadIdx.x;
     const int gj = ga + blockIdx.y;
-    if (i >= w.W) return;
+    if (i >= w.x1) return;
     const long c = (long)(gj - w.g0) * w.W + i;
     p_out[c] = value * p[c];
 }
@@ -112,9 +112,9 @@ __global__ void __launch_bounds__(BX) k_clear(Win w, const float* __restrict__ p
 __global__ void __launch_bounds__(BX) k_jacobi(Win w, const float* __restrict__ p, const float* __restrict__ div,
                                                 float* __restrict__ p_out, int ga)
 {
-    const int i = blockIdx.x * BX + threadIdx.x;
+    const int i = w.x0 + blockIdx.x * BX + threadIdx.x;
     const int gj = ga + blockIdx.y;
-    if (i >= w.W) return;
+    if (i >= w.x1) return;
     const long c = (long)(gj - w.g0) * w.W + i;
     const float L = p[widx(w, gj, i - 1)];
     const float R = p[widx(w, gj, i + 1)];
@@ -127,9 +127,9 @@ __global__ void __launch_bounds__(BX) k_jacobi(Win w, const float* __restrict__ 
 __global__ void __launch_bounds__(BX) k_gradsub(Win w, const float* __restrict__ p, const float2* __restrict__ vel,
                                                  float2* __restrict__ vel_out, int ga)
 {
-    const int i = blockIdx.x * BX + threadIdx.x;
+    const int i = w.x0 + blockIdx.x * BX + threadIdx.x;
     const int gj = ga + blockIdx.y;
-    if (i >= w.W) return;
+    if (i >= w.x1) return;
     const long c = (long)(gj - w.g0) * w.W + i;
     const float L = p[widx(w, gj, i - 1)];
     const float R = p[widx(w, gj, i + 1)];
@@ -159,7 +159,8 @@ __device__ __forceinline__ Taps bil_taps(const Win& w, float u, float v)
     const int i0 = (int)fi, j0 = (int)fj;
     const int ia = clampi(i0, 0, w.W - 1), ib = clampi(i0 + 1, 0, w.W - 1);
     const int ja = clampi(j0, 0, w.H - 1), jb = clampi(j0 + 1, 0, w.H - 1);  // CLAMP_TO_EDGE first, in global rows
-    t.miss = (ja < w.v0 || ja >= w.v1) + (jb < w.v0 || jb >= w.v1);         // then: is that row fresh in this window?
+    t.miss = (ja < w.v0 || ja >= w.v1) + (jb < w.v0 || jb >= w.v1)          // then: is that row fresh in this window?
+             + (ia < w.u0 || ia >= w.u1) + (ib < w.u0 || ib >= w.u1);       //       ... and that column (2-D tiles)
     const int la = clampi(ja - w.g0, 0, w.rows - 1), lb = clampi(jb - w.g0, 0, w.rows - 1);
     t.a = (long)la * w.W + ia;
     t.b = (long)la * w.W + ib;
@@ -195,9 +196,9 @@ __global__ void __launch_bounds__(BX) k_advect_velocity(Win w, const float2* __r
                                                          float dt, float dissipation, float tsx, float tsy, int ga,
                                                          unsigned int* __restrict__ miss_out)
 {
-    const int i = blockIdx.x * BX + threadIdx.x;
+    const int i = w.x0 + blockIdx.x * BX + threadIdx.x;
     const int gj = ga + blockIdx.y;
-    if (i >= w.W) return;
+    if (i >= w.x1) return;
     const float u = ((float)i + 0.5f) / (float)w.W;
     const float v = ((float)gj + 0.5f) / (float)w.H;
     const long c = (long)(gj - w.g0) * w.W + i;
@@ -217,9 +218,9 @@ __global__ void __launch_bounds__(BX) k_advect_dye(Win vw, const float2* __restr
                                                     float4* __restrict__ out, float dt, float dissipation, float tsx, float tsy,
                                                     int ga, unsigned int* __restrict__ miss_out)
 {
-    const int i = blockIdx.x * BX + threadIdx.x;
+    const int i = dw.x0 + blockIdx.x * BX + threadIdx.x;
     const int gj = ga + blockIdx.y;
-    if (i >= dw.W) return;
+    if (i >= dw.x1) return;
     const float u = ((float)i + 0.5f) / (float)dw.W;
     const float v = ((float)gj + 0.5f) / (float)dw.H;
     int miss = 0;
@@ -256,9 +257,9 @@ __global__ void __launch_bounds__(BX) k_advect_both(Win w, const float2* __restr
                                                      float vel_dissipation, float dye_dissipation, float tsx, float tsy, int ga, int gb,
                                                      unsigned int* __restrict__ miss_out)
 {
-    const int i = blockIdx.x * BX + threadIdx.x;
+    const int i = w.x0 + blockIdx.x * BX + threadIdx.x;
     const int gj0 = ga + blockIdx.y * ROWS;
-    if (i >= w.W) return;
+    if (i >= w.x1) return;
     const float u = ((float)i + 0.5f) / (float)w.W;
     const float vdecay = 1.0f + vel_dissipation * dt, ddecay = 1.0f + dye_dissipation * dt;
     int miss = 0;
@@ -321,9 +322,9 @@ __device__ __forceinline__ float splat_weight(const Win& w, int i, int gj, float
 __global__ void __launch_bounds__(BX) k_splat_velocity(Win w, const float2* __restrict__ base, float2* __restrict__ out, float x, float y,
                                                         float aspect, float radius, float c0, float c1, int ga)
 {
-    const int i = blockIdx.x * BX + threadIdx.x;
+    const int i = w.x0 + blockIdx.x * BX + threadIdx.x;
     const int gj = ga + blockIdx.y;
-    if (i >= w.W) return;
+    if (i >= w.x1) return;
     const long c = (long)(gj - w.g0) * w.W + i;
     const float g = splat_weight(w, i, gj, x, y, aspect, radius);
     const float2 b = base[c];
@@ -333,9 +334,9 @@ __global__ void __launch_bounds__(BX) k_splat_velocity(Win w, const float2* __re
 __global__ void __launch_bounds__(BX) k_splat_dye(Win w, const float4* __restrict__ base, float4* __restrict__ out, float x, float y,
                                                    float aspect, float radius, float c0, float c1, float c2, int ga)
 {
-    const int i = blockIdx.x * BX + threadIdx.x;
+    const int i = w.x0 + blockIdx.x * BX + threadIdx.x;
     const int gj = ga + blockIdx.y;
-    if (i >= w.W) return;
+    if (i >= w.x1) return;
     const long c = (long)(gj - w.g0) * w.W + i;
     const float g = splat_weight(w, i, gj, x, y, aspect, radius);
     const float4 b = base[c];
@@ -590,7 +591,7 @@ __device__ __forceinline__ void jacobi_tb_body(const Win& w, const float* __rest
 
     // store the texels the apron kept exact
     int xa, xb, out_lo, out_hi;
-    tile_exact(x0, G::TX, HX, w.W, 0, w.W, xa, xb);
+    tile_exact(x0, G::TX, HX, w.W, w.x0, w.x1, xa, xb);
     tile_exact(y0, G::TY, HY, w.H, ga, gb, out_lo, out_hi);
     const bool col_store = (cx >= xa) && (cx < xb);
 #pragma unroll
@@ -606,13 +607,13 @@ __device__ __forceinline__ void jacobi_tb_body(const Win& w, const float* __rest
 template <int NW, int RY, int HX, int HY, int BPC>
 __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb(Win w, const float* __restrict__ p, const float* __restrict__ div,
                                                         float* __restrict__ p_out, float pscale, int iters, int ga, int gb,
-                                                        int ys, int nx, int ny, int remap)
+                                                        int xs, int ys, int nx, int ny, int remap)
 {
     using G = JacobiTB<NW, RY, HX, HY>;
     __shared__ float4 mail[2][NW][2][64];
     int bx, by;
     tile_of_block((int)blockIdx.x, nx, ny, remap, bx, by);
-    const int x0 = bx * G::VX, y0 = ys + by * G::VY;
+    const int x0 = xs + bx * G::VX, y0 = ys + by * G::VY;
     const bool edge = (x0 <= 0) || (x0 + G::TX >= w.W) || (y0 <= 0) || (y0 + G::TY >= w.H);
     if (edge) jacobi_tb_body<NW, RY, HX, HY, true>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
     else jacobi_tb_body<NW, RY, HX, HY, false>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
@@ -628,8 +629,8 @@ __global__ void __launch_bounds__(256) k_gradsub4(Win w, const float* __restrict
 {
     const int lane = threadIdx.x;
     const int gj = ga + (int)blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y);
-    const int cx = (int)blockIdx.x * 256 + 4 * lane;
-    if (gj >= gb || cx >= w.W) return;  // W % 4 == 0: a lane is either fully inside or fully outside
+    const int cx = w.x0 + (int)blockIdx.x * 256 + 4 * lane;  // x0, x1 multiples of 4 (the launcher rounds them outward)
+    if (gj >= gb || cx >= w.x1) return;
     const size_t rowC = (size_t)(gj - w.g0) * (size_t)w.W;
     const size_t rowT = (size_t)(min(gj + 1, w.H - 1) - w.g0) * (size_t)w.W;
     const size_t rowB = (size_t)(max(gj - 1, 0) - w.g0) * (size_t)w.W;
@@ -640,7 +641,7 @@ __global__ void __launch_bounds__(256) k_gradsub4(Win w, const float* __restrict
     const float4 vb = *reinterpret_cast<const float4*>(vel + rowC + cx + 2);
     float L = from_left_lane(C.w), R = from_right_lane(C.x);
     if (lane == 0) L = cx > 0 ? p[rowC + cx - 1] : C.x;                    // CLAMP_TO_EDGE at the domain border
-    if (lane == 63 || cx + 4 >= w.W) R = cx + 4 < w.W ? p[rowC + cx + 4] : C.w;
+    if (lane == 63 || cx + 4 >= w.x1) R = cx + 4 < w.W ? p[rowC + cx + 4] : C.w;
     float4 oa, ob;
     oa.x = va.x - (C.y - L);
     oa.y = va.y - (T.x - B.x);
@@ -776,7 +777,7 @@ __device__ __forceinline__ void vort_div_body(const Win& w, const float2* __rest
     const float4 nyb = mail[wb][1][0][lane], nya = mail[wa][0][0][lane];
 
     int xa, xb, out_lo, out_hi;
-    tile_exact(x0, G::TX, G::AX, w.W, 0, w.W, xa, xb);
+    tile_exact(x0, G::TX, G::AX, w.W, w.x0, w.x1, xa, xb);
     tile_exact(y0, G::TY, G::AY, w.H, ga, gb, out_lo, out_hi);
     const bool col_store = (cx >= xa) && (cx < xb);
 #pragma unroll
@@ -815,14 +816,14 @@ __device__ __forceinline__ void vort_div_body(const Win& w, const float2* __rest
 template <int NW, int RY>
 __global__ void __launch_bounds__(64 * NW, VD_WAVES_PER_EU) k_curl_vort_div(Win w, const float2* __restrict__ vel, float* __restrict__ curl_out,
                                                             float2* __restrict__ vel_out, float* __restrict__ div_out,
-                                                            float curl_strength, float dt, int ga, int gb, int ys, int nx, int ny,
+                                                            float curl_strength, float dt, int ga, int gb, int xs, int ys, int nx, int ny,
                                                             int remap)
 {
     using G = VortDiv<NW, RY>;
     __shared__ float4 mail[NW][2][2][64];
     int bx, by;
     tile_of_block((int)blockIdx.x, nx, ny, remap, bx, by);
-    const int x0 = bx * G::VX, y0 = ys + by * G::VY;
+    const int x0 = xs + bx * G::VX, y0 = ys + by * G::VY;
     const bool edge = (x0 <= 0) || (x0 + G::TX >= w.W) || (y0 <= 0) || (y0 + G::TY >= w.H);
     if (edge) vort_div_body<NW, RY, true>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
     else vort_div_body<NW, RY, false>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
@@ -875,13 +876,13 @@ template <int NW, int RY, int HX, int HY, int BPC>
 hipError_t launch_tb(hipStream_t s, Win w, const float* p, const float* div, float* p_out, float pscale, int iters, int ga, int gb)
 {
     using G = JacobiTB<NW, RY, HX, HY>;
-    const Axis ax = make_axis(0, w.W, w.W, G::TX, HX), ay = make_axis(ga, gb, w.H, G::TY, HY);
-    k_jacobi_tb<NW, RY, HX, HY, BPC><<<dim3(ax.n * ay.n, 1, 1), dim3(64, NW, 1), 0, s>>>(w, p, div, p_out, pscale, iters, ga, gb, ay.S, ax.n,
+    const Axis ax = make_axis(w.x0, w.x1, w.W, G::TX, HX), ay = make_axis(ga, gb, w.H, G::TY, HY);
+    k_jacobi_tb<NW, RY, HX, HY, BPC><<<dim3(ax.n * ay.n, 1, 1), dim3(64, NW, 1), 0, s>>>(w, p, div, p_out, pscale, iters, ga, gb, ax.S, ay.S, ax.n,
                                                                                  ay.n, xcd_remap());
     return hipGetLastError();
 }
 
-inline dim3 row_grid(int W, int ga, int gb) { return dim3((W + BX - 1) / BX, gb - ga, 1); }
+inline dim3 row_grid(const Win& w, int ga, int gb) { return dim3((w.x1 - w.x0 + BX - 1) / BX, gb - ga, 1); }  // columns [x0, x1) x rows [ga, gb)
 
 }  // namespace
 
@@ -892,7 +893,7 @@ inline dim3 row_grid(int W, int ga, int gb) { return dim3((W + BX - 1) / BX, gb 
 hipError_t launch_curl(hipStream_t s, Win w, const float2* vel, float* curl, int ga, int gb)
 {
     ROWS_OR_RETURN();
-    k_curl<<<row_grid(w.W, ga, gb), BX, 0, s>>>(w, vel, curl, ga);
+    k_curl<<<row_grid(w, ga, gb), BX, 0, s>>>(w, vel, curl, ga);
     return hipGetLastError();
 }
 
@@ -900,35 +901,35 @@ hipError_t launch_vorticity(hipStream_t s, Win w, const float2* vel, const float
                             float dt, int ga, int gb)
 {
     ROWS_OR_RETURN();
-    k_vorticity<<<row_grid(w.W, ga, gb), BX, 0, s>>>(w, vel, curl, vel_out, curl_strength, dt, ga);
+    k_vorticity<<<row_grid(w, ga, gb), BX, 0, s>>>(w, vel, curl, vel_out, curl_strength, dt, ga);
     return hipGetLastError();
 }
 
 hipError_t launch_divergence(hipStream_t s, Win w, const float2* vel, float* div, int ga, int gb)
 {
     ROWS_OR_RETURN();
-    k_divergence<<<row_grid(w.W, ga, gb), BX, 0, s>>>(w, vel, div, ga);
+    k_divergence<<<row_grid(w, ga, gb), BX, 0, s>>>(w, vel, div, ga);
     return hipGetLastError();
 }
 
 hipError_t launch_clear(hipStream_t s, Win w, const float* p, float* p_out, float value, int ga, int gb)
 {
     ROWS_OR_RETURN();
-    k_clear<<<row_grid(w.W, ga, gb), BX, 0, s>>>(w, p, p_out, value, ga);
+    k_clear<<<row_grid(w, ga, gb), BX, 0, s>>>(w, p, p_out, value, ga);
     return hipGetLastError();
 }
 
 hipError_t launch_jacobi(hipStream_t s, Win w, const float* p, const float* div, float* p_out, int ga, int gb)
 {
     ROWS_OR_RETURN();
-    k_jacobi<<<row_grid(w.W, ga, gb), BX, 0, s>>>(w, p, div, p_out, ga);
+    k_jacobi<<<row_grid(w, ga, gb), BX, 0, s>>>(w, p, div, p_out, ga);
     return hipGetLastError();
 }
 
 hipError_t launch_gradsub(hipStream_t s, Win w, const float* p, const float2* vel, float2* vel_out, int ga, int gb)
 {
     ROWS_OR_RETURN();
-    k_gradsub<<<row_grid(w.W, ga, gb), BX, 0, s>>>(w, p, vel, vel_out, ga);
+    k_gradsub<<<row_grid(w, ga, gb), BX, 0, s>>>(w, p, vel, vel_out, ga);
     return hipGetLastError();
 }
 
@@ -936,7 +937,10 @@ hipError_t launch_gradsub4(hipStream_t s, Win w, const float* p, const float2* v
 {
     ROWS_OR_RETURN();
     if (!fused_supported(w)) return hipErrorInvalidValue;
-    k_gradsub4<<<dim3((w.W + 255) / 256, (gb - ga + 3) / 4, 1), dim3(64, 4, 1), 0, s>>>(w, p, vel, vel_out, ga, gb);
+    w.x0 &= ~3;  // whole float4 groups: a few columns beyond the requested range are (re)computed as well
+    w.x1 = (w.x1 + 3) & ~3;
+    if (w.x1 > w.W) w.x1 = w.W;
+    k_gradsub4<<<dim3((w.x1 - w.x0 + 255) / 256, (gb - ga + 3) / 4, 1), dim3(64, 4, 1), 0, s>>>(w, p, vel, vel_out, ga, gb);
     return hipGetLastError();
 }
 
@@ -944,7 +948,7 @@ hipError_t launch_advect_velocity(hipStream_t s, Win w, const float2* vel, float
                                   int gb, unsigned int* miss)
 {
     ROWS_OR_RETURN();
-    k_advect_velocity<<<row_grid(w.W, ga, gb), BX, 0, s>>>(w, vel, out, dt, dissipation, (float)(1.0 / w.W), (float)(1.0 / w.H), ga, miss);
+    k_advect_velocity<<<row_grid(w, ga, gb), BX, 0, s>>>(w, vel, out, dt, dissipation, (float)(1.0 / w.W), (float)(1.0 / w.H), ga, miss);
     return hipGetLastError();
 }
 
@@ -954,9 +958,9 @@ hipError_t launch_advect_dye(hipStream_t s, Win vw, const float2* vel, Win dw, c
     ROWS_OR_RETURN();
     const float tsx = (float)(1.0 / vw.W), tsy = (float)(1.0 / vw.H);  // velocity.texelSizeX/Y, script.js:1061-1062, 1276
     if (vw.W == dw.W && vw.H == dw.H)
-        k_advect_dye<true><<<row_grid(dw.W, ga, gb), BX, 0, s>>>(vw, vel, dw, dye, out, dt, dissipation, tsx, tsy, ga, miss);
+        k_advect_dye<true><<<row_grid(dw, ga, gb), BX, 0, s>>>(vw, vel, dw, dye, out, dt, dissipation, tsx, tsy, ga, miss);
     else
-        k_advect_dye<false><<<row_grid(dw.W, ga, gb), BX, 0, s>>>(vw, vel, dw, dye, out, dt, dissipation, tsx, tsy, ga, miss);
+        k_advect_dye<false><<<row_grid(dw, ga, gb), BX, 0, s>>>(vw, vel, dw, dye, out, dt, dissipation, tsx, tsy, ga, miss);
     return hipGetLastError();
 }
 
@@ -970,7 +974,7 @@ hipError_t launch_advect_both(hipStream_t s, Win w, const float2* vel, float2* v
         return (k == 1 || k == 2 || k == 4) ? k : 2;
     }();
     const float tsx = (float)(1.0 / w.W), tsy = (float)(1.0 / w.H);
-    const dim3 g((w.W + BX - 1) / BX, (gb - ga + rows_per_thread - 1) / rows_per_thread, 1);
+    const dim3 g((w.x1 - w.x0 + BX - 1) / BX, (gb - ga + rows_per_thread - 1) / rows_per_thread, 1);
     if (rows_per_thread == 1) k_advect_both<1><<<g, BX, 0, s>>>(w, vel, vel_out, dye, dye_out, dt, vel_dissipation, dye_dissipation, tsx, tsy, ga, gb, miss);
     else if (rows_per_thread == 2) k_advect_both<2><<<g, BX, 0, s>>>(w, vel, vel_out, dye, dye_out, dt, vel_dissipation, dye_dissipation, tsx, tsy, ga, gb, miss);
     else k_advect_both<4><<<g, BX, 0, s>>>(w, vel, vel_out, dye, dye_out, dt, vel_dissipation, dye_dissipation, tsx, tsy, ga, gb, miss);
@@ -981,7 +985,7 @@ hipError_t launch_splat_velocity(hipStream_t s, Win w, const float2* base, float
                                  float radius, float c0, float c1, int ga, int gb)
 {
     ROWS_OR_RETURN();
-    k_splat_velocity<<<row_grid(w.W, ga, gb), BX, 0, s>>>(w, base, out, x, y, aspect, radius, c0, c1, ga);
+    k_splat_velocity<<<row_grid(w, ga, gb), BX, 0, s>>>(w, base, out, x, y, aspect, radius, c0, c1, ga);
     return hipGetLastError();
 }
 
@@ -989,7 +993,7 @@ hipError_t launch_splat_dye(hipStream_t s, Win w, const float4* base, float4* ou
                             float c0, float c1, float c2, int ga, int gb)
 {
     ROWS_OR_RETURN();
-    k_splat_dye<<<row_grid(w.W, ga, gb), BX, 0, s>>>(w, base, out, x, y, aspect, radius, c0, c1, c2, ga);
+    k_splat_dye<<<row_grid(w, ga, gb), BX, 0, s>>>(w, base, out, x, y, aspect, radius, c0, c1, c2, ga);
     return hipGetLastError();
 }
 
@@ -1020,11 +1024,11 @@ hipError_t launch_curl_vort_div(hipStream_t s, Win w, const float2* vel, float* 
     ROWS_OR_RETURN();
     if (!fused_supported(w)) return hipErrorInvalidValue;
     using G = VortDiv<VD_NW, VD_RY>;
-    const Axis ax = make_axis(0, w.W, w.W, G::TX, G::AX), ay = make_axis(ga, gb, w.H, G::TY, G::AY);
+    const Axis ax = make_axis(w.x0, w.x1, w.W, G::TX, G::AX), ay = make_axis(ga, gb, w.H, G::TY, G::AY);
     // plain column-major tile order here: with a 3-row apron there is little to share, and the XCD-contiguous
     // order measured 11 % slower for this kernel (profiles/r01/xcd_remap_ab.txt)
     k_curl_vort_div<VD_NW, VD_RY><<<dim3(ax.n * ay.n, 1, 1), dim3(64, VD_NW, 1), 0, s>>>(w, vel, curl, vel_out, div, curl_strength, dt,
-                                                                                    ga, gb, ay.S, ax.n, ay.n, 0);
+                                                                                    ga, gb, ax.S, ay.S, ax.n, ay.n, 0);
     return hipGetLastError();
 }
 

@@ -47,7 +47,14 @@ int set_geometry(fluid_ctx* c, int sw, int sh, int dw, int dh)
     const fluid_desc& d = c->desc;
     if (sw < 1 || sh < 1 || dw < 1 || dh < 1) return c->fail(FLUID_ERR_INVALID, "field sizes must be >= 1");
     if (d.parts < 1 || d.part < 0 || d.part >= d.parts) return c->fail(FLUID_ERR_INVALID, "bad stripe index");
+    if (d.parts_x < 1 || d.part_x < 0 || d.part_x >= d.parts_x) return c->fail(FLUID_ERR_INVALID, "bad tile column index");
     if (d.halo < 0) return c->fail(FLUID_ERR_INVALID, "negative halo");
+    if (d.parts_x > 1) {
+        if (sw % d.parts_x || dw % d.parts_x) return c->fail(FLUID_ERR_INVALID, "sim_w and dye_w must divide by parts_x");
+        if ((sw / d.parts_x) % 4 || (dw / d.parts_x) % 4) return c->fail(FLUID_ERR_INVALID, "tile widths must be multiples of 4");
+        if (d.halo < 4) return c->fail(FLUID_ERR_INVALID, "a tile needs halo >= 4");
+        if (d.halo > sw / d.parts_x) return c->fail(FLUID_ERR_INVALID, "halo wider than a tile");
+    }
     if (d.parts > 1) {
         if (sh % d.parts || dh % d.parts) return c->fail(FLUID_ERR_INVALID, "sim_h and dye_h must divide by parts");
         if (d.halo < 4) return c->fail(FLUID_ERR_INVALID, "a stripe needs halo >= 4");
@@ -58,6 +65,11 @@ int set_geometry(fluid_ctx* c, int sw, int sh, int dw, int dh)
     c->dye_rows = dh / d.parts;
     c->dye_row0 = d.part * c->dye_rows;
     c->dye_halo = d.parts > 1 ? (int)(((long)d.halo * dh + sh - 1) / sh) : 0;
+    c->sim_ncols = sw / d.parts_x;
+    c->sim_col0 = d.part_x * c->sim_ncols;
+    c->dye_ncols = dw / d.parts_x;
+    c->dye_col0 = d.part_x * c->dye_ncols;
+    c->dye_halo_x = d.parts_x > 1 ? (int)(((long)d.halo * dw + sw - 1) / sw) : 0;
     const int sh_halo = d.parts > 1 ? d.halo : 0;
     c->sim = make_win(sw, sh, c->sim_row0 - sh_halo, c->sim_rows + 2 * sh_halo);
     c->dye = make_win(dw, dh, c->dye_row0 - c->dye_halo, c->dye_rows + 2 * c->dye_halo);
@@ -112,13 +124,26 @@ int check_ext(fluid_ctx* c, int ext, int need_in)
 
 namespace fluid_impl {
 
+// The window of a launch that computes the owned columns +- ext (2-D tiles; whole float4 groups, clipped to the
+// domain).  The arrays span the full width in every decomposition, so only the launch's column range changes.
+Win cols_of(Win w, int parts_x, int col0, int cols, int ext)
+{
+    if (parts_x > 1) {
+        w.x0 = std::max((col0 - ext) & ~3, 0);
+        w.x1 = std::min((col0 + cols + ext + 3) & ~3, w.W);
+    }
+    return w;
+}
+Win sim_cols(const fluid_ctx* c, int ext) { return cols_of(c->sim, c->desc.parts_x, c->sim_col0, c->sim_ncols, ext); }
+Win dye_cols(const fluid_ctx* c, int ext) { return cols_of(c->dye, c->desc.parts_x, c->dye_col0, c->dye_ncols, ext); }
+
 // ---- passes -------------------------------------------------------------------------------------
 int pass_curl(fluid_ctx* c, int ext)
 {
     CK(check_ext(c, ext, 1));
     int ga, gb;
     row_range(c->sim, c->sim_row0, c->sim_rows, ext, ga, gb);
-    return c->hip(launch_curl(c->stream, c->sim, c->vel[0], c->curl, ga, gb), "curl");
+    return c->hip(launch_curl(c->stream, sim_cols(c, ext), c->vel[0], c->curl, ga, gb), "curl");
 }
 
 int pass_vorticity(fluid_ctx* c, float curl, float dt, int ext)
@@ -126,7 +151,7 @@ int pass_vorticity(fluid_ctx* c, float curl, float dt, int ext)
     CK(check_ext(c, ext, 1));
     int ga, gb;
     row_range(c->sim, c->sim_row0, c->sim_rows, ext, ga, gb);
-    CK(c->hip(launch_vorticity(c->stream, c->sim, c->vel[0], c->curl, c->vel[1], curl, dt, ga, gb), "vorticity"));
+    CK(c->hip(launch_vorticity(c->stream, sim_cols(c, ext), c->vel[0], c->curl, c->vel[1], curl, dt, ga, gb), "vorticity"));
     std::swap(c->vel[0], c->vel[1]);
     return FLUID_OK;
 }
@@ -136,7 +161,7 @@ int pass_divergence(fluid_ctx* c, int ext)
     CK(check_ext(c, ext, 1));
     int ga, gb;
     row_range(c->sim, c->sim_row0, c->sim_rows, ext, ga, gb);
-    return c->hip(launch_divergence(c->stream, c->sim, c->vel[0], c->div, ga, gb), "divergence");
+    return c->hip(launch_divergence(c->stream, sim_cols(c, ext), c->vel[0], c->div, ga, gb), "divergence");
 }
 
 // K1 + K2 + K3; one kernel when the fused schedule applies, the three passes otherwise (same bits either way)
@@ -146,7 +171,7 @@ int pass_curl_vort_div(fluid_ctx* c, float curl, float dt, int ext, Timer* t)
         CK(check_ext(c, ext, 3));
         int ga, gb;
         row_range(c->sim, c->sim_row0, c->sim_rows, ext, ga, gb);
-        CK(c->hip(launch_curl_vort_div(c->stream, c->sim, c->vel[0], c->curl, c->vel[1], c->div, curl, dt, ga, gb), "curl_vort_div"));
+        CK(c->hip(launch_curl_vort_div(c->stream, sim_cols(c, ext), c->vel[0], c->curl, c->vel[1], c->div, curl, dt, ga, gb), "curl_vort_div"));
         std::swap(c->vel[0], c->vel[1]);
         if (t) t->mark(P_VORT);
         return FLUID_OK;
@@ -165,7 +190,7 @@ int pass_clear(fluid_ctx* c, float value, int ext)
     CK(check_ext(c, ext, 0));
     int ga, gb;
     row_range(c->sim, c->sim_row0, c->sim_rows, ext, ga, gb);
-    CK(c->hip(launch_clear(c->stream, c->sim, c->prs[0], c->prs[1], value, ga, gb), "clear"));
+    CK(c->hip(launch_clear(c->stream, sim_cols(c, ext), c->prs[0], c->prs[1], value, ga, gb), "clear"));
     std::swap(c->prs[0], c->prs[1]);
     return FLUID_OK;
 }
@@ -186,12 +211,12 @@ int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launche
             const int k = (iters - done + launches_left - 1) / launches_left;
             launches_left--;
             row_range(c->sim, c->sim_row0, c->sim_rows, ext_out + (iters - done - k), ga, gb);
-            CK(c->hip(launch_jacobi_tb(c->stream, c->sim, c->prs[0], c->div, c->prs[1], done == 0 ? pscale : 1.0f, k, ga, gb),
+            CK(c->hip(launch_jacobi_tb(c->stream, sim_cols(c, ext_out + (iters - done - k)), c->prs[0], c->div, c->prs[1], done == 0 ? pscale : 1.0f, k, ga, gb),
                       "jacobi_tb"));
             done += k;
         } else {
             row_range(c->sim, c->sim_row0, c->sim_rows, ext_out + (iters - done - 1), ga, gb);
-            CK(c->hip(launch_jacobi(c->stream, c->sim, c->prs[0], c->div, c->prs[1], ga, gb), "jacobi"));
+            CK(c->hip(launch_jacobi(c->stream, sim_cols(c, ext_out + (iters - done - 1)), c->prs[0], c->div, c->prs[1], ga, gb), "jacobi"));
             done += 1;
         }
         std::swap(c->prs[0], c->prs[1]);
@@ -216,9 +241,9 @@ int pass_gradsub(fluid_ctx* c, int ext)
     int ga, gb;
     row_range(c->sim, c->sim_row0, c->sim_rows, ext, ga, gb);
     if (c->desc.schedule == FLUID_SCHED_FUSED && fused_supported(c->sim))
-        CK(c->hip(launch_gradsub4(c->stream, c->sim, c->prs[0], c->vel[0], c->vel[1], ga, gb), "gradsub"));
+        CK(c->hip(launch_gradsub4(c->stream, sim_cols(c, ext), c->prs[0], c->vel[0], c->vel[1], ga, gb), "gradsub"));
     else
-        CK(c->hip(launch_gradsub(c->stream, c->sim, c->prs[0], c->vel[0], c->vel[1], ga, gb), "gradsub"));
+        CK(c->hip(launch_gradsub(c->stream, sim_cols(c, ext), c->prs[0], c->vel[0], c->vel[1], ga, gb), "gradsub"));
     std::swap(c->vel[0], c->vel[1]);
     return FLUID_OK;
 }
@@ -228,7 +253,7 @@ int pass_advect_velocity(fluid_ctx* c, float dt, float dissipation, int ext)
     CK(check_ext(c, ext, 0));
     int ga, gb;
     row_range(c->sim, c->sim_row0, c->sim_rows, ext, ga, gb);
-    CK(c->hip(launch_advect_velocity(c->stream, c->sim, c->vel[0], c->vel[1], dt, dissipation, ga, gb, c->miss), "advect velocity"));
+    CK(c->hip(launch_advect_velocity(c->stream, sim_cols(c, ext), c->vel[0], c->vel[1], dt, dissipation, ga, gb, c->miss), "advect velocity"));
     std::swap(c->vel[0], c->vel[1]);
     return FLUID_OK;
 }
@@ -237,7 +262,7 @@ int pass_advect_dye(fluid_ctx* c, float dt, float dissipation)
 {
     int ga, gb;
     row_range(c->dye, c->dye_row0, c->dye_rows, 0, ga, gb);
-    CK(c->hip(launch_advect_dye(c->stream, c->sim, c->vel[0], c->dye, c->dyeb[0], c->dyeb[1], dt, dissipation, ga, gb, c->miss),
+    CK(c->hip(launch_advect_dye(c->stream, c->sim, c->vel[0], dye_cols(c, 0), c->dyeb[0], c->dyeb[1], dt, dissipation, ga, gb, c->miss),
               "advect dye"));
     std::swap(c->dyeb[0], c->dyeb[1]);
     return FLUID_OK;
@@ -251,7 +276,7 @@ int pass_advect(fluid_ctx* c, float dt, float vel_diss, float dye_diss, Timer* t
     if (c->desc.schedule == FLUID_SCHED_FUSED && same) {
         int ga, gb;
         row_range(c->sim, c->sim_row0, c->sim_rows, 0, ga, gb);
-        CK(c->hip(launch_advect_both(c->stream, c->sim, c->vel[0], c->vel[1], c->dyeb[0], c->dyeb[1], dt, vel_diss, dye_diss, ga, gb,
+        CK(c->hip(launch_advect_both(c->stream, sim_cols(c, 0), c->vel[0], c->vel[1], c->dyeb[0], c->dyeb[1], dt, vel_diss, dye_diss, ga, gb,
                                      c->miss),
                   "advect"));
         std::swap(c->vel[0], c->vel[1]);
@@ -333,13 +358,13 @@ namespace fluid_impl {
 
 int field_ref(fluid_ctx* c, int field, FieldRef* f)
 {
-    const int h = c->desc.parts > 1 ? c->desc.halo : 0;
+    const int h = c->desc.parts > 1 ? c->desc.halo : 0, hx = c->desc.parts_x > 1 ? c->desc.halo : 0;
     switch (field) {
-    case FLUID_VELOCITY: *f = { c->vel[0], &c->sim, c->sim_row0, c->sim_rows, h, 2 }; break;
-    case FLUID_PRESSURE: *f = { c->prs[0], &c->sim, c->sim_row0, c->sim_rows, h, 1 }; break;
-    case FLUID_DIVERGENCE: *f = { c->div, &c->sim, c->sim_row0, c->sim_rows, h, 1 }; break;
-    case FLUID_CURL: *f = { c->curl, &c->sim, c->sim_row0, c->sim_rows, h, 1 }; break;
-    case FLUID_DYE: *f = { c->dyeb[0], &c->dye, c->dye_row0, c->dye_rows, c->dye_halo, 4 }; break;
+    case FLUID_VELOCITY: *f = { c->vel[0], &c->sim, c->sim_row0, c->sim_rows, h, 2, c->sim_col0, c->sim_ncols, hx }; break;
+    case FLUID_PRESSURE: *f = { c->prs[0], &c->sim, c->sim_row0, c->sim_rows, h, 1, c->sim_col0, c->sim_ncols, hx }; break;
+    case FLUID_DIVERGENCE: *f = { c->div, &c->sim, c->sim_row0, c->sim_rows, h, 1, c->sim_col0, c->sim_ncols, hx }; break;
+    case FLUID_CURL: *f = { c->curl, &c->sim, c->sim_row0, c->sim_rows, h, 1, c->sim_col0, c->sim_ncols, hx }; break;
+    case FLUID_DYE: *f = { c->dyeb[0], &c->dye, c->dye_row0, c->dye_rows, c->dye_halo, 4, c->dye_col0, c->dye_ncols, c->dye_halo_x }; break;
     default: return c->fail(FLUID_ERR_INVALID, "unknown field id");
     }
     return FLUID_OK;
@@ -399,7 +424,8 @@ int fluid_create(const fluid_desc* desc, fluid_ctx** out)
     if (!c) return FLUID_ERR_OOM;
     c->desc = *desc;
     if (c->desc.parts < 1) c->desc.parts = 1;
-    if (c->desc.parts == 1) c->desc.halo = 0;
+    if (c->desc.parts_x < 1) c->desc.parts_x = 1;
+    if (c->desc.parts == 1 && c->desc.parts_x == 1) c->desc.halo = 0;
     c->device = desc->device;
     int rc = FLUID_OK;
     do {
@@ -443,7 +469,7 @@ int fluid_destroy(fluid_ctx* c)
 int fluid_resize(fluid_ctx* c, int sw, int sh, int dw, int dh)
 {
     if (!c) return FLUID_ERR_INVALID;
-    if (c->desc.parts != 1) return c->fail(FLUID_ERR_UNSUPPORTED, "resize of a stripe context");
+    if (c->desc.parts != 1 || c->desc.parts_x != 1) return c->fail(FLUID_ERR_UNSUPPORTED, "resize of a stripe / tile context");
     if (sw < 1 || sh < 1 || dw < 1 || dh < 1) return c->fail(FLUID_ERR_INVALID, "field sizes must be >= 1");
     HIPCK(c, hipSetDevice(c->device));
     const Win osim = c->sim, odye = c->dye;
@@ -519,11 +545,11 @@ int fluid_pass_splat(fluid_ctx* c, int field, float x, float y, float aspect, fl
     int ga, gb;
     if (field == FLUID_VELOCITY) {
         row_range(c->sim, c->sim.g0, c->sim.rows, 0, ga, gb);
-        CK(c->hip(launch_splat_velocity(c->stream, c->sim, c->vel[0], c->vel[1], x, y, aspect, radius, c0, c1, ga, gb), "splat velocity"));
+        CK(c->hip(launch_splat_velocity(c->stream, sim_cols(c, c->desc.halo), c->vel[0], c->vel[1], x, y, aspect, radius, c0, c1, ga, gb), "splat velocity"));
         std::swap(c->vel[0], c->vel[1]);
     } else if (field == FLUID_DYE) {
         row_range(c->dye, c->dye.g0, c->dye.rows, 0, ga, gb);
-        CK(c->hip(launch_splat_dye(c->stream, c->dye, c->dyeb[0], c->dyeb[1], x, y, aspect, radius, c0, c1, c2, ga, gb), "splat dye"));
+        CK(c->hip(launch_splat_dye(c->stream, dye_cols(c, c->dye_halo_x), c->dyeb[0], c->dyeb[1], x, y, aspect, radius, c0, c1, c2, ga, gb), "splat dye"));
         std::swap(c->dyeb[0], c->dyeb[1]);
     } else {
         return c->fail(FLUID_ERR_INVALID, "splat target must be velocity or dye");
@@ -543,7 +569,7 @@ int fluid_step_n(fluid_ctx* c, int n, float dt, const fluid_params* P)
     if (n < 0) return c->fail(FLUID_ERR_INVALID, "negative step count");
     if (P->iterations < 0) return c->fail(FLUID_ERR_INVALID, "negative PRESSURE_ITERATIONS");
     HIPCK(c, hipSetDevice(c->device));
-    if (c->desc.parts != 1) return stripe_step_n(c, n, dt, P);  // ghost-row exchanges over RCCL (fluid_stripes.cpp)
+    if (c->desc.parts != 1 || c->desc.parts_x != 1) return stripe_step_n(c, n, dt, P);  // ghost-row exchanges over RCCL (fluid_stripes.cpp)
     for (int k = 0; k < n; k++) CK(step_once(c, dt, P));
     return FLUID_OK;
 }
@@ -563,7 +589,7 @@ int fluid_field_info_get(const fluid_ctx* c, int field, fluid_field_info* out)
     if (!c || !out) return FLUID_ERR_INVALID;
     FieldRef f;
     CK(field_ref(const_cast<fluid_ctx*>(c), field, &f));
-    *out = fluid_field_info{ f.win->W, f.win->H, f.nc, f.row0, f.rows, f.halo };
+    *out = fluid_field_info{ f.win->W, f.win->H, f.nc, f.row0, f.rows, f.halo, f.col0, f.cols, f.halo_x };
     return FLUID_OK;
 }
 
@@ -572,11 +598,11 @@ int fluid_read_field(fluid_ctx* c, int field, float* host, size_t bytes)
     if (!c || !host) return FLUID_ERR_INVALID;
     FieldRef f;
     CK(field_ref(c, field, &f));
-    const size_t want = (size_t)f.rows * f.win->W * f.nc * sizeof(float);
-    if (bytes != want) return c->fail(FLUID_ERR_INVALID, "read_field: byte count does not match the owned rows");
+    const size_t texel = f.nc * sizeof(float), pitch = (size_t)f.win->W * texel, line = (size_t)f.cols * texel;
+    if (bytes != (size_t)f.rows * line) return c->fail(FLUID_ERR_INVALID, "read_field: byte count does not match the owned rows x columns");
     HIPCK(c, hipSetDevice(c->device));
-    const char* src = (const char*)f.ptr + (size_t)(f.row0 - f.win->g0) * f.win->W * f.nc * sizeof(float);
-    HIPCK(c, hipMemcpyAsync(host, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    const char* src = (const char*)f.ptr + (size_t)(f.row0 - f.win->g0) * pitch + (size_t)f.col0 * texel;
+    HIPCK(c, hipMemcpy2DAsync(host, line, src, pitch, line, f.rows, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
     return FLUID_OK;
 }
@@ -586,11 +612,11 @@ int fluid_write_field(fluid_ctx* c, int field, const float* host, size_t bytes)
     if (!c || !host) return FLUID_ERR_INVALID;
     FieldRef f;
     CK(field_ref(c, field, &f));
-    const size_t want = (size_t)f.rows * f.win->W * f.nc * sizeof(float);
-    if (bytes != want) return c->fail(FLUID_ERR_INVALID, "write_field: byte count does not match the owned rows");
+    const size_t texel = f.nc * sizeof(float), pitch = (size_t)f.win->W * texel, line = (size_t)f.cols * texel;
+    if (bytes != (size_t)f.rows * line) return c->fail(FLUID_ERR_INVALID, "write_field: byte count does not match the owned rows x columns");
     HIPCK(c, hipSetDevice(c->device));
-    char* dst = (char*)f.ptr + (size_t)(f.row0 - f.win->g0) * f.win->W * f.nc * sizeof(float);
-    HIPCK(c, hipMemcpyAsync(dst, host, bytes, hipMemcpyHostToDevice, c->stream));
+    char* dst = (char*)f.ptr + (size_t)(f.row0 - f.win->g0) * pitch + (size_t)f.col0 * texel;
+    HIPCK(c, hipMemcpy2DAsync(dst, pitch, host, line, line, f.rows, hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
     return FLUID_OK;
 }

@@ -102,6 +102,10 @@ int build_plan(int halo, int dye_halo, int iterations, int advect_rows, int adve
     return FLUID_OK;
 }
 
+// ghost depth of the dye field in dye rows (what `halo` sim rows are on the dye grid), whether or not this context has
+// ghost ROWS at all (a 1 x N tile set only has ghost columns)
+int dye_ghost_depth(const fluid_ctx* c) { return (int)(((long)c->desc.halo * c->dye.H + c->sim.H - 1) / c->sim.H); }
+
 // rows refreshed in front of the advection: the reach of a back-trace (one more when the dye grid differs from the
 // sim grid: the dye pass samples the NEW velocity bilinearly, so that is advected one ghost row out), and the same
 // distance in dye rows
@@ -111,7 +115,7 @@ void advect_rows(const fluid_ctx* c, int* vel_rows, int* dye_rows)
     int va = c->reach + (same ? 0 : 1);
     if (va > c->desc.halo) va = c->desc.halo;
     long vd = same ? va : ((long)c->reach * c->dye.H + c->sim.H - 1) / c->sim.H + 1;
-    if (vd > c->dye_halo) vd = c->dye_halo;
+    if (vd > dye_ghost_depth(c)) vd = dye_ghost_depth(c);
     if (vd < 1) vd = 1;
     if (va < 1) va = 1;
     *vel_rows = va;
@@ -237,6 +241,7 @@ int ensure_comm_stream(fluid_ctx* c)
     HIPCK(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
     HIPCK(c, hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
     HIPCK(c, hipEventCreateWithFlags(&c->ev_landed, hipEventDisableTiming));
+    HIPCK(c, hipEventCreateWithFlags(&c->ev_mid, hipEventDisableTiming));
     if (const char* e = getenv("FLUID_STRIPE_OVERLAP")) c->overlap = atoi(e) != 0;
     return FLUID_OK;
 }
@@ -322,6 +327,193 @@ int group_exchange_end(fluid_ctx** cs, int n)
     return FLUID_OK;
 }
 
+// ---- 2-D tiles (parts_x > 1): ghost COLUMNS as well ---------------------------------------------------------------
+// Rank = part * parts_x + part_x.  An exchange has two phases: A moves ghost columns between left / right neighbours
+// (owned rows only), B then moves ghost rows between lower / upper neighbours over the owned columns PLUS the ghost
+// columns that phase A just filled — so the corner blocks arrive without diagonal messages.  Column blocks are strided
+// in the full-width arrays: they travel through contiguous staging buffers (hipMemcpy2DAsync on the comm stream packs and
+// unpacks them); row blocks that span the whole width go in place.  One message per neighbour and phase carries all the
+// fields of the exchange.  No interior-first overlap in this mode yet: the exchange is synchronous on the comm stream.
+struct Rect {
+    char* p;             // first texel
+    size_t pitch, line;  // bytes between rows, bytes per row of the block
+    int nrows;
+    size_t bytes() const { return line * (size_t)nrows; }
+};
+
+enum Dir { LEFT = 0, RIGHT = 1, DOWN = 2, UP = 3 };
+
+struct Blocks {
+    Rect send[4], recv[4];
+};
+
+int col_depth(const fluid_ctx* c, const FieldRef& f, int n)  // ghost columns that go with n ghost rows of this field
+{
+    if (f.nc != 4) return n < f.halo_x ? n : f.halo_x;      // sim fields: same depth both ways
+    const long num = (long)n * c->dye.W * c->sim.H, den = (long)c->dye.H * c->sim.W;  // dye: same physical distance
+    long nx = (num + den - 1) / den + 1;
+    if (nx > f.halo_x) nx = f.halo_x;
+    return (int)nx;
+}
+
+int blocks_of(fluid_ctx* c, int field, int n, Blocks* b)
+{
+    FieldRef f;
+    CK(field_ref(c, field, &f));
+    if (n < 1 || (c->desc.parts > 1 && (n > f.halo || n > f.rows))) return c->fail(FLUID_ERR_INVALID, "exchange rows exceed the ghost rows / the tile");
+    const size_t texel = f.nc * sizeof(float), pitch = (size_t)f.win->W * texel;
+    const int nx = col_depth(c, f, n);
+    if (nx < 1 || nx > f.cols) return c->fail(FLUID_ERR_INVALID, "exchange columns exceed the ghost columns / the tile");
+    const int h = f.halo, R = f.rows, c0 = f.col0, c1 = f.col0 + f.cols;
+    auto rect = [&](int arow, int nrows, int col, int ncols) {
+        return Rect{ (char*)f.ptr + (size_t)arow * pitch + (size_t)col * texel, pitch, (size_t)ncols * texel, nrows };
+    };
+    // phase A: owned rows, columns next to the left / right tile border
+    b->send[LEFT] = rect(h, R, c0, nx);
+    b->recv[LEFT] = rect(h, R, c0 - nx, nx);
+    b->send[RIGHT] = rect(h, R, c1 - nx, nx);
+    b->recv[RIGHT] = rect(h, R, c1, nx);
+    // phase B: owned + freshly received ghost columns, rows next to the lower / upper tile border
+    const int cs = c->desc.part_x > 0 ? c0 - nx : c0, ce = c->desc.part_x < c->desc.parts_x - 1 ? c1 + nx : c1;
+    b->send[DOWN] = rect(h, n, cs, ce - cs);
+    b->recv[DOWN] = rect(h - n, n, cs, ce - cs);
+    b->send[UP] = rect(h + R - n, n, cs, ce - cs);
+    b->recv[UP] = rect(h + R, n, cs, ce - cs);
+    return FLUID_OK;
+}
+
+bool has_neighbour(const fluid_ctx* c, int dir)
+{
+    const fluid_desc& d = c->desc;
+    return dir == LEFT ? d.part_x > 0 : dir == RIGHT ? d.part_x < d.parts_x - 1 : dir == DOWN ? d.part > 0 : d.part < d.parts - 1;
+}
+
+int neighbour_rank(const fluid_ctx* c, int dir)
+{
+    const int r = c->desc.part * c->desc.parts_x + c->desc.part_x;
+    return dir == LEFT ? r - 1 : dir == RIGHT ? r + 1 : dir == DOWN ? r - c->desc.parts_x : r + c->desc.parts_x;
+}
+
+int copy_rect(fluid_ctx* c, const Rect& dst, const Rect& src, hipStream_t s)
+{
+    if (dst.line != src.line || dst.nrows != src.nrows) return c->fail(FLUID_ERR_INVALID, "exchange blocks of neighbouring tiles differ in shape");
+    HIPCK(c, hipMemcpy2DAsync(dst.p, dst.pitch, src.p, src.pitch, src.line, src.nrows, hipMemcpyDeviceToDevice, s));
+    return FLUID_OK;
+}
+
+int ensure_stage(fluid_ctx* c, int slot, size_t bytes)
+{
+    if (c->stage_bytes[slot] >= bytes) return FLUID_OK;
+    if (c->stage[slot]) (void)hipFree(c->stage[slot]);
+    c->stage[slot] = nullptr;
+    c->stage_bytes[slot] = 0;
+    HIPCK(c, hipMalloc(&c->stage[slot], bytes));
+    c->stage_bytes[slot] = bytes;
+    return FLUID_OK;
+}
+
+// the whole exchange over RCCL, synchronous with respect to the context stream
+int rccl_exchange_2d(fluid_ctx* c, const fluid_stripe_op& op)
+{
+    const Rccl* R = rccl(nullptr);
+    if (!R || !c->comm) return c->fail(FLUID_ERR_COMM, "tile context has no communicator (fluid_comm_init)");
+    ncclComm_t comm = (ncclComm_t)c->comm;
+    Blocks blk[2];
+    for (int i = 0; i < op.n_items; i++) CK(blocks_of(c, op.field[i], op.rows[i], &blk[i]));
+    HIPCK(c, hipEventRecord(c->ev_ready, c->stream));
+    HIPCK(c, hipStreamWaitEvent(c->comm_stream, c->ev_ready, 0));
+    for (int phase = 0; phase < 2; phase++) {
+        const int dirs[2] = { phase == 0 ? LEFT : DOWN, phase == 0 ? RIGHT : UP };
+        size_t total[2] = { 0, 0 };
+        for (int k = 0; k < 2; k++) {
+            if (!has_neighbour(c, dirs[k])) continue;
+            for (int i = 0; i < op.n_items; i++) total[k] += blk[i].send[dirs[k]].bytes();
+            CK(ensure_stage(c, 2 * dirs[k], total[k]));      // send staging of this direction
+            CK(ensure_stage(c, 2 * dirs[k] + 1, total[k]));  // receive staging (the neighbour's block has the same shape)
+            size_t off = 0;
+            for (int i = 0; i < op.n_items; i++) {           // pack
+                const Rect& sr = blk[i].send[dirs[k]];
+                HIPCK(c, hipMemcpy2DAsync((char*)c->stage[2 * dirs[k]] + off, sr.line, sr.p, sr.pitch, sr.line, sr.nrows, hipMemcpyDeviceToDevice,
+                                          c->comm_stream));
+                off += sr.bytes();
+            }
+        }
+        if (!total[0] && !total[1]) continue;
+        NCCLCK(c, R, R->GroupStart());
+        for (int k = 0; k < 2; k++)
+            if (total[k]) {
+                NCCLCK(c, R, R->Send(c->stage[2 * dirs[k]], total[k] / sizeof(float), ncclFloat, neighbour_rank(c, dirs[k]), comm, c->comm_stream));
+                NCCLCK(c, R, R->Recv(c->stage[2 * dirs[k] + 1], total[k] / sizeof(float), ncclFloat, neighbour_rank(c, dirs[k]), comm, c->comm_stream));
+            }
+        NCCLCK(c, R, R->GroupEnd());
+        for (int k = 0; k < 2; k++)
+            if (total[k]) {
+                size_t off = 0;
+                for (int i = 0; i < op.n_items; i++) {       // unpack
+                    const Rect& rr = blk[i].recv[dirs[k]];
+                    HIPCK(c, hipMemcpy2DAsync(rr.p, rr.pitch, (char*)c->stage[2 * dirs[k] + 1] + off, rr.line, rr.line, rr.nrows,
+                                              hipMemcpyDeviceToDevice, c->comm_stream));
+                    off += rr.bytes();
+                }
+            }
+    }
+    HIPCK(c, hipEventRecord(c->ev_landed, c->comm_stream));
+    HIPCK(c, hipStreamWaitEvent(c->stream, c->ev_landed, 0));
+    c->exchanges++;
+    return FLUID_OK;
+}
+
+// the same exchange for a whole tile set inside one process: direct rectangle copies, phase B after the neighbours' phase A
+int group_exchange_2d(fluid_ctx** cs, int n, const fluid_stripe_op& op)
+{
+    const int px = cs[0]->desc.parts_x;
+    std::vector<Blocks> blk((size_t)n * 2);
+    for (int r = 0; r < n; r++) {
+        HIPCK(cs[r], hipSetDevice(cs[r]->device));
+        for (int i = 0; i < op.n_items; i++) CK(blocks_of(cs[r], op.field[i], op.rows[i], &blk[(size_t)r * 2 + i]));
+        HIPCK(cs[r], hipEventRecord(cs[r]->ev_ready, cs[r]->stream));
+    }
+    auto wait_neighbours = [&](int r, hipStream_t s, bool phase_a_done) -> int {
+        fluid_ctx* c = cs[r];
+        for (int dir = 0; dir < 4; dir++)
+            if (has_neighbour(c, dir)) {
+                fluid_ctx* o = cs[neighbour_rank(c, dir)];
+                HIPCK(c, hipStreamWaitEvent(s, phase_a_done ? o->ev_mid : o->ev_ready, 0));
+            }
+        return FLUID_OK;
+    };
+    for (int r = 0; r < n; r++) {  // phase A
+        fluid_ctx* c = cs[r];
+        HIPCK(c, hipSetDevice(c->device));
+        HIPCK(c, hipStreamWaitEvent(c->comm_stream, c->ev_ready, 0));
+        CK(wait_neighbours(r, c->comm_stream, false));
+        for (int i = 0; i < op.n_items; i++) {
+            if (has_neighbour(c, LEFT)) CK(copy_rect(c, blk[(size_t)r * 2 + i].recv[LEFT], blk[(size_t)(r - 1) * 2 + i].send[RIGHT], c->comm_stream));
+            if (has_neighbour(c, RIGHT)) CK(copy_rect(c, blk[(size_t)r * 2 + i].recv[RIGHT], blk[(size_t)(r + 1) * 2 + i].send[LEFT], c->comm_stream));
+        }
+        HIPCK(c, hipEventRecord(c->ev_mid, c->comm_stream));
+    }
+    for (int r = 0; r < n; r++) {  // phase B
+        fluid_ctx* c = cs[r];
+        HIPCK(c, hipSetDevice(c->device));
+        CK(wait_neighbours(r, c->comm_stream, true));
+        for (int i = 0; i < op.n_items; i++) {
+            if (has_neighbour(c, DOWN)) CK(copy_rect(c, blk[(size_t)r * 2 + i].recv[DOWN], blk[(size_t)(r - px) * 2 + i].send[UP], c->comm_stream));
+            if (has_neighbour(c, UP)) CK(copy_rect(c, blk[(size_t)r * 2 + i].recv[UP], blk[(size_t)(r + px) * 2 + i].send[DOWN], c->comm_stream));
+        }
+        HIPCK(c, hipEventRecord(c->ev_landed, c->comm_stream));
+        c->exchanges++;
+    }
+    for (int r = 0; r < n; r++) {  // own blocks have landed; no neighbour still copies out of this tile
+        fluid_ctx* c = cs[r];
+        HIPCK(c, hipSetDevice(c->device));
+        HIPCK(c, hipStreamWaitEvent(c->stream, c->ev_landed, 0));
+        for (int dir = 0; dir < 4; dir++)
+            if (has_neighbour(c, dir)) HIPCK(c, hipStreamWaitEvent(c->stream, cs[neighbour_rank(c, dir)]->ev_landed, 0));
+    }
+    return FLUID_OK;
+}
+
 // ---- interior-first forms of the two single-kernel pass groups ----------------------------------------------------
 // rows of the band [ga, gb) that do not depend on ghost rows when every output row reads `dep` rows on each side
 struct Split {
@@ -349,7 +541,7 @@ int exchanged_reach(const fluid_ctx* c)  // velocity rows the exchange in front 
 
 bool overlap_ok(const fluid_ctx* c, const fluid_stripe_op& pass)
 {
-    if (!c->overlap) return false;
+    if (!c->overlap || c->desc.parts_x > 1) return false;
     if (pass.kind == FLUID_OP_CURL_VORT_DIV) return fused_cvd_applies(c) && c->sim_rows > 6;
     if (pass.kind == FLUID_OP_ADVECT) return fused_advect_applies(c) && c->sim_rows > 2 * exchanged_reach(c);
     return false;
@@ -396,9 +588,19 @@ int pass_whole(fluid_ctx* c, const fluid_stripe_op& op, float dt, const fluid_pa
     c->sim.v1 = c->sim_row0 + c->sim_rows + va;
     c->dye.v0 = c->dye_row0 - vd;
     c->dye.v1 = c->dye_row0 + c->dye_rows + vd;
+    if (c->desc.parts_x > 1) {  // 2-D tiles: the same for the columns
+        FieldRef fv, fd;
+        CK(field_ref(c, FLUID_VELOCITY, &fv));
+        CK(field_ref(c, FLUID_DYE, &fd));
+        const int ax = col_depth(c, fv, va), dx = col_depth(c, fd, vd);
+        c->sim.u0 = c->sim_col0 - ax;
+        c->sim.u1 = c->sim_col0 + c->sim_ncols + ax;
+        c->dye.u0 = c->dye_col0 - dx;
+        c->dye.u1 = c->dye_col0 + c->dye_ncols + dx;
+    }
     const int rc = run_pass(c, op, dt, P);
-    c->sim.v0 = sim.v0; c->sim.v1 = sim.v1;
-    c->dye.v0 = dye.v0; c->dye.v1 = dye.v1;
+    c->sim = sim;
+    c->dye = dye;
     return rc;
 }
 
@@ -406,7 +608,7 @@ int plan_for(fluid_ctx* c, const fluid_params* P, std::vector<fluid_stripe_op>& 
 {
     int va, vd;
     advect_rows(c, &va, &vd);
-    if (build_plan(c->desc.halo, c->dye_halo, P->iterations, va, vd, ops) != FLUID_OK)
+    if (build_plan(c->desc.halo, dye_ghost_depth(c), P->iterations, va, vd, ops) != FLUID_OK)
         return c->fail(FLUID_ERR_INVALID, "stripe plan: bad halo / iterations / reach");
     return FLUID_OK;
 }
@@ -427,6 +629,10 @@ int stripe_step_n(fluid_ctx* c, int n, float dt, const fluid_params* P)
             const fluid_stripe_op& op = ops[i];
             if (op.kind != FLUID_OP_EXCHANGE) {
                 CK(pass_whole(c, op, dt, P));
+                continue;
+            }
+            if (c->desc.parts_x > 1) {
+                CK(rccl_exchange_2d(c, op));
                 continue;
             }
             CK(rccl_exchange_begin(c, op));
@@ -456,7 +662,13 @@ void stripes_release(fluid_ctx* c)
     }
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
     if (c->ev_landed) (void)hipEventDestroy(c->ev_landed);
-    c->ev_ready = c->ev_landed = nullptr;
+    if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
+    c->ev_ready = c->ev_landed = c->ev_mid = nullptr;
+    for (int k = 0; k < 8; k++) {
+        if (c->stage[k]) (void)hipFree(c->stage[k]);
+        c->stage[k] = nullptr;
+        c->stage_bytes[k] = 0;
+    }
 }
 
 }  // namespace fluid_impl
@@ -537,7 +749,7 @@ int fluid_comm_init(fluid_ctx* c, const fluid_comm_id* id)
     ncclUniqueId u;
     std::memcpy(&u, id, sizeof u);
     ncclComm_t comm = nullptr;
-    NCCLCK(c, R, R->CommInitRank(&comm, c->desc.parts, u, c->desc.part));
+    NCCLCK(c, R, R->CommInitRank(&comm, c->desc.parts * c->desc.parts_x, u, c->desc.part * c->desc.parts_x + c->desc.part_x));
     c->comm = comm;
     return FLUID_OK;
 }
@@ -589,7 +801,9 @@ int fluid_group_step_n(fluid_ctx** cs, int n_ctx, int steps, float dt, const flu
     if (!cs || n_ctx < 1 || !P || steps < 0) return FLUID_ERR_INVALID;
     for (int r = 0; r < n_ctx; r++) {
         if (!cs[r]) return FLUID_ERR_INVALID;
-        if (cs[r]->desc.parts != n_ctx || cs[r]->desc.part != r) return cs[r]->fail(FLUID_ERR_INVALID, "group must hold stripes 0..parts-1 in order");
+        const fluid_desc& d = cs[r]->desc;
+        if (d.parts * d.parts_x != n_ctx || d.part * d.parts_x + d.part_x != r)
+            return cs[r]->fail(FLUID_ERR_INVALID, "group must hold every tile, ordered by stripe then tile column");
         if (cs[r]->desc.halo != cs[0]->desc.halo || cs[r]->reach != cs[0]->reach || cs[r]->desc.schedule != cs[0]->desc.schedule)
             return cs[r]->fail(FLUID_ERR_INVALID, "stripes of a group share halo, reach and schedule");
     }
@@ -611,6 +825,10 @@ int fluid_group_step_n(fluid_ctx** cs, int n_ctx, int steps, float dt, const flu
             const fluid_stripe_op& op = ops[i];
             if (op.kind != FLUID_OP_EXCHANGE) {
                 CK(each([&](fluid_ctx* c) { return pass_whole(c, op, dt, P); }));
+                continue;
+            }
+            if (cs[0]->desc.parts_x > 1) {
+                CK(group_exchange_2d(cs, n_ctx, op));
                 continue;
             }
             CK(group_exchange_begin(cs, n_ctx, op));

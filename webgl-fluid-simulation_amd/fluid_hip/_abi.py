@@ -27,7 +27,7 @@ class FluidError(RuntimeError):
 
 
 class Desc(C.Structure):
-    _fields_ = [(k, C.c_int) for k in ("sim_w", "sim_h", "dye_w", "dye_h", "device", "part", "parts", "halo", "schedule")]
+    _fields_ = [(k, C.c_int) for k in ("sim_w", "sim_h", "dye_w", "dye_h", "device", "part", "parts", "halo", "schedule", "part_x", "parts_x")]
 
 
 class Params(C.Structure):
@@ -36,7 +36,7 @@ class Params(C.Structure):
 
 
 class FieldInfo(C.Structure):
-    _fields_ = [(k, C.c_int) for k in ("width", "height", "channels", "row0", "rows", "halo")]
+    _fields_ = [(k, C.c_int) for k in ("width", "height", "channels", "row0", "rows", "halo", "col0", "cols", "halo_x")]
 
 
 class Timings(C.Structure):
@@ -160,7 +160,7 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the header and the library disagree
             fn.restype = res
             fn.argtypes = args
-        if L.fluid_abi_version() != 3:
+        if L.fluid_abi_version() != 4:
             raise FluidError(ERR_UNSUPPORTED, "ABI version mismatch")
         _lib = L
         _point_at_torch_rccl(L)

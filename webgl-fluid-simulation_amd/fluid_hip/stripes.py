@@ -60,12 +60,12 @@ class HipStripeEngine:
     """One stripe context of libfluid_hip.so; ghost rows are staged through torch device tensors and all
     work is enqueued on torch's current stream so RCCL send/recv order correctly against the kernels."""
 
-    def __init__(self, sim_wh, dye_wh, part, parts, halo, schedule, device):
+    def __init__(self, sim_wh, dye_wh, part, parts, halo, schedule, device, part_x=0, parts_x=1):
         import torch
         self.torch = torch
         self.lib = _abi.lib()
         self.device = device
-        d = _abi.Desc(sim_wh[0], sim_wh[1], dye_wh[0], dye_wh[1], device, part, parts, halo, schedule)
+        d = _abi.Desc(sim_wh[0], sim_wh[1], dye_wh[0], dye_wh[1], device, part, parts, halo, schedule, part_x, parts_x)
         ctx = C.c_void_p()
         rc = self.lib.fluid_create(C.byref(d), C.byref(ctx))
         if rc != _abi.FLUID_OK:
@@ -131,8 +131,8 @@ class HipStripeEngine:
         self._ck(self.lib.fluid_splat(self.ctx, x, y, dx, dy, r, g, b, aspect, radius))
 
     def read(self, name):
-        fi = self.info(name)
-        shape = (fi.rows, fi.width) if fi.channels == 1 else (fi.rows, fi.width, fi.channels)
+        fi = self.info(name)   # the owned rows x owned columns (all columns unless the context is a 2-D tile)
+        shape = (fi.rows, fi.cols) if fi.channels == 1 else (fi.rows, fi.cols, fi.channels)
         out = np.empty(shape, np.float32)
         self._ck(self.lib.fluid_read_field(self.ctx, FIELD_IDS[name], out.ctypes.data_as(C.c_void_p), out.nbytes))
         return out
@@ -271,7 +271,9 @@ class StripeSim:
     def __init__(self, canvas=(512, 512), config: Optional[dict] = None, halo: int = 32, schedule: str = "fused",
                  random: Optional[Callable[[], float]] = None, device: int = 0, comm=None,
                  engine_factory: Optional[Callable] = None, native: Optional[bool] = None, reach: Optional[int] = None,
-                 overlap: Optional[bool] = None):
+                 overlap: Optional[bool] = None, tiles_x: int = 1):
+        """tiles_x > 1: 2-D decomposition, world // tiles_x row stripes x tiles_x column tiles, rank = stripe * tiles_x +
+        tile column (native driver only; the hosted schedule below is 1-D)"""
         self.canvas = canvas if isinstance(canvas, Canvas) else Canvas(*canvas)
         self.config = dict(DEFAULT_CONFIG)
         if config:
@@ -279,6 +281,9 @@ class StripeSim:
         self.random = random or _random.random
         self.comm = comm if comm is not None else TorchDistComm()
         self.rank, self.world = self.comm.rank, self.comm.world
+        self.tiles_x = int(tiles_x)
+        if self.tiles_x > 1:
+            return self._init_tiles(halo, schedule, device, reach)
         sim = getResolution(self.config["SIM_RESOLUTION"], self.canvas.width, self.canvas.height)
         dye = getResolution(self.config["DYE_RESOLUTION"], self.canvas.width, self.canvas.height)
         self.sim_wh = (sim["width"], sim["height"])
@@ -298,21 +303,39 @@ class StripeSim:
             native = (engine_factory is None and isinstance(self.comm, TorchDistComm) and self.comm.backend == "nccl")
         self.native = bool(native)
         if self.native:
-            self.engine.use_own_stream()
-            if reach is not None:
-                self.engine.set_reach(reach)
-            if overlap is not None:
-                self.engine.set_overlap(overlap)
-            payload = None
-            if self.rank == 0:   # a failure on rank 0 must reach every rank, or they would wait in the broadcast forever
-                try:
-                    payload = new_comm_id()
-                except _abi.FluidError as ex:
-                    payload = b"ERR:" + str(ex).encode()
-            payload = self.comm.broadcast_bytes(payload)
-            if payload[:4] == b"ERR:":
-                raise _abi.FluidError(_abi.ERR_COMM, payload[4:].decode())
-            self.engine.comm_init(payload)
+            self._native_comm(reach, overlap)
+
+    def _init_tiles(self, halo, schedule, device, reach):
+        if self.world % self.tiles_x:
+            raise ValueError("world size %d is not a multiple of tiles_x %d" % (self.world, self.tiles_x))
+        sim = getResolution(self.config["SIM_RESOLUTION"], self.canvas.width, self.canvas.height)
+        dye = getResolution(self.config["DYE_RESOLUTION"], self.canvas.width, self.canvas.height)
+        self.sim_wh, self.dye_wh = (sim["width"], sim["height"]), (dye["width"], dye["height"])
+        self.halo = int(halo)
+        sched = {"passes": _abi.SCHED_PASSES, "fused": _abi.SCHED_FUSED}[schedule]
+        self.engine = HipStripeEngine(self.sim_wh, self.dye_wh, self.rank // self.tiles_x, self.world // self.tiles_x, self.halo, sched,
+                                      device, part_x=self.rank % self.tiles_x, parts_x=self.tiles_x)
+        self.same_res = self.sim_wh == self.dye_wh
+        self._hosted_exchanges = 0
+        self.native = True
+        self._native_comm(reach, None)
+
+    def _native_comm(self, reach, overlap):
+        self.engine.use_own_stream()
+        if reach is not None:
+            self.engine.set_reach(reach)
+        if overlap is not None:
+            self.engine.set_overlap(overlap)
+        payload = None
+        if self.rank == 0:   # a failure on rank 0 must reach every rank, or they would wait in the broadcast forever
+            try:
+                payload = new_comm_id()
+            except _abi.FluidError as ex:
+                payload = b"ERR:" + str(ex).encode()
+        payload = self.comm.broadcast_bytes(payload)
+        if payload[:4] == b"ERR:":
+            raise _abi.FluidError(_abi.ERR_COMM, payload[4:].decode())
+        self.engine.comm_init(payload)
 
     @property
     def exchanges(self):
@@ -428,7 +451,11 @@ class StripeGroup:
 
     def __init__(self, world: int, canvas=(512, 512), config: Optional[dict] = None, halo: int = 32, schedule: str = "fused",
                  random: Optional[Callable[[], float]] = None, device: int = 0, reach: Optional[int] = None,
-                 overlap: Optional[bool] = None):
+                 overlap: Optional[bool] = None, tiles_x: int = 1):
+        """`world` contexts: world // tiles_x row stripes x tiles_x column tiles (tiles_x = 1: the 1-D stripe set)"""
+        if world % tiles_x:
+            raise ValueError("world must be a multiple of tiles_x")
+        self.tiles_x, self.tiles_y = tiles_x, world // tiles_x
         self.canvas = canvas if isinstance(canvas, Canvas) else Canvas(*canvas)
         self.config = dict(DEFAULT_CONFIG)
         if config:
@@ -438,8 +465,9 @@ class StripeGroup:
         sim = getResolution(self.config["SIM_RESOLUTION"], self.canvas.width, self.canvas.height)
         dye = getResolution(self.config["DYE_RESOLUTION"], self.canvas.width, self.canvas.height)
         sched = {"passes": _abi.SCHED_PASSES, "fused": _abi.SCHED_FUSED}[schedule]
-        self.engines = [HipStripeEngine((sim["width"], sim["height"]), (dye["width"], dye["height"]), r, world,
-                                        halo if world > 1 else 0, sched, device) for r in range(world)]
+        self.engines = [HipStripeEngine((sim["width"], sim["height"]), (dye["width"], dye["height"]), r // tiles_x, self.tiles_y,
+                                        halo if world > 1 else 0, sched, device, part_x=r % tiles_x, parts_x=tiles_x)
+                        for r in range(world)]
         for e in self.engines:
             e.use_own_stream()
             if reach is not None:
@@ -493,7 +521,9 @@ class StripeGroup:
             e.check_halo()
 
     def read(self, name: str) -> np.ndarray:
-        return np.concatenate([e.read(name) for e in self.engines], axis=0)
+        rows = [np.concatenate([self.engines[y * self.tiles_x + x].read(name) for x in range(self.tiles_x)], axis=1)
+                for y in range(self.tiles_y)]
+        return np.concatenate(rows, axis=0)
 
     @property
     def exchanges(self):
