@@ -172,8 +172,9 @@ def main():
     sync(); barrier(); sync()
     t0 = time.perf_counter()
     run(args.steps)
-    sync(); barrier(); sync()
-    elapsed = time.perf_counter() - t0
+    sync()                                # this rank's K steps are done on the device ...
+    elapsed = time.perf_counter() - t0    # ... (the MAX over ranks is taken below: the job is as slow as its slowest rank)
+    barrier(); sync()
     striped = N > 1 or args.stripes
     if striped:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
