@@ -172,9 +172,8 @@ def main():
     sync(); barrier(); sync()
     t0 = time.perf_counter()
     run(args.steps)
-    sync()                                # this rank's K steps are done on the device ...
-    elapsed = time.perf_counter() - t0    # ... (the MAX over ranks is taken below: the job is as slow as its slowest rank)
-    barrier(); sync()
+    sync(); barrier(); sync()
+    elapsed = time.perf_counter() - t0
     striped = N > 1 or args.stripes
     if striped:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
