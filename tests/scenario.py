@@ -14,9 +14,9 @@ FIELDS = ("velocity", "pressure", "divergence", "curl", "dye")
 
 
 def golden_names(prefix=""):
-    """driver / single-pass scenarios (the input-replay and display fixtures have their own tests: test_input_replay.py, test_display.py)"""
+    """driver / single-pass scenarios (the input-replay and display fixtures have their own tests: test_input_replay.py, test_display.py, test_long_horizon.py)"""
     names = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
-    return [n for n in names if not n.startswith(("input_", "display_"))]
+    return [n for n in names if not n.startswith(("input_", "display_", "long50_"))]
 
 
 def load(name):
