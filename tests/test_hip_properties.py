@@ -109,3 +109,35 @@ def test_step_n_equals_n_steps():
             assert np.array_equal(a.read(k), b.read(k))
     finally:
         a.close(); b.close()
+
+
+def _random_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    cases = []
+    for _ in range(n):
+        w = int(rng.integers(1, 180)) * 4 if rng.random() < 0.8 else int(rng.integers(5, 700))     # mostly W % 4 == 0 (fused kernels)
+        h = int(rng.integers(4, 700))
+        res = min(w, h)
+        canvas = (w, h)
+        dye = res if rng.random() < 0.6 else int(res * rng.choice([0.5, 1.5, 2.0]))
+        cases.append((canvas, res, max(dye, 4), int(rng.integers(0, 61)), float(rng.choice([0.0, 30.0, 55.5])), int(rng.integers(1, 4))))
+    return cases
+
+
+@pytest.mark.parametrize("canvas,res,dye,iters,curl,steps", _random_cases(40, 2024))
+def test_fused_equals_passes_bitwise_random_shapes(canvas, res, dye, iters, curl, steps):
+    """randomised differential test of the two schedules: ragged widths / heights around the tile sizes (256 x 40 and
+    256 x 80 texel tiles, aprons 3 / 4 and 10 / 12), grids smaller than a tile, 0 … 60 Jacobi iterations, dye != sim"""
+    import fluid_hip
+    cfg = {"SIM_RESOLUTION": res, "DYE_RESOLUTION": dye, "PRESSURE_ITERATIONS": iters, "CURL": curl}
+    sims = [fluid_hip.FluidSim(canvas=canvas, config=cfg, schedule=s, random=fluid_hip.mulberry32(17)) for s in ("passes", "fused")]
+    try:
+        for s in sims:
+            s.multipleSplats(5)
+            s.step(0.016666, steps)
+        assert [sims[0].velocity.width, sims[0].velocity.height] == [sims[1].velocity.width, sims[1].velocity.height]
+        for k in ("velocity", "pressure", "divergence", "curl", "dye"):
+            assert np.array_equal(sims[0].read(k), sims[1].read(k)), (k, canvas, cfg)
+    finally:
+        for s in sims:
+            s.close()

@@ -282,3 +282,44 @@ def test_native_rccl_path_2d_tiles_with_several_ranks_bitwise(ty, tx, halo, cfg)
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["ok"], out
+
+
+def _random_decompositions(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        ty, tx = int(rng.choice([1, 2, 3, 4, 8])), int(rng.choice([1, 1, 2, 3, 4]))
+        if ty * tx < 2 or ty * tx > 12:
+            continue
+        halo = int(rng.integers(3, 11)) * 4                              # 12 … 40
+        rows, cols = int(rng.integers(halo, 4 * halo)), int(rng.integers(max(halo // 4, 6), 60)) * 4
+        w, h = cols * tx, rows * ty
+        if (cols < halo and tx > 1) or w < 16 or h < 16 or w > 1400 or h > 1400:
+            continue
+        res = min(w, h)
+        same = rng.random() < 0.7
+        dye = res if same else res * 2
+        out.append(((w, h), {"SIM_RESOLUTION": res, "DYE_RESOLUTION": dye, "PRESSURE_ITERATIONS": int(rng.integers(0, 61)),
+                             "CURL": float(rng.choice([0.0, 30.0]))}, halo, ty, tx, int(rng.integers(1, 3))))
+    return out
+
+
+@pytest.mark.parametrize("canvas,cfg,halo,ty,tx,steps", _random_decompositions(24, 7))
+def test_native_random_decompositions_equal_single_domain_bitwise(canvas, cfg, halo, ty, tx, steps):
+    """randomised stripe / tile sets: ragged tile sizes, halo 12 … 40, 0 … 60 Jacobi iterations (1 … 7 pressure blocks),
+    dye grid = or 2 x the sim grid, 1-D and 2-D — the decomposed result equals the single domain bit for bit"""
+    import fluid_hip
+    from fluid_hip.stripes import StripeGroup
+    with fluid_hip.FluidSim(canvas=canvas, config=cfg, random=fluid_hip.mulberry32(3)) as one:
+        one.multipleSplats(5)
+        one.step(0.016666, steps)
+        want = one.fields()
+    g = StripeGroup(ty * tx, canvas=canvas, config=cfg, halo=halo, random=fluid_hip.mulberry32(3), tiles_x=tx)
+    try:
+        g.multipleSplats(5)
+        g.step(0.016666, steps)
+        g.check_halo()
+        for k in S.FIELDS:
+            assert np.array_equal(g.read(k), want[k]), (k, canvas, cfg, halo, ty, tx)
+    finally:
+        g.close()
