@@ -101,3 +101,26 @@ def test_node_and_python_hosts_agree_bitwise(addon, tmp_path, schedule):
         assert np.array_equal(raw[off:off + n].reshape(want[k].shape), want[k]), k
         off += n
     assert off == raw.size
+
+
+@pytest.mark.gpu
+@needs_node
+def test_node_host_drives_a_tile_rank(addon, tmp_path):
+    """the multi-GPU entry points from JavaScript: commUniqueId (ncclGetUniqueId), createTile + commInit (ncclCommInitRank),
+    step() through the stripe driver.  One rank is what a single-GPU box hosts; result equals the plain context bitwise."""
+    import fluid_hip
+    cfg = {"SIM_RESOLUTION": 128, "DYE_RESOLUTION": 128, "PRESSURE_ITERATIONS": 20}
+    args = {"canvas": {"width": 512, "height": 512}, "config": cfg, "seed": 99, "randomSplats": 4, "steps": 3, "dt": 0.016666,
+            "out": str(tmp_path / "fields.bin")}
+    meta = node("run_tile_rank.js", args)
+    assert meta == {"idBytes": 128, "exchanges": 0}
+    with fluid_hip.FluidSim(canvas=(512, 512), config=cfg, random=fluid_hip.mulberry32(99)) as sim:
+        sim.multipleSplats(4)
+        sim.step(0.016666, 3)
+        want = sim.fields()
+    raw = np.fromfile(args["out"], dtype=np.float32)
+    off = 0
+    for k in S.FIELDS:
+        n = want[k].size
+        assert np.array_equal(raw[off:off + n].reshape(want[k].shape), want[k]), k
+        off += n

@@ -121,7 +121,12 @@ function wrap (value, min, max) {
 }
 
 // options: { canvas: {width, height}, config: {...overrides}, device, schedule: 'fused'|'passes',
-//            random: () => number (defaults to Math.random), backend: <object with the addon's functions> }
+//            random: () => number (defaults to Math.random), backend: <object with the addon's functions>,
+//            tile: { rank, world, tilesX = 1, halo = 56, commId: Buffer } }
+// `tile`: this process is one rank of a multi-GPU run (one process per GPU).  The rank owns row stripe
+// floor(rank / tilesX) of world / tilesX, column tile rank % tilesX; rank 0 creates the id with commUniqueId() and
+// ships it to the other ranks (file, env, socket — any transport); after that step() exchanges ghost rows / columns with
+// its neighbours by ncclSend / ncclRecv inside libfluid_hip.so.  Every rank issues the same splats (same seed).
 function createFluid (options) {
     options = options || {};
     const native = options.backend || loadBackend();
@@ -173,7 +178,13 @@ function createFluid (options) {
     sim.initFramebuffers = function () {
         const simRes = sim.getResolution(sim.config.SIM_RESOLUTION);
         const dyeRes = sim.getResolution(sim.config.DYE_RESOLUTION);
-        if (handle == null) handle = native.create(simRes.width, simRes.height, dyeRes.width, dyeRes.height, device, schedule);
+        if (handle == null && options.tile) {
+            const t = options.tile, tilesX = t.tilesX || 1;
+            handle = native.createTile(simRes.width, simRes.height, dyeRes.width, dyeRes.height, device, schedule,
+                Math.floor(t.rank / tilesX), t.world / tilesX, t.rank % tilesX, tilesX, t.halo === undefined ? 56 : t.halo);
+            if (t.reach !== undefined) native.setReach(handle, t.reach);
+            native.commInit(handle, t.commId);          // collective: every rank of the run calls it
+        } else if (handle == null) handle = native.create(simRes.width, simRes.height, dyeRes.width, dyeRes.height, device, schedule);
         else native.resize(handle, simRes.width, simRes.height, dyeRes.width, dyeRes.height);
     };
 
@@ -414,6 +425,8 @@ function createFluid (options) {
     sim.readField = function (name) { return native.readField(handle, FIELD[name]); };
     sim.writeField = function (name, data) { native.writeField(handle, FIELD[name], data); };
     sim.sync = function () { native.sync(handle); };
+    sim.checkHalo = function () { native.haloCheck(handle); };         // multi-GPU: throws if a back-trace outran the ghost rows
+    sim.exchangeCount = function () { return native.exchangeCount(handle); };
     sim.setTiming = function (on) { native.setTiming(handle, on ? 1 : 0); };
     sim.getTimings = function () { return native.getTimings(handle); };
     sim.destroy = function () { if (handle != null) { native.destroy(handle); handle = null; } };
@@ -422,4 +435,6 @@ function createFluid (options) {
     return sim;
 }
 
-module.exports = { createFluid, HSVtoRGB, normalizeColor, mulberry32, pointerPrototype, defaultConfig, FIELD, SCHEDULE };
+function commUniqueId () { return loadBackend().commUniqueId(); }
+
+module.exports = { createFluid, commUniqueId, HSVtoRGB, normalizeColor, mulberry32, pointerPrototype, defaultConfig, FIELD, SCHEDULE };

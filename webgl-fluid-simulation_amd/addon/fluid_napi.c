@@ -112,6 +112,88 @@ static napi_value n_create(napi_env env, napi_callback_info info)
     return ext;
 }
 
+/* createTile(simW, simH, dyeW, dyeH, device, schedule, part, parts, partX, partsX, halo) -> handle: one rank's share of a
+ * multi-GPU run (row stripe `part` of `parts`, column tile `partX` of `partsX`, `halo` ghost rows / columns) */
+static napi_value n_create_tile(napi_env env, napi_callback_info info)
+{
+    napi_value a[11];
+    if (!get_args(env, info, 11, a)) return NULL;
+    fluid_desc d;
+    memset(&d, 0, sizeof d);
+    if (!get_i(env, a[0], &d.sim_w) || !get_i(env, a[1], &d.sim_h) || !get_i(env, a[2], &d.dye_w) || !get_i(env, a[3], &d.dye_h) ||
+        !get_i(env, a[4], &d.device) || !get_i(env, a[5], &d.schedule) || !get_i(env, a[6], &d.part) || !get_i(env, a[7], &d.parts) ||
+        !get_i(env, a[8], &d.part_x) || !get_i(env, a[9], &d.parts_x) || !get_i(env, a[10], &d.halo))
+        return NULL;
+    fluid_ctx *ctx = NULL;
+    int rc = fluid_create(&d, &ctx);
+    if (rc != FLUID_OK) return throw_status(env, NULL, rc);
+    fluid_ctx **cell = (fluid_ctx **)malloc(sizeof *cell);
+    *cell = ctx;
+    napi_value ext;
+    NAPI_OK(napi_create_external(env, cell, finalize_ctx, NULL, &ext));
+    return ext;
+}
+
+/* commUniqueId() -> Buffer(128): rank 0 creates it (ncclGetUniqueId) and hands it to the other ranks */
+static napi_value n_comm_unique_id(napi_env env, napi_callback_info info)
+{
+    (void)info;
+    fluid_comm_id id;
+    int rc = fluid_comm_unique_id(&id);
+    if (rc != FLUID_OK) return throw_status(env, NULL, rc);
+    napi_value buf;
+    void *data = NULL;
+    NAPI_OK(napi_create_buffer_copy(env, sizeof id.bytes, id.bytes, &data, &buf));
+    return buf;
+}
+
+/* commInit(h, Buffer id): collective over the tile set (ncclCommInitRank); afterwards step() exchanges ghost rows itself */
+static napi_value n_comm_init(napi_env env, napi_callback_info info)
+{
+    napi_value a[2];
+    fluid_ctx *c;
+    void *data = NULL;
+    size_t len = 0;
+    if (!get_args(env, info, 2, a) || !get_ctx(env, a[0], &c)) return NULL;
+    if (napi_get_buffer_info(env, a[1], &data, &len) != napi_ok || len != sizeof(fluid_comm_id)) {
+        napi_throw_type_error(env, NULL, "fluid_napi: commInit expects the 128-byte Buffer of commUniqueId()");
+        return NULL;
+    }
+    fluid_comm_id id;
+    memcpy(id.bytes, data, sizeof id.bytes);
+    int rc = fluid_comm_init(c, &id);
+    return rc == FLUID_OK ? NULL : throw_status(env, c, rc);
+}
+
+static napi_value n_set_reach(napi_env env, napi_callback_info info)
+{
+    napi_value a[2];
+    fluid_ctx *c;
+    int rows;
+    if (!get_args(env, info, 2, a) || !get_ctx(env, a[0], &c) || !get_i(env, a[1], &rows)) return NULL;
+    int rc = fluid_set_reach(c, rows);
+    return rc == FLUID_OK ? NULL : throw_status(env, c, rc);
+}
+
+/* haloCheck(h): throws (code -5) if an advection back-trace left the refreshed ghost rows / columns */
+static napi_value n_halo_check(napi_env env, napi_callback_info info)
+{
+    napi_value a[1];
+    fluid_ctx *c;
+    if (!get_args(env, info, 1, a) || !get_ctx(env, a[0], &c)) return NULL;
+    int rc = fluid_halo_check(c);
+    return rc == FLUID_OK ? NULL : throw_status(env, c, rc);
+}
+
+static napi_value n_exchange_count(napi_env env, napi_callback_info info)
+{
+    napi_value a[1], v;
+    fluid_ctx *c;
+    if (!get_args(env, info, 1, a) || !get_ctx(env, a[0], &c)) return NULL;
+    NAPI_OK(napi_create_int64(env, (int64_t)fluid_exchange_count(c), &v));
+    return v;
+}
+
 static napi_value n_destroy(napi_env env, napi_callback_info info)
 {
     napi_value a[1];
@@ -202,6 +284,12 @@ static napi_value n_field_info(napi_env env, napi_callback_info info)
     NAPI_OK(napi_set_named_property(env, obj, "height", v));
     NAPI_OK(napi_create_int32(env, fi.channels, &v));
     NAPI_OK(napi_set_named_property(env, obj, "channels", v));
+    const int owned[4] = { fi.row0, fi.rows, fi.col0, fi.cols };   /* the block readField returns (the whole field unless a tile) */
+    const char *names[4] = { "row0", "rows", "col0", "cols" };
+    for (int k = 0; k < 4; k++) {
+        NAPI_OK(napi_create_int32(env, owned[k], &v));
+        NAPI_OK(napi_set_named_property(env, obj, names[k], v));
+    }
     return obj;
 }
 
@@ -367,7 +455,8 @@ static napi_value n_get_timings(napi_env env, napi_callback_info info)
 static napi_value init(napi_env env, napi_value exports)
 {
     const struct { const char *name; napi_callback fn; } fns[] = {
-        { "create", n_create }, { "destroy", n_destroy }, { "resize", n_resize }, { "splat", n_splat },
+        { "create", n_create }, { "createTile", n_create_tile }, { "commUniqueId", n_comm_unique_id }, { "commInit", n_comm_init },
+        { "setReach", n_set_reach }, { "haloCheck", n_halo_check }, { "exchangeCount", n_exchange_count }, { "destroy", n_destroy }, { "resize", n_resize }, { "splat", n_splat },
         { "step", n_step }, { "sync", n_sync }, { "setSchedule", n_set_schedule }, { "fieldInfo", n_field_info },
         { "readField", n_read_field }, { "writeField", n_write_field }, { "deviceCount", n_device_count },
         { "setTiming", n_set_timing }, { "getTimings", n_get_timings },
