@@ -14,7 +14,7 @@ import ctypes as C
 import math
 import os
 import subprocess
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 

@@ -15,12 +15,12 @@ from __future__ import annotations
 import ctypes as C
 import math
 import random as _random
-from typing import Callable, Dict, Optional, Sequence, Tuple, Union
+from typing import Callable, Dict, Optional, Tuple, Union
 
 import numpy as np
 
 from . import _abi
-from ._abi import FIELD_CHANNELS, FIELD_IDS, FluidError
+from ._abi import FIELD_IDS, FluidError  # noqa: F401  (FluidError is re-exported)
 
 # config keys the simulation path reads (script.js:59-85); display-only keys are not modelled
 DEFAULT_CONFIG = {

@@ -44,7 +44,7 @@ from __future__ import annotations
 import ctypes as C
 import queue
 import random as _random
-from typing import Callable, Dict, List, Optional, Tuple
+from typing import Callable, List, Optional
 
 import numpy as np
 
