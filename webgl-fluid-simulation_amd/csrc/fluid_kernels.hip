@@ -862,6 +862,15 @@ int xcd_remap()  // FLUID_XCD_REMAP: tile order of the Jacobi kernel (A/B knob);
     return v;
 }
 
+int cvd_remap()  // FLUID_CVD_REMAP: tile order of the fused curl/vorticity/divergence kernel (same encoding)
+{
+    static const int v = [] {
+        const char* e = getenv("FLUID_CVD_REMAP");
+        return (e ? atoi(e) : 3) & 3;  // row-major XCD runs, as for the Jacobi kernel (82 us vs 85 us column-major at 4096^2)
+    }();
+    return v;
+}
+
 int tb_variant()
 {
     static const int v = [] {
@@ -1025,10 +1034,8 @@ hipError_t launch_curl_vort_div(hipStream_t s, Win w, const float2* vel, float* 
     if (!fused_supported(w)) return hipErrorInvalidValue;
     using G = VortDiv<VD_NW, VD_RY>;
     const Axis ax = make_axis(w.x0, w.x1, w.W, G::TX, G::AX), ay = make_axis(ga, gb, w.H, G::TY, G::AY);
-    // plain column-major tile order here: with a 3-row apron there is little to share, and the XCD-contiguous
-    // order measured 11 % slower for this kernel (profiles/r01/xcd_remap_ab.txt)
     k_curl_vort_div<VD_NW, VD_RY><<<dim3(ax.n * ay.n, 1, 1), dim3(64, VD_NW, 1), 0, s>>>(w, vel, curl, vel_out, div, curl_strength, dt,
-                                                                                    ga, gb, ax.S, ay.S, ax.n, ay.n, 0);
+                                                                                    ga, gb, ax.S, ay.S, ax.n, ay.n, cvd_remap());
     return hipGetLastError();
 }
 
