@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--stripes", action="store_true", help="use the multi-GPU stripe driver even at N = 1 (exercises that code path)")
     ap.add_argument("--tiles-x", type=int, default=1, help="N > 1: 2-D decomposition, N // tiles_x row stripes x tiles_x column tiles "
                                                            "(global grid size*tiles_x x size*N/tiles_x); default 1 = row stripes")
+    ap.add_argument("--strong", action="store_true", help="N > 1: strong scaling — the global grid stays --size x --size and is cut into N "
+                                                          "stripes / tiles (BASELINE configs[3]: --size 8192 --tiles-x 2 on 4 GPUs; configs[4]: "
+                                                          "--size 16384 --iters 200 on 8 GPUs); default: weak scaling, --size x --size per GPU")
     ap.add_argument("--hosted", action="store_true", help="N > 1: drive the passes from Python with torch.distributed send/recv "
                                                           "instead of the native plan + RCCL inside libfluid_hip.so")
     args = ap.parse_args()
@@ -144,7 +147,7 @@ def main():
         # global grid: `size` columns x `size * N` rows -> canvas of the same aspect, SIM_RESOLUTION = short side
         # (--tiles-x T: size * T columns x size * N / T rows, every rank still owns size x size texels)
         tx = max(1, args.tiles_x)
-        gw, gh = size * tx, size * N // tx
+        gw, gh = (size, size) if args.strong else (size * tx, size * N // tx)
         cfg = dict(cfg, SIM_RESOLUTION=min(gw, gh), DYE_RESOLUTION=min(gw, gh))
         try:
             sim = StripeSim(canvas=(gw, gh), config=cfg, halo=args.halo, schedule=args.schedule,
@@ -190,10 +193,10 @@ def main():
         "steps_per_sec": round(steps_per_s, 3),
         "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if (args.strong and N > 1) else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "configs[2]: %dx%d sim = dye grid%s, %d Jacobi iters/step, dt=%.6f, 20 splats mulberry32(1234), defaults otherwise"
-                               % (grid_w, grid_h, "" if N == 1 else " (%d row stripes of %dx%d, halo %d)" % (N, size, size, args.halo), iters, DT),
+                               % (grid_w, grid_h, "" if N == 1 else " (%d ranks of %dx%d, halo %d)" % (N, grid_w // max(1, args.tiles_x), grid_h * max(1, args.tiles_x) // N, args.halo), iters, DT),
                    "schedule": args.schedule,
                    "parallelism": "single" if N == 1 else ("stripes%d" % N if args.tiles_x <= 1 else "tiles%dx%d" % (N // args.tiles_x, args.tiles_x))},
         "step_algorithmic_GBps": round(alg_step_bytes * steps_per_s / 1e9, 1),
