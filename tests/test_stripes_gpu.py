@@ -222,9 +222,9 @@ TILE_CASES = [
 ]
 
 
-@pytest.mark.parametrize("schedule", ["fused", "passes"])
+@pytest.mark.parametrize("schedule,overlap", [("fused", True), ("fused", False), ("passes", True)])
 @pytest.mark.parametrize("canvas,cfg,halo,ty,tx,steps", TILE_CASES)
-def test_native_tile_group_equals_single_domain_bitwise(canvas, cfg, halo, ty, tx, steps, schedule):
+def test_native_tile_group_equals_single_domain_bitwise(canvas, cfg, halo, ty, tx, steps, schedule, overlap):
     """tiles_y x tiles_x contexts in one process (fluid_group_step_n): ghost columns between left / right neighbours, then
     ghost rows including the fresh ghost columns (corners without diagonal messages) — bitwise equal to the single domain"""
     import fluid_hip
@@ -233,7 +233,8 @@ def test_native_tile_group_equals_single_domain_bitwise(canvas, cfg, halo, ty, t
         one.multipleSplats(6)
         one.step(0.016666, steps)
         want = one.fields()
-    g = StripeGroup(ty * tx, canvas=canvas, config=cfg, halo=halo, schedule=schedule, random=fluid_hip.mulberry32(9), tiles_x=tx)
+    g = StripeGroup(ty * tx, canvas=canvas, config=cfg, halo=halo, schedule=schedule, random=fluid_hip.mulberry32(9), tiles_x=tx,
+                    overlap=overlap)
     try:
         g.multipleSplats(6)
         g.step(0.016666, steps)

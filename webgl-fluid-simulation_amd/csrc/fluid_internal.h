@@ -118,9 +118,9 @@ bool fused_advect_applies(const fluid_ctx* c);
 void sim_band(const fluid_ctx* c, int ext, int& ga, int& gb);  // owned rows +- ext, clipped to domain and window
 fluid::Win sim_cols(const fluid_ctx* c, int ext);              // the window with this launch's column range (2-D tiles)
 fluid::Win dye_cols(const fluid_ctx* c, int ext);
-int cvd_band(fluid_ctx* c, float curl, float dt, int ga, int gb);
+int cvd_band(fluid_ctx* c, float curl, float dt, int ga, int gb, int xa, int xb);
 void cvd_swap(fluid_ctx* c);
-int advect_both_band(fluid_ctx* c, float dt, float vel_diss, float dye_diss, int ga, int gb, int v0, int v1);
+int advect_both_band(fluid_ctx* c, float dt, float vel_diss, float dye_diss, int ga, int gb, int xa, int xb, int v0, int v1, int u0, int u1);
 void advect_both_swap(fluid_ctx* c);
 
 // fluid_stripes.cpp

@@ -302,18 +302,25 @@ bool fused_advect_applies(const fluid_ctx* c)
 
 void sim_band(const fluid_ctx* c, int ext, int& ga, int& gb) { row_range(c->sim, c->sim_row0, c->sim_rows, ext, ga, gb); }
 
-int cvd_band(fluid_ctx* c, float curl, float dt, int ga, int gb)
+int cvd_band(fluid_ctx* c, float curl, float dt, int ga, int gb, int xa, int xb)
 {
-    return c->hip(launch_curl_vort_div(c->stream, c->sim, c->vel[0], c->curl, c->vel[1], c->div, curl, dt, ga, gb), "curl_vort_div");
+    Win w = c->sim;
+    w.x0 = xa;
+    w.x1 = xb;
+    return c->hip(launch_curl_vort_div(c->stream, w, c->vel[0], c->curl, c->vel[1], c->div, curl, dt, ga, gb), "curl_vort_div");
 }
 
 void cvd_swap(fluid_ctx* c) { std::swap(c->vel[0], c->vel[1]); }
 
-int advect_both_band(fluid_ctx* c, float dt, float vel_diss, float dye_diss, int ga, int gb, int v0, int v1)
+int advect_both_band(fluid_ctx* c, float dt, float vel_diss, float dye_diss, int ga, int gb, int xa, int xb, int v0, int v1, int u0, int u1)
 {
     Win w = c->sim;  // dye grid == sim grid: one window serves both gathers
+    w.x0 = xa;
+    w.x1 = xb;
     w.v0 = v0;
     w.v1 = v1;
+    w.u0 = u0;
+    w.u1 = u1;
     return c->hip(launch_advect_both(c->stream, w, c->vel[0], c->vel[1], c->dyeb[0], c->dyeb[1], dt, vel_diss, dye_diss, ga, gb, c->miss),
                   "advect");
 }

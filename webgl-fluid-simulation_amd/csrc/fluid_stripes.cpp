@@ -333,7 +333,7 @@ int group_exchange_end(fluid_ctx** cs, int n)
 // columns that phase A just filled — so the corner blocks arrive without diagonal messages.  Column blocks are strided
 // in the full-width arrays: they travel through contiguous staging buffers (hipMemcpy2DAsync on the comm stream packs and
 // unpacks them); row blocks that span the whole width go in place.  One message per neighbour and phase carries all the
-// fields of the exchange.  No interior-first overlap in this mode yet: the exchange is synchronous on the comm stream.
+// fields of the exchange.  The interior-first overlap works as for stripes, with four strips around the interior.
 struct Rect {
     char* p;             // first texel
     size_t pitch, line;  // bytes between rows, bytes per row of the block
@@ -412,8 +412,8 @@ int ensure_stage(fluid_ctx* c, int slot, size_t bytes)
     return FLUID_OK;
 }
 
-// the whole exchange over RCCL, synchronous with respect to the context stream
-int rccl_exchange_2d(fluid_ctx* c, const fluid_stripe_op& op)
+// the whole exchange over RCCL on the comm stream (begun here, ended by rccl_exchange_end)
+int rccl_exchange_2d_begin(fluid_ctx* c, const fluid_stripe_op& op)
 {
     const Rccl* R = rccl(nullptr);
     if (!R || !c->comm) return c->fail(FLUID_ERR_COMM, "tile context has no communicator (fluid_comm_init)");
@@ -458,13 +458,12 @@ int rccl_exchange_2d(fluid_ctx* c, const fluid_stripe_op& op)
             }
     }
     HIPCK(c, hipEventRecord(c->ev_landed, c->comm_stream));
-    HIPCK(c, hipStreamWaitEvent(c->stream, c->ev_landed, 0));
     c->exchanges++;
-    return FLUID_OK;
+    return FLUID_OK;  // rccl_exchange_end() makes the context stream wait for it
 }
 
 // the same exchange for a whole tile set inside one process: direct rectangle copies, phase B after the neighbours' phase A
-int group_exchange_2d(fluid_ctx** cs, int n, const fluid_stripe_op& op)
+int group_exchange_2d_begin(fluid_ctx** cs, int n, const fluid_stripe_op& op)
 {
     const int px = cs[0]->desc.parts_x;
     std::vector<Blocks> blk((size_t)n * 2);
@@ -504,6 +503,11 @@ int group_exchange_2d(fluid_ctx** cs, int n, const fluid_stripe_op& op)
         HIPCK(c, hipEventRecord(c->ev_landed, c->comm_stream));
         c->exchanges++;
     }
+    return FLUID_OK;
+}
+
+int group_exchange_2d_end(fluid_ctx** cs, int n)
+{
     for (int r = 0; r < n; r++) {  // own blocks have landed; no neighbour still copies out of this tile
         fluid_ctx* c = cs[r];
         HIPCK(c, hipSetDevice(c->device));
@@ -517,18 +521,29 @@ int group_exchange_2d(fluid_ctx** cs, int n, const fluid_stripe_op& op)
 // ---- interior-first forms of the two single-kernel pass groups ----------------------------------------------------
 // rows of the band [ga, gb) that do not depend on ghost rows when every output row reads `dep` rows on each side
 struct Split {
-    int ga, gb;  // whole band
-    int ia, ib;  // interior
+    int ga, gb, ia, ib;  // rows: whole band, interior
+    int xa, xb, ja, jb;  // columns: whole band, interior (the whole width unless 2-D tiles)
 };
 
-Split split_band(const fluid_ctx* c, int ext, int dep)
+// the band of a pass (owned rows / columns +- ext) and the part of it whose inputs are all owned when every output texel
+// reads `dep` texels to each side (`depx` columns: whole float4 groups for the register-tile kernels)
+Split split_band(const fluid_ctx* c, int ext, int dep, int depx)
 {
     Split s;
     sim_band(c, ext, s.ga, s.gb);
-    const int r0 = c->sim_row0, r1 = c->sim_row0 + c->sim_rows;
-    s.ia = c->desc.part > 0 ? r0 + dep : s.ga;                   // rank 0 has no lower neighbour: its low rows are interior
-    s.ib = c->desc.part < c->desc.parts - 1 ? r1 - dep : s.gb;
-    if (s.ia > s.ib) s.ia = s.ib = s.ga;                         // stripe thinner than 2 * dep: no interior
+    const Win w = sim_cols(c, ext);
+    s.xa = w.x0;
+    s.xb = w.x1;
+    const fluid_desc& d = c->desc;
+    const int r0 = c->sim_row0, r1 = r0 + c->sim_rows, c0 = c->sim_col0, c1 = c0 + c->sim_ncols;
+    s.ia = d.part > 0 ? r0 + dep : s.ga;  // the bottom stripe has no lower neighbour: its low rows are interior
+    s.ib = d.part < d.parts - 1 ? r1 - dep : s.gb;
+    s.ja = d.part_x > 0 ? c0 + depx : s.xa;
+    s.jb = d.part_x < d.parts_x - 1 ? c1 - depx : s.xb;
+    if (s.ia > s.ib || s.ja > s.jb) {  // tile thinner than 2 * dep: no interior
+        s.ia = s.ib = s.ga;
+        s.ja = s.jb = s.xa;
+    }
     return s;
 }
 
@@ -541,38 +556,56 @@ int exchanged_reach(const fluid_ctx* c)  // velocity rows the exchange in front 
 
 bool overlap_ok(const fluid_ctx* c, const fluid_stripe_op& pass)
 {
-    if (!c->overlap || c->desc.parts_x > 1) return false;
-    if (pass.kind == FLUID_OP_CURL_VORT_DIV) return fused_cvd_applies(c) && c->sim_rows > 6;
-    if (pass.kind == FLUID_OP_ADVECT) return fused_advect_applies(c) && c->sim_rows > 2 * exchanged_reach(c);
+    if (!c->overlap) return false;
+    const int A = exchanged_reach(c);
+    const bool tiles = c->desc.parts_x > 1;
+    if (pass.kind == FLUID_OP_CURL_VORT_DIV) return fused_cvd_applies(c) && c->sim_rows > 6 && (!tiles || c->sim_ncols > 8);
+    if (pass.kind == FLUID_OP_ADVECT) return fused_advect_applies(c) && c->sim_rows > 2 * A && (!tiles || c->sim_ncols > 2 * A);
     return false;
+}
+
+// the four strips of a band around its interior: bottom and top over the full column range, left and right beside the interior
+template <class F>
+int for_each_strip(const Split& s, F&& launch)
+{
+    if (s.ia > s.ga) CK(launch(s.ga, s.ia, s.xa, s.xb));
+    if (s.gb > s.ib) CK(launch(s.ib, s.gb, s.xa, s.xb));
+    if (s.ib > s.ia && s.ja > s.xa) CK(launch(s.ia, s.ib, s.xa, s.ja));
+    if (s.ib > s.ia && s.xb > s.jb) CK(launch(s.ia, s.ib, s.jb, s.xb));
+    return FLUID_OK;
 }
 
 int pass_interior(fluid_ctx* c, const fluid_stripe_op& op, float dt, const fluid_params* P)
 {
     if (op.kind == FLUID_OP_CURL_VORT_DIV) {
-        const Split s = split_band(c, op.ext, 3);  // a divergence row reads velocity 3 rows up and down
-        return s.ib > s.ia ? cvd_band(c, P->curl, dt, s.ia, s.ib) : FLUID_OK;
+        const Split s = split_band(c, op.ext, 3, 4);  // a divergence texel reads velocity 3 texels away (4: float4 groups)
+        return s.ib > s.ia && s.jb > s.ja ? cvd_band(c, P->curl, dt, s.ia, s.ib, s.ja, s.jb) : FLUID_OK;
     }
-    const Split s = split_band(c, 0, exchanged_reach(c));  // an advected row gathers from at most `reach` rows away ...
-    const int r0 = c->sim_row0, r1 = c->sim_row0 + c->sim_rows;
-    // ... and is held to it: only the owned rows count as fresh for this launch
-    return s.ib > s.ia ? advect_both_band(c, dt, P->velocity_dissipation, P->density_dissipation, s.ia, s.ib, r0, r1) : FLUID_OK;
+    const int A = exchanged_reach(c);
+    const Split s = split_band(c, 0, A, A);  // an advected texel gathers from at most `reach` texels away ...
+    const int r0 = c->sim_row0, r1 = r0 + c->sim_rows, c0 = c->sim_col0, c1 = c0 + c->sim_ncols;
+    // ... and is held to it: only the owned rows and columns count as fresh for this launch
+    return s.ib > s.ia && s.jb > s.ja
+               ? advect_both_band(c, dt, P->velocity_dissipation, P->density_dissipation, s.ia, s.ib, s.ja, s.jb, r0, r1, c0, c1)
+               : FLUID_OK;
 }
 
 int pass_strips(fluid_ctx* c, const fluid_stripe_op& op, float dt, const fluid_params* P)
 {
     if (op.kind == FLUID_OP_CURL_VORT_DIV) {
-        const Split s = split_band(c, op.ext, 3);
-        if (s.ia > s.ga) CK(cvd_band(c, P->curl, dt, s.ga, s.ia));
-        if (s.gb > s.ib) CK(cvd_band(c, P->curl, dt, s.ib, s.gb));
+        const Split s = split_band(c, op.ext, 3, 4);
+        CK(for_each_strip(s, [&](int ga, int gb, int xa, int xb) { return cvd_band(c, P->curl, dt, ga, gb, xa, xb); }));
         cvd_swap(c);
         return FLUID_OK;
     }
     const int A = exchanged_reach(c);
-    const Split s = split_band(c, 0, A);
-    const int v0 = c->sim_row0 - A, v1 = c->sim_row0 + c->sim_rows + A;  // owned + the rows just exchanged
-    if (s.ia > s.ga) CK(advect_both_band(c, dt, P->velocity_dissipation, P->density_dissipation, s.ga, s.ia, v0, v1));
-    if (s.gb > s.ib) CK(advect_both_band(c, dt, P->velocity_dissipation, P->density_dissipation, s.ib, s.gb, v0, v1));
+    const Split s = split_band(c, 0, A, A);
+    // fresh now: owned + the rows / columns just exchanged
+    const int v0 = c->sim_row0 - A, v1 = c->sim_row0 + c->sim_rows + A;
+    const int u0 = c->desc.parts_x > 1 ? c->sim_col0 - A : 0, u1 = c->desc.parts_x > 1 ? c->sim_col0 + c->sim_ncols + A : c->sim.W;
+    CK(for_each_strip(s, [&](int ga, int gb, int xa, int xb) {
+        return advect_both_band(c, dt, P->velocity_dissipation, P->density_dissipation, ga, gb, xa, xb, v0, v1, u0, u1);
+    }));
     advect_both_swap(c);
     return FLUID_OK;
 }
@@ -631,11 +664,8 @@ int stripe_step_n(fluid_ctx* c, int n, float dt, const fluid_params* P)
                 CK(pass_whole(c, op, dt, P));
                 continue;
             }
-            if (c->desc.parts_x > 1) {
-                CK(rccl_exchange_2d(c, op));
-                continue;
-            }
-            CK(rccl_exchange_begin(c, op));
+            if (c->desc.parts_x > 1) CK(rccl_exchange_2d_begin(c, op));
+            else CK(rccl_exchange_begin(c, op));
             if (i + 1 < ops.size() && overlap_ok(c, ops[i + 1])) {
                 CK(pass_interior(c, ops[i + 1], dt, P));  // computes while the ghost rows travel
                 CK(rccl_exchange_end(c));
@@ -827,19 +857,17 @@ int fluid_group_step_n(fluid_ctx** cs, int n_ctx, int steps, float dt, const flu
                 CK(each([&](fluid_ctx* c) { return pass_whole(c, op, dt, P); }));
                 continue;
             }
-            if (cs[0]->desc.parts_x > 1) {
-                CK(group_exchange_2d(cs, n_ctx, op));
-                continue;
-            }
-            CK(group_exchange_begin(cs, n_ctx, op));
+            const bool tiles = cs[0]->desc.parts_x > 1;
+            if (tiles) CK(group_exchange_2d_begin(cs, n_ctx, op));
+            else CK(group_exchange_begin(cs, n_ctx, op));
             if (i + 1 < ops.size() && overlap_ok(cs[0], ops[i + 1])) {
                 const fluid_stripe_op& next = ops[i + 1];
                 CK(each([&](fluid_ctx* c) { return pass_interior(c, next, dt, P); }));
-                CK(group_exchange_end(cs, n_ctx));
+                CK(tiles ? group_exchange_2d_end(cs, n_ctx) : group_exchange_end(cs, n_ctx));
                 CK(each([&](fluid_ctx* c) { return pass_strips(c, next, dt, P); }));
                 i++;
             } else {
-                CK(group_exchange_end(cs, n_ctx));
+                CK(tiles ? group_exchange_2d_end(cs, n_ctx) : group_exchange_end(cs, n_ctx));
             }
         }
     return FLUID_OK;
