@@ -204,6 +204,26 @@ def test_resize_preserves_dye_and_velocity(oracle):
         assert not got[k].any()
 
 
+def test_failed_resize_keeps_the_fields():
+    """a resize that cannot be allocated reports out-of-memory and leaves the context as it was (still steps, same bits)"""
+    import fluid_hip
+    cfg = {"SIM_RESOLUTION": 64, "DYE_RESOLUTION": 128}
+    sim = fluid_hip.FluidSim(canvas=(512, 512), config=cfg, random=fluid_hip.mulberry32(5))
+    twin = fluid_hip.FluidSim(canvas=(512, 512), config=cfg, random=fluid_hip.mulberry32(5))
+    try:
+        sim.multipleSplats(3); twin.multipleSplats(3)
+        sim.step(0.016666, 2); twin.step(0.016666, 2)
+        rc = sim._lib.fluid_resize(sim._ctx, 1 << 19, 1 << 19, 1 << 19, 1 << 19)  # 2 TB per velocity buffer
+        assert rc == fluid_hip._abi.ERR_OOM, rc
+        assert b"hipMalloc" in sim._lib.fluid_last_error(sim._ctx)
+        sim.step(0.016666, 2); twin.step(0.016666, 2)
+        a, b = sim.fields(), twin.fields()
+        for k in S.FIELDS:
+            assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), k
+    finally:
+        sim.close(); twin.close()
+
+
 def test_framebuffer_to_texture_padding():
     import fluid_hip
     sim = fluid_hip.FluidSim(canvas=(64, 64), config={"SIM_RESOLUTION": 8, "DYE_RESOLUTION": 8})

@@ -91,6 +91,21 @@ static void finalize_ctx(napi_env env, void *data, void *hint)
     }
 }
 
+/* the JS handle of a context: an external holding a heap cell, freed (and the context destroyed) by the finalizer */
+static napi_value wrap_ctx(napi_env env, fluid_ctx *ctx)
+{
+    napi_value ext;
+    fluid_ctx **cell = (fluid_ctx **)malloc(sizeof *cell);
+    if (cell) *cell = ctx;
+    if (!cell || napi_create_external(env, cell, finalize_ctx, NULL, &ext) != napi_ok) {
+        fluid_destroy(ctx);
+        free(cell);
+        napi_throw_error(env, NULL, "fluid_napi: cannot create the context handle");
+        return NULL;
+    }
+    return ext;
+}
+
 /* create(simW, simH, dyeW, dyeH, device, schedule) -> handle */
 static napi_value n_create(napi_env env, napi_callback_info info)
 {
@@ -105,11 +120,7 @@ static napi_value n_create(napi_env env, napi_callback_info info)
     fluid_ctx *ctx = NULL;
     int rc = fluid_create(&d, &ctx);
     if (rc != FLUID_OK) return throw_status(env, NULL, rc);
-    fluid_ctx **cell = (fluid_ctx **)malloc(sizeof *cell);
-    *cell = ctx;
-    napi_value ext;
-    NAPI_OK(napi_create_external(env, cell, finalize_ctx, NULL, &ext));
-    return ext;
+    return wrap_ctx(env, ctx);
 }
 
 /* createTile(simW, simH, dyeW, dyeH, device, schedule, part, parts, partX, partsX, halo) -> handle: one rank's share of a
@@ -127,11 +138,7 @@ static napi_value n_create_tile(napi_env env, napi_callback_info info)
     fluid_ctx *ctx = NULL;
     int rc = fluid_create(&d, &ctx);
     if (rc != FLUID_OK) return throw_status(env, NULL, rc);
-    fluid_ctx **cell = (fluid_ctx **)malloc(sizeof *cell);
-    *cell = ctx;
-    napi_value ext;
-    NAPI_OK(napi_create_external(env, cell, finalize_ctx, NULL, &ext));
-    return ext;
+    return wrap_ctx(env, ctx);
 }
 
 /* commUniqueId() -> Buffer(128): rank 0 creates it (ncclGetUniqueId) and hands it to the other ranks */
@@ -240,6 +247,7 @@ static napi_value n_step(napi_env env, napi_callback_info info)
     int n;
     float dt;
     fluid_params P;
+    memset(&P, 0, sizeof P);
     if (!get_args(env, info, 8, a) || !get_ctx(env, a[0], &c)) return NULL;
     if (!get_i(env, a[1], &n) || !get_f(env, a[2], &dt) || !get_f(env, a[3], &P.curl) || !get_f(env, a[4], &P.pressure) ||
         !get_i(env, a[5], &P.iterations) || !get_f(env, a[6], &P.velocity_dissipation) || !get_f(env, a[7], &P.density_dissipation))
@@ -365,6 +373,7 @@ static napi_value n_render(napi_env env, napi_callback_info info)
     fluid_ctx *c;
     int w, h;
     fluid_display_params P;
+    memset(&P, 0, sizeof P);
     if (!get_args(env, info, 19, a) || !get_ctx(env, a[0], &c)) return NULL;
     if (!get_i(env, a[1], &w) || !get_i(env, a[2], &h) || !get_i(env, a[3], &P.shading) || !get_i(env, a[4], &P.bloom) ||
         !get_i(env, a[5], &P.sunrays) || !get_i(env, a[6], &P.transparent) || !get_f(env, a[7], &P.back_r) || !get_f(env, a[8], &P.back_g) ||

@@ -4,6 +4,7 @@
 #include "fluid_display.h"
 #include "fluid_internal.h"
 
+#include <new>
 #include <vector>
 
 using namespace fluid;
@@ -40,7 +41,7 @@ int ensure(fluid_ctx* c, fluid_display_state::Buf& b, int w, int h, size_t texel
 
 fluid_display_state* state(fluid_ctx* c)
 {
-    if (!c->display) c->display = new fluid_display_state();
+    if (!c->display) c->display = new (std::nothrow) fluid_display_state();
     return c->display;
 }
 
@@ -131,6 +132,7 @@ int fluid_set_dither(fluid_ctx* c, const float* host_r, int w, int h)
     if (!c || !host_r || w < 1 || h < 1) return FLUID_ERR_INVALID;
     HIPCK(c, hipSetDevice(c->device));
     fluid_display_state* d = state(c);
+    if (!d) return c->fail(FLUID_ERR_OOM, "out of host memory");
     CK(ensure(c, d->dither, w, h, sizeof(float)));
     HIPCK(c, hipMemcpyAsync(d->dither.p, host_r, (size_t)w * h * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
@@ -140,12 +142,13 @@ int fluid_set_dither(fluid_ctx* c, const float* host_r, int w, int h)
 int fluid_render(fluid_ctx* c, int width, int height, const fluid_display_params* P)
 {
     if (!c || !P) return FLUID_ERR_INVALID;
-    if (c->desc.parts != 1) return c->fail(FLUID_ERR_UNSUPPORTED, "render of a stripe context");
+    if (c->desc.parts != 1 || c->desc.parts_x != 1) return c->fail(FLUID_ERR_UNSUPPORTED, "render of a stripe / tile context");
     if (width < 1 || height < 1) return c->fail(FLUID_ERR_INVALID, "frame size must be >= 1");
     if (P->bloom && (P->bloom_w < 1 || P->bloom_h < 1 || P->bloom_iterations < 0)) return c->fail(FLUID_ERR_INVALID, "bad bloom size");
     if (P->sunrays && (P->sunrays_w < 1 || P->sunrays_h < 1)) return c->fail(FLUID_ERR_INVALID, "bad sunrays size");
     HIPCK(c, hipSetDevice(c->device));
     fluid_display_state* d = state(c);
+    if (!d) return c->fail(FLUID_ERR_OOM, "out of host memory");
     CK(default_dither(c, d));
     if (P->bloom) CK(apply_bloom(c, d, P));
     if (P->sunrays) CK(apply_sunrays(c, d, P));

@@ -481,42 +481,52 @@ int fluid_resize(fluid_ctx* c, int sw, int sh, int dw, int dh)
     HIPCK(c, hipSetDevice(c->device));
     const Win osim = c->sim, odye = c->dye;
     const bool sim_changed = (sw != osim.W || sh != osim.H), dye_changed = (dw != odye.W || dh != odye.H);
-    // resizeDoubleFBO (script.js:1116-1126): read <- bilinear copy of the old read, write <- fresh zero texture
-    if (dye_changed) {
-        const Win nd = make_win(dw, dh, 0, dh);
-        float4 *nr = nullptr, *nw = nullptr;
-        HIPCK(c, hipMalloc((void**)&nr, cells(nd) * sizeof(float4)));
-        HIPCK(c, hipMalloc((void**)&nw, cells(nd) * sizeof(float4)));
-        HIPCK(c, launch_resample(c->stream, odye, (const float*)c->dyeb[0], 4, nd, (float*)nr));
-        HIPCK(c, launch_fill(c->stream, (float*)nw, cells(nd), 4, 0.f, 0.f, 0.f, 1.f));
-        HIPCK(c, hipStreamSynchronize(c->stream));
-        (void)hipFree(c->dyeb[0]);
-        (void)hipFree(c->dyeb[1]);
-        c->dyeb[0] = nr;
-        c->dyeb[1] = nw;
+    const Win ns = make_win(sw, sh, 0, sh), nd = make_win(dw, dh, 0, dh);
+    // Everything new is allocated and filled first; the context only changes once nothing can fail any more, so a
+    // failed resize (out of memory at a larger size) leaves the old fields in place and usable.
+    float4* ndye[2] = { nullptr, nullptr };
+    float2* nvel[2] = { nullptr, nullptr };
+    float* nscal[4] = { nullptr, nullptr, nullptr, nullptr };  // pressure.read, pressure.write, divergence, curl
+    int rc = FLUID_OK;
+    do {
+        // resizeDoubleFBO (script.js:1116-1126): read <- bilinear copy of the old read, write <- fresh zero texture
+        if (dye_changed) {
+            for (int k = 0; k < 2 && !rc; k++) rc = c->hip(hipMalloc((void**)&ndye[k], cells(nd) * sizeof(float4)), "hipMalloc dye");
+            if (rc) break;
+            if ((rc = c->hip(launch_resample(c->stream, odye, (const float*)c->dyeb[0], 4, nd, (float*)ndye[0]), "resample dye"))) break;
+            if ((rc = c->hip(launch_fill(c->stream, (float*)ndye[1], cells(nd), 4, 0.f, 0.f, 0.f, 1.f), "fill dye"))) break;
+        }
+        if (sim_changed) {
+            for (int k = 0; k < 2 && !rc; k++) rc = c->hip(hipMalloc((void**)&nvel[k], cells(ns) * sizeof(float2)), "hipMalloc velocity");
+            for (int k = 0; k < 4 && !rc; k++) rc = c->hip(hipMalloc((void**)&nscal[k], cells(ns) * sizeof(float)), "hipMalloc scalar field");
+            if (rc) break;
+            if ((rc = c->hip(launch_resample(c->stream, osim, (const float*)c->vel[0], 2, ns, (float*)nvel[0]), "resample velocity"))) break;
+            if ((rc = c->hip(hipMemsetAsync(nvel[1], 0, cells(ns) * sizeof(float2), c->stream), "memset velocity"))) break;
+        }
+        rc = c->hip(hipStreamSynchronize(c->stream), "sync");
+    } while (0);
+    if (rc != FLUID_OK) {
+        for (auto p : ndye) if (p) (void)hipFree(p);
+        for (auto p : nvel) if (p) (void)hipFree(p);
+        for (auto p : nscal) if (p) (void)hipFree(p);
+        return rc;
     }
-    if (sim_changed) {
-        const Win ns = make_win(sw, sh, 0, sh);
-        float2 *nr = nullptr, *nw = nullptr;
-        HIPCK(c, hipMalloc((void**)&nr, cells(ns) * sizeof(float2)));
-        HIPCK(c, hipMalloc((void**)&nw, cells(ns) * sizeof(float2)));
-        HIPCK(c, launch_resample(c->stream, osim, (const float*)c->vel[0], 2, ns, (float*)nr));
-        HIPCK(c, hipMemsetAsync(nw, 0, cells(ns) * sizeof(float2), c->stream));
-        HIPCK(c, hipStreamSynchronize(c->stream));
-        (void)hipFree(c->vel[0]);
-        (void)hipFree(c->vel[1]);
-        c->vel[0] = nr;
-        c->vel[1] = nw;
+    if (dye_changed)
         for (int k = 0; k < 2; k++) {
+            (void)hipFree(c->dyeb[k]);
+            c->dyeb[k] = ndye[k];
+        }
+    if (sim_changed) {
+        for (int k = 0; k < 2; k++) {
+            (void)hipFree(c->vel[k]);
             (void)hipFree(c->prs[k]);
-            c->prs[k] = nullptr;
+            c->vel[k] = nvel[k];
+            c->prs[k] = nscal[k];
         }
         (void)hipFree(c->div);
         (void)hipFree(c->curl);
-        c->div = c->curl = nullptr;
-        for (int k = 0; k < 2; k++) HIPCK(c, hipMalloc((void**)&c->prs[k], cells(ns) * sizeof(float)));
-        HIPCK(c, hipMalloc((void**)&c->div, cells(ns) * sizeof(float)));
-        HIPCK(c, hipMalloc((void**)&c->curl, cells(ns) * sizeof(float)));
+        c->div = nscal[2];
+        c->curl = nscal[3];
     }
     c->desc.sim_w = sw;
     c->desc.sim_h = sh;

@@ -188,7 +188,8 @@ const Rccl* rccl(std::string* why)
     for (const std::string& n : names) {
         void* h = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL);
         if (!h) {
-            tried += n + ": " + (dlerror() ? dlerror() : "?") + "; ";
+            const char* e = dlerror();  // a second call would return NULL: read it once
+            tried += n + ": " + (e ? e : "?") + "; ";
             continue;
         }
         Rccl r;
@@ -680,13 +681,13 @@ int stripe_step_n(fluid_ctx* c, int n, float dt, const fluid_params* P)
 
 void stripes_release(fluid_ctx* c)
 {
+    if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);  // nothing of this context is still in flight on the communicator
     if (c->comm) {
         const Rccl* R = rccl(nullptr);
         if (R) (void)R->CommDestroy((ncclComm_t)c->comm);
         c->comm = nullptr;
     }
     if (c->comm_stream) {
-        (void)hipStreamSynchronize(c->comm_stream);
         (void)hipStreamDestroy(c->comm_stream);
         c->comm_stream = nullptr;
     }
@@ -803,7 +804,7 @@ int fluid_comm_selftest(fluid_ctx* c, int nfloats)
         if ((rc = c->hip(hipEventRecord(c->ev_ready, c->stream), "record"))) break;
         if ((rc = c->hip(hipStreamWaitEvent(c->comm_stream, c->ev_ready, 0), "wait"))) break;
         ncclComm_t comm = (ncclComm_t)c->comm;
-        const int me = c->desc.part;
+        const int me = c->desc.part * c->desc.parts_x + c->desc.part_x;
         ncclResult_t e;
         if ((e = R->GroupStart()) != ncclSuccess || (e = R->Send(a, nfloats, ncclFloat, me, comm, c->comm_stream)) != ncclSuccess ||
             (e = R->Recv(b, nfloats, ncclFloat, me, comm, c->comm_stream)) != ncclSuccess || (e = R->GroupEnd()) != ncclSuccess) {
