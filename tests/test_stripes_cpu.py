@@ -100,6 +100,9 @@ def _gloo_worker(rank, world, port, canvas, cfg, halo, steps, out_dir):
             sim.step(0.016666)
         sim.check_halo()
         full = {k: sim.read(k) for k in ("velocity", "pressure", "divergence", "curl", "dye")}
+        # the 2-D read-back (rank = stripe * tiles_x + tile column): two column tiles of one stripe land side by side
+        tile = np.full((3, 2, 2), float(rank), np.float32)
+        full["tiles_1x2"] = sim.comm.gather_tiles(tile, 2)
         if rank == 0:
             np.savez(os.path.join(out_dir, "stripes.npz"), **full)
     finally:
@@ -114,6 +117,8 @@ def test_gloo_world2_bitwise(oracle, tmp_path):
     got = np.load(os.path.join(str(tmp_path), "stripes.npz"))
     for k in S.FIELDS:
         assert np.array_equal(got[k], want[k]), k
+    t = got["tiles_1x2"]
+    assert t.shape == (3, 4, 2) and (t[:, :2] == 0).all() and (t[:, 2:] == 1).all()
 
 
 # ---- the NATIVE plan (csrc/fluid_stripes.cpp, what bench.py --gpus N executes over RCCL) is the schedule above ----

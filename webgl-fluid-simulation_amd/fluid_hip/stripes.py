@@ -219,6 +219,12 @@ class TorchDistComm:
         self.dist.all_gather_object(parts, arr, group=self.group)
         return np.concatenate(parts, axis=0)
 
+    def gather_tiles(self, arr: np.ndarray, tiles_x: int) -> np.ndarray:
+        """2-D decomposition (rank = stripe * tiles_x + tile column): the global field on every rank"""
+        parts = [None] * self.world
+        self.dist.all_gather_object(parts, arr, group=self.group)
+        return np.concatenate([np.concatenate(parts[y * tiles_x:(y + 1) * tiles_x], axis=1) for y in range(self.world // tiles_x)], axis=0)
+
 
 class LocalComm:
     """all stripes inside ONE process (one thread per stripe, all contexts on one device): the way the
@@ -438,11 +444,16 @@ class StripeSim:
     def read(self, name: str) -> np.ndarray:
         """the GLOBAL field on every rank (test / checkpoint path; goes through the host)"""
         local = self.read_local(name)
-        return local if self.world == 1 else self.comm.gather_rows(local)
+        if self.world == 1:
+            return local
+        if self.tiles_x > 1:   # tiles of one stripe side by side first, then the stripes on top of each other
+            local = self.comm.gather_tiles(local, self.tiles_x)
+            return local
+        return self.comm.gather_rows(local)
 
     def write(self, name: str, global_arr: np.ndarray):
         fi = self.engine.info(name)
-        self.engine.write(name, np.ascontiguousarray(global_arr[fi.row0:fi.row0 + fi.rows]))
+        self.engine.write(name, np.ascontiguousarray(global_arr[fi.row0:fi.row0 + fi.rows, fi.col0:fi.col0 + fi.cols]))
 
 
 class StripeGroup:
