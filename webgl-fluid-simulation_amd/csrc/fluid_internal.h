@@ -58,6 +58,7 @@ struct fluid_ctx {
     {
         if (e == hipSuccess) return FLUID_OK;
         err = std::string(what) + ": " + hipGetErrorString(e);
+        (void)hipGetLastError();  // the runtime keeps the error until it is read: do not let it fail the next launch check
         return e == hipErrorOutOfMemory ? FLUID_ERR_OOM : FLUID_ERR_HIP;
     }
 };
