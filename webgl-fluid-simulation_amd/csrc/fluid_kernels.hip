@@ -507,9 +507,17 @@ __device__ __forceinline__ Quad jacobi_row(const Quad C, Quad T, Quad B, const Q
         if (gj == H - 1) T = C;
     }
     const v2f quarter = v2f{ 0.25f, 0.25f };
-    v2f h_o;
-    h_o.x = L + C.i.x;                                               // texel 0: left + c1
-    h_o.y = C.i.y + R;                                               // texel 3: c2 + right
+    float h0 = L + C.i.x;  // texel 0: left + c1
+    float h3 = C.i.y + R;  // texel 3: c2 + right
+#ifndef FLUID_NO_DPP_FOLD  // (A/B switch, tools/ab_build_bench.sh)
+    if (!EDGE) {
+        // keep these two adds scalar: as a packed pair (what the SLP vectoriser makes of them) they need two
+        // v_mov_b32_dpp in front; scalar, the lane shift folds into the add itself (v_add_f32_dpp)
+        asm("" : "+v"(h0));
+        asm("" : "+v"(h3));
+    }
+#endif
+    const v2f h_o = v2f{ h0, h3 };
     const v2f h_i = C.o + __builtin_shufflevector(C.i, C.i, 1, 0);   // texels 1, 2: c0 + c2, c3 + c1
     Quad n;
     n.o = (h_o + B.o + T.o - D.o) * quarter;
