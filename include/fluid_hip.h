@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define FLUID_ABI_VERSION 4
+#define FLUID_ABI_VERSION 5
 
 typedef enum fluid_status {
     FLUID_OK = 0,
@@ -63,6 +63,15 @@ typedef enum fluid_schedule {
     FLUID_SCHED_FUSED = 1   /* fused / temporally blocked kernels; same results bit for bit */
 } fluid_schedule;
 
+/* Storage of the simulation fields.  The reference keeps them in half-float textures on a real GPU (halfFloatTexType,
+ * script.js:138; formats 145-147); the headless SwiftShader build the goldens come from keeps fp32.  Arithmetic is fp32
+ * in both modes; FLUID_STORE_F16 rounds every pass output to fp16 (nearest even) and moves half the bytes per step.
+ * The host boundary (read / write field) speaks fp32 in both modes. */
+typedef enum fluid_storage {
+    FLUID_STORE_F32 = 0,
+    FLUID_STORE_F16 = 1
+} fluid_storage;
+
 /* replaces the size / format part of initFramebuffers(), script.js:982-1010 */
 typedef struct fluid_desc {
     int sim_w, sim_h;   /* GLOBAL velocity/pressure/divergence/curl size (getResolution(SIM_RESOLUTION)) */
@@ -73,6 +82,7 @@ typedef struct fluid_desc {
     int schedule;       /* fluid_schedule for fluid_step()                                               */
     int part_x, parts_x; /* 2-D tile decomposition: column tile part_x of parts_x (0, 1 or 0, 0: full width); the   */
                         /* rank owns rows of stripe `part` x columns of tile `part_x`, ghost depth `halo` all round */
+    int storage;        /* fluid_storage: FLUID_STORE_F32 (0, default) or FLUID_STORE_F16                */
 } fluid_desc;
 
 /* the per-step uniforms step() reads from `config`, script.js:1243, 1255, 1262, 1283, 1291 */
@@ -91,6 +101,7 @@ typedef struct fluid_field_info {
     int halo;           /* ghost rows each side, in this field's rows    */
     int col0, cols;     /* owned global columns [col0, col0 + cols)      */
     int halo_x;         /* ghost columns each side (0 unless parts_x > 1) */
+    int bytes_per_channel; /* 4 (FLUID_STORE_F32) or 2 (FLUID_STORE_F16): element size of the DEVICE array       */
 } fluid_field_info;
 
 /* per-pass device time of the last fluid_step*(), filled when timing is enabled */

@@ -59,9 +59,25 @@ def lib():
         L.fo_splat.argtypes = [WP, FP, C.c_int, FP] + [C.c_float] * 7 + [C.c_int, C.c_int]
         L.fo_resample.argtypes = [WP, FP, C.c_int, WP, FP]
         L.fo_step.argtypes = [C.c_int] * 4 + [C.POINTER(FP)] * 3 + [FP, FP, C.c_float, C.POINTER(Params)]
+        L.fo_step_f16.argtypes = L.fo_step.argtypes
+        L.fo_round_half.argtypes = [FP, C.c_long]
         L.fo_num_threads.restype = C.c_int
         _lib = L
     return _lib
+
+
+def round_half(a: np.ndarray) -> np.ndarray:
+    """what a write to a half-float render target keeps of fp32 values: nearest fp16, ties to even (fo_round_half)"""
+    out = np.ascontiguousarray(a, np.float32).copy()
+    lib().fo_round_half(_p(out), out.size)
+    return out
+
+
+def stored(a: np.ndarray, storage: str) -> np.ndarray:
+    """a pass output as the field keeps it: unchanged (storage "f32") or rounded to fp16 ("f16")"""
+    if storage not in ("f32", "f16"):
+        raise ValueError(storage)
+    return round_half(a) if storage == "f16" else a
 
 
 def _p(a: np.ndarray):
@@ -209,7 +225,11 @@ DEFAULT_CONFIG = dict(SIM_RESOLUTION=128, DYE_RESOLUTION=1024, DENSITY_DISSIPATI
 class RefSim:
     """Whole-domain CPU simulation with the reference's driver semantics."""
 
-    def __init__(self, canvas: Tuple[int, int] = (512, 512), config: Optional[dict] = None, seed: int = 1234):
+    def __init__(self, canvas: Tuple[int, int] = (512, 512), config: Optional[dict] = None, seed: int = 1234, storage: str = "f32"):
+        """storage "f16": every pass output is rounded to fp16 as it is stored (the reference's half-float textures)"""
+        if storage not in ("f32", "f16"):
+            raise ValueError(storage)
+        self.storage = storage
         self.canvas = canvas
         self.config = dict(DEFAULT_CONFIG)
         self.config.update(config or {})
@@ -228,11 +248,11 @@ class RefSim:
         elif self.dye[0].shape[:2] != (dh, dw):
             d2 = np.zeros((dh, dw, 4), np.float32)
             d2[..., 3] = 1.0
-            self.dye = [resample(self.dye[0], dw, dh), d2]
+            self.dye = [stored(resample(self.dye[0], dw, dh), self.storage), d2]
         if self.vel is None:
             self.vel = [np.zeros((sh, sw, 2), np.float32), np.zeros((sh, sw, 2), np.float32)]
         elif self.vel[0].shape[:2] != (sh, sw):
-            self.vel = [resample(self.vel[0], sw, sh), np.zeros((sh, sw, 2), np.float32)]
+            self.vel = [stored(resample(self.vel[0], sw, sh), self.storage), np.zeros((sh, sw, 2), np.float32)]
         self.div = np.zeros((sh, sw), np.float32)
         self.curl = np.zeros((sh, sw), np.float32)
         self.prs = [np.zeros((sh, sw), np.float32), np.zeros((sh, sw), np.float32)]
@@ -246,8 +266,8 @@ class RefSim:
         if aspect > 1:
             radius *= aspect
         a, r = f32(aspect), f32(radius)
-        self.vel[0] = splat(self.vel[0], f32(x), f32(y), a, r, (f32(dx), f32(dy), 0.0))
-        self.dye[0] = splat(self.dye[0], f32(x), f32(y), a, r, tuple(f32(c) for c in color))
+        self.vel[0] = stored(splat(self.vel[0], f32(x), f32(y), a, r, (f32(dx), f32(dy), 0.0)), self.storage)
+        self.dye[0] = stored(splat(self.dye[0], f32(x), f32(y), a, r, tuple(f32(c) for c in color)), self.storage)
 
     # script.js:1427-1439 + 1565-1571: five Math.random draws per splat: hue, x, y, dx, dy
     def multiple_splats(self, amount: int) -> List[List[float]]:
@@ -276,7 +296,8 @@ class RefSim:
             vel = (FP * 2)(_p(self.vel[0]), _p(self.vel[1]))
             prs = (FP * 2)(_p(self.prs[0]), _p(self.prs[1]))
             dye = (FP * 2)(_p(self.dye[0]), _p(self.dye[1]))
-            lib().fo_step(sw, sh, dw, dh, vel, prs, dye, _p(self.div), _p(self.curl), f32(dt), C.byref(P))
+            step_fn = lib().fo_step_f16 if self.storage == "f16" else lib().fo_step
+            step_fn(sw, sh, dw, dh, vel, prs, dye, _p(self.div), _p(self.curl), f32(dt), C.byref(P))
             # read back which buffer is now "read" (pointer identity)
             for pair, arr in ((vel, self.vel), (prs, self.prs), (dye, self.dye)):
                 if C.addressof(pair[0].contents) != arr[0].ctypes.data:

@@ -21,7 +21,7 @@
 extern "C" {
 
 typedef enum { ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclSystemError = 2, ncclInternalError = 3, ncclInvalidArgument = 4 } ncclResult_t;
-typedef enum { ncclFloat = 7 } ncclDataType_t;
+typedef enum { ncclChar = 0, ncclFloat = 7 } ncclDataType_t;
 typedef struct { char internal[128]; } ncclUniqueId;
 typedef struct FakeComm* ncclComm_t;
 
@@ -171,8 +171,8 @@ ncclResult_t ncclGroupEnd()
 
 static ncclResult_t enqueue(bool send, void* ptr, size_t count, ncclDataType_t type, int peer, ncclComm_t comm, hipStream_t stream)
 {
-    if (!comm || type != ncclFloat || peer < 0 || peer >= comm->nranks) return ncclInvalidArgument;
-    t_ops.push_back(Op{ send, ptr, count * sizeof(float), peer, comm, stream });
+    if (!comm || (type != ncclFloat && type != ncclChar) || peer < 0 || peer >= comm->nranks) return ncclInvalidArgument;
+    t_ops.push_back(Op{ send, ptr, count * (type == ncclFloat ? sizeof(float) : 1), peer, comm, stream });
     if (t_depth == 0) {
         std::vector<Op> ops;
         ops.swap(t_ops);

@@ -30,13 +30,14 @@ def rel_err(a, b):
 
 
 class OracleAdapter:
-    def __init__(self, O, canvas, config, seed):
+    def __init__(self, O, canvas, config, seed, storage="f32"):
         self.O = O
-        self.sim = O.RefSim(canvas=canvas, config=config, seed=seed)
+        self.storage = storage
+        self.sim = O.RefSim(canvas=canvas, config=config, seed=seed, storage=storage)
 
     def write(self, name, a):
         s = self.sim
-        a = np.ascontiguousarray(a, np.float32).copy()
+        a = self.O.stored(np.ascontiguousarray(a, np.float32).copy(), self.storage)   # an upload into a half-float texture rounds too
         if name == "velocity": s.vel[0] = a
         elif name == "pressure": s.prs[0] = a
         elif name == "divergence": s.div = a
@@ -53,14 +54,15 @@ class OracleAdapter:
         O, s = self.O, self.sim
         P = s.params()
         dt = O.f32(dt)
-        if p == "curl": s.curl = O.curl(s.vel[0])
-        elif p == "vorticity": s.vel[0] = O.vorticity(s.vel[0], s.curl, P.curl, dt)
-        elif p == "divergence": s.div = O.divergence(s.vel[0])
-        elif p == "clear": s.prs[0] = O.clear(s.prs[0], P.pressure)
-        elif p == "jacobi": s.prs[0] = O.jacobi(s.prs[0], s.div)
-        elif p == "gradsub": s.vel[0] = O.gradsub(s.prs[0], s.vel[0])
-        elif p == "advect_velocity": s.vel[0] = O.advect(s.vel[0], s.vel[0], dt, P.velocity_dissipation)
-        elif p == "advect_dye": s.dye[0] = O.advect(s.vel[0], s.dye[0], dt, P.density_dissipation)
+        st = lambda a: O.stored(a, self.storage)  # noqa: E731  (the pass output as the field keeps it)
+        if p == "curl": s.curl = st(O.curl(s.vel[0]))
+        elif p == "vorticity": s.vel[0] = st(O.vorticity(s.vel[0], s.curl, P.curl, dt))
+        elif p == "divergence": s.div = st(O.divergence(s.vel[0]))
+        elif p == "clear": s.prs[0] = st(O.clear(s.prs[0], P.pressure))
+        elif p == "jacobi": s.prs[0] = st(O.jacobi(s.prs[0], s.div))
+        elif p == "gradsub": s.vel[0] = st(O.gradsub(s.prs[0], s.vel[0]))
+        elif p == "advect_velocity": s.vel[0] = st(O.advect(s.vel[0], s.vel[0], dt, P.velocity_dissipation))
+        elif p == "advect_dye": s.dye[0] = st(O.advect(s.vel[0], s.dye[0], dt, P.density_dissipation))
         else: raise ValueError(p)
 
     def step(self, dt, n):
@@ -75,9 +77,9 @@ class OracleAdapter:
 
 
 class HipAdapter:
-    def __init__(self, canvas, config, seed, schedule="fused"):
+    def __init__(self, canvas, config, seed, schedule="fused", storage="f32"):
         import fluid_hip
-        self.sim = fluid_hip.FluidSim(canvas=canvas, config=config, schedule=schedule, random=fluid_hip.mulberry32(seed))
+        self.sim = fluid_hip.FluidSim(canvas=canvas, config=config, schedule=schedule, random=fluid_hip.mulberry32(seed), storage=storage)
 
     def write(self, name, a):
         self.sim.write(name, a)

@@ -41,7 +41,7 @@ def test_js_host_logic_matches_reference_recording():
     assert (d["DENSITY_DISSIPATION"], d["VELOCITY_DISSIPATION"], d["PRESSURE"], d["SPLAT_RADIUS"], d["SPLAT_FORCE"]) == (1, 0.2, 0.8, 0.25, 6000)
     assert out["res"] == {"sim": {"width": 64, "height": 32}, "dye": {"width": 96, "height": 48}}   # as the live reference (golden step3_wide)
     calls = out["calls"]
-    assert calls[0] == ["create", 64, 32, 96, 48, 0, 1]
+    assert calls[0] == ["create", 64, 32, 96, 48, 0, 1, 0]   # ..., device, schedule (fused), storage (fp32)
     splats = [c for c in calls if c[0] == "splat"]
     # the first 20 are multipleSplats: x, y, dx, dy, r, g, b must equal the stream the REFERENCE issued for this seed
     got = np.array([c[1:8] for c in splats[:20]], dtype=np.float64)

@@ -41,3 +41,10 @@ HIP_VS_ORACLE_STEP = 3e-5
 
 # input replay (tests/test_input_replay.py): 16 frames, 14 of them stepped, CURL = 30 -> the 10-step regime above
 INPUT_REPLAY = 1e-3
+
+# fp16-storage mode (tests/test_hip_f16.py), HIP vs the oracle's fp16 mode.  A single pass: identical, or one fp16 ulp
+# apart on the few texels whose fp32 results (a libm ulp apart) straddle an fp16 rounding boundary.
+F16_FLIP_FRACTION = 5e-3
+# three steps, relative to max|field|: one flipped fp16 ulp is 2^-11 = 4.9e-4 of a value, and CURL = 30 amplifies it
+F16_STEP_CURL0 = 2e-3
+F16_STEP = 2e-2

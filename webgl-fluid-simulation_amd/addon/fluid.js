@@ -120,9 +120,11 @@ function wrap (value, min, max) {
     return (value - min) % range + min;
 }
 
-// options: { canvas: {width, height}, config: {...overrides}, device, schedule: 'fused'|'passes',
+// options: { canvas: {width, height}, config: {...overrides}, device, schedule: 'fused'|'passes', storage: 'f32'|'f16',
 //            random: () => number (defaults to Math.random), backend: <object with the addon's functions>,
 //            tile: { rank, world, tilesX = 1, halo = 56, commId: Buffer } }
+// `storage`: 'f32' keeps fp32 fields (what the headless reference build keeps); 'f16' keeps half texels like the reference's
+// half-float textures on a real GPU (ext.halfFloatTexType): every pass output is rounded to fp16, a step moves half the bytes.
 // `tile`: this process is one rank of a multi-GPU run (one process per GPU).  The rank owns row stripe
 // floor(rank / tilesX) of world / tilesX, column tile rank % tilesX; rank 0 creates the id with commUniqueId() and
 // ships it to the other ranks (file, env, socket — any transport); after that step() exchanges ghost rows / columns with
@@ -143,6 +145,8 @@ function createFluid (options) {
     let colorUpdateTimer = 0.0;
     const schedule = SCHEDULE[options.schedule || 'fused'];
     const device = options.device || 0;
+    const storage = { f32: 0, f16: 1 }[options.storage || 'f32'];
+    if (storage === undefined) throw new Error("fluid: storage must be 'f32' or 'f16'");
 
     function fieldView (name, isDouble) {
         const view = {
@@ -181,10 +185,10 @@ function createFluid (options) {
         if (handle == null && options.tile) {
             const t = options.tile, tilesX = t.tilesX || 1;
             handle = native.createTile(simRes.width, simRes.height, dyeRes.width, dyeRes.height, device, schedule,
-                Math.floor(t.rank / tilesX), t.world / tilesX, t.rank % tilesX, tilesX, t.halo === undefined ? 56 : t.halo);
+                Math.floor(t.rank / tilesX), t.world / tilesX, t.rank % tilesX, tilesX, t.halo === undefined ? 56 : t.halo, storage);
             if (t.reach !== undefined) native.setReach(handle, t.reach);
             native.commInit(handle, t.commId);          // collective: every rank of the run calls it
-        } else if (handle == null) handle = native.create(simRes.width, simRes.height, dyeRes.width, dyeRes.height, device, schedule);
+        } else if (handle == null) handle = native.create(simRes.width, simRes.height, dyeRes.width, dyeRes.height, device, schedule, storage);
         else native.resize(handle, simRes.width, simRes.height, dyeRes.width, dyeRes.height);
     };
 

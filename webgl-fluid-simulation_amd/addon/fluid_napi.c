@@ -34,6 +34,26 @@ static napi_value throw_status(napi_env env, fluid_ctx *ctx, int rc)
     return NULL;
 }
 
+/* an optional trailing integer argument (absent or undefined -> dflt) */
+static int get_opt_i(napi_env env, napi_callback_info info, size_t index, int dflt, int *out)
+{
+    napi_value argv[16];
+    size_t argc = 16;
+    napi_valuetype t;
+    *out = dflt;
+    if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) != napi_ok) return 0;
+    if (index >= argc || index >= 16) return 1;
+    if (napi_typeof(env, argv[index], &t) != napi_ok) return 0;
+    if (t == napi_undefined) return 1;
+    int32_t v;
+    if (napi_get_value_int32(env, argv[index], &v) != napi_ok) {
+        napi_throw_type_error(env, NULL, "fluid_napi: expected an integer");
+        return 0;
+    }
+    *out = (int)v;
+    return 1;
+}
+
 static int get_args(napi_env env, napi_callback_info info, size_t want, napi_value *argv)
 {
     size_t argc = want;
@@ -106,7 +126,7 @@ static napi_value wrap_ctx(napi_env env, fluid_ctx *ctx)
     return ext;
 }
 
-/* create(simW, simH, dyeW, dyeH, device, schedule) -> handle */
+/* create(simW, simH, dyeW, dyeH, device, schedule[, storage]) -> handle; storage 0 = fp32 fields (default), 1 = fp16 */
 static napi_value n_create(napi_env env, napi_callback_info info)
 {
     napi_value a[6];
@@ -115,7 +135,8 @@ static napi_value n_create(napi_env env, napi_callback_info info)
     memset(&d, 0, sizeof d);
     d.parts = 1;
     if (!get_i(env, a[0], &d.sim_w) || !get_i(env, a[1], &d.sim_h) || !get_i(env, a[2], &d.dye_w) ||
-        !get_i(env, a[3], &d.dye_h) || !get_i(env, a[4], &d.device) || !get_i(env, a[5], &d.schedule))
+        !get_i(env, a[3], &d.dye_h) || !get_i(env, a[4], &d.device) || !get_i(env, a[5], &d.schedule) ||
+        !get_opt_i(env, info, 6, FLUID_STORE_F32, &d.storage))
         return NULL;
     fluid_ctx *ctx = NULL;
     int rc = fluid_create(&d, &ctx);
@@ -123,7 +144,7 @@ static napi_value n_create(napi_env env, napi_callback_info info)
     return wrap_ctx(env, ctx);
 }
 
-/* createTile(simW, simH, dyeW, dyeH, device, schedule, part, parts, partX, partsX, halo) -> handle: one rank's share of a
+/* createTile(simW, simH, dyeW, dyeH, device, schedule, part, parts, partX, partsX, halo[, storage]) -> handle: one rank's share of a
  * multi-GPU run (row stripe `part` of `parts`, column tile `partX` of `partsX`, `halo` ghost rows / columns) */
 static napi_value n_create_tile(napi_env env, napi_callback_info info)
 {
@@ -133,7 +154,8 @@ static napi_value n_create_tile(napi_env env, napi_callback_info info)
     memset(&d, 0, sizeof d);
     if (!get_i(env, a[0], &d.sim_w) || !get_i(env, a[1], &d.sim_h) || !get_i(env, a[2], &d.dye_w) || !get_i(env, a[3], &d.dye_h) ||
         !get_i(env, a[4], &d.device) || !get_i(env, a[5], &d.schedule) || !get_i(env, a[6], &d.part) || !get_i(env, a[7], &d.parts) ||
-        !get_i(env, a[8], &d.part_x) || !get_i(env, a[9], &d.parts_x) || !get_i(env, a[10], &d.halo))
+        !get_i(env, a[8], &d.part_x) || !get_i(env, a[9], &d.parts_x) || !get_i(env, a[10], &d.halo) ||
+        !get_opt_i(env, info, 11, FLUID_STORE_F32, &d.storage))
         return NULL;
     fluid_ctx *ctx = NULL;
     int rc = fluid_create(&d, &ctx);

@@ -16,6 +16,7 @@ struct fluid_display_state {
         size_t bytes = 0;
     };
     Buf bloom, sunrays, sunrays_tmp, frame, frame8, dither;
+    Buf dye32[2];  // fp16 storage: fp32 copy of dye.read / stand-in for dye.write (the compositor computes on fp32 texels)
     std::vector<Buf> levels;
     bool bloom_valid = false;
 };
@@ -56,8 +57,25 @@ int default_dither(fluid_ctx* c, fluid_display_state* d)
     return FLUID_OK;
 }
 
+// dye.read / dye.write as fp32 texels.  With fp16 storage the compositor works on a widened copy of dye.read (exact) and
+// scribbles the sunrays mask on a scratch buffer instead of dye.write; its own intermediates (bloom pyramid, sunrays) stay
+// fp32 in both modes.
+int dye_texels(fluid_ctx* c, fluid_display_state* d, const float4** read, float4** write)
+{
+    if (c->storage == FLUID_STORE_F32) {
+        *read = (const float4*)c->dyeb[0];
+        *write = (float4*)c->dyeb[1];
+        return FLUID_OK;
+    }
+    for (auto& b : d->dye32) CK(ensure(c, b, c->dye.W, c->dye.H, sizeof(float4)));
+    HIPCK(c, launch_widen(c->stream, (const __half*)c->dyeb[0], (float*)d->dye32[0].p, (size_t)c->dye.W * c->dye.H * 4));
+    *read = (const float4*)d->dye32[0].p;
+    *write = (float4*)d->dye32[1].p;
+    return FLUID_OK;
+}
+
 // applyBloom(dye.read, bloom), script.js:1346-1389
-int apply_bloom(fluid_ctx* c, fluid_display_state* d, const fluid_display_params* P)
+int apply_bloom(fluid_ctx* c, fluid_display_state* d, const fluid_display_params* P, const float4* dye)
 {
     std::vector<std::pair<int, int>> sizes;
     for (int i = 0; i < P->bloom_iterations; i++) {  // initBloomFramebuffers, script.js:1012-1032
@@ -77,7 +95,7 @@ int apply_bloom(fluid_ctx* c, fluid_display_state* d, const fluid_display_params
     // the uniforms are computed in JS doubles and narrowed by gl.uniform3f / uniform1f
     const double knee = P->bloom_threshold * P->bloom_soft_knee + 0.0001;
     const float c0 = (float)(P->bloom_threshold - knee), c1 = (float)(knee * 2), c2 = (float)(0.25 / knee);
-    HIPCK(c, launch_bloom_prefilter(c->stream, c->dyeb[0], c->dye.W, c->dye.H, (float4*)d->bloom.p, d->bloom.w, d->bloom.h, c0, c1, c2,
+    HIPCK(c, launch_bloom_prefilter(c->stream, dye, c->dye.W, c->dye.H, (float4*)d->bloom.p, d->bloom.w, d->bloom.h, c0, c1, c2,
                                     (float)P->bloom_threshold));
     const fluid_display_state::Buf* last = &d->bloom;
     for (auto& lv : d->levels) {
@@ -95,13 +113,13 @@ int apply_bloom(fluid_ctx* c, fluid_display_state* d, const fluid_display_params
 }
 
 // applySunrays(dye.read, dye.write, sunrays); blur(sunrays, sunraysTemp, 1) — script.js:1391-1419
-int apply_sunrays(fluid_ctx* c, fluid_display_state* d, const fluid_display_params* P)
+int apply_sunrays(fluid_ctx* c, fluid_display_state* d, const fluid_display_params* P, const float4* dye, float4* dye_write)
 {
     CK(ensure(c, d->sunrays, P->sunrays_w, P->sunrays_h, sizeof(float)));
     CK(ensure(c, d->sunrays_tmp, P->sunrays_w, P->sunrays_h, sizeof(float)));
     const size_t n = (size_t)c->dye.W * c->dye.H;
-    HIPCK(c, launch_sunrays_mask(c->stream, c->dyeb[0], c->dyeb[1], n));  // the reference scribbles the mask on dye.write too
-    HIPCK(c, launch_sunrays(c->stream, c->dyeb[1], c->dye.W, c->dye.H, (float*)d->sunrays.p, d->sunrays.w, d->sunrays.h, (float)P->sunrays_weight));
+    HIPCK(c, launch_sunrays_mask(c->stream, dye, dye_write, n));  // the reference scribbles the mask on dye.write too
+    HIPCK(c, launch_sunrays(c->stream, dye_write, c->dye.W, c->dye.H, (float*)d->sunrays.p, d->sunrays.w, d->sunrays.h, (float)P->sunrays_weight));
     HIPCK(c, launch_blur3(c->stream, (const float*)d->sunrays.p, (float*)d->sunrays_tmp.p, d->sunrays.w, d->sunrays.h, 1));
     HIPCK(c, launch_blur3(c->stream, (const float*)d->sunrays_tmp.p, (float*)d->sunrays.p, d->sunrays.w, d->sunrays.h, 0));
     return FLUID_OK;
@@ -115,7 +133,7 @@ void display_release(fluid_ctx* c)
 {
     fluid_display_state* d = c->display;
     if (!d) return;
-    for (auto* b : { &d->bloom, &d->sunrays, &d->sunrays_tmp, &d->frame, &d->frame8, &d->dither })
+    for (auto* b : { &d->bloom, &d->sunrays, &d->sunrays_tmp, &d->frame, &d->frame8, &d->dither, &d->dye32[0], &d->dye32[1] })
         if (b->p) (void)hipFree(b->p);
     for (auto& b : d->levels)
         if (b.p) (void)hipFree(b.p);
@@ -150,11 +168,14 @@ int fluid_render(fluid_ctx* c, int width, int height, const fluid_display_params
     fluid_display_state* d = state(c);
     if (!d) return c->fail(FLUID_ERR_OOM, "out of host memory");
     CK(default_dither(c, d));
-    if (P->bloom) CK(apply_bloom(c, d, P));
-    if (P->sunrays) CK(apply_sunrays(c, d, P));
+    const float4* dye = nullptr;
+    float4* dye_write = nullptr;
+    CK(dye_texels(c, d, &dye, &dye_write));
+    if (P->bloom) CK(apply_bloom(c, d, P, dye));
+    if (P->sunrays) CK(apply_sunrays(c, d, P, dye, dye_write));
     CK(ensure(c, d->frame, width, height, sizeof(float4)));
     DisplayArgs a{};
-    a.dye = c->dyeb[0];
+    a.dye = dye;
     a.dye_w = c->dye.W;
     a.dye_h = c->dye.H;
     a.bloom = P->bloom ? (const float4*)d->bloom.p : nullptr;

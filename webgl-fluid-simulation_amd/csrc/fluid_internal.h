@@ -22,11 +22,14 @@ struct fluid_ctx {
     int sim_row0 = 0, sim_rows = 0, dye_row0 = 0, dye_rows = 0, dye_halo = 0;
     int sim_col0 = 0, sim_ncols = 0, dye_col0 = 0, dye_ncols = 0, dye_halo_x = 0;  // 2-D tiles: owned columns
 
-    float2* vel[2] = { nullptr, nullptr };   // velocity.read / velocity.write
-    float* prs[2] = { nullptr, nullptr };    // pressure.read / pressure.write
-    float4* dyeb[2] = { nullptr, nullptr };  // dye.read / dye.write
-    float* div = nullptr;
-    float* curl = nullptr;
+    // field arrays: fp32 texels (float2 / float / float4) or, with desc.storage == FLUID_STORE_F16, half texels
+    int storage = FLUID_STORE_F32;
+    size_t esz = sizeof(float);            // bytes per channel
+    void* vel[2] = { nullptr, nullptr };   // velocity.read / velocity.write   (2 channels)
+    void* prs[2] = { nullptr, nullptr };   // pressure.read / pressure.write   (1)
+    void* dyeb[2] = { nullptr, nullptr };  // dye.read / dye.write             (4)
+    void* div = nullptr;
+    void* curl = nullptr;
     unsigned int* miss = nullptr;  // advection taps that fell outside the window
 
     bool timing = false;
@@ -70,6 +73,17 @@ struct fluid_ctx {
     } while (0)
 #define HIPCK(ctx, expr) CK((ctx)->hip((expr), #expr))
 
+// A launcher call on the context's fields in whichever storage they have: `expr` is compiled once per storage type with
+// S = fluid::StoreF32 / fluid::StoreF16, and VEL / PRS / DYE / DIVG / CURL give the typed pointers.
+#define STORE_CALL(c, expr)                                                                                    \
+    ((c)->storage == FLUID_STORE_F16 ? [&] { using S = fluid::StoreF16; return (expr); }()                     \
+                                     : [&] { using S = fluid::StoreF32; return (expr); }())
+#define VEL(c, k) ((S::T2*)(c)->vel[k])
+#define PRS(c, k) ((S::T1*)(c)->prs[k])
+#define DYE(c, k) ((S::T4*)(c)->dyeb[k])
+#define DIVG(c) ((S::T1*)(c)->div)
+#define CURL(c) ((S::T1*)(c)->curl)
+
 namespace fluid_impl {
 
 struct FieldRef {
@@ -77,6 +91,8 @@ struct FieldRef {
     const fluid::Win* win;
     int row0, rows, halo, nc;
     int col0, cols, halo_x;  // owned columns and ghost columns (2-D tiles; 0, W, 0 otherwise)
+    size_t esz;              // bytes per channel of the device array (4, or 2 with fp16 storage)
+    size_t texel() const { return (size_t)nc * esz; }
 };
 int field_ref(fluid_ctx* c, int field, FieldRef* f);
 
@@ -114,6 +130,7 @@ int pass_advect_dye(fluid_ctx* c, float dt, float dissipation);
 int pass_advect(fluid_ctx* c, float dt, float vel_diss, float dye_diss, Timer* t);
 
 // band forms (no ping-pong swap) of the single-kernel passes, for interior-first overlap in the stripe driver
+bool fused_f32(const fluid_ctx* c);  // fused schedule on fp32 fields: the register-tile kernels of fluid_kernels.hip apply
 bool fused_cvd_applies(const fluid_ctx* c);
 bool fused_advect_applies(const fluid_ctx* c);
 void sim_band(const fluid_ctx* c, int ext, int& ga, int& gb);  // owned rows +- ext, clipped to domain and window

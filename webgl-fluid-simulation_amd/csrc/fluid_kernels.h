@@ -1,6 +1,7 @@
 // fluid_kernels.h — launch interface between the solver core (fluid_solver.cpp) and the
 // gfx950 kernels (fluid_kernels.hip).  Internal; the public boundary is include/fluid_hip.h.
 #pragma once
+#include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 
 namespace fluid {
@@ -22,6 +23,23 @@ struct Win {
     int u0, u1;
 };
 inline Win make_win(int W, int H, int g0, int rows) { return Win{ W, H, g0, rows, g0, g0 + rows, 0, W, 0, W }; }
+
+// Storage of the fields (fluid_desc.storage): fp32 texels, or half texels (FLUID_STORE_F16: what the reference's
+// half-float textures hold on a real GPU, script.js:138, 145-147).  Arithmetic is fp32 either way; a store to a half
+// field rounds to nearest even.
+struct alignas(8) half4 {
+    __half2 lo, hi;
+};
+struct StoreF32 {
+    using T1 = float;
+    using T2 = float2;
+    using T4 = float4;
+};
+struct StoreF16 {
+    using T1 = __half;
+    using T2 = __half2;
+    using T4 = half4;
+};
 
 // All launchers enqueue on `s` and return hipGetLastError().  Row ranges [ga, gb) are GLOBAL rows.
 hipError_t launch_curl(hipStream_t s, Win w, const float2* vel, float* curl, int ga, int gb);
@@ -62,5 +80,30 @@ int jacobi_tb_max_iters();
 bool jacobi_tb_supported(Win w);
 hipError_t launch_jacobi_tb(hipStream_t s, Win w, const float* p, const float* div, float* p_out, float pscale,
                             int iters, int ga, int gb);
+
+
+// ---- the same passes on fp16-storage fields (fluid_kernels_f16.hip): one kernel per reference pass, plus a temporally
+//      blocked Jacobi that rounds the pressure to fp16 after EVERY iteration, as the reference's per-iteration render
+//      to a half-float texture does ----
+hipError_t launch_curl(hipStream_t s, Win w, const __half2* vel, __half* curl, int ga, int gb);
+hipError_t launch_vorticity(hipStream_t s, Win w, const __half2* vel, const __half* curl, __half2* vel_out, float curl_strength, float dt,
+                            int ga, int gb);
+hipError_t launch_divergence(hipStream_t s, Win w, const __half2* vel, __half* div, int ga, int gb);
+hipError_t launch_clear(hipStream_t s, Win w, const __half* p, __half* p_out, float value, int ga, int gb);
+hipError_t launch_jacobi(hipStream_t s, Win w, const __half* p, const __half* div, __half* p_out, int ga, int gb);
+hipError_t launch_gradsub(hipStream_t s, Win w, const __half* p, const __half2* vel, __half2* vel_out, int ga, int gb);
+hipError_t launch_advect_velocity(hipStream_t s, Win w, const __half2* vel, __half2* out, float dt, float dissipation, int ga, int gb,
+                                  unsigned int* miss);
+hipError_t launch_advect_dye(hipStream_t s, Win vw, const __half2* vel, Win dw, const half4* dye, half4* out, float dt, float dissipation,
+                             int ga, int gb, unsigned int* miss);
+hipError_t launch_splat_velocity(hipStream_t s, Win w, const __half2* base, __half2* out, float x, float y, float aspect, float radius,
+                                 float c0, float c1, int ga, int gb);
+hipError_t launch_splat_dye(hipStream_t s, Win w, const half4* base, half4* out, float x, float y, float aspect, float radius, float c0,
+                            float c1, float c2, int ga, int gb);
+hipError_t launch_resample(hipStream_t s, Win sw, const __half* src, int nc, Win dw, __half* dst);
+hipError_t launch_fill(hipStream_t s, __half* dst, size_t n_vec, int nc, float v0, float v1, float v2, float v3);
+// host boundary (fluid_read_field / fluid_write_field speak fp32): n scalars, exact widening / round-to-nearest-even narrowing
+hipError_t launch_widen(hipStream_t s, const __half* src, float* dst, size_t n);
+hipError_t launch_narrow(hipStream_t s, const float* src, __half* dst, size_t n);
 
 }  // namespace fluid

@@ -25,158 +25,68 @@ namespace {
 constexpr int BX = 256;  // threads per block for the per-pass kernels: 4 waves along a row
 
 // ------------------------------------------------------------------------------------------------
-// K1 curl — curlShader script.js:814-833
+// One kernel per reference pass: thread (i, gj) is one texel, the arithmetic is the pass's `*_texel` body of
+// fluid_math.h (shared with the fp16-storage kernels of fluid_kernels_f16.hip).
+#define TEXEL_OR_RETURN(win)                                  \
+    const int i = (win).x0 + blockIdx.x * BX + threadIdx.x; \
+    const int gj = ga + blockIdx.y;                           \
+    if (i >= (win).x1) return
+
 __global__ void __launch_bounds__(BX) k_curl(Win w, const float2* __restrict__ vel, float* __restrict__ curl, int ga)
 {
-    const int i = w.x0 + blockIdx.x * BX + threadIdx.x;
-    const int gj = ga + blockIdx.y;
-    if (i >= w.x1) return;
-    const float L = vel[widx(w, gj, i - 1)].y;
-    const float R = vel[widx(w, gj, i + 1)].y;
-    const float T = vel[widx(w, gj + 1, i)].x;
-    const float B = vel[widx(w, gj - 1, i)].x;
-    const float vort = R - L - T + B;
-    curl[(long)(gj - w.g0) * w.W + i] = 0.5f * vort;
+    TEXEL_OR_RETURN(w);
+    curl_texel(w, vel, curl, i, gj);
 }
 
-// K2 vorticity confinement — vorticityShader script.js:835-866 (vorticity_cell, fluid_math.h)
 __global__ void __launch_bounds__(BX) k_vorticity(Win w, const float2* __restrict__ vel, const float* __restrict__ curl,
                                                    float2* __restrict__ vel_out, float curl_strength, float dt, int ga)
 {
-    const int i = w.x0 + blockIdx.x * BX + threadIdx.x;
-    const int gj = ga + blockIdx.y;
-    if (i >= w.x1) return;
-    const long c = (long)(gj - w.g0) * w.W + i;
-    const float L = curl[widx(w, gj, i - 1)];
-    const float R = curl[widx(w, gj, i + 1)];
-    const float T = curl[widx(w, gj + 1, i)];
-    const float B = curl[widx(w, gj - 1, i)];
-    vel_out[c] = vorticity_cell(L, R, T, B, curl[c], vel[c], curl_strength, dt);
+    TEXEL_OR_RETURN(w);
+    vorticity_texel(w, vel, curl, vel_out, curl_strength, dt, i, gj);
 }
 
-// K3 divergence with the reflecting-wall rule — divergenceShader script.js:786-812
 __global__ void __launch_bounds__(BX) k_divergence(Win w, const float2* __restrict__ vel, float* __restrict__ div, int ga)
 {
-    const int i = w.x0 + blockIdx.x * BX + threadIdx.x;
-    const int gj = ga + blockIdx.y;
-    if (i >= w.x1) return;
-    const long c = (long)(gj - w.g0) * w.W + i;
-    float L = vel[widx(w, gj, i - 1)].x;
-    float R = vel[widx(w, gj, i + 1)].x;
-    float T = vel[widx(w, gj + 1, i)].y;
-    float B = vel[widx(w, gj - 1, i)].y;
-    const float2 C = vel[c];
-    if (i == 0) L = -C.x;
-    if (i == w.W - 1) R = -C.x;
-    if (gj == w.H - 1) T = -C.y;
-    if (gj == 0) B = -C.y;
-    div[c] = 0.5f * (R - L + T - B);
+    TEXEL_OR_RETURN(w);
+    divergence_texel(w, vel, div, i, gj);
 }
 
-// K4 clear — clearShader script.js:508-519
 __global__ void __launch_bounds__(BX) k_clear(Win w, const float* __restrict__ p, float* __restrict__ p_out, float value, int ga)
 {
-    const int i = w.x0 + blockIdx.x * BX + threadIdx.x;
-    const int gj = ga + blockIdx.y;
-    if (i >= w.x1) return;
-    const long c = (long)(gj - w.g0) * w.W + i;
-    p_out[c] = value * p[c];
+    TEXEL_OR_RETURN(w);
+    clear_texel(w, p, p_out, value, i, gj);
 }
 
-// K5 one Jacobi iteration — pressureShader script.js:868-890 (operand order of line 887)
 __global__ void __launch_bounds__(BX) k_jacobi(Win w, const float* __restrict__ p, const float* __restrict__ div,
                                                 float* __restrict__ p_out, int ga)
 {
-    const int i = w.x0 + blockIdx.x * BX + threadIdx.x;
-    const int gj = ga + blockIdx.y;
-    if (i >= w.x1) return;
-    const long c = (long)(gj - w.g0) * w.W + i;
-    const float L = p[widx(w, gj, i - 1)];
-    const float R = p[widx(w, gj, i + 1)];
-    const float T = p[widx(w, gj + 1, i)];
-    const float B = p[widx(w, gj - 1, i)];
-    p_out[c] = (L + R + B + T - div[c]) * 0.25f;
+    TEXEL_OR_RETURN(w);
+    jacobi_texel(w, p, div, p_out, i, gj);
 }
 
-// K6 gradient subtract — gradientSubtractShader script.js:892-913
 __global__ void __launch_bounds__(BX) k_gradsub(Win w, const float* __restrict__ p, const float2* __restrict__ vel,
                                                  float2* __restrict__ vel_out, int ga)
 {
-    const int i = w.x0 + blockIdx.x * BX + threadIdx.x;
-    const int gj = ga + blockIdx.y;
-    if (i >= w.x1) return;
-    const long c = (long)(gj - w.g0) * w.W + i;
-    const float L = p[widx(w, gj, i - 1)];
-    const float R = p[widx(w, gj, i + 1)];
-    const float T = p[widx(w, gj + 1, i)];
-    const float B = p[widx(w, gj - 1, i)];
-    const float2 v = vel[c];
-    vel_out[c] = make_float2(v.x - (R - L), v.y - (T - B));
+    TEXEL_OR_RETURN(w);
+    gradsub_texel(w, p, vel, vel_out, i, gj);
 }
 
-// ------------------------------------------------------------------------------------------------
-// GL LINEAR fetch with CLAMP_TO_EDGE: taps and weights from bil_taps (fluid_math.h)
-__device__ __forceinline__ float2 bil2(const Win& w, const float2* __restrict__ F, float u, float v, int& miss)
-{
-    const Taps t = bil_taps(w, u, v);
-    miss += t.miss;
-    const float2 a = F[t.a], b = F[t.b], c = F[t.c], d = F[t.d];
-    return make_float2(mixf(mixf(a.x, b.x, t.fx), mixf(c.x, d.x, t.fx), t.fy),
-                       mixf(mixf(a.y, b.y, t.fx), mixf(c.y, d.y, t.fx), t.fy));
-}
-
-__device__ __forceinline__ float4 bil4(const Win& w, const float4* __restrict__ F, float u, float v, int& miss)
-{
-    const Taps t = bil_taps(w, u, v);
-    miss += t.miss;
-    const float4 a = F[t.a], b = F[t.b], c = F[t.c], d = F[t.d];
-    return make_float4(mixf(mixf(a.x, b.x, t.fx), mixf(c.x, d.x, t.fx), t.fy),
-                       mixf(mixf(a.y, b.y, t.fx), mixf(c.y, d.y, t.fx), t.fy),
-                       mixf(mixf(a.z, b.z, t.fx), mixf(c.z, d.z, t.fx), t.fy),
-                       mixf(mixf(a.w, b.w, t.fx), mixf(c.w, d.w, t.fx), t.fy));
-}
-
-// K7a velocity self-advection — advectionShader script.js:746-784, call 1275-1285
 __global__ void __launch_bounds__(BX) k_advect_velocity(Win w, const float2* __restrict__ vel, float2* __restrict__ out,
                                                          float dt, float dissipation, float tsx, float tsy, int ga,
                                                          unsigned int* __restrict__ miss_out)
 {
-    const int i = w.x0 + blockIdx.x * BX + threadIdx.x;
-    const int gj = ga + blockIdx.y;
-    if (i >= w.x1) return;
-    const float u = ((float)i + 0.5f) / (float)w.W;
-    const float v = ((float)gj + 0.5f) / (float)w.H;
-    const long c = (long)(gj - w.g0) * w.W + i;
-    const float2 vv = vel[c];
-    const float cu = u - dt * vv.x * tsx;
-    const float cv = v - dt * vv.y * tsy;
-    int miss = 0;
-    const float2 r = bil2(w, vel, cu, cv, miss);
-    const float decay = 1.0f + dissipation * dt;
-    out[c] = make_float2(r.x / decay, r.y / decay);
+    TEXEL_OR_RETURN(w);
+    const int miss = advect_velocity_texel(w, vel, out, dt, dissipation, tsx, tsy, i, gj);
     if (miss) atomicAdd(miss_out, (unsigned)miss);
 }
 
-// K7b dye advection — same program, call script.js:1287-1293: the back-trace uses the SIM texel size (1276)
 template <bool SAME_RES>
 __global__ void __launch_bounds__(BX) k_advect_dye(Win vw, const float2* __restrict__ vel, Win dw, const float4* __restrict__ dye,
                                                     float4* __restrict__ out, float dt, float dissipation, float tsx, float tsy,
                                                     int ga, unsigned int* __restrict__ miss_out)
 {
-    const int i = dw.x0 + blockIdx.x * BX + threadIdx.x;
-    const int gj = ga + blockIdx.y;
-    if (i >= dw.x1) return;
-    const float u = ((float)i + 0.5f) / (float)dw.W;
-    const float v = ((float)gj + 0.5f) / (float)dw.H;
-    int miss = 0;
-    float2 vv;
-    if (SAME_RES) vv = vel[(long)(gj - vw.g0) * vw.W + i];
-    else vv = bil2(vw, vel, u, v, miss);
-    const float cu = u - dt * vv.x * tsx;
-    const float cv = v - dt * vv.y * tsy;
-    const float4 r = bil4(dw, dye, cu, cv, miss);
-    const float decay = 1.0f + dissipation * dt;
-    out[(long)(gj - dw.g0) * dw.W + i] = make_float4(r.x / decay, r.y / decay, r.z / decay, r.w / decay);
+    TEXEL_OR_RETURN(dw);
+    const int miss = advect_dye_texel<SAME_RES>(vw, vel, dw, dye, out, dt, dissipation, tsx, tsy, i, gj);
     if (miss) atomicAdd(miss_out, (unsigned)miss);
 }
 
@@ -254,45 +164,27 @@ __global__ void __launch_bounds__(BX) k_advect_both(Win w, const float2* __restr
     if (miss) atomicAdd(miss_out, (unsigned)miss);
 }
 
-// K8 splat — splatShader script.js:726-744 (splat_weight, fluid_math.h)
 __global__ void __launch_bounds__(BX) k_splat_velocity(Win w, const float2* __restrict__ base, float2* __restrict__ out, float x, float y,
                                                         float aspect, float radius, float c0, float c1, int ga)
 {
-    const int i = w.x0 + blockIdx.x * BX + threadIdx.x;
-    const int gj = ga + blockIdx.y;
-    if (i >= w.x1) return;
-    const long c = (long)(gj - w.g0) * w.W + i;
-    const float g = splat_weight(w, i, gj, x, y, aspect, radius);
-    const float2 b = base[c];
-    out[c] = make_float2(b.x + g * c0, b.y + g * c1);
+    TEXEL_OR_RETURN(w);
+    splat_velocity_texel(w, base, out, x, y, aspect, radius, c0, c1, i, gj);
 }
 
 __global__ void __launch_bounds__(BX) k_splat_dye(Win w, const float4* __restrict__ base, float4* __restrict__ out, float x, float y,
                                                    float aspect, float radius, float c0, float c1, float c2, int ga)
 {
-    const int i = w.x0 + blockIdx.x * BX + threadIdx.x;
-    const int gj = ga + blockIdx.y;
-    if (i >= w.x1) return;
-    const long c = (long)(gj - w.g0) * w.W + i;
-    const float g = splat_weight(w, i, gj, x, y, aspect, radius);
-    const float4 b = base[c];
-    out[c] = make_float4(b.x + g * c0, b.y + g * c1, b.z + g * c2, 1.0f);
+    TEXEL_OR_RETURN(w);
+    splat_dye_texel(w, base, out, x, y, aspect, radius, c0, c1, c2, i, gj);
 }
 
-// copyShader resample for resizeFBO — script.js:496-506, 1108-1114
 template <int NC>
 __global__ void __launch_bounds__(BX) k_resample(Win sw, const float* __restrict__ src, Win dw, float* __restrict__ dst)
 {
     const int i = blockIdx.x * BX + threadIdx.x;
     const int gj = blockIdx.y;
     if (i >= dw.W) return;
-    const float u = ((float)i + 0.5f) / (float)dw.W;
-    const float v = ((float)gj + 0.5f) / (float)dw.H;
-    const Taps t = bil_taps(sw, u, v);
-    for (int k = 0; k < NC; k++) {
-        const float a = src[t.a * NC + k], b = src[t.b * NC + k], c = src[t.c * NC + k], d = src[t.d * NC + k];
-        dst[((long)gj * dw.W + i) * NC + k] = mixf(mixf(a, b, t.fx), mixf(c, d, t.fx), t.fy);
-    }
+    resample_texel<NC>(sw, src, dw, dst, i, gj);
 }
 
 template <int NC>

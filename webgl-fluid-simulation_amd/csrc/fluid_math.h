@@ -1,11 +1,38 @@
 // fluid_math.h — per-texel device arithmetic shared by the fp32-storage kernels (fluid_kernels.hip) and the
-// fp16-storage kernels (fluid_kernels_f16.hip): everything here computes in fp32, whatever the storage type.
-// Internal; each function cites the shader lines of the reference (script.js) it follows.
+// fp16-storage kernels (fluid_kernels_f16.hip): storage access (ld / st), the GL bilinear fetch, and one `*_texel`
+// body per reference pass.  Everything computes in fp32, whatever the storage type; a store to an fp16 field rounds
+// to nearest even.  Internal; each function cites the shader lines of the reference (script.js) it follows.
 #pragma once
 #include "fluid_kernels.h"
 
 namespace fluid {
 namespace {
+
+// ---- storage access: a field is an array of fp32 texels or (FLUID_STORE_F16) of half texels; `ld` widens to fp32,
+//      `st` narrows with round-to-nearest-even — what a write to a half-float render target does (script.js:138, 145-147)
+__device__ __forceinline__ float ld(const float* p, long i) { return p[i]; }
+__device__ __forceinline__ float2 ld(const float2* p, long i) { return p[i]; }
+__device__ __forceinline__ float4 ld(const float4* p, long i) { return p[i]; }
+__device__ __forceinline__ float ld(const __half* p, long i) { return __half2float(p[i]); }
+__device__ __forceinline__ float2 ld(const __half2* p, long i) { return __half22float2(p[i]); }
+__device__ __forceinline__ float4 ld(const half4* p, long i)
+{
+    const half4 v = p[i];
+    const float2 a = __half22float2(v.lo), b = __half22float2(v.hi);
+    return make_float4(a.x, a.y, b.x, b.y);
+}
+__device__ __forceinline__ void st(float* p, long i, float v) { p[i] = v; }
+__device__ __forceinline__ void st(float2* p, long i, float2 v) { p[i] = v; }
+__device__ __forceinline__ void st(float4* p, long i, float4 v) { p[i] = v; }
+__device__ __forceinline__ void st(__half* p, long i, float v) { p[i] = __float2half_rn(v); }
+__device__ __forceinline__ void st(__half2* p, long i, float2 v) { p[i] = __float22half2_rn(v); }
+__device__ __forceinline__ void st(half4* p, long i, float4 v)
+{
+    half4 h;
+    h.lo = __float22half2_rn(make_float2(v.x, v.y));
+    h.hi = __float22half2_rn(make_float2(v.z, v.w));
+    p[i] = h;
+}
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -74,6 +101,180 @@ __device__ __forceinline__ float splat_weight(const Win& w, int i, int gj, float
     const float px = (u - x) * aspect;
     const float py = v - y;
     return expf(-(px * px + py * py) / radius);
+}
+
+// ================================================================================================================
+// One texel of each reference pass, templated on the storage types of the fields it touches (V2 = velocity texel,
+// S1 = scalar texel, D4 = dye texel: float2 / float / float4 or __half2 / __half / half4).  The per-pass kernels of
+// both storage modes are thin wrappers around these; all arithmetic is fp32 in the shader's operand order.
+
+// K1 curl — curlShader script.js:814-833
+template <class V2, class S1>
+__device__ __forceinline__ void curl_texel(const Win& w, const V2* __restrict__ vel, S1* __restrict__ curl, int i, int gj)
+{
+    const float L = ld(vel, widx(w, gj, i - 1)).y;
+    const float R = ld(vel, widx(w, gj, i + 1)).y;
+    const float T = ld(vel, widx(w, gj + 1, i)).x;
+    const float B = ld(vel, widx(w, gj - 1, i)).x;
+    const float vort = R - L - T + B;
+    st(curl, (long)(gj - w.g0) * w.W + i, 0.5f * vort);
+}
+
+// K2 vorticity confinement — vorticityShader script.js:835-866
+template <class V2, class S1>
+__device__ __forceinline__ void vorticity_texel(const Win& w, const V2* __restrict__ vel, const S1* __restrict__ curl, V2* __restrict__ vel_out,
+                                                float curl_strength, float dt, int i, int gj)
+{
+    const long c = (long)(gj - w.g0) * w.W + i;
+    const float L = ld(curl, widx(w, gj, i - 1));
+    const float R = ld(curl, widx(w, gj, i + 1));
+    const float T = ld(curl, widx(w, gj + 1, i));
+    const float B = ld(curl, widx(w, gj - 1, i));
+    st(vel_out, c, vorticity_cell(L, R, T, B, ld(curl, c), ld(vel, c), curl_strength, dt));
+}
+
+// K3 divergence with the reflecting-wall rule — divergenceShader script.js:786-812
+template <class V2, class S1>
+__device__ __forceinline__ void divergence_texel(const Win& w, const V2* __restrict__ vel, S1* __restrict__ div, int i, int gj)
+{
+    const long c = (long)(gj - w.g0) * w.W + i;
+    float L = ld(vel, widx(w, gj, i - 1)).x;
+    float R = ld(vel, widx(w, gj, i + 1)).x;
+    float T = ld(vel, widx(w, gj + 1, i)).y;
+    float B = ld(vel, widx(w, gj - 1, i)).y;
+    const float2 C = ld(vel, c);
+    if (i == 0) L = -C.x;
+    if (i == w.W - 1) R = -C.x;
+    if (gj == w.H - 1) T = -C.y;
+    if (gj == 0) B = -C.y;
+    st(div, c, 0.5f * (R - L + T - B));
+}
+
+// K4 clear — clearShader script.js:508-519
+template <class S1>
+__device__ __forceinline__ void clear_texel(const Win& w, const S1* __restrict__ p, S1* __restrict__ p_out, float value, int i, int gj)
+{
+    const long c = (long)(gj - w.g0) * w.W + i;
+    st(p_out, c, value * ld(p, c));
+}
+
+// K5 one Jacobi iteration — pressureShader script.js:868-890 (operand order of line 887)
+template <class S1>
+__device__ __forceinline__ void jacobi_texel(const Win& w, const S1* __restrict__ p, const S1* __restrict__ div, S1* __restrict__ p_out, int i, int gj)
+{
+    const long c = (long)(gj - w.g0) * w.W + i;
+    const float L = ld(p, widx(w, gj, i - 1));
+    const float R = ld(p, widx(w, gj, i + 1));
+    const float T = ld(p, widx(w, gj + 1, i));
+    const float B = ld(p, widx(w, gj - 1, i));
+    st(p_out, c, (L + R + B + T - ld(div, c)) * 0.25f);
+}
+
+// K6 gradient subtract — gradientSubtractShader script.js:892-913
+template <class S1, class V2>
+__device__ __forceinline__ void gradsub_texel(const Win& w, const S1* __restrict__ p, const V2* __restrict__ vel, V2* __restrict__ vel_out, int i, int gj)
+{
+    const long c = (long)(gj - w.g0) * w.W + i;
+    const float L = ld(p, widx(w, gj, i - 1));
+    const float R = ld(p, widx(w, gj, i + 1));
+    const float T = ld(p, widx(w, gj + 1, i));
+    const float B = ld(p, widx(w, gj - 1, i));
+    const float2 v = ld(vel, c);
+    st(vel_out, c, make_float2(v.x - (R - L), v.y - (T - B)));
+}
+
+// GL LINEAR fetch with CLAMP_TO_EDGE of a two- / four-channel field (the filter runs in fp32 on the widened taps)
+template <class V2>
+__device__ __forceinline__ float2 bil2(const Win& w, const V2* __restrict__ F, float u, float v, int& miss)
+{
+    const Taps t = bil_taps(w, u, v);
+    miss += t.miss;
+    const float2 a = ld(F, t.a), b = ld(F, t.b), c = ld(F, t.c), d = ld(F, t.d);
+    return make_float2(mixf(mixf(a.x, b.x, t.fx), mixf(c.x, d.x, t.fx), t.fy),
+                       mixf(mixf(a.y, b.y, t.fx), mixf(c.y, d.y, t.fx), t.fy));
+}
+
+template <class D4>
+__device__ __forceinline__ float4 bil4(const Win& w, const D4* __restrict__ F, float u, float v, int& miss)
+{
+    const Taps t = bil_taps(w, u, v);
+    miss += t.miss;
+    const float4 a = ld(F, t.a), b = ld(F, t.b), c = ld(F, t.c), d = ld(F, t.d);
+    return make_float4(mixf(mixf(a.x, b.x, t.fx), mixf(c.x, d.x, t.fx), t.fy),
+                       mixf(mixf(a.y, b.y, t.fx), mixf(c.y, d.y, t.fx), t.fy),
+                       mixf(mixf(a.z, b.z, t.fx), mixf(c.z, d.z, t.fx), t.fy),
+                       mixf(mixf(a.w, b.w, t.fx), mixf(c.w, d.w, t.fx), t.fy));
+}
+
+// K7a velocity self-advection — advectionShader script.js:746-784, call 1275-1285; returns the taps that missed the window
+template <class V2>
+__device__ __forceinline__ int advect_velocity_texel(const Win& w, const V2* __restrict__ vel, V2* __restrict__ out, float dt, float dissipation,
+                                                     float tsx, float tsy, int i, int gj)
+{
+    const float u = ((float)i + 0.5f) / (float)w.W;
+    const float v = ((float)gj + 0.5f) / (float)w.H;
+    const long c = (long)(gj - w.g0) * w.W + i;
+    const float2 vv = ld(vel, c);
+    const float cu = u - dt * vv.x * tsx;
+    const float cv = v - dt * vv.y * tsy;
+    int miss = 0;
+    const float2 r = bil2(w, vel, cu, cv, miss);
+    const float decay = 1.0f + dissipation * dt;
+    st(out, c, make_float2(r.x / decay, r.y / decay));
+    return miss;
+}
+
+// K7b dye advection — same program, call script.js:1287-1293: the back-trace uses the SIM texel size (1276)
+template <bool SAME_RES, class V2, class D4>
+__device__ __forceinline__ int advect_dye_texel(const Win& vw, const V2* __restrict__ vel, const Win& dw, const D4* __restrict__ dye,
+                                                D4* __restrict__ out, float dt, float dissipation, float tsx, float tsy, int i, int gj)
+{
+    const float u = ((float)i + 0.5f) / (float)dw.W;
+    const float v = ((float)gj + 0.5f) / (float)dw.H;
+    int miss = 0;
+    float2 vv;
+    if (SAME_RES) vv = ld(vel, (long)(gj - vw.g0) * vw.W + i);
+    else vv = bil2(vw, vel, u, v, miss);
+    const float cu = u - dt * vv.x * tsx;
+    const float cv = v - dt * vv.y * tsy;
+    const float4 r = bil4(dw, dye, cu, cv, miss);
+    const float decay = 1.0f + dissipation * dt;
+    st(out, (long)(gj - dw.g0) * dw.W + i, make_float4(r.x / decay, r.y / decay, r.z / decay, r.w / decay));
+    return miss;
+}
+
+// K8 splat — splatShader script.js:726-744 (the dye target's alpha is forced to 1.0, line 742)
+template <class V2>
+__device__ __forceinline__ void splat_velocity_texel(const Win& w, const V2* __restrict__ base, V2* __restrict__ out, float x, float y,
+                                                     float aspect, float radius, float c0, float c1, int i, int gj)
+{
+    const long c = (long)(gj - w.g0) * w.W + i;
+    const float g = splat_weight(w, i, gj, x, y, aspect, radius);
+    const float2 b = ld(base, c);
+    st(out, c, make_float2(b.x + g * c0, b.y + g * c1));
+}
+
+template <class D4>
+__device__ __forceinline__ void splat_dye_texel(const Win& w, const D4* __restrict__ base, D4* __restrict__ out, float x, float y, float aspect,
+                                                float radius, float c0, float c1, float c2, int i, int gj)
+{
+    const long c = (long)(gj - w.g0) * w.W + i;
+    const float g = splat_weight(w, i, gj, x, y, aspect, radius);
+    const float4 b = ld(base, c);
+    st(out, c, make_float4(b.x + g * c0, b.y + g * c1, b.z + g * c2, 1.0f));
+}
+
+// copyShader resample for resizeFBO — script.js:496-506, 1108-1114 (T = float or __half, NC channels per texel)
+template <int NC, class T>
+__device__ __forceinline__ void resample_texel(const Win& sw, const T* __restrict__ src, const Win& dw, T* __restrict__ dst, int i, int gj)
+{
+    const float u = ((float)i + 0.5f) / (float)dw.W;
+    const float v = ((float)gj + 0.5f) / (float)dw.H;
+    const Taps t = bil_taps(sw, u, v);
+    for (int k = 0; k < NC; k++) {
+        const float a = ld(src, t.a * NC + k), b = ld(src, t.b * NC + k), c = ld(src, t.c * NC + k), d = ld(src, t.d * NC + k);
+        st(dst, ((long)gj * dw.W + i) * NC + k, mixf(mixf(a, b, t.fx), mixf(c, d, t.fx), t.fy));
+    }
 }
 
 }  // namespace

@@ -79,10 +79,7 @@ int set_geometry(fluid_ctx* c, int sw, int sh, int dw, int dh)
 // gl.clear after createFBO (script.js:1059) with clearColor (0,0,0,1) (script.js:136): dye alpha starts at 1
 int zero_scalar_fields(fluid_ctx* c)
 {
-    HIPCK(c, hipMemsetAsync(c->prs[0], 0, cells(c->sim) * sizeof(float), c->stream));
-    HIPCK(c, hipMemsetAsync(c->prs[1], 0, cells(c->sim) * sizeof(float), c->stream));
-    HIPCK(c, hipMemsetAsync(c->div, 0, cells(c->sim) * sizeof(float), c->stream));
-    HIPCK(c, hipMemsetAsync(c->curl, 0, cells(c->sim) * sizeof(float), c->stream));
+    for (void* p : { c->prs[0], c->prs[1], c->div, c->curl }) HIPCK(c, hipMemsetAsync(p, 0, cells(c->sim) * c->esz, c->stream));
     return FLUID_OK;
 }
 
@@ -90,15 +87,15 @@ int alloc_fields(fluid_ctx* c)
 {
     const size_t ns = cells(c->sim), nd = cells(c->dye);
     for (int k = 0; k < 2; k++) {
-        HIPCK(c, hipMalloc((void**)&c->vel[k], ns * sizeof(float2)));
-        HIPCK(c, hipMalloc((void**)&c->prs[k], ns * sizeof(float)));
-        HIPCK(c, hipMalloc((void**)&c->dyeb[k], nd * sizeof(float4)));
+        HIPCK(c, hipMalloc(&c->vel[k], ns * 2 * c->esz));
+        HIPCK(c, hipMalloc(&c->prs[k], ns * c->esz));
+        HIPCK(c, hipMalloc(&c->dyeb[k], nd * 4 * c->esz));
     }
-    HIPCK(c, hipMalloc((void**)&c->div, ns * sizeof(float)));
-    HIPCK(c, hipMalloc((void**)&c->curl, ns * sizeof(float)));
+    HIPCK(c, hipMalloc(&c->div, ns * c->esz));
+    HIPCK(c, hipMalloc(&c->curl, ns * c->esz));
     for (int k = 0; k < 2; k++) {
-        HIPCK(c, hipMemsetAsync(c->vel[k], 0, ns * sizeof(float2), c->stream));
-        HIPCK(c, launch_fill(c->stream, (float*)c->dyeb[k], nd, 4, 0.f, 0.f, 0.f, 1.f));
+        HIPCK(c, hipMemsetAsync(c->vel[k], 0, ns * 2 * c->esz, c->stream));
+        HIPCK(c, STORE_CALL(c, launch_fill(c->stream, (S::T1*)c->dyeb[k], nd, 4, 0.f, 0.f, 0.f, 1.f)));
     }
     return zero_scalar_fields(c);
 }
@@ -143,7 +140,7 @@ int pass_curl(fluid_ctx* c, int ext)
     CK(check_ext(c, ext, 1));
     int ga, gb;
     row_range(c->sim, c->sim_row0, c->sim_rows, ext, ga, gb);
-    return c->hip(launch_curl(c->stream, sim_cols(c, ext), c->vel[0], c->curl, ga, gb), "curl");
+    return c->hip(STORE_CALL(c, launch_curl(c->stream, sim_cols(c, ext), VEL(c, 0), CURL(c), ga, gb)), "curl");
 }
 
 int pass_vorticity(fluid_ctx* c, float curl, float dt, int ext)
@@ -151,7 +148,7 @@ int pass_vorticity(fluid_ctx* c, float curl, float dt, int ext)
     CK(check_ext(c, ext, 1));
     int ga, gb;
     row_range(c->sim, c->sim_row0, c->sim_rows, ext, ga, gb);
-    CK(c->hip(launch_vorticity(c->stream, sim_cols(c, ext), c->vel[0], c->curl, c->vel[1], curl, dt, ga, gb), "vorticity"));
+    CK(c->hip(STORE_CALL(c, launch_vorticity(c->stream, sim_cols(c, ext), VEL(c, 0), CURL(c), VEL(c, 1), curl, dt, ga, gb)), "vorticity"));
     std::swap(c->vel[0], c->vel[1]);
     return FLUID_OK;
 }
@@ -161,17 +158,19 @@ int pass_divergence(fluid_ctx* c, int ext)
     CK(check_ext(c, ext, 1));
     int ga, gb;
     row_range(c->sim, c->sim_row0, c->sim_rows, ext, ga, gb);
-    return c->hip(launch_divergence(c->stream, sim_cols(c, ext), c->vel[0], c->div, ga, gb), "divergence");
+    return c->hip(STORE_CALL(c, launch_divergence(c->stream, sim_cols(c, ext), VEL(c, 0), DIVG(c), ga, gb)), "divergence");
 }
 
 // K1 + K2 + K3; one kernel when the fused schedule applies, the three passes otherwise (same bits either way)
 int pass_curl_vort_div(fluid_ctx* c, float curl, float dt, int ext, Timer* t)
 {
-    if (c->desc.schedule == FLUID_SCHED_FUSED && fused_supported(c->sim)) {
+    if (fused_cvd_applies(c)) {
         CK(check_ext(c, ext, 3));
         int ga, gb;
         row_range(c->sim, c->sim_row0, c->sim_rows, ext, ga, gb);
-        CK(c->hip(launch_curl_vort_div(c->stream, sim_cols(c, ext), c->vel[0], c->curl, c->vel[1], c->div, curl, dt, ga, gb), "curl_vort_div"));
+        CK(c->hip(launch_curl_vort_div(c->stream, sim_cols(c, ext), (const float2*)c->vel[0], (float*)c->curl, (float2*)c->vel[1], (float*)c->div,
+                                       curl, dt, ga, gb),
+                  "curl_vort_div"));
         std::swap(c->vel[0], c->vel[1]);
         if (t) t->mark(P_VORT);
         return FLUID_OK;
@@ -190,7 +189,7 @@ int pass_clear(fluid_ctx* c, float value, int ext)
     CK(check_ext(c, ext, 0));
     int ga, gb;
     row_range(c->sim, c->sim_row0, c->sim_rows, ext, ga, gb);
-    CK(c->hip(launch_clear(c->stream, sim_cols(c, ext), c->prs[0], c->prs[1], value, ga, gb), "clear"));
+    CK(c->hip(STORE_CALL(c, launch_clear(c->stream, sim_cols(c, ext), PRS(c, 0), PRS(c, 1), value, ga, gb)), "clear"));
     std::swap(c->prs[0], c->prs[1]);
     return FLUID_OK;
 }
@@ -200,7 +199,7 @@ int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launche
 {
     if (iters < 0) return c->fail(FLUID_ERR_INVALID, "negative iteration count");
     CK(check_ext(c, ext_out, iters));
-    const bool tb = c->desc.schedule == FLUID_SCHED_FUSED && jacobi_tb_supported(c->sim);
+    const bool tb = fused_f32(c) && jacobi_tb_supported(c->sim);
     int done = 0;
     if (!tb && pscale != 1.0f) return c->fail(FLUID_ERR_INVALID, "pscale needs the fused schedule");
     // balanced blocks: ceil(iters / max) launches of nearly equal depth (50 with max 8 -> 8,7,7,7,7,7,7)
@@ -211,12 +210,14 @@ int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launche
             const int k = (iters - done + launches_left - 1) / launches_left;
             launches_left--;
             row_range(c->sim, c->sim_row0, c->sim_rows, ext_out + (iters - done - k), ga, gb);
-            CK(c->hip(launch_jacobi_tb(c->stream, sim_cols(c, ext_out + (iters - done - k)), c->prs[0], c->div, c->prs[1], done == 0 ? pscale : 1.0f, k, ga, gb),
+            CK(c->hip(launch_jacobi_tb(c->stream, sim_cols(c, ext_out + (iters - done - k)), (const float*)c->prs[0], (const float*)c->div,
+                                       (float*)c->prs[1], done == 0 ? pscale : 1.0f, k, ga, gb),
                       "jacobi_tb"));
             done += k;
         } else {
             row_range(c->sim, c->sim_row0, c->sim_rows, ext_out + (iters - done - 1), ga, gb);
-            CK(c->hip(launch_jacobi(c->stream, sim_cols(c, ext_out + (iters - done - 1)), c->prs[0], c->div, c->prs[1], ga, gb), "jacobi"));
+            CK(c->hip(STORE_CALL(c, launch_jacobi(c->stream, sim_cols(c, ext_out + (iters - done - 1)), PRS(c, 0), DIVG(c), PRS(c, 1), ga, gb)),
+                      "jacobi"));
             done += 1;
         }
         std::swap(c->prs[0], c->prs[1]);
@@ -229,7 +230,7 @@ int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launche
 int pass_clear_jacobi(fluid_ctx* c, float value, int iters, int ext_out, int* launches)
 {
     if (iters < 0) return c->fail(FLUID_ERR_INVALID, "negative iteration count");
-    const bool fold = c->desc.schedule == FLUID_SCHED_FUSED && jacobi_tb_supported(c->sim) && iters > 0;
+    const bool fold = fused_f32(c) && jacobi_tb_supported(c->sim) && iters > 0;
     if (fold) return pass_jacobi(c, iters, ext_out, value, launches);
     CK(pass_clear(c, value, ext_out + iters));
     return pass_jacobi(c, iters, ext_out, 1.0f, launches);
@@ -240,10 +241,10 @@ int pass_gradsub(fluid_ctx* c, int ext)
     CK(check_ext(c, ext, 1));
     int ga, gb;
     row_range(c->sim, c->sim_row0, c->sim_rows, ext, ga, gb);
-    if (c->desc.schedule == FLUID_SCHED_FUSED && fused_supported(c->sim))
-        CK(c->hip(launch_gradsub4(c->stream, sim_cols(c, ext), c->prs[0], c->vel[0], c->vel[1], ga, gb), "gradsub"));
+    if (fused_f32(c) && fused_supported(c->sim))
+        CK(c->hip(launch_gradsub4(c->stream, sim_cols(c, ext), (const float*)c->prs[0], (const float2*)c->vel[0], (float2*)c->vel[1], ga, gb), "gradsub"));
     else
-        CK(c->hip(launch_gradsub(c->stream, sim_cols(c, ext), c->prs[0], c->vel[0], c->vel[1], ga, gb), "gradsub"));
+        CK(c->hip(STORE_CALL(c, launch_gradsub(c->stream, sim_cols(c, ext), PRS(c, 0), VEL(c, 0), VEL(c, 1), ga, gb)), "gradsub"));
     std::swap(c->vel[0], c->vel[1]);
     return FLUID_OK;
 }
@@ -253,7 +254,8 @@ int pass_advect_velocity(fluid_ctx* c, float dt, float dissipation, int ext)
     CK(check_ext(c, ext, 0));
     int ga, gb;
     row_range(c->sim, c->sim_row0, c->sim_rows, ext, ga, gb);
-    CK(c->hip(launch_advect_velocity(c->stream, sim_cols(c, ext), c->vel[0], c->vel[1], dt, dissipation, ga, gb, c->miss), "advect velocity"));
+    CK(c->hip(STORE_CALL(c, launch_advect_velocity(c->stream, sim_cols(c, ext), VEL(c, 0), VEL(c, 1), dt, dissipation, ga, gb, c->miss)),
+              "advect velocity"));
     std::swap(c->vel[0], c->vel[1]);
     return FLUID_OK;
 }
@@ -262,7 +264,7 @@ int pass_advect_dye(fluid_ctx* c, float dt, float dissipation)
 {
     int ga, gb;
     row_range(c->dye, c->dye_row0, c->dye_rows, 0, ga, gb);
-    CK(c->hip(launch_advect_dye(c->stream, c->sim, c->vel[0], dye_cols(c, 0), c->dyeb[0], c->dyeb[1], dt, dissipation, ga, gb, c->miss),
+    CK(c->hip(STORE_CALL(c, launch_advect_dye(c->stream, c->sim, VEL(c, 0), dye_cols(c, 0), DYE(c, 0), DYE(c, 1), dt, dissipation, ga, gb, c->miss)),
               "advect dye"));
     std::swap(c->dyeb[0], c->dyeb[1]);
     return FLUID_OK;
@@ -273,11 +275,11 @@ int pass_advect_dye(fluid_ctx* c, float dt, float dissipation)
 int pass_advect(fluid_ctx* c, float dt, float vel_diss, float dye_diss, Timer* t)
 {
     const bool same = c->sim.W == c->dye.W && c->sim.H == c->dye.H;
-    if (c->desc.schedule == FLUID_SCHED_FUSED && same) {
+    if (fused_advect_applies(c)) {
         int ga, gb;
         row_range(c->sim, c->sim_row0, c->sim_rows, 0, ga, gb);
-        CK(c->hip(launch_advect_both(c->stream, sim_cols(c, 0), c->vel[0], c->vel[1], c->dyeb[0], c->dyeb[1], dt, vel_diss, dye_diss, ga, gb,
-                                     c->miss),
+        CK(c->hip(launch_advect_both(c->stream, sim_cols(c, 0), (const float2*)c->vel[0], (float2*)c->vel[1], (const float4*)c->dyeb[0],
+                                     (float4*)c->dyeb[1], dt, vel_diss, dye_diss, ga, gb, c->miss),
                   "advect"));
         std::swap(c->vel[0], c->vel[1]);
         std::swap(c->dyeb[0], c->dyeb[1]);
@@ -293,12 +295,11 @@ int pass_advect(fluid_ctx* c, float dt, float vel_diss, float dye_diss, Timer* t
 
 // ---- band forms for the stripe driver: one row band of a single-kernel pass, WITHOUT the ping-pong swap, so that a
 //      pass can run as "interior rows while the ghost rows are in flight, then the strips next to them" ----
-bool fused_cvd_applies(const fluid_ctx* c) { return c->desc.schedule == FLUID_SCHED_FUSED && fused_supported(c->sim); }
+bool fused_f32(const fluid_ctx* c) { return c->desc.schedule == FLUID_SCHED_FUSED && c->storage == FLUID_STORE_F32; }
 
-bool fused_advect_applies(const fluid_ctx* c)
-{
-    return c->desc.schedule == FLUID_SCHED_FUSED && c->sim.W == c->dye.W && c->sim.H == c->dye.H;
-}
+bool fused_cvd_applies(const fluid_ctx* c) { return fused_f32(c) && fused_supported(c->sim); }
+
+bool fused_advect_applies(const fluid_ctx* c) { return fused_f32(c) && c->sim.W == c->dye.W && c->sim.H == c->dye.H; }
 
 void sim_band(const fluid_ctx* c, int ext, int& ga, int& gb) { row_range(c->sim, c->sim_row0, c->sim_rows, ext, ga, gb); }
 
@@ -307,7 +308,8 @@ int cvd_band(fluid_ctx* c, float curl, float dt, int ga, int gb, int xa, int xb)
     Win w = c->sim;
     w.x0 = xa;
     w.x1 = xb;
-    return c->hip(launch_curl_vort_div(c->stream, w, c->vel[0], c->curl, c->vel[1], c->div, curl, dt, ga, gb), "curl_vort_div");
+    return c->hip(launch_curl_vort_div(c->stream, w, (const float2*)c->vel[0], (float*)c->curl, (float2*)c->vel[1], (float*)c->div, curl, dt, ga, gb),
+                  "curl_vort_div");
 }
 
 void cvd_swap(fluid_ctx* c) { std::swap(c->vel[0], c->vel[1]); }
@@ -321,7 +323,8 @@ int advect_both_band(fluid_ctx* c, float dt, float vel_diss, float dye_diss, int
     w.v1 = v1;
     w.u0 = u0;
     w.u1 = u1;
-    return c->hip(launch_advect_both(c->stream, w, c->vel[0], c->vel[1], c->dyeb[0], c->dyeb[1], dt, vel_diss, dye_diss, ga, gb, c->miss),
+    return c->hip(launch_advect_both(c->stream, w, (const float2*)c->vel[0], (float2*)c->vel[1], (const float4*)c->dyeb[0], (float4*)c->dyeb[1], dt,
+                                     vel_diss, dye_diss, ga, gb, c->miss),
                   "advect");
 }
 
@@ -342,7 +345,7 @@ int step_once(fluid_ctx* c, float dt, const fluid_params* P)
     Timer t(c);
     CK(pass_curl_vort_div(c, P->curl, dt, 0, &t));
     int launches = 0;
-    const bool fold_clear = c->desc.schedule == FLUID_SCHED_FUSED && jacobi_tb_supported(c->sim) && P->iterations > 0;
+    const bool fold_clear = fused_f32(c) && jacobi_tb_supported(c->sim) && P->iterations > 0;
     if (!fold_clear) {
         CK(pass_clear(c, P->pressure, 0));
         t.mark(P_CLEAR);
@@ -367,11 +370,11 @@ int field_ref(fluid_ctx* c, int field, FieldRef* f)
 {
     const int h = c->desc.parts > 1 ? c->desc.halo : 0, hx = c->desc.parts_x > 1 ? c->desc.halo : 0;
     switch (field) {
-    case FLUID_VELOCITY: *f = { c->vel[0], &c->sim, c->sim_row0, c->sim_rows, h, 2, c->sim_col0, c->sim_ncols, hx }; break;
-    case FLUID_PRESSURE: *f = { c->prs[0], &c->sim, c->sim_row0, c->sim_rows, h, 1, c->sim_col0, c->sim_ncols, hx }; break;
-    case FLUID_DIVERGENCE: *f = { c->div, &c->sim, c->sim_row0, c->sim_rows, h, 1, c->sim_col0, c->sim_ncols, hx }; break;
-    case FLUID_CURL: *f = { c->curl, &c->sim, c->sim_row0, c->sim_rows, h, 1, c->sim_col0, c->sim_ncols, hx }; break;
-    case FLUID_DYE: *f = { c->dyeb[0], &c->dye, c->dye_row0, c->dye_rows, c->dye_halo, 4, c->dye_col0, c->dye_ncols, c->dye_halo_x }; break;
+    case FLUID_VELOCITY: *f = { c->vel[0], &c->sim, c->sim_row0, c->sim_rows, h, 2, c->sim_col0, c->sim_ncols, hx, c->esz }; break;
+    case FLUID_PRESSURE: *f = { c->prs[0], &c->sim, c->sim_row0, c->sim_rows, h, 1, c->sim_col0, c->sim_ncols, hx, c->esz }; break;
+    case FLUID_DIVERGENCE: *f = { c->div, &c->sim, c->sim_row0, c->sim_rows, h, 1, c->sim_col0, c->sim_ncols, hx, c->esz }; break;
+    case FLUID_CURL: *f = { c->curl, &c->sim, c->sim_row0, c->sim_rows, h, 1, c->sim_col0, c->sim_ncols, hx, c->esz }; break;
+    case FLUID_DYE: *f = { c->dyeb[0], &c->dye, c->dye_row0, c->dye_rows, c->dye_halo, 4, c->dye_col0, c->dye_ncols, c->dye_halo_x, c->esz }; break;
     default: return c->fail(FLUID_ERR_INVALID, "unknown field id");
     }
     return FLUID_OK;
@@ -433,6 +436,13 @@ int fluid_create(const fluid_desc* desc, fluid_ctx** out)
     if (c->desc.parts < 1) c->desc.parts = 1;
     if (c->desc.parts_x < 1) c->desc.parts_x = 1;
     if (c->desc.parts == 1 && c->desc.parts_x == 1) c->desc.halo = 0;
+    if (desc->storage != FLUID_STORE_F32 && desc->storage != FLUID_STORE_F16) {
+        g_create_error = "unknown storage mode";
+        delete c;
+        return FLUID_ERR_INVALID;
+    }
+    c->storage = desc->storage;
+    c->esz = desc->storage == FLUID_STORE_F16 ? 2 : sizeof(float);
     c->device = desc->device;
     int rc = FLUID_OK;
     do {
@@ -484,24 +494,24 @@ int fluid_resize(fluid_ctx* c, int sw, int sh, int dw, int dh)
     const Win ns = make_win(sw, sh, 0, sh), nd = make_win(dw, dh, 0, dh);
     // Everything new is allocated and filled first; the context only changes once nothing can fail any more, so a
     // failed resize (out of memory at a larger size) leaves the old fields in place and usable.
-    float4* ndye[2] = { nullptr, nullptr };
-    float2* nvel[2] = { nullptr, nullptr };
-    float* nscal[4] = { nullptr, nullptr, nullptr, nullptr };  // pressure.read, pressure.write, divergence, curl
+    void* ndye[2] = { nullptr, nullptr };
+    void* nvel[2] = { nullptr, nullptr };
+    void* nscal[4] = { nullptr, nullptr, nullptr, nullptr };  // pressure.read, pressure.write, divergence, curl
     int rc = FLUID_OK;
     do {
         // resizeDoubleFBO (script.js:1116-1126): read <- bilinear copy of the old read, write <- fresh zero texture
         if (dye_changed) {
-            for (int k = 0; k < 2 && !rc; k++) rc = c->hip(hipMalloc((void**)&ndye[k], cells(nd) * sizeof(float4)), "hipMalloc dye");
+            for (int k = 0; k < 2 && !rc; k++) rc = c->hip(hipMalloc(&ndye[k], cells(nd) * 4 * c->esz), "hipMalloc dye");
             if (rc) break;
-            if ((rc = c->hip(launch_resample(c->stream, odye, (const float*)c->dyeb[0], 4, nd, (float*)ndye[0]), "resample dye"))) break;
-            if ((rc = c->hip(launch_fill(c->stream, (float*)ndye[1], cells(nd), 4, 0.f, 0.f, 0.f, 1.f), "fill dye"))) break;
+            if ((rc = c->hip(STORE_CALL(c, launch_resample(c->stream, odye, (const S::T1*)c->dyeb[0], 4, nd, (S::T1*)ndye[0])), "resample dye"))) break;
+            if ((rc = c->hip(STORE_CALL(c, launch_fill(c->stream, (S::T1*)ndye[1], cells(nd), 4, 0.f, 0.f, 0.f, 1.f)), "fill dye"))) break;
         }
         if (sim_changed) {
-            for (int k = 0; k < 2 && !rc; k++) rc = c->hip(hipMalloc((void**)&nvel[k], cells(ns) * sizeof(float2)), "hipMalloc velocity");
-            for (int k = 0; k < 4 && !rc; k++) rc = c->hip(hipMalloc((void**)&nscal[k], cells(ns) * sizeof(float)), "hipMalloc scalar field");
+            for (int k = 0; k < 2 && !rc; k++) rc = c->hip(hipMalloc(&nvel[k], cells(ns) * 2 * c->esz), "hipMalloc velocity");
+            for (int k = 0; k < 4 && !rc; k++) rc = c->hip(hipMalloc(&nscal[k], cells(ns) * c->esz), "hipMalloc scalar field");
             if (rc) break;
-            if ((rc = c->hip(launch_resample(c->stream, osim, (const float*)c->vel[0], 2, ns, (float*)nvel[0]), "resample velocity"))) break;
-            if ((rc = c->hip(hipMemsetAsync(nvel[1], 0, cells(ns) * sizeof(float2), c->stream), "memset velocity"))) break;
+            if ((rc = c->hip(STORE_CALL(c, launch_resample(c->stream, osim, (const S::T1*)c->vel[0], 2, ns, (S::T1*)nvel[0])), "resample velocity"))) break;
+            if ((rc = c->hip(hipMemsetAsync(nvel[1], 0, cells(ns) * 2 * c->esz, c->stream), "memset velocity"))) break;
         }
         rc = c->hip(hipStreamSynchronize(c->stream), "sync");
     } while (0);
@@ -562,11 +572,13 @@ int fluid_pass_splat(fluid_ctx* c, int field, float x, float y, float aspect, fl
     int ga, gb;
     if (field == FLUID_VELOCITY) {
         row_range(c->sim, c->sim.g0, c->sim.rows, 0, ga, gb);
-        CK(c->hip(launch_splat_velocity(c->stream, sim_cols(c, c->desc.halo), c->vel[0], c->vel[1], x, y, aspect, radius, c0, c1, ga, gb), "splat velocity"));
+        CK(c->hip(STORE_CALL(c, launch_splat_velocity(c->stream, sim_cols(c, c->desc.halo), VEL(c, 0), VEL(c, 1), x, y, aspect, radius, c0, c1, ga, gb)),
+                  "splat velocity"));
         std::swap(c->vel[0], c->vel[1]);
     } else if (field == FLUID_DYE) {
         row_range(c->dye, c->dye.g0, c->dye.rows, 0, ga, gb);
-        CK(c->hip(launch_splat_dye(c->stream, dye_cols(c, c->dye_halo_x), c->dyeb[0], c->dyeb[1], x, y, aspect, radius, c0, c1, c2, ga, gb), "splat dye"));
+        CK(c->hip(STORE_CALL(c, launch_splat_dye(c->stream, dye_cols(c, c->dye_halo_x), DYE(c, 0), DYE(c, 1), x, y, aspect, radius, c0, c1, c2, ga, gb)),
+                  "splat dye"));
         std::swap(c->dyeb[0], c->dyeb[1]);
     } else {
         return c->fail(FLUID_ERR_INVALID, "splat target must be velocity or dye");
@@ -606,36 +618,76 @@ int fluid_field_info_get(const fluid_ctx* c, int field, fluid_field_info* out)
     if (!c || !out) return FLUID_ERR_INVALID;
     FieldRef f;
     CK(field_ref(const_cast<fluid_ctx*>(c), field, &f));
-    *out = fluid_field_info{ f.win->W, f.win->H, f.nc, f.row0, f.rows, f.halo, f.col0, f.cols, f.halo_x };
+    *out = fluid_field_info{ f.win->W, f.win->H, f.nc, f.row0, f.rows, f.halo, f.col0, f.cols, f.halo_x, (int)f.esz };
     return FLUID_OK;
 }
+
+// The host side of read / write speaks fp32 whatever the storage.  With fp16 storage the owned rows go through a
+// temporary fp32 copy on the device (widening is exact; narrowing rounds to nearest even, like any other store).
+namespace {
+
+struct HostBlock {
+    FieldRef f;
+    size_t line, rows_n;  // fp32 bytes per owned row segment, scalars in the owned rows over the full width
+    char* first_row;      // device address of the first owned row (column 0)
+};
+
+int host_block(fluid_ctx* c, int field, size_t bytes, const char* who, HostBlock* b)
+{
+    CK(field_ref(c, field, &b->f));
+    const FieldRef& f = b->f;
+    b->line = (size_t)f.cols * f.nc * sizeof(float);
+    if (bytes != (size_t)f.rows * b->line) return c->fail(FLUID_ERR_INVALID, std::string(who) + ": byte count does not match the owned rows x columns (fp32)");
+    b->rows_n = (size_t)f.rows * f.win->W * f.nc;
+    b->first_row = (char*)f.ptr + (size_t)(f.row0 - f.win->g0) * f.win->W * f.texel();
+    return FLUID_OK;
+}
+
+}  // namespace
 
 int fluid_read_field(fluid_ctx* c, int field, float* host, size_t bytes)
 {
     if (!c || !host) return FLUID_ERR_INVALID;
-    FieldRef f;
-    CK(field_ref(c, field, &f));
-    const size_t texel = f.nc * sizeof(float), pitch = (size_t)f.win->W * texel, line = (size_t)f.cols * texel;
-    if (bytes != (size_t)f.rows * line) return c->fail(FLUID_ERR_INVALID, "read_field: byte count does not match the owned rows x columns");
+    HostBlock b;
+    CK(host_block(c, field, bytes, "read_field", &b));
     HIPCK(c, hipSetDevice(c->device));
-    const char* src = (const char*)f.ptr + (size_t)(f.row0 - f.win->g0) * pitch + (size_t)f.col0 * texel;
-    HIPCK(c, hipMemcpy2DAsync(host, line, src, pitch, line, f.rows, hipMemcpyDeviceToHost, c->stream));
-    HIPCK(c, hipStreamSynchronize(c->stream));
-    return FLUID_OK;
+    const size_t pitch32 = (size_t)b.f.win->W * b.f.nc * sizeof(float);
+    if (c->storage == FLUID_STORE_F32) {
+        HIPCK(c, hipMemcpy2DAsync(host, b.line, b.first_row + (size_t)b.f.col0 * b.f.texel(), pitch32, b.line, b.f.rows, hipMemcpyDeviceToHost, c->stream));
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        return FLUID_OK;
+    }
+    float* tmp = nullptr;
+    HIPCK(c, hipMalloc((void**)&tmp, b.rows_n * sizeof(float)));
+    int rc = c->hip(launch_widen(c->stream, (const __half*)b.first_row, tmp, b.rows_n), "widen");
+    if (!rc) rc = c->hip(hipMemcpy2DAsync(host, b.line, (char*)tmp + (size_t)b.f.col0 * b.f.nc * sizeof(float), pitch32, b.line, b.f.rows, hipMemcpyDeviceToHost, c->stream), "copy");
+    if (!rc) rc = c->hip(hipStreamSynchronize(c->stream), "sync");
+    (void)hipFree(tmp);
+    return rc;
 }
 
 int fluid_write_field(fluid_ctx* c, int field, const float* host, size_t bytes)
 {
     if (!c || !host) return FLUID_ERR_INVALID;
-    FieldRef f;
-    CK(field_ref(c, field, &f));
-    const size_t texel = f.nc * sizeof(float), pitch = (size_t)f.win->W * texel, line = (size_t)f.cols * texel;
-    if (bytes != (size_t)f.rows * line) return c->fail(FLUID_ERR_INVALID, "write_field: byte count does not match the owned rows x columns");
+    HostBlock b;
+    CK(host_block(c, field, bytes, "write_field", &b));
     HIPCK(c, hipSetDevice(c->device));
-    char* dst = (char*)f.ptr + (size_t)(f.row0 - f.win->g0) * pitch + (size_t)f.col0 * texel;
-    HIPCK(c, hipMemcpy2DAsync(dst, pitch, host, line, line, f.rows, hipMemcpyHostToDevice, c->stream));
-    HIPCK(c, hipStreamSynchronize(c->stream));
-    return FLUID_OK;
+    const size_t pitch32 = (size_t)b.f.win->W * b.f.nc * sizeof(float);
+    if (c->storage == FLUID_STORE_F32) {
+        HIPCK(c, hipMemcpy2DAsync(b.first_row + (size_t)b.f.col0 * b.f.texel(), pitch32, host, b.line, b.line, b.f.rows, hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        return FLUID_OK;
+    }
+    // the columns of these rows that this context does not own keep their values: widen, overlay the owned block, narrow
+    float* tmp = nullptr;
+    HIPCK(c, hipMalloc((void**)&tmp, b.rows_n * sizeof(float)));
+    int rc = FLUID_OK;
+    if (b.f.cols != b.f.win->W) rc = c->hip(launch_widen(c->stream, (const __half*)b.first_row, tmp, b.rows_n), "widen");
+    if (!rc) rc = c->hip(hipMemcpy2DAsync((char*)tmp + (size_t)b.f.col0 * b.f.nc * sizeof(float), pitch32, host, b.line, b.line, b.f.rows, hipMemcpyHostToDevice, c->stream), "copy");
+    if (!rc) rc = c->hip(launch_narrow(c->stream, tmp, (__half*)b.first_row, b.rows_n), "narrow");
+    if (!rc) rc = c->hip(hipStreamSynchronize(c->stream), "sync");
+    (void)hipFree(tmp);
+    return rc;
 }
 
 #define PASS_PROLOGUE()                      \
@@ -707,7 +759,7 @@ static int halo_copy(fluid_ctx* c, int field, int side, int nrows, void* buf, bo
     if (nrows < 1 || nrows > f.halo || nrows > f.rows) return c->fail(FLUID_ERR_INVALID, "halo rows out of range");
     if (side != 0 && side != 1) return c->fail(FLUID_ERR_INVALID, "side must be 0 (bottom) or 1 (top)");
     HIPCK(c, hipSetDevice(c->device));
-    const size_t row_bytes = (size_t)f.win->W * f.nc * sizeof(float);
+    const size_t row_bytes = (size_t)f.win->W * f.texel();
     int first;  // first array row of the block
     if (pack) first = side == 0 ? f.halo : f.halo + f.rows - nrows;
     else first = side == 0 ? f.halo - nrows : f.halo + f.rows;

@@ -135,10 +135,10 @@ int run_pass(fluid_ctx* c, const fluid_stripe_op& op, float dt, const fluid_para
     }
 }
 
-// ghost / owned row blocks of one exchange item, as float pointers + float counts
+// ghost / owned row blocks of one exchange item: addresses and bytes (fp32 or fp16 texels: the exchange moves bytes)
 struct Rows {
-    float *send_lo, *recv_lo, *send_hi, *recv_hi;
-    size_t count;
+    char *send_lo, *recv_lo, *send_hi, *recv_hi;
+    size_t bytes;
 };
 
 int rows_of(fluid_ctx* c, int field, int n, Rows* r)
@@ -146,14 +146,14 @@ int rows_of(fluid_ctx* c, int field, int n, Rows* r)
     FieldRef f;
     CK(field_ref(c, field, &f));
     if (n < 1 || n > f.halo || n > f.rows) return c->fail(FLUID_ERR_INVALID, "exchange rows exceed the ghost rows / the stripe");
-    const size_t rowf = (size_t)f.win->W * f.nc;
-    float* base = (float*)f.ptr;
+    const size_t rowf = (size_t)f.win->W * f.texel();  // bytes per row
+    char* base = (char*)f.ptr;
     const int h = f.halo, rr = f.rows;
     r->send_lo = base + (size_t)h * rowf;             // my lowest owned rows   -> lower neighbour's top ghost rows
     r->recv_lo = base + (size_t)(h - n) * rowf;       // my bottom ghost rows   <- lower neighbour's highest owned rows
     r->send_hi = base + (size_t)(h + rr - n) * rowf;  // my highest owned rows  -> upper neighbour's bottom ghost rows
     r->recv_hi = base + (size_t)(h + rr) * rowf;      // my top ghost rows      <- upper neighbour's lowest owned rows
-    r->count = (size_t)n * rowf;
+    r->bytes = (size_t)n * rowf;
     return FLUID_OK;
 }
 
@@ -261,13 +261,13 @@ int rccl_exchange_begin(fluid_ctx* c, const fluid_stripe_op& op)
     // per peer, sends and receives are issued in item order on both sides, so they pair up
     if (rank > 0)
         for (int i = 0; i < op.n_items; i++) {
-            NCCLCK(c, R, R->Send(rows[i].send_lo, rows[i].count, ncclFloat, rank - 1, comm, c->comm_stream));
-            NCCLCK(c, R, R->Recv(rows[i].recv_lo, rows[i].count, ncclFloat, rank - 1, comm, c->comm_stream));
+            NCCLCK(c, R, R->Send(rows[i].send_lo, rows[i].bytes, ncclChar, rank - 1, comm, c->comm_stream));
+            NCCLCK(c, R, R->Recv(rows[i].recv_lo, rows[i].bytes, ncclChar, rank - 1, comm, c->comm_stream));
         }
     if (rank < world - 1)
         for (int i = 0; i < op.n_items; i++) {
-            NCCLCK(c, R, R->Send(rows[i].send_hi, rows[i].count, ncclFloat, rank + 1, comm, c->comm_stream));
-            NCCLCK(c, R, R->Recv(rows[i].recv_hi, rows[i].count, ncclFloat, rank + 1, comm, c->comm_stream));
+            NCCLCK(c, R, R->Send(rows[i].send_hi, rows[i].bytes, ncclChar, rank + 1, comm, c->comm_stream));
+            NCCLCK(c, R, R->Recv(rows[i].recv_hi, rows[i].bytes, ncclChar, rank + 1, comm, c->comm_stream));
         }
     NCCLCK(c, R, R->GroupEnd());
     HIPCK(c, hipEventRecord(c->ev_landed, c->comm_stream));
@@ -302,11 +302,11 @@ int group_exchange_begin(fluid_ctx** cs, int n, const fluid_stripe_op& op)
             CK(rows_of(c, op.field[i], op.rows[i], &me));
             if (r > 0) {
                 CK(rows_of(cs[r - 1], op.field[i], op.rows[i], &lo));
-                HIPCK(c, hipMemcpyAsync(me.recv_lo, lo.send_hi, me.count * sizeof(float), hipMemcpyDeviceToDevice, c->comm_stream));
+                HIPCK(c, hipMemcpyAsync(me.recv_lo, lo.send_hi, me.bytes, hipMemcpyDeviceToDevice, c->comm_stream));
             }
             if (r < n - 1) {
                 CK(rows_of(cs[r + 1], op.field[i], op.rows[i], &hi));
-                HIPCK(c, hipMemcpyAsync(me.recv_hi, hi.send_lo, me.count * sizeof(float), hipMemcpyDeviceToDevice, c->comm_stream));
+                HIPCK(c, hipMemcpyAsync(me.recv_hi, hi.send_lo, me.bytes, hipMemcpyDeviceToDevice, c->comm_stream));
             }
         }
         HIPCK(c, hipEventRecord(c->ev_landed, c->comm_stream));
@@ -362,7 +362,7 @@ int blocks_of(fluid_ctx* c, int field, int n, Blocks* b)
     FieldRef f;
     CK(field_ref(c, field, &f));
     if (n < 1 || (c->desc.parts > 1 && (n > f.halo || n > f.rows))) return c->fail(FLUID_ERR_INVALID, "exchange rows exceed the ghost rows / the tile");
-    const size_t texel = f.nc * sizeof(float), pitch = (size_t)f.win->W * texel;
+    const size_t texel = f.texel(), pitch = (size_t)f.win->W * texel;
     const int nx = col_depth(c, f, n);
     if (nx < 1 || nx > f.cols) return c->fail(FLUID_ERR_INVALID, "exchange columns exceed the ghost columns / the tile");
     const int h = f.halo, R = f.rows, c0 = f.col0, c1 = f.col0 + f.cols;
@@ -443,8 +443,8 @@ int rccl_exchange_2d_begin(fluid_ctx* c, const fluid_stripe_op& op)
         NCCLCK(c, R, R->GroupStart());
         for (int k = 0; k < 2; k++)
             if (total[k]) {
-                NCCLCK(c, R, R->Send(c->stage[2 * dirs[k]], total[k] / sizeof(float), ncclFloat, neighbour_rank(c, dirs[k]), comm, c->comm_stream));
-                NCCLCK(c, R, R->Recv(c->stage[2 * dirs[k] + 1], total[k] / sizeof(float), ncclFloat, neighbour_rank(c, dirs[k]), comm, c->comm_stream));
+                NCCLCK(c, R, R->Send(c->stage[2 * dirs[k]], total[k], ncclChar, neighbour_rank(c, dirs[k]), comm, c->comm_stream));
+                NCCLCK(c, R, R->Recv(c->stage[2 * dirs[k] + 1], total[k], ncclChar, neighbour_rank(c, dirs[k]), comm, c->comm_stream));
             }
         NCCLCK(c, R, R->GroupEnd());
         for (int k = 0; k < 2; k++)
@@ -835,8 +835,9 @@ int fluid_group_step_n(fluid_ctx** cs, int n_ctx, int steps, float dt, const flu
         const fluid_desc& d = cs[r]->desc;
         if (d.parts * d.parts_x != n_ctx || d.part * d.parts_x + d.part_x != r)
             return cs[r]->fail(FLUID_ERR_INVALID, "group must hold every tile, ordered by stripe then tile column");
-        if (cs[r]->desc.halo != cs[0]->desc.halo || cs[r]->reach != cs[0]->reach || cs[r]->desc.schedule != cs[0]->desc.schedule)
-            return cs[r]->fail(FLUID_ERR_INVALID, "stripes of a group share halo, reach and schedule");
+        if (cs[r]->desc.halo != cs[0]->desc.halo || cs[r]->reach != cs[0]->reach || cs[r]->desc.schedule != cs[0]->desc.schedule ||
+            cs[r]->storage != cs[0]->storage)
+            return cs[r]->fail(FLUID_ERR_INVALID, "stripes of a group share halo, reach, schedule and storage");
     }
     if (n_ctx == 1) return fluid_step_n(cs[0], steps, dt, P);
     for (int r = 0; r < n_ctx; r++) CK(ensure_comm_stream(cs[r]));

@@ -26,8 +26,12 @@ class FluidError(RuntimeError):
         self.status = status
 
 
+STORE_F32, STORE_F16 = 0, 1
+STORAGE = {"f32": STORE_F32, "f16": STORE_F16}   # fluid_storage
+
+
 class Desc(C.Structure):
-    _fields_ = [(k, C.c_int) for k in ("sim_w", "sim_h", "dye_w", "dye_h", "device", "part", "parts", "halo", "schedule", "part_x", "parts_x")]
+    _fields_ = [(k, C.c_int) for k in ("sim_w", "sim_h", "dye_w", "dye_h", "device", "part", "parts", "halo", "schedule", "part_x", "parts_x", "storage")]
 
 
 class Params(C.Structure):
@@ -36,7 +40,7 @@ class Params(C.Structure):
 
 
 class FieldInfo(C.Structure):
-    _fields_ = [(k, C.c_int) for k in ("width", "height", "channels", "row0", "rows", "halo", "col0", "cols", "halo_x")]
+    _fields_ = [(k, C.c_int) for k in ("width", "height", "channels", "row0", "rows", "halo", "col0", "cols", "halo_x", "bytes_per_channel")]
 
 
 class Timings(C.Structure):
@@ -160,7 +164,7 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the header and the library disagree
             fn.restype = res
             fn.argtypes = args
-        if L.fluid_abi_version() != 4:
+        if L.fluid_abi_version() != 5:
             raise FluidError(ERR_UNSUPPORTED, "ABI version mismatch")
         _lib = L
         _point_at_torch_rccl(L)

@@ -151,7 +151,9 @@ class Pointer:
 
 class FluidSim:
     def __init__(self, canvas: Union[Canvas, Tuple[int, int]] = (512, 512), config: Optional[dict] = None,
-                 device: int = 0, schedule: str = "fused", random: Optional[Callable[[], float]] = None):
+                 device: int = 0, schedule: str = "fused", random: Optional[Callable[[], float]] = None, storage: str = "f32"):
+        """storage: "f32" (what the headless reference the goldens come from keeps) or "f16" (what the reference's half-float
+        textures hold on a real GPU, script.js:138: every pass output rounded to fp16, half the bytes per step)"""
         self._lib = _abi.lib()
         self.canvas = canvas if isinstance(canvas, Canvas) else Canvas(*canvas)
         self.config = dict(DEFAULT_CONFIG)
@@ -164,6 +166,7 @@ class FluidSim:
         self._colorUpdateTimer = 0.0
         self._device = device
         self._schedule = SCHEDULES[schedule]
+        self._storage = _abi.STORAGE[storage]
         self._ctx = None
         self.initFramebuffers()
         self.velocity = FieldView(self, "velocity", True)
@@ -203,7 +206,7 @@ class FluidSim:
         sim = getResolution(self.config["SIM_RESOLUTION"], self.canvas.width, self.canvas.height)
         dye = getResolution(self.config["DYE_RESOLUTION"], self.canvas.width, self.canvas.height)
         if self._ctx is None:
-            d = _abi.Desc(sim["width"], sim["height"], dye["width"], dye["height"], self._device, 0, 1, 0, self._schedule)
+            d = _abi.Desc(sim["width"], sim["height"], dye["width"], dye["height"], self._device, 0, 1, 0, self._schedule, 0, 1, self._storage)
             ctx = C.c_void_p()
             rc = self._lib.fluid_create(C.byref(d), C.byref(ctx))
             if rc != _abi.FLUID_OK:

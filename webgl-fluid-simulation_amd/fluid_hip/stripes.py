@@ -60,12 +60,12 @@ class HipStripeEngine:
     """One stripe context of libfluid_hip.so; ghost rows are staged through torch device tensors and all
     work is enqueued on torch's current stream so RCCL send/recv order correctly against the kernels."""
 
-    def __init__(self, sim_wh, dye_wh, part, parts, halo, schedule, device, part_x=0, parts_x=1):
+    def __init__(self, sim_wh, dye_wh, part, parts, halo, schedule, device, part_x=0, parts_x=1, storage="f32"):
         import torch
         self.torch = torch
         self.lib = _abi.lib()
         self.device = device
-        d = _abi.Desc(sim_wh[0], sim_wh[1], dye_wh[0], dye_wh[1], device, part, parts, halo, schedule, part_x, parts_x)
+        d = _abi.Desc(sim_wh[0], sim_wh[1], dye_wh[0], dye_wh[1], device, part, parts, halo, schedule, part_x, parts_x, _abi.STORAGE[storage])
         ctx = C.c_void_p()
         rc = self.lib.fluid_create(C.byref(d), C.byref(ctx))
         if rc != _abi.FLUID_OK:
@@ -109,7 +109,7 @@ class HipStripeEngine:
             shape = (fi.rows + 2 * fi.halo, fi.width, fi.channels)
 
             class _DeviceArray:  # minimal CUDA-array-interface carrier
-                __cuda_array_interface__ = {"shape": shape, "typestr": "<f4", "data": (ptr.value, False), "version": 2}
+                __cuda_array_interface__ = {"shape": shape, "typestr": "<f%d" % fi.bytes_per_channel, "data": (ptr.value, False), "version": 2}
 
             t = self.torch.as_tensor(_DeviceArray(), device="cuda:%d" % self.device)
             self._views[key] = t
@@ -277,7 +277,7 @@ class StripeSim:
     def __init__(self, canvas=(512, 512), config: Optional[dict] = None, halo: int = 32, schedule: str = "fused",
                  random: Optional[Callable[[], float]] = None, device: int = 0, comm=None,
                  engine_factory: Optional[Callable] = None, native: Optional[bool] = None, reach: Optional[int] = None,
-                 overlap: Optional[bool] = None, tiles_x: int = 1):
+                 overlap: Optional[bool] = None, tiles_x: int = 1, storage: str = "f32"):
         """tiles_x > 1: 2-D decomposition, world // tiles_x row stripes x tiles_x column tiles, rank = stripe * tiles_x +
         tile column (native driver only; the hosted schedule below is 1-D)"""
         self.canvas = canvas if isinstance(canvas, Canvas) else Canvas(*canvas)
@@ -288,6 +288,7 @@ class StripeSim:
         self.comm = comm if comm is not None else TorchDistComm()
         self.rank, self.world = self.comm.rank, self.comm.world
         self.tiles_x = int(tiles_x)
+        self.storage = storage
         if self.tiles_x > 1:
             return self._init_tiles(halo, schedule, device, reach)
         sim = getResolution(self.config["SIM_RESOLUTION"], self.canvas.width, self.canvas.height)
@@ -300,8 +301,10 @@ class StripeSim:
         if self.world > 1 and self.halo < 4:
             raise ValueError("halo must be >= 4")
         sched = {"passes": _abi.SCHED_PASSES, "fused": _abi.SCHED_FUSED}[schedule]
-        factory = engine_factory or HipStripeEngine
-        self.engine = factory(self.sim_wh, self.dye_wh, self.rank, self.world, self.halo, sched, device)
+        if engine_factory is None:
+            self.engine = HipStripeEngine(self.sim_wh, self.dye_wh, self.rank, self.world, self.halo, sched, device, storage=storage)
+        else:
+            self.engine = engine_factory(self.sim_wh, self.dye_wh, self.rank, self.world, self.halo, sched, device)
         self.same_res = self.sim_wh == self.dye_wh
         self._hosted_exchanges = 0
         # native driver: default whenever the ranks are connected by RCCL (torch.distributed backend nccl)
@@ -320,7 +323,7 @@ class StripeSim:
         self.halo = int(halo)
         sched = {"passes": _abi.SCHED_PASSES, "fused": _abi.SCHED_FUSED}[schedule]
         self.engine = HipStripeEngine(self.sim_wh, self.dye_wh, self.rank // self.tiles_x, self.world // self.tiles_x, self.halo, sched,
-                                      device, part_x=self.rank % self.tiles_x, parts_x=self.tiles_x)
+                                      device, part_x=self.rank % self.tiles_x, parts_x=self.tiles_x, storage=self.storage)
         self.same_res = self.sim_wh == self.dye_wh
         self._hosted_exchanges = 0
         self.native = True
@@ -462,7 +465,7 @@ class StripeGroup:
 
     def __init__(self, world: int, canvas=(512, 512), config: Optional[dict] = None, halo: int = 32, schedule: str = "fused",
                  random: Optional[Callable[[], float]] = None, device: int = 0, reach: Optional[int] = None,
-                 overlap: Optional[bool] = None, tiles_x: int = 1):
+                 overlap: Optional[bool] = None, tiles_x: int = 1, storage: str = "f32"):
         """`world` contexts: world // tiles_x row stripes x tiles_x column tiles (tiles_x = 1: the 1-D stripe set)"""
         if world % tiles_x:
             raise ValueError("world must be a multiple of tiles_x")
@@ -477,7 +480,7 @@ class StripeGroup:
         dye = getResolution(self.config["DYE_RESOLUTION"], self.canvas.width, self.canvas.height)
         sched = {"passes": _abi.SCHED_PASSES, "fused": _abi.SCHED_FUSED}[schedule]
         self.engines = [HipStripeEngine((sim["width"], sim["height"]), (dye["width"], dye["height"]), r // tiles_x, self.tiles_y,
-                                        halo if world > 1 else 0, sched, device, part_x=r % tiles_x, parts_x=tiles_x)
+                                        halo if world > 1 else 0, sched, device, part_x=r % tiles_x, parts_x=tiles_x, storage=storage)
                         for r in range(world)]
         for e in self.engines:
             e.use_own_stream()
