@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--size", type=int, default=4096, help="grid edge per GPU (BASELINE config: 4096)")
     ap.add_argument("--iters", type=int, default=50, help="PRESSURE_ITERATIONS (BASELINE config: 50)")
     ap.add_argument("--schedule", default="fused", choices=["fused", "passes"])
+    ap.add_argument("--storage", default="f32", choices=["f32", "f16"], help="field storage; f32 is the headline, f16 (the reference's "
+                    "half-float textures, SURVEY 8f N4) is a side measurement and says so in the JSON line")
     ap.add_argument("--halo", type=int, default=56, help="ghost rows per stripe side (N > 1); >= 54 keeps 50 Jacobi iterations in one "
                                                         "block: 2 exchanges per step (profiles/r01/stripe_overhead_one_gpu.txt)")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-oracle work for cpu_baseline (0 = skip)")
@@ -126,7 +128,7 @@ def main():
 
     if N == 1 and not args.stripes:
         sim = fluid_hip.FluidSim(canvas=(size, size), config=cfg, device=local_rank, schedule=args.schedule,
-                                 random=fluid_hip.mulberry32(1234))
+                                 random=fluid_hip.mulberry32(1234), storage=args.storage)
         sim.multipleSplats(20)
 
         def run(k):
@@ -151,7 +153,7 @@ def main():
         cfg = dict(cfg, SIM_RESOLUTION=min(gw, gh), DYE_RESOLUTION=min(gw, gh))
         try:
             sim = StripeSim(canvas=(gw, gh), config=cfg, halo=args.halo, schedule=args.schedule,
-                            random=fluid_hip.mulberry32(1234), device=local_rank, native=not args.hosted, tiles_x=tx)
+                            random=fluid_hip.mulberry32(1234), device=local_rank, native=not args.hosted, tiles_x=tx, storage=args.storage)
         except fluid_hip.FluidError as ex:
             # the native driver needs RCCL inside libfluid_hip.so (dlopen + ncclCommInitRank); if that cannot be set up,
             # say so loudly and drive the SAME kernels pass by pass with torch.distributed's RCCL send/recv instead
@@ -159,7 +161,7 @@ def main():
                 raise
             print("bench.py: native RCCL driver unavailable (%s); using the hosted torch.distributed driver" % ex, file=sys.stderr)
             sim = StripeSim(canvas=(gw, gh), config=cfg, halo=args.halo, schedule=args.schedule,
-                            random=fluid_hip.mulberry32(1234), device=local_rank, native=False)
+                            random=fluid_hip.mulberry32(1234), device=local_rank, native=False, storage=args.storage)
         sim.multipleSplats(20)
 
         def run(k):
@@ -186,7 +188,7 @@ def main():
 
     steps_per_s = args.steps / elapsed
     glups = grid_w * grid_h * steps_per_s / 1e9
-    alg_step_bytes = algorithmic_bytes_per_cell(iters) * grid_w * grid_h
+    alg_step_bytes = algorithmic_bytes_per_cell(iters) * grid_w * grid_h * (0.5 if args.storage == "f16" else 1.0)
     out = {
         "metric": "cell-updates/sec (GLUPS) at %d^2 per GPU, %d Jacobi iters/step" % (size, iters),
         "value": round(glups, 4), "unit": "GLUPS",
@@ -194,10 +196,11 @@ def main():
         "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4),
         "higher_is_better": True, "scaling": "strong" if (args.strong and N > 1) else "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if args.storage == "f32" else "f32 arithmetic on f16-stored fields (side measurement, not the headline)",
+        "data": "synthetic",
         "config": {"workload": "configs[2]: %dx%d sim = dye grid%s, %d Jacobi iters/step, dt=%.6f, 20 splats mulberry32(1234), defaults otherwise"
                                % (grid_w, grid_h, "" if N == 1 else " (%d ranks of %dx%d, halo %d)" % (N, grid_w // max(1, args.tiles_x), grid_h * max(1, args.tiles_x) // N, args.halo), iters, DT),
-                   "schedule": args.schedule,
+                   "schedule": args.schedule, "storage": args.storage,
                    "parallelism": "single" if N == 1 else ("stripes%d" % N if args.tiles_x <= 1 else "tiles%dx%d" % (N // args.tiles_x, args.tiles_x))},
         "step_algorithmic_GBps": round(alg_step_bytes * steps_per_s / 1e9, 1),
         "step_roofline_frac": round(alg_step_bytes * steps_per_s / 1e9 / (HBM_PEAK_GBPS * N), 4),
@@ -213,6 +216,8 @@ def main():
         launches = max(tm["jacobi_launches"], 1)
         avg_ms = tm["jacobi_ms"] / launches
         alg_launch = 12.0 * iters * size * size * tm["steps"] / launches  # 12 B/cell/iteration, SURVEY.md §8(d)
+        if args.storage == "f16":
+            alg_launch *= 0.5
         achieved = alg_launch / (avg_ms * 1e-3) / 1e9
         traffic = load_traffic()
         out["roofline"] = {

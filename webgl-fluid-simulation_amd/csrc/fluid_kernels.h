@@ -80,11 +80,14 @@ int jacobi_tb_max_iters();
 bool jacobi_tb_supported(Win w);
 hipError_t launch_jacobi_tb(hipStream_t s, Win w, const float* p, const float* div, float* p_out, float pscale,
                             int iters, int ga, int gb);
+// the same on fp16-storage fields: the clear (pscale) and every iteration round their output to fp16, so the launch is
+// bitwise equal to `iters` launches of the half launch_jacobi
+int jacobi_tb_max_iters_f16();
+hipError_t launch_jacobi_tb(hipStream_t s, Win w, const __half* p, const __half* div, __half* p_out, float pscale, int iters, int ga,
+                            int gb);
 
 
-// ---- the same passes on fp16-storage fields (fluid_kernels_f16.hip): one kernel per reference pass, plus a temporally
-//      blocked Jacobi that rounds the pressure to fp16 after EVERY iteration, as the reference's per-iteration render
-//      to a half-float texture does ----
+// ---- the same passes on fp16-storage fields (fluid_kernels_f16.hip): one kernel per reference pass ----
 hipError_t launch_curl(hipStream_t s, Win w, const __half2* vel, __half* curl, int ga, int gb);
 hipError_t launch_vorticity(hipStream_t s, Win w, const __half2* vel, const __half* curl, __half2* vel_out, float curl_strength, float dt,
                             int ga, int gb);

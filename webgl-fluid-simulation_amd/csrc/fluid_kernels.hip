@@ -321,9 +321,37 @@ __device__ __forceinline__ Quad quad_of_raw(float4 v)
     return q;
 }
 
+// a lane's four texels to / from a pressure or divergence array: fp32 texels (16-byte access) or, with fp16 storage,
+// half texels (8-byte access; widening is exact, the store narrows values that already are halves)
+__device__ __forceinline__ Quad load_quad(const float* p, size_t idx) { return quad_of(*reinterpret_cast<const float4*>(p + idx)); }
+__device__ __forceinline__ void store_quad(float* p, size_t idx, Quad q) { *reinterpret_cast<float4*>(p + idx) = float4_of(q); }
+__device__ __forceinline__ Quad load_quad(const __half* p, size_t idx)
+{
+    const half4 h = *reinterpret_cast<const half4*>(p + idx);
+    const float2 a = __half22float2(h.lo), b = __half22float2(h.hi);
+    Quad q;
+    q.o = v2f{ a.x, b.y };
+    q.i = v2f{ a.y, b.x };
+    return q;
+}
+__device__ __forceinline__ void store_quad(__half* p, size_t idx, Quad q)
+{
+    half4 h;
+    h.lo = __float22half2_rn(make_float2(q.o.x, q.i.x));
+    h.hi = __float22half2_rn(make_float2(q.i.y, q.o.y));
+    *reinterpret_cast<half4*>(p + idx) = h;
+}
+// what a half-float render target keeps of two fp32 values (round to nearest even), widened again
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f round_half(v2f v)
+{
+    return __builtin_convertvector(__builtin_convertvector(v, v2h), v2f);  // fptrunc (RTNE: one v_cvt_pk_f16_f32 on gfx950) + fpext
+}
+
 // One texel row of a Jacobi iteration (pressureShader script.js:881-888, operand order of line 887:
-// ((L + R) + B) + T - div) * 0.25): 11 VALU instructions for the lane's four texels.
-template <bool EDGE>
+// ((L + R) + B) + T - div) * 0.25): 11 VALU instructions for the lane's four texels.  HALF: the iteration's output goes
+// through fp16, as it does when the reference renders it into a half-float texture.
+template <bool EDGE, bool HALF = false>
 __device__ __forceinline__ Quad jacobi_row(const Quad C, Quad T, Quad B, const Quad D, int gj, int H, bool at_left, bool at_right)
 {
     float L = from_left_lane(C.o.y);   // column 4*lane - 1 = the left lane's c3
@@ -350,6 +378,10 @@ __device__ __forceinline__ Quad jacobi_row(const Quad C, Quad T, Quad B, const Q
     Quad n;
     n.o = (h_o + B.o + T.o - D.o) * quarter;
     n.i = (h_i + B.i + T.i - D.i) * quarter;
+    if (HALF) {
+        n.o = round_half(n.o);
+        n.i = round_half(n.i);
+    }
     return n;
 }
 
@@ -357,7 +389,7 @@ __device__ __forceinline__ Quad jacobi_row(const Quad C, Quad T, Quad B, const Q
 // neighbouring waves (LDS mailbox, `box` is this iteration's slot); every other row only needs the wave's own
 // registers.  So: publish, sweep the inner rows (one delay register carries the old row below), THEN meet the other
 // waves at the barrier and finish the two outer rows — the mailbox round trip hides behind RY - 2 rows of arithmetic.
-template <int NW, int RY, bool EDGE>
+template <int NW, int RY, bool EDGE, bool HALF>
 __device__ __forceinline__ void jacobi_sweep(Quad (&P)[RY], const Quad (&D)[RY], float4 (*box)[2][64], int wv, int lane, int gy,
                                              int H, bool at_left, bool at_right)
 {
@@ -369,22 +401,24 @@ __device__ __forceinline__ void jacobi_sweep(Quad (&P)[RY], const Quad (&D)[RY],
 #pragma unroll
     for (int r = 1; r < RY - 1; r++) {
         const Quad C = P[r];
-        P[r] = jacobi_row<EDGE>(C, P[r + 1], below, D[r], gy + r, H, at_left, at_right);
+        P[r] = jacobi_row<EDGE, HALF>(C, P[r + 1], below, D[r], gy + r, H, at_left, at_right);
         below = C;
     }
     __syncthreads();
     // unconditional b128 reads: the first/last wave reads its own mailbox, which only feeds the stale apron
     const Quad lo = quad_of_raw(box[wv > 0 ? wv - 1 : 0][1][lane]);
     const Quad hi = quad_of_raw(box[wv < NW - 1 ? wv + 1 : NW - 1][0][lane]);
-    P[RY - 1] = jacobi_row<EDGE>(P[RY - 1], hi, below, D[RY - 1], gy + RY - 1, H, at_left, at_right);
-    P[0] = jacobi_row<EDGE>(old0, old1, lo, D[0], gy, H, at_left, at_right);
+    P[RY - 1] = jacobi_row<EDGE, HALF>(P[RY - 1], hi, below, D[RY - 1], gy + RY - 1, H, at_left, at_right);
+    P[0] = jacobi_row<EDGE, HALF>(old0, old1, lo, D[0], gy, H, at_left, at_right);
 }
 
-template <int NW, int RY, int HX, int HY, bool EDGE>
-__device__ __forceinline__ void jacobi_tb_body(const Win& w, const float* __restrict__ p, const float* __restrict__ div,
-                                               float* __restrict__ p_out, float pscale, int iters, int ga, int gb, int x0,
+// T = float (fp32 fields) or __half (fp16 storage: the clear and every iteration round their output to fp16)
+template <int NW, int RY, int HX, int HY, bool EDGE, class T>
+__device__ __forceinline__ void jacobi_tb_body(const Win& w, const T* __restrict__ p, const T* __restrict__ div,
+                                               T* __restrict__ p_out, float pscale, int iters, int ga, int gb, int x0,
                                                int y0, float4 (*mail)[NW][2][64])
 {
+    constexpr bool HALF = sizeof(T) == 2;
     using G = JacobiTB<NW, RY, HX, HY>;
     const int lane = threadIdx.x;
     // the block is (64, NW): threadIdx.y is the wave index — tell the compiler it is wave-uniform so that all
@@ -405,13 +439,17 @@ __device__ __forceinline__ void jacobi_tb_body(const Win& w, const float* __rest
     for (int r = 0; r < RY; r++) {
         const int lr = min(max(gy + r - w.g0, 0), w.rows - 1);
         const size_t row = (size_t)lr * (size_t)w.W;  // wave-uniform
-        P[r] = quad_of(*reinterpret_cast<const float4*>(p + row + cxs));
-        D[r] = quad_of(*reinterpret_cast<const float4*>(div + row + cxs));
+        P[r] = load_quad(p, row + cxs);
+        D[r] = load_quad(div, row + cxs);
     }
 #pragma unroll
     for (int r = 0; r < RY; r++) {  // clearShader folded in: value * p, same rounding as the separate pass
         P[r].o = ps * P[r].o;
         P[r].i = ps * P[r].i;
+        if (HALF) {  // the clear pass renders into a half-float texture too (pscale == 1: already halves, unchanged)
+            P[r].o = round_half(P[r].o);
+            P[r].i = round_half(P[r].i);
+        }
     }
 
     const bool at_left = (cx == 0), at_right = (cx + 3 == w.W - 1);
@@ -420,10 +458,10 @@ __device__ __forceinline__ void jacobi_tb_body(const Win& w, const float* __rest
     // second sweep's results back to the registers the first one read (no copies on the loop back-edge)
     int it = 0;
     for (; it + 2 <= iters; it += 2) {
-        jacobi_sweep<NW, RY, EDGE>(P, D, mail[0], wv, lane, gy, w.H, at_left, at_right);
-        jacobi_sweep<NW, RY, EDGE>(P, D, mail[1], wv, lane, gy, w.H, at_left, at_right);
+        jacobi_sweep<NW, RY, EDGE, HALF>(P, D, mail[0], wv, lane, gy, w.H, at_left, at_right);
+        jacobi_sweep<NW, RY, EDGE, HALF>(P, D, mail[1], wv, lane, gy, w.H, at_left, at_right);
     }
-    if (it < iters) jacobi_sweep<NW, RY, EDGE>(P, D, mail[0], wv, lane, gy, w.H, at_left, at_right);
+    if (it < iters) jacobi_sweep<NW, RY, EDGE, HALF>(P, D, mail[0], wv, lane, gy, w.H, at_left, at_right);
 
     // store the texels the apron kept exact
     int xa, xb, out_lo, out_hi;
@@ -434,7 +472,7 @@ __device__ __forceinline__ void jacobi_tb_body(const Win& w, const float* __rest
     for (int r = 0; r < RY; r++) {
         const int gj = gy + r;
         if (col_store && gj >= out_lo && gj < out_hi)
-            *reinterpret_cast<float4*>(p_out + (size_t)(gj - w.g0) * (size_t)w.W + (unsigned)cx) = float4_of(P[r]);
+            store_quad(p_out, (size_t)(gj - w.g0) * (size_t)w.W + (unsigned)cx, P[r]);
     }
 }
 
@@ -444,6 +482,23 @@ template <int NW, int RY, int HX, int HY, int BPC>
 __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb(Win w, const float* __restrict__ p, const float* __restrict__ div,
                                                         float* __restrict__ p_out, float pscale, int iters, int ga, int gb,
                                                         int xs, int ys, int nx, int ny, int remap)
+{
+    using G = JacobiTB<NW, RY, HX, HY>;
+    __shared__ float4 mail[2][NW][2][64];
+    int bx, by;
+    tile_of_block((int)blockIdx.x, nx, ny, remap, bx, by);
+    const int x0 = xs + bx * G::VX, y0 = ys + by * G::VY;
+    const bool edge = (x0 <= 0) || (x0 + G::TX >= w.W) || (y0 <= 0) || (y0 + G::TY >= w.H);
+    if (edge) jacobi_tb_body<NW, RY, HX, HY, true>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
+    else jacobi_tb_body<NW, RY, HX, HY, false>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
+}
+
+// the same tile on fp16-storage fields (FLUID_STORE_F16): half the bytes per launch; every iteration's output is rounded to
+// fp16 in registers, exactly where the reference's per-iteration render into a half-float texture rounds it
+template <int NW, int RY, int HX, int HY, int BPC>
+__global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_h(Win w, const __half* __restrict__ p, const __half* __restrict__ div,
+                                                          __half* __restrict__ p_out, float pscale, int iters, int ga, int gb,
+                                                          int xs, int ys, int nx, int ny, int remap)
 {
     using G = JacobiTB<NW, RY, HX, HY>;
     __shared__ float4 mail[2][NW][2][64];
@@ -876,6 +931,22 @@ hipError_t launch_curl_vort_div(hipStream_t s, Win w, const float2* vel, float* 
 }
 
 int jacobi_tb_max_iters() { return kTB[tb_variant()].hy; }
+
+// fp16 storage: the default tile shape only (8 waves x 10 rows, apron 12 x 10)
+constexpr int kHalfTB[5] = { 8, 10, 12, 10, 2 };
+int jacobi_tb_max_iters_f16() { return kHalfTB[3]; }
+
+hipError_t launch_jacobi_tb(hipStream_t s, Win w, const __half* p, const __half* div, __half* p_out, float pscale, int iters, int ga, int gb)
+{
+    ROWS_OR_RETURN();
+    if (iters < 1 || iters > jacobi_tb_max_iters_f16() || !jacobi_tb_supported(w)) return hipErrorInvalidValue;
+    constexpr int NW = kHalfTB[0], RY = kHalfTB[1], HX = kHalfTB[2], HY = kHalfTB[3], BPC = kHalfTB[4];
+    using G = JacobiTB<NW, RY, HX, HY>;
+    const Axis ax = make_axis(w.x0, w.x1, w.W, G::TX, HX), ay = make_axis(ga, gb, w.H, G::TY, HY);
+    k_jacobi_tb_h<NW, RY, HX, HY, BPC><<<dim3(ax.n * ay.n, 1, 1), dim3(64, NW, 1), 0, s>>>(w, p, div, p_out, pscale, iters, ga, gb, ax.S, ay.S,
+                                                                                        ax.n, ay.n, xcd_remap());
+    return hipGetLastError();
+}
 
 bool jacobi_tb_supported(Win w) { return w.W % 4 == 0 && w.W >= 4; }
 

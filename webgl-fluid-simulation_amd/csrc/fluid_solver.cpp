@@ -199,19 +199,20 @@ int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launche
 {
     if (iters < 0) return c->fail(FLUID_ERR_INVALID, "negative iteration count");
     CK(check_ext(c, ext_out, iters));
-    const bool tb = fused_f32(c) && jacobi_tb_supported(c->sim);
+    const bool tb = jacobi_tb_applies(c);
     int done = 0;
     if (!tb && pscale != 1.0f) return c->fail(FLUID_ERR_INVALID, "pscale needs the fused schedule");
     // balanced blocks: ceil(iters / max) launches of nearly equal depth (50 with max 8 -> 8,7,7,7,7,7,7)
-    int launches_left = tb ? (iters + jacobi_tb_max_iters() - 1) / jacobi_tb_max_iters() : iters;
+    const int tb_max = c->storage == FLUID_STORE_F16 ? jacobi_tb_max_iters_f16() : jacobi_tb_max_iters();
+    int launches_left = tb ? (iters + tb_max - 1) / tb_max : iters;
     while (done < iters) {
         int ga, gb;
         if (tb) {
             const int k = (iters - done + launches_left - 1) / launches_left;
             launches_left--;
             row_range(c->sim, c->sim_row0, c->sim_rows, ext_out + (iters - done - k), ga, gb);
-            CK(c->hip(launch_jacobi_tb(c->stream, sim_cols(c, ext_out + (iters - done - k)), (const float*)c->prs[0], (const float*)c->div,
-                                       (float*)c->prs[1], done == 0 ? pscale : 1.0f, k, ga, gb),
+            CK(c->hip(STORE_CALL(c, launch_jacobi_tb(c->stream, sim_cols(c, ext_out + (iters - done - k)), (const S::T1*)c->prs[0], (const S::T1*)c->div,
+                                                     (S::T1*)c->prs[1], done == 0 ? pscale : 1.0f, k, ga, gb)),
                       "jacobi_tb"));
             done += k;
         } else {
@@ -230,7 +231,7 @@ int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launche
 int pass_clear_jacobi(fluid_ctx* c, float value, int iters, int ext_out, int* launches)
 {
     if (iters < 0) return c->fail(FLUID_ERR_INVALID, "negative iteration count");
-    const bool fold = fused_f32(c) && jacobi_tb_supported(c->sim) && iters > 0;
+    const bool fold = jacobi_tb_applies(c) && iters > 0;
     if (fold) return pass_jacobi(c, iters, ext_out, value, launches);
     CK(pass_clear(c, value, ext_out + iters));
     return pass_jacobi(c, iters, ext_out, 1.0f, launches);
@@ -297,6 +298,9 @@ int pass_advect(fluid_ctx* c, float dt, float vel_diss, float dye_diss, Timer* t
 //      pass can run as "interior rows while the ghost rows are in flight, then the strips next to them" ----
 bool fused_f32(const fluid_ctx* c) { return c->desc.schedule == FLUID_SCHED_FUSED && c->storage == FLUID_STORE_F32; }
 
+// the temporally blocked Jacobi kernel exists for both storage types
+bool jacobi_tb_applies(const fluid_ctx* c) { return c->desc.schedule == FLUID_SCHED_FUSED && jacobi_tb_supported(c->sim); }
+
 bool fused_cvd_applies(const fluid_ctx* c) { return fused_f32(c) && fused_supported(c->sim); }
 
 bool fused_advect_applies(const fluid_ctx* c) { return fused_f32(c) && c->sim.W == c->dye.W && c->sim.H == c->dye.H; }
@@ -345,7 +349,7 @@ int step_once(fluid_ctx* c, float dt, const fluid_params* P)
     Timer t(c);
     CK(pass_curl_vort_div(c, P->curl, dt, 0, &t));
     int launches = 0;
-    const bool fold_clear = fused_f32(c) && jacobi_tb_supported(c->sim) && P->iterations > 0;
+    const bool fold_clear = jacobi_tb_applies(c) && P->iterations > 0;
     if (!fold_clear) {
         CK(pass_clear(c, P->pressure, 0));
         t.mark(P_CLEAR);
