@@ -130,7 +130,6 @@ int pass_advect_dye(fluid_ctx* c, float dt, float dissipation);
 int pass_advect(fluid_ctx* c, float dt, float vel_diss, float dye_diss, Timer* t);
 
 // band forms (no ping-pong swap) of the single-kernel passes, for interior-first overlap in the stripe driver
-bool fused_f32(const fluid_ctx* c);  // fused schedule on fp32 fields: the register-tile kernels of fluid_kernels.hip apply
 bool jacobi_tb_applies(const fluid_ctx* c);
 bool fused_cvd_applies(const fluid_ctx* c);
 bool fused_advect_applies(const fluid_ctx* c);

@@ -80,6 +80,14 @@ int jacobi_tb_max_iters();
 bool jacobi_tb_supported(Win w);
 hipError_t launch_jacobi_tb(hipStream_t s, Win w, const float* p, const float* div, float* p_out, float pscale,
                             int iters, int ga, int gb);
+// the fused kernels on fp16-storage fields: every intermediate the reference would have rendered to a half-float texture
+// between two of the fused passes (curl, the confined velocity, the advected velocity) is rounded to fp16 in registers,
+// so each is bitwise equal to its single-pass half kernels run in turn
+hipError_t launch_curl_vort_div(hipStream_t s, Win w, const __half2* vel, __half* curl, __half2* vel_out, __half* div, float curl_strength,
+                                float dt, int ga, int gb);
+hipError_t launch_gradsub4(hipStream_t s, Win w, const __half* p, const __half2* vel, __half2* vel_out, int ga, int gb);
+hipError_t launch_advect_both(hipStream_t s, Win w, const __half2* vel, __half2* vel_out, const half4* dye, half4* dye_out, float dt,
+                              float vel_dissipation, float dye_dissipation, int ga, int gb, unsigned int* miss);
 // the same on fp16-storage fields: the clear (pscale) and every iteration round their output to fp16, so the launch is
 // bitwise equal to `iters` launches of the half launch_jacobi
 int jacobi_tb_max_iters_f16();

@@ -106,11 +106,10 @@ struct Fetch4 {
     float fx, fy;
 };
 
-template <int ROWS>
-__global__ void __launch_bounds__(BX) k_advect_both(Win w, const float2* __restrict__ vel, float2* __restrict__ vel_out,
-                                                     const float4* __restrict__ dye, float4* __restrict__ dye_out, float dt,
-                                                     float vel_dissipation, float dye_dissipation, float tsx, float tsy, int ga, int gb,
-                                                     unsigned int* __restrict__ miss_out)
+template <int ROWS, class V2, class D4>
+__device__ __forceinline__ void advect_both_body(const Win& w, const V2* __restrict__ vel, V2* __restrict__ vel_out, const D4* __restrict__ dye,
+                                                 D4* __restrict__ dye_out, float dt, float vel_dissipation, float dye_dissipation, float tsx,
+                                                 float tsy, int ga, int gb, unsigned int* __restrict__ miss_out)
 {
     const int i = w.x0 + blockIdx.x * BX + threadIdx.x;
     const int gj0 = ga + blockIdx.y * ROWS;
@@ -129,14 +128,14 @@ __global__ void __launch_bounds__(BX) k_advect_both(Win w, const float2* __restr
         const int gjc = on[k] ? gj : gb - 1;  // a row past the band repeats the last one (loads stay in bounds, nothing stored)
         v[k] = ((float)gjc + 0.5f) / (float)w.H;
         c[k] = (long)(gjc - w.g0) * w.W + i;
-        vv[k] = vel[c[k]];
+        vv[k] = ld(vel, c[k]);
     }
     Fetch2 f2[ROWS];
 #pragma unroll
     for (int k = 0; k < ROWS; k++) {
         const Taps t = bil_taps(w, u - dt * vv[k].x * tsx, v[k] - dt * vv[k].y * tsy);
         if (on[k]) miss += t.miss;
-        f2[k].a = vel[t.a]; f2[k].b = vel[t.b]; f2[k].c = vel[t.c]; f2[k].d = vel[t.d];
+        f2[k].a = ld(vel, t.a); f2[k].b = ld(vel, t.b); f2[k].c = ld(vel, t.c); f2[k].d = ld(vel, t.d);
         f2[k].fx = t.fx; f2[k].fy = t.fy;
     }
     Fetch4 f4[ROWS];
@@ -145,11 +144,12 @@ __global__ void __launch_bounds__(BX) k_advect_both(Win w, const float2* __restr
         const Fetch2& f = f2[k];
         const float rx = mixf(mixf(f.a.x, f.b.x, f.fx), mixf(f.c.x, f.d.x, f.fx), f.fy);
         const float ry = mixf(mixf(f.a.y, f.b.y, f.fx), mixf(f.c.y, f.d.y, f.fx), f.fy);
-        nv[k] = make_float2(rx / vdecay, ry / vdecay);
-        if (on[k]) vel_out[c[k]] = nv[k];
+        // the dye pass reads the velocity TEXTURE the velocity pass wrote: with fp16 storage that is the rounded value
+        nv[k] = make_float2(kept(vel_out, rx / vdecay), kept(vel_out, ry / vdecay));
+        if (on[k]) st(vel_out, c[k], nv[k]);
         const Taps t = bil_taps(w, u - dt * nv[k].x * tsx, v[k] - dt * nv[k].y * tsy);
         if (on[k]) miss += t.miss;
-        f4[k].a = dye[t.a]; f4[k].b = dye[t.b]; f4[k].c = dye[t.c]; f4[k].d = dye[t.d];
+        f4[k].a = ld(dye, t.a); f4[k].b = ld(dye, t.b); f4[k].c = ld(dye, t.c); f4[k].d = ld(dye, t.d);
         f4[k].fx = t.fx; f4[k].fy = t.fy;
     }
 #pragma unroll
@@ -159,9 +159,27 @@ __global__ void __launch_bounds__(BX) k_advect_both(Win w, const float2* __restr
                                      mixf(mixf(f.a.y, f.b.y, f.fx), mixf(f.c.y, f.d.y, f.fx), f.fy),
                                      mixf(mixf(f.a.z, f.b.z, f.fx), mixf(f.c.z, f.d.z, f.fx), f.fy),
                                      mixf(mixf(f.a.w, f.b.w, f.fx), mixf(f.c.w, f.d.w, f.fx), f.fy));
-        if (on[k]) dye_out[c[k]] = make_float4(d.x / ddecay, d.y / ddecay, d.z / ddecay, d.w / ddecay);
+        if (on[k]) st(dye_out, c[k], make_float4(d.x / ddecay, d.y / ddecay, d.z / ddecay, d.w / ddecay));
     }
     if (miss) atomicAdd(miss_out, (unsigned)miss);
+}
+
+template <int ROWS>
+__global__ void __launch_bounds__(BX) k_advect_both(Win w, const float2* __restrict__ vel, float2* __restrict__ vel_out,
+                                                     const float4* __restrict__ dye, float4* __restrict__ dye_out, float dt,
+                                                     float vel_dissipation, float dye_dissipation, float tsx, float tsy, int ga, int gb,
+                                                     unsigned int* __restrict__ miss_out)
+{
+    advect_both_body<ROWS>(w, vel, vel_out, dye, dye_out, dt, vel_dissipation, dye_dissipation, tsx, tsy, ga, gb, miss_out);
+}
+
+template <int ROWS>
+__global__ void __launch_bounds__(BX) k_advect_both_h(Win w, const __half2* __restrict__ vel, __half2* __restrict__ vel_out,
+                                                       const half4* __restrict__ dye, half4* __restrict__ dye_out, float dt,
+                                                       float vel_dissipation, float dye_dissipation, float tsx, float tsy, int ga, int gb,
+                                                       unsigned int* __restrict__ miss_out)
+{
+    advect_both_body<ROWS>(w, vel, vel_out, dye, dye_out, dt, vel_dissipation, dye_dissipation, tsx, tsy, ga, gb, miss_out);
 }
 
 __global__ void __launch_bounds__(BX) k_splat_velocity(Win w, const float2* __restrict__ base, float2* __restrict__ out, float x, float y,
@@ -511,12 +529,70 @@ __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_h(Win
 }
 
 // ------------------------------------------------------------------------------------------------
+// Four consecutive texels of a lane, to / from fp32 or fp16 fields (the register-tile kernels below are templated on the
+// storage type; the fp32 instantiations are the kernels the headline runs, the half ones serve FLUID_STORE_F16).
+// (`kept(field, v)`, fluid_math.h: what a field of that storage keeps of v — applied to every intermediate the reference
+// would have written to a texture between two of the fused passes.)
+
+__device__ __forceinline__ float4 load_s4(const float* p, size_t idx) { return *reinterpret_cast<const float4*>(p + idx); }
+__device__ __forceinline__ float4 load_s4(const __half* p, size_t idx)
+{
+    const half4 h = *reinterpret_cast<const half4*>(p + idx);
+    const float2 a = __half22float2(h.lo), b = __half22float2(h.hi);
+    return make_float4(a.x, a.y, b.x, b.y);
+}
+__device__ __forceinline__ void store_s4(float* p, size_t idx, float4 v) { *reinterpret_cast<float4*>(p + idx) = v; }
+__device__ __forceinline__ void store_s4(__half* p, size_t idx, float4 v)
+{
+    half4 h;
+    h.lo = __float22half2_rn(make_float2(v.x, v.y));
+    h.hi = __float22half2_rn(make_float2(v.z, v.w));
+    *reinterpret_cast<half4*>(p + idx) = h;
+}
+// four velocity texels as two (x0 y0 x1 y1) groups
+__device__ __forceinline__ void load_v4(const float2* vel, size_t idx, float4& a, float4& b)
+{
+    const float4* src = reinterpret_cast<const float4*>(vel + idx);
+    a = src[0];
+    b = src[1];
+}
+__device__ __forceinline__ void load_v4(const __half2* vel, size_t idx, float4& a, float4& b)
+{
+    struct alignas(16) H8 {
+        __half2 t[4];
+    };
+    const H8 h = *reinterpret_cast<const H8*>(vel + idx);
+    const float2 t0 = __half22float2(h.t[0]), t1 = __half22float2(h.t[1]), t2 = __half22float2(h.t[2]), t3 = __half22float2(h.t[3]);
+    a = make_float4(t0.x, t0.y, t1.x, t1.y);
+    b = make_float4(t2.x, t2.y, t3.x, t3.y);
+}
+__device__ __forceinline__ void store_v4(float2* vel, size_t idx, float4 a, float4 b)
+{
+    float4* dst = reinterpret_cast<float4*>(vel + idx);
+    dst[0] = a;
+    dst[1] = b;
+}
+__device__ __forceinline__ void store_v4(__half2* vel, size_t idx, float4 a, float4 b)
+{
+    struct alignas(16) H8 {
+        __half2 t[4];
+    };
+    H8 h;
+    h.t[0] = __float22half2_rn(make_float2(a.x, a.y));
+    h.t[1] = __float22half2_rn(make_float2(a.z, a.w));
+    h.t[2] = __float22half2_rn(make_float2(b.x, b.y));
+    h.t[3] = __float22half2_rn(make_float2(b.z, b.w));
+    *reinterpret_cast<H8*>(vel + idx) = h;
+}
+
+// ------------------------------------------------------------------------------------------------
 // K6 gradient subtract, four texels per lane (fused schedule): the per-texel kernel issues six memory instructions for
 // 20 bytes; here a wave moves one 256-texel row segment with five 16-byte loads and two 16-byte stores per lane, the
 // horizontal pressure neighbours come from the lane's own float4 and the adjacent lanes (DPP), and only the two
 // lanes at the segment ends fetch their outside neighbour.  Same subtraction per texel, hence the same bits.
-__global__ void __launch_bounds__(256) k_gradsub4(Win w, const float* __restrict__ p, const float2* __restrict__ vel,
-                                                   float2* __restrict__ vel_out, int ga, int gb)
+template <class S1, class V2>
+__device__ __forceinline__ void gradsub4_body(const Win& w, const S1* __restrict__ p, const V2* __restrict__ vel, V2* __restrict__ vel_out, int ga,
+                                              int gb)
 {
     const int lane = threadIdx.x;
     const int gj = ga + (int)blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y);
@@ -525,14 +601,14 @@ __global__ void __launch_bounds__(256) k_gradsub4(Win w, const float* __restrict
     const size_t rowC = (size_t)(gj - w.g0) * (size_t)w.W;
     const size_t rowT = (size_t)(min(gj + 1, w.H - 1) - w.g0) * (size_t)w.W;
     const size_t rowB = (size_t)(max(gj - 1, 0) - w.g0) * (size_t)w.W;
-    const float4 C = *reinterpret_cast<const float4*>(p + rowC + cx);
-    const float4 T = *reinterpret_cast<const float4*>(p + rowT + cx);
-    const float4 B = *reinterpret_cast<const float4*>(p + rowB + cx);
-    const float4 va = *reinterpret_cast<const float4*>(vel + rowC + cx);
-    const float4 vb = *reinterpret_cast<const float4*>(vel + rowC + cx + 2);
+    const float4 C = load_s4(p, rowC + cx);
+    const float4 T = load_s4(p, rowT + cx);
+    const float4 B = load_s4(p, rowB + cx);
+    float4 va, vb;
+    load_v4(vel, rowC + cx, va, vb);
     float L = from_left_lane(C.w), R = from_right_lane(C.x);
-    if (lane == 0) L = cx > 0 ? p[rowC + cx - 1] : C.x;                    // CLAMP_TO_EDGE at the domain border
-    if (lane == 63 || cx + 4 >= w.x1) R = cx + 4 < w.W ? p[rowC + cx + 4] : C.w;
+    if (lane == 0) L = cx > 0 ? ld(p, (long)(rowC + cx - 1)) : C.x;                    // CLAMP_TO_EDGE at the domain border
+    if (lane == 63 || cx + 4 >= w.x1) R = cx + 4 < w.W ? ld(p, (long)(rowC + cx + 4)) : C.w;
     float4 oa, ob;
     oa.x = va.x - (C.y - L);
     oa.y = va.y - (T.x - B.x);
@@ -542,8 +618,19 @@ __global__ void __launch_bounds__(256) k_gradsub4(Win w, const float* __restrict
     ob.y = vb.y - (T.z - B.z);
     ob.z = vb.z - (R - C.z);
     ob.w = vb.w - (T.w - B.w);
-    *reinterpret_cast<float4*>(vel_out + rowC + cx) = oa;
-    *reinterpret_cast<float4*>(vel_out + rowC + cx + 2) = ob;
+    store_v4(vel_out, rowC + cx, oa, ob);
+}
+
+__global__ void __launch_bounds__(256) k_gradsub4(Win w, const float* __restrict__ p, const float2* __restrict__ vel,
+                                                   float2* __restrict__ vel_out, int ga, int gb)
+{
+    gradsub4_body(w, p, vel, vel_out, ga, gb);
+}
+
+__global__ void __launch_bounds__(256) k_gradsub4_h(Win w, const __half* __restrict__ p, const __half2* __restrict__ vel,
+                                                     __half2* __restrict__ vel_out, int ga, int gb)
+{
+    gradsub4_body(w, p, vel, vel_out, ga, gb);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -572,9 +659,9 @@ struct Row4 {  // four texels of one row held by a lane
     float x[4], y[4];
 };
 
-template <int NW, int RY, bool EDGE>
-__device__ __forceinline__ void vort_div_body(const Win& w, const float2* __restrict__ vel, float* __restrict__ curl_out,
-                                              float2* __restrict__ vel_out, float* __restrict__ div_out, float curl_strength,
+template <int NW, int RY, bool EDGE, class V2, class S1>
+__device__ __forceinline__ void vort_div_body(const Win& w, const V2* __restrict__ vel, S1* __restrict__ curl_out,
+                                              V2* __restrict__ vel_out, S1* __restrict__ div_out, float curl_strength,
                                               float dt, int ga, int gb, int x0, int y0, float4 (*mail)[2][2][64])
 {
     using G = VortDiv<NW, RY>;
@@ -590,8 +677,8 @@ __device__ __forceinline__ void vort_div_body(const Win& w, const float2* __rest
 #pragma unroll
     for (int r = 0; r < RY; r++) {
         const int lr = min(max(gy + r - w.g0, 0), w.rows - 1);
-        const float4* src = reinterpret_cast<const float4*>(vel + (long)lr * w.W + cxs);
-        const float4 a = src[0], b = src[1];
+        float4 a, b;
+        load_v4(vel, (size_t)((long)lr * w.W + cxs), a, b);
         V[r].x[0] = a.x; V[r].y[0] = a.y; V[r].x[1] = a.z; V[r].y[1] = a.w;
         V[r].x[2] = b.x; V[r].y[2] = b.y; V[r].x[3] = b.z; V[r].y[3] = b.w;
     }
@@ -624,7 +711,7 @@ __device__ __forceinline__ void vort_div_body(const Win& w, const float2* __rest
                 if (gj == w.H - 1) T = V[r].x[k];
             }
             const float vort = R - L - T + B;
-            C[r][k] = 0.5f * vort;
+            C[r][k] = kept(curl_out, 0.5f * vort);  // the vorticity pass reads the curl TEXTURE: fp16 storage rounds it here
         }
     }
 
@@ -655,8 +742,8 @@ __device__ __forceinline__ void vort_div_body(const Win& w, const float2* __rest
                 if (gj == w.H - 1) T = C[r][k];
             }
             const float2 nv = vorticity_cell(L, R, T, B, C[r][k], make_float2(V[r].x[k], V[r].y[k]), curl_strength, dt);
-            N[r].x[k] = nv.x;
-            N[r].y[k] = nv.y;
+            N[r].x[k] = kept(vel_out, nv.x);  // likewise the divergence pass reads the stored velocity
+            N[r].y[k] = kept(vel_out, nv.y);
         }
     }
 
@@ -694,12 +781,10 @@ __device__ __forceinline__ void vort_div_body(const Win& w, const float2* __rest
             dv[k] = 0.5f * (R - L + T - B);
         }
         if (col_store && gj >= out_lo && gj < out_hi) {
-            const long c = (long)(gj - w.g0) * w.W + cx;
-            *reinterpret_cast<float4*>(curl_out + c) = make_float4(C[r][0], C[r][1], C[r][2], C[r][3]);
-            *reinterpret_cast<float4*>(div_out + c) = make_float4(dv[0], dv[1], dv[2], dv[3]);
-            float4* vo = reinterpret_cast<float4*>(vel_out + c);
-            vo[0] = make_float4(N[r].x[0], N[r].y[0], N[r].x[1], N[r].y[1]);
-            vo[1] = make_float4(N[r].x[2], N[r].y[2], N[r].x[3], N[r].y[3]);
+            const size_t c = (size_t)((long)(gj - w.g0) * w.W + cx);
+            store_s4(curl_out, c, make_float4(C[r][0], C[r][1], C[r][2], C[r][3]));
+            store_s4(div_out, c, make_float4(dv[0], dv[1], dv[2], dv[3]));
+            store_v4(vel_out, c, make_float4(N[r].x[0], N[r].y[0], N[r].x[1], N[r].y[1]), make_float4(N[r].x[2], N[r].y[2], N[r].x[3], N[r].y[3]));
         }
     }
 }
@@ -709,6 +794,22 @@ __global__ void __launch_bounds__(64 * NW, VD_WAVES_PER_EU) k_curl_vort_div(Win 
                                                             float2* __restrict__ vel_out, float* __restrict__ div_out,
                                                             float curl_strength, float dt, int ga, int gb, int xs, int ys, int nx, int ny,
                                                             int remap)
+{
+    using G = VortDiv<NW, RY>;
+    __shared__ float4 mail[NW][2][2][64];
+    int bx, by;
+    tile_of_block((int)blockIdx.x, nx, ny, remap, bx, by);
+    const int x0 = xs + bx * G::VX, y0 = ys + by * G::VY;
+    const bool edge = (x0 <= 0) || (x0 + G::TX >= w.W) || (y0 <= 0) || (y0 + G::TY >= w.H);
+    if (edge) vort_div_body<NW, RY, true>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
+    else vort_div_body<NW, RY, false>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
+}
+
+template <int NW, int RY>
+__global__ void __launch_bounds__(64 * NW, VD_WAVES_PER_EU) k_curl_vort_div_h(Win w, const __half2* __restrict__ vel, __half* __restrict__ curl_out,
+                                                              __half2* __restrict__ vel_out, __half* __restrict__ div_out,
+                                                              float curl_strength, float dt, int ga, int gb, int xs, int ys, int nx, int ny,
+                                                              int remap)
 {
     using G = VortDiv<NW, RY>;
     __shared__ float4 mail[NW][2][2][64];
@@ -844,6 +945,17 @@ hipError_t launch_gradsub4(hipStream_t s, Win w, const float* p, const float2* v
     return hipGetLastError();
 }
 
+hipError_t launch_gradsub4(hipStream_t s, Win w, const __half* p, const __half2* vel, __half2* vel_out, int ga, int gb)
+{
+    ROWS_OR_RETURN();
+    if (!fused_supported(w)) return hipErrorInvalidValue;
+    w.x0 &= ~3;
+    w.x1 = (w.x1 + 3) & ~3;
+    if (w.x1 > w.W) w.x1 = w.W;
+    k_gradsub4_h<<<dim3((w.x1 - w.x0 + 255) / 256, (gb - ga + 3) / 4, 1), dim3(64, 4, 1), 0, s>>>(w, p, vel, vel_out, ga, gb);
+    return hipGetLastError();
+}
+
 hipError_t launch_advect_velocity(hipStream_t s, Win w, const float2* vel, float2* out, float dt, float dissipation, int ga,
                                   int gb, unsigned int* miss)
 {
@@ -878,6 +990,22 @@ hipError_t launch_advect_both(hipStream_t s, Win w, const float2* vel, float2* v
     if (rows_per_thread == 1) k_advect_both<1><<<g, BX, 0, s>>>(w, vel, vel_out, dye, dye_out, dt, vel_dissipation, dye_dissipation, tsx, tsy, ga, gb, miss);
     else if (rows_per_thread == 2) k_advect_both<2><<<g, BX, 0, s>>>(w, vel, vel_out, dye, dye_out, dt, vel_dissipation, dye_dissipation, tsx, tsy, ga, gb, miss);
     else k_advect_both<4><<<g, BX, 0, s>>>(w, vel, vel_out, dye, dye_out, dt, vel_dissipation, dye_dissipation, tsx, tsy, ga, gb, miss);
+    return hipGetLastError();
+}
+
+hipError_t launch_advect_both(hipStream_t s, Win w, const __half2* vel, __half2* vel_out, const half4* dye, half4* dye_out, float dt,
+                              float vel_dissipation, float dye_dissipation, int ga, int gb, unsigned int* miss)
+{
+    ROWS_OR_RETURN();
+    static const int rows = [] {  // FLUID_ADVECT_ROWS_F16: 2 or 4 texels per thread (A/B knob)
+        const char* e = getenv("FLUID_ADVECT_ROWS_F16");
+        const int k = e ? atoi(e) : 2;
+        return (k == 2 || k == 4) ? k : 2;
+    }();
+    const float tsx = (float)(1.0 / w.W), tsy = (float)(1.0 / w.H);
+    const dim3 g((w.x1 - w.x0 + BX - 1) / BX, (gb - ga + rows - 1) / rows, 1);
+    if (rows == 2) k_advect_both_h<2><<<g, BX, 0, s>>>(w, vel, vel_out, dye, dye_out, dt, vel_dissipation, dye_dissipation, tsx, tsy, ga, gb, miss);
+    else k_advect_both_h<4><<<g, BX, 0, s>>>(w, vel, vel_out, dye, dye_out, dt, vel_dissipation, dye_dissipation, tsx, tsy, ga, gb, miss);
     return hipGetLastError();
 }
 
@@ -927,6 +1055,18 @@ hipError_t launch_curl_vort_div(hipStream_t s, Win w, const float2* vel, float* 
     const Axis ax = make_axis(w.x0, w.x1, w.W, G::TX, G::AX), ay = make_axis(ga, gb, w.H, G::TY, G::AY);
     k_curl_vort_div<VD_NW, VD_RY><<<dim3(ax.n * ay.n, 1, 1), dim3(64, VD_NW, 1), 0, s>>>(w, vel, curl, vel_out, div, curl_strength, dt,
                                                                                     ga, gb, ax.S, ay.S, ax.n, ay.n, cvd_remap());
+    return hipGetLastError();
+}
+
+hipError_t launch_curl_vort_div(hipStream_t s, Win w, const __half2* vel, __half* curl, __half2* vel_out, __half* div, float curl_strength,
+                                float dt, int ga, int gb)
+{
+    ROWS_OR_RETURN();
+    if (!fused_supported(w)) return hipErrorInvalidValue;
+    using G = VortDiv<VD_NW, VD_RY>;
+    const Axis ax = make_axis(w.x0, w.x1, w.W, G::TX, G::AX), ay = make_axis(ga, gb, w.H, G::TY, G::AY);
+    k_curl_vort_div_h<VD_NW, VD_RY><<<dim3(ax.n * ay.n, 1, 1), dim3(64, VD_NW, 1), 0, s>>>(w, vel, curl, vel_out, div, curl_strength, dt, ga,
+                                                                                      gb, ax.S, ay.S, ax.n, ay.n, cvd_remap());
     return hipGetLastError();
 }
 

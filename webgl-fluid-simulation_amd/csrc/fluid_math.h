@@ -21,6 +21,11 @@ __device__ __forceinline__ float4 ld(const half4* p, long i)
     const float2 a = __half22float2(v.lo), b = __half22float2(v.hi);
     return make_float4(a.x, a.y, b.x, b.y);
 }
+// what a field of that storage keeps of an fp32 value: v itself, or v rounded to fp16
+__device__ __forceinline__ float kept(const float*, float v) { return v; }
+__device__ __forceinline__ float kept(const float2*, float v) { return v; }
+__device__ __forceinline__ float kept(const __half*, float v) { return __half2float(__float2half_rn(v)); }
+__device__ __forceinline__ float kept(const __half2*, float v) { return __half2float(__float2half_rn(v)); }
 __device__ __forceinline__ void st(float* p, long i, float v) { p[i] = v; }
 __device__ __forceinline__ void st(float2* p, long i, float2 v) { p[i] = v; }
 __device__ __forceinline__ void st(float4* p, long i, float4 v) { p[i] = v; }

@@ -168,8 +168,7 @@ int pass_curl_vort_div(fluid_ctx* c, float curl, float dt, int ext, Timer* t)
         CK(check_ext(c, ext, 3));
         int ga, gb;
         row_range(c->sim, c->sim_row0, c->sim_rows, ext, ga, gb);
-        CK(c->hip(launch_curl_vort_div(c->stream, sim_cols(c, ext), (const float2*)c->vel[0], (float*)c->curl, (float2*)c->vel[1], (float*)c->div,
-                                       curl, dt, ga, gb),
+        CK(c->hip(STORE_CALL(c, launch_curl_vort_div(c->stream, sim_cols(c, ext), VEL(c, 0), CURL(c), VEL(c, 1), DIVG(c), curl, dt, ga, gb)),
                   "curl_vort_div"));
         std::swap(c->vel[0], c->vel[1]);
         if (t) t->mark(P_VORT);
@@ -242,8 +241,8 @@ int pass_gradsub(fluid_ctx* c, int ext)
     CK(check_ext(c, ext, 1));
     int ga, gb;
     row_range(c->sim, c->sim_row0, c->sim_rows, ext, ga, gb);
-    if (fused_f32(c) && fused_supported(c->sim))
-        CK(c->hip(launch_gradsub4(c->stream, sim_cols(c, ext), (const float*)c->prs[0], (const float2*)c->vel[0], (float2*)c->vel[1], ga, gb), "gradsub"));
+    if (c->desc.schedule == FLUID_SCHED_FUSED && fused_supported(c->sim))
+        CK(c->hip(STORE_CALL(c, launch_gradsub4(c->stream, sim_cols(c, ext), PRS(c, 0), VEL(c, 0), VEL(c, 1), ga, gb)), "gradsub"));
     else
         CK(c->hip(STORE_CALL(c, launch_gradsub(c->stream, sim_cols(c, ext), PRS(c, 0), VEL(c, 0), VEL(c, 1), ga, gb)), "gradsub"));
     std::swap(c->vel[0], c->vel[1]);
@@ -279,8 +278,8 @@ int pass_advect(fluid_ctx* c, float dt, float vel_diss, float dye_diss, Timer* t
     if (fused_advect_applies(c)) {
         int ga, gb;
         row_range(c->sim, c->sim_row0, c->sim_rows, 0, ga, gb);
-        CK(c->hip(launch_advect_both(c->stream, sim_cols(c, 0), (const float2*)c->vel[0], (float2*)c->vel[1], (const float4*)c->dyeb[0],
-                                     (float4*)c->dyeb[1], dt, vel_diss, dye_diss, ga, gb, c->miss),
+        CK(c->hip(STORE_CALL(c, launch_advect_both(c->stream, sim_cols(c, 0), VEL(c, 0), VEL(c, 1), DYE(c, 0), DYE(c, 1), dt, vel_diss, dye_diss, ga, gb,
+                                                   c->miss)),
                   "advect"));
         std::swap(c->vel[0], c->vel[1]);
         std::swap(c->dyeb[0], c->dyeb[1]);
@@ -296,14 +295,12 @@ int pass_advect(fluid_ctx* c, float dt, float vel_diss, float dye_diss, Timer* t
 
 // ---- band forms for the stripe driver: one row band of a single-kernel pass, WITHOUT the ping-pong swap, so that a
 //      pass can run as "interior rows while the ghost rows are in flight, then the strips next to them" ----
-bool fused_f32(const fluid_ctx* c) { return c->desc.schedule == FLUID_SCHED_FUSED && c->storage == FLUID_STORE_F32; }
-
 // the temporally blocked Jacobi kernel exists for both storage types
 bool jacobi_tb_applies(const fluid_ctx* c) { return c->desc.schedule == FLUID_SCHED_FUSED && jacobi_tb_supported(c->sim); }
 
-bool fused_cvd_applies(const fluid_ctx* c) { return fused_f32(c) && fused_supported(c->sim); }
+bool fused_cvd_applies(const fluid_ctx* c) { return c->desc.schedule == FLUID_SCHED_FUSED && fused_supported(c->sim); }
 
-bool fused_advect_applies(const fluid_ctx* c) { return fused_f32(c) && c->sim.W == c->dye.W && c->sim.H == c->dye.H; }
+bool fused_advect_applies(const fluid_ctx* c) { return c->desc.schedule == FLUID_SCHED_FUSED && c->sim.W == c->dye.W && c->sim.H == c->dye.H; }
 
 void sim_band(const fluid_ctx* c, int ext, int& ga, int& gb) { row_range(c->sim, c->sim_row0, c->sim_rows, ext, ga, gb); }
 
@@ -312,8 +309,7 @@ int cvd_band(fluid_ctx* c, float curl, float dt, int ga, int gb, int xa, int xb)
     Win w = c->sim;
     w.x0 = xa;
     w.x1 = xb;
-    return c->hip(launch_curl_vort_div(c->stream, w, (const float2*)c->vel[0], (float*)c->curl, (float2*)c->vel[1], (float*)c->div, curl, dt, ga, gb),
-                  "curl_vort_div");
+    return c->hip(STORE_CALL(c, launch_curl_vort_div(c->stream, w, VEL(c, 0), CURL(c), VEL(c, 1), DIVG(c), curl, dt, ga, gb)), "curl_vort_div");
 }
 
 void cvd_swap(fluid_ctx* c) { std::swap(c->vel[0], c->vel[1]); }
@@ -327,8 +323,7 @@ int advect_both_band(fluid_ctx* c, float dt, float vel_diss, float dye_diss, int
     w.v1 = v1;
     w.u0 = u0;
     w.u1 = u1;
-    return c->hip(launch_advect_both(c->stream, w, (const float2*)c->vel[0], (float2*)c->vel[1], (const float4*)c->dyeb[0], (float4*)c->dyeb[1], dt,
-                                     vel_diss, dye_diss, ga, gb, c->miss),
+    return c->hip(STORE_CALL(c, launch_advect_both(c->stream, w, VEL(c, 0), VEL(c, 1), DYE(c, 0), DYE(c, 1), dt, vel_diss, dye_diss, ga, gb, c->miss)),
                   "advect");
 }
 
