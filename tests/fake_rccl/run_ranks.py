@@ -22,8 +22,9 @@ def main():
     world, halo, steps, cfg, canvas = a["world"], a["halo"], a["steps"], a["config"], tuple(a["canvas"])
     tx = a.get("tiles_x", 1)
     ty = world // tx
+    storage = a.get("storage", "f32")
     full = dict(fluid_hip.DEFAULT_CONFIG, **cfg)
-    with fluid_hip.FluidSim(canvas=canvas, config=cfg, random=fluid_hip.mulberry32(9)) as one:
+    with fluid_hip.FluidSim(canvas=canvas, config=cfg, random=fluid_hip.mulberry32(9), storage=storage) as one:
         splats = one.multipleSplats(6)
         one.step(0.016666, steps)
         want = one.fields()
@@ -37,7 +38,7 @@ def main():
     def rank(r):
         try:
             e = HipStripeEngine((sim["width"], sim["height"]), (dye["width"], dye["height"]), r // tx, ty, halo, _abi.SCHED_FUSED, 0,
-                                part_x=r % tx, parts_x=tx)
+                                part_x=r % tx, parts_x=tx, storage=storage)
             e.use_own_stream()
             if "overlap" in a:
                 e.set_overlap(a["overlap"])

@@ -210,3 +210,23 @@ def test_display_of_an_fp16_dye_field():
     want = D.capture(dye, (256, 256), dict(D.DISPLAY_DEFAULTS), None)
     err = np.abs(frame - want["frame"]).max() / max(float(np.abs(want["frame"]).max()), 1e-30)
     assert err <= 4e-6, err
+
+
+@pytest.mark.parametrize("world,tx,halo,cfg", [(2, 1, 56, {"SIM_RESOLUTION": 512, "DYE_RESOLUTION": 512, "PRESSURE_ITERATIONS": 50}),
+                                               (4, 2, 24, {"SIM_RESOLUTION": 256, "DYE_RESOLUTION": 512, "PRESSURE_ITERATIONS": 25})])
+def test_rccl_exchange_of_half_fields_with_several_ranks_bitwise(world, tx, halo, cfg):
+    """the native RCCL driver moves BYTES (ncclChar): rank threads against the in-process RCCL stand-in, fp16 fields,
+    interior-first overlap on the fused half kernels; assembled result bitwise equal to the single fp16 domain"""
+    import json
+    import os
+    import subprocess
+    import sys
+    from test_stripes_gpu import fake_rccl_lib
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = fake_rccl_lib()
+    args = {"world": world, "tiles_x": tx, "halo": halo, "config": cfg, "canvas": [512, 512], "steps": 2, "storage": "f16"}
+    r = subprocess.run([sys.executable, os.path.join(here, "fake_rccl", "run_ranks.py"), json.dumps(args)], env=dict(os.environ, FLUID_RCCL_LIB=lib),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["ok"] and out["exchanges"] > 0, out

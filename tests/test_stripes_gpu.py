@@ -175,6 +175,17 @@ def test_rccl_communicator_and_stream_ordered_self_exchange():
         e.close()
 
 
+def fake_rccl_lib():
+    """tests/fake_rccl/libfake_rccl.so, rebuilt when its source is newer (the in-process stand-in for librccl)"""
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib, src = os.path.join(here, "fake_rccl", "libfake_rccl.so"), os.path.join(here, "fake_rccl", "fake_rccl.cpp")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+        subprocess.check_call(["bash", os.path.join(here, "fake_rccl", "build.sh")], stdout=subprocess.DEVNULL)
+    return lib
+
+
 # ---- the RCCL leg with SEVERAL ranks: rank threads in a fresh process, the in-process stand-in loaded as librccl ----------
 @pytest.mark.parametrize("world,halo,overlap,cfg,canvas,steps", [
     (2, 56, True, {"SIM_RESOLUTION": 512, "DYE_RESOLUTION": 512, "PRESSURE_ITERATIONS": 50}, (512, 512), 2),
@@ -192,9 +203,7 @@ def test_native_rccl_path_with_several_ranks_bitwise(world, halo, overlap, cfg, 
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    lib = os.path.join(here, "fake_rccl", "libfake_rccl.so")
-    if not os.path.exists(lib):
-        subprocess.check_call(["bash", os.path.join(here, "fake_rccl", "build.sh")], stdout=subprocess.DEVNULL)
+    lib = fake_rccl_lib()
     args = {"world": world, "halo": halo, "overlap": overlap, "config": cfg, "canvas": list(canvas), "steps": steps}
     env = dict(os.environ, FLUID_RCCL_LIB=lib)
     r = subprocess.run([sys.executable, os.path.join(here, "fake_rccl", "run_ranks.py"), json.dumps(args)], env=env,
@@ -274,9 +283,7 @@ def test_native_rccl_path_2d_tiles_with_several_ranks_bitwise(ty, tx, halo, cfg)
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    lib = os.path.join(here, "fake_rccl", "libfake_rccl.so")
-    if not os.path.exists(lib):
-        subprocess.check_call(["bash", os.path.join(here, "fake_rccl", "build.sh")], stdout=subprocess.DEVNULL)
+    lib = fake_rccl_lib()
     args = {"world": ty * tx, "tiles_x": tx, "halo": halo, "config": cfg, "canvas": [512, 512], "steps": 2}
     r = subprocess.run([sys.executable, os.path.join(here, "fake_rccl", "run_ranks.py"), json.dumps(args)], env=dict(os.environ, FLUID_RCCL_LIB=lib),
                        capture_output=True, text=True, timeout=600)
