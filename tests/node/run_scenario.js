@@ -5,7 +5,7 @@ const fs = require('fs');
 const path = require('path');
 const fluid = require(path.join(__dirname, '..', '..', 'webgl-fluid-simulation_amd', 'addon', 'fluid.js'));
 const args = JSON.parse(process.argv[2]);
-const sim = fluid.createFluid({ canvas: args.canvas, config: args.config, random: fluid.mulberry32(args.seed), schedule: args.schedule });
+const sim = fluid.createFluid({ canvas: args.canvas, config: args.config, random: fluid.mulberry32(args.seed), schedule: args.schedule, storage: args.storage });
 sim.multipleSplats(args.randomSplats);
 for (let i = 0; i < args.steps; i++) sim.step(args.dt);
 if (args.resizeTo) { Object.assign(sim.config, args.resizeTo); sim.initFramebuffers(); }

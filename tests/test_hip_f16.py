@@ -141,7 +141,9 @@ def test_steps_against_the_oracle(oracle, canvas, cfg, curl, tol):
 
 
 @pytest.mark.parametrize("canvas,cfg", [((512, 512), {"SIM_RESOLUTION": 128, "DYE_RESOLUTION": 128, "PRESSURE_ITERATIONS": 50}),
-                                        ((512, 256), {"SIM_RESOLUTION": 100, "DYE_RESOLUTION": 260, "PRESSURE_ITERATIONS": 23})])
+                                        ((512, 256), {"SIM_RESOLUTION": 100, "DYE_RESOLUTION": 260, "PRESSURE_ITERATIONS": 23}),
+                                        ((1000, 500), {"SIM_RESOLUTION": 250, "DYE_RESOLUTION": 250, "PRESSURE_ITERATIONS": 31}),   # W % 4 != 0 on neither grid… 500 x 250
+                                        ((2048, 2048), {"SIM_RESOLUTION": 2048, "DYE_RESOLUTION": 2048, "PRESSURE_ITERATIONS": 50})])
 def test_fused_equals_passes_bitwise(canvas, cfg):
     out = []
     for schedule in ("passes", "fused"):
@@ -230,3 +232,28 @@ def test_rccl_exchange_of_half_fields_with_several_ranks_bitwise(world, tx, halo
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["ok"] and out["exchanges"] > 0, out
+
+
+def test_node_host_in_fp16_mode_agrees_with_python_bitwise(tmp_path):
+    """createFluid({storage: 'f16'}) — the JavaScript host reaches the same half fields as the Python host"""
+    import shutil
+    import fluid_hip
+    if shutil.which("node") is None:
+        pytest.skip("node not installed")
+    from test_node_shim import node
+    cfg = {"SIM_RESOLUTION": 96, "DYE_RESOLUTION": 160, "PRESSURE_ITERATIONS": 25}
+    args = {"canvas": {"width": 600, "height": 300}, "config": cfg, "seed": 77, "randomSplats": 5, "steps": 3, "dt": 0.016666,
+            "schedule": "fused", "storage": "f16", "out": str(tmp_path / "fields.bin")}
+    node("run_scenario.js", args)
+    with fluid_hip.FluidSim(canvas=(600, 300), config=cfg, storage="f16", random=fluid_hip.mulberry32(77)) as sim:
+        sim.multipleSplats(5)
+        for _ in range(3):
+            sim.step(0.016666)
+        want = sim.fields()
+    raw = np.fromfile(args["out"], dtype=np.float32)
+    off = 0
+    for k in S.FIELDS:
+        n = want[k].size
+        got = raw[off:off + n].reshape(want[k].shape)
+        assert np.array_equal(got, want[k]) and np.array_equal(got, half(got)), k
+        off += n
