@@ -37,6 +37,10 @@ echo "== bench --stripes (stripe driver at N=1) ==" | tee -a "$OUT/log.txt"
 timeout 600 python bench.py --stripes --cpu-budget 0 >"$OUT/bench_stripes1.json" 2>>"$OUT/bench.err"
 cat "$OUT/bench_stripes1.json" | tee -a "$OUT/log.txt"
 
+echo "== bench --storage f16 (side mode, SURVEY 8f N4) ==" | tee -a "$OUT/log.txt"
+timeout 600 python bench.py --storage f16 --cpu-budget 0 >"$OUT/bench_f16.json" 2>>"$OUT/bench.err"
+cat "$OUT/bench_f16.json" | tee -a "$OUT/log.txt"
+
 echo "== rocprofv3 kernel trace ==" | tee -a "$OUT/log.txt"
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o ks -- \
     python "$GRAFT_REPO_ROOT/bench.py" --steps 20 --warmup 3 --cpu-budget 0 >"$OUT/bench_under_rocprof.json" 2>"$OUT/rocprof.err" )
