@@ -219,9 +219,11 @@ def main():
         if args.storage == "f16":
             alg_launch *= 0.5
         achieved = alg_launch / (avg_ms * 1e-3) / 1e9
-        traffic = load_traffic()
+        # the committed PMC passes measured the default configuration's Jacobi kernel; other schedules / storages: not collected
+        traffic = load_traffic() if (args.schedule == "fused" and args.storage == "f32" and size == 4096) else None
         out["roofline"] = {
-            "kernel": "k_jacobi_tb (temporally blocked Jacobi)" if args.schedule == "fused" else "k_jacobi",
+            "kernel": ("k_jacobi_tb%s (temporally blocked Jacobi)" if args.schedule == "fused" else "k%s_jacobi")
+                      % (("_h" if args.schedule == "fused" else "_h") if args.storage == "f16" else ""),
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "traffic": (traffic or {}).get("bytes_per_launch"),
