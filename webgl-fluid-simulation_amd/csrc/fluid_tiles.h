@@ -1,0 +1,101 @@
+// fluid_tiles.h — what the register-tile kernels share (fluid_kernels.hip, fluid_kernels_f16.hip): the tiling of an output
+// range by apron-carrying tiles, the XCD-aware order in which workgroups take tiles, and the full-wave DPP lane shifts.
+// Internal.
+#pragma once
+#include "fluid_kernels.h"
+
+#include <cstdlib>
+
+namespace fluid {
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Tiling of an output range [lo, hi) of a domain [0, dom) by tiles of span T that lose an apron A on each
+// side — except on a side where the tile contains the domain edge: CLAMP_TO_EDGE makes the edge exact, so
+// no apron is needed there (at W = 4096, T = 256, A = 8 exactly 17 column tiles cover the row instead of 18).
+// Tile b spans [S + b*V, S + b*V + T) with V = T - 2A and S = max(lo - A, 0).
+struct Axis {
+    int S, V, n;
+};
+
+__host__ __device__ inline int ceil_div_pos(int a, int b) { return a <= 0 ? 0 : (a + b - 1) / b; }
+
+__host__ inline Axis make_axis(int lo, int hi, int dom, int T, int A)
+{
+    Axis ax;
+    ax.V = T - 2 * A;
+    ax.S = lo - A > 0 ? lo - A : 0;
+    const int n1 = ceil_div_pos(hi - ax.S - T + A, ax.V) + 1;  // last tile's exact range reaches hi
+    const int n2 = ceil_div_pos(dom - ax.S - T, ax.V) + 1;     // or the last tile contains the far domain edge
+    ax.n = n1 < n2 ? n1 : n2;
+    return ax;
+}
+
+// XCD-aware tile order (MI355X: 8 XCDs with private 4 MiB L2s; workgroup b is dispatched to XCD b % 8).
+// Adjacent tiles share their aprons, so each XCD is handed a CONTIGUOUS run of the tile sequence (remap bit 0): the
+// ~64 workgroups resident on an XCD at any time are then neighbours and the shared apron texels hit that XCD's L2
+// instead of being fetched once per tile.  Bit 1 picks the sequence: row-major (the tiles in flight together span
+// whole rows of the field, i.e. long contiguous address runs — measured 7 % faster for the Jacobi kernel at 4096^2,
+// profiles/r01/jacobi_tile_order.txt) or column-major.  Bijective for any tile count; placement only affects
+// speed, never results.
+__device__ __forceinline__ void tile_of_block(int b, int nx, int ny, int remap, int& bx, int& by)
+{
+    const int n = nx * ny;
+    int t = b;
+    if (remap & 1) {
+        const int q = n >> 3, r = n & 7, xcd = b & 7, slot = b >> 3;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    if (remap & 2) {  // row-major tile sequence: the tiles in flight together span whole rows of the field
+        by = t / nx;
+        bx = t - by * nx;
+    } else {
+        bx = t / ny;
+        by = t - bx * ny;
+    }
+}
+
+// exact (storable) global range [a, b) of the tile starting at t0, intersected with [lo, hi)
+__device__ __forceinline__ void tile_exact(int t0, int T, int A, int dom, int lo, int hi, int& a, int& b)
+{
+    a = t0 <= 0 ? 0 : t0 + A;
+    b = t0 + T >= dom ? dom : t0 + T - A;
+    a = max(a, lo);
+    b = min(b, hi);
+}
+
+// geometry of a temporally blocked Jacobi tile (see fluid_kernels.hip)
+template <int NW, int RY, int HX, int HY>
+struct JacobiTB {
+    static constexpr int TX = 256;          // columns per tile (64 lanes x float4)
+    static constexpr int TY = NW * RY;      // rows per tile
+    static constexpr int VX = TX - 2 * HX;  // HX-column / HY-row apron: up to min(HX, HY) iterations per launch
+    static constexpr int VY = TY - 2 * HY;
+    static_assert(HX % 4 == 0, "column apron must keep float4 alignment");
+    static_assert(HX >= HY, "iterations per launch are bounded by the row apron");
+    static_assert(VX > 0 && VY > 0, "tile smaller than its apron");
+};
+
+// Undefined `old` operand (mov_dpp, not update_dpp with a zero): the lane without a source gets an unspecified value
+// — every caller either overrides it (EDGE) or only feeds the stale apron with it — and the DPP-combine pass is then
+// free to fold the shift into the consuming v_add_f32 (v_add_f32_dpp: no extra instruction, no zero-initialisation).
+__device__ __forceinline__ float from_left_lane(float v)  // value held by lane-1 (unspecified in lane 0)
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float from_right_lane(float v)  // value held by lane+1 (unspecified in lane 63)
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, true));
+}
+
+inline int xcd_remap()  // FLUID_XCD_REMAP: tile order of the Jacobi kernel (A/B knob); bit 0 = XCD-contiguous runs, bit 1 = row-major
+{
+    static const int v = [] {
+        const char* e = getenv("FLUID_XCD_REMAP");
+        return (e ? atoi(e) : 3) & 3;
+    }();
+    return v;
+}
+
+}  // namespace
+}  // namespace fluid
