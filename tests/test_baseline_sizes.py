@@ -17,11 +17,13 @@ def _free():
     gc.collect()
 
 
-def test_config3_8192_sq_fused_equals_passes_bitwise():
-    """configs[3] workload: 8192^2 sim = dye, 50 Jacobi iterations"""
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_config3_8192_sq_fused_equals_passes_bitwise(storage):
+    """configs[3] workload: 8192^2 sim = dye, 50 Jacobi iterations (fp32 fields: the headline; and the fp16-storage side mode)"""
     import fluid_hip
     cfg = {"SIM_RESOLUTION": 8192, "DYE_RESOLUTION": 8192, "PRESSURE_ITERATIONS": 50}
-    sims = [fluid_hip.FluidSim(canvas=(8192, 8192), config=cfg, schedule=s, random=fluid_hip.mulberry32(8)) for s in ("passes", "fused")]
+    sims = [fluid_hip.FluidSim(canvas=(8192, 8192), config=cfg, schedule=s, random=fluid_hip.mulberry32(8), storage=storage)
+            for s in ("passes", "fused")]
     try:
         for s in sims:
             s.multipleSplats(6)
