@@ -80,8 +80,10 @@ def load_traffic():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    # defaults: the GPU needs ~30 ms of work to reach its steady clocks (profiles/r01/bench_warmup_sensitivity.txt: with 50 warm-up
+    # steps even 5 timed steps read the steady 0.539 ms/step; with 3 they read 0.595), so warm up for 50 steps and time 200
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--size", type=int, default=4096, help="grid edge per GPU (BASELINE config: 4096)")
     ap.add_argument("--iters", type=int, default=50, help="PRESSURE_ITERATIONS (BASELINE config: 50)")
     ap.add_argument("--schedule", default="fused", choices=["fused", "passes"])
