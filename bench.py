@@ -91,6 +91,8 @@ def main():
                     "half-float textures, SURVEY 8f N4) is a side measurement and says so in the JSON line")
     ap.add_argument("--halo", type=int, default=56, help="ghost rows per stripe side (N > 1); >= 54 keeps 50 Jacobi iterations in one "
                                                         "block: 2 exchanges per step (profiles/r01/stripe_overhead_one_gpu.txt)")
+    ap.add_argument("--reach", type=int, default=32, help="N > 1: ghost rows refreshed in front of the advection (rows a back-trace may span); "
+                    "the 4096 x 32768 grid of the 8-rank run reaches |v| = 1106 = 18.4 rows (tools/max_velocity.py), the library default is 24")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-oracle work for cpu_baseline (0 = skip)")
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the HIP-event instrumented pass")
     ap.add_argument("--stripes", action="store_true", help="use the multi-GPU stripe driver even at N = 1 (exercises that code path)")
@@ -155,7 +157,8 @@ def main():
         cfg = dict(cfg, SIM_RESOLUTION=min(gw, gh), DYE_RESOLUTION=min(gw, gh))
         try:
             sim = StripeSim(canvas=(gw, gh), config=cfg, halo=args.halo, schedule=args.schedule,
-                            random=fluid_hip.mulberry32(1234), device=local_rank, native=not args.hosted, tiles_x=tx, storage=args.storage)
+                            random=fluid_hip.mulberry32(1234), device=local_rank, native=not args.hosted, tiles_x=tx, storage=args.storage,
+                            reach=min(args.reach, args.halo))
         except fluid_hip.FluidError as ex:
             # the native driver needs RCCL inside libfluid_hip.so (dlopen + ncclCommInitRank); if that cannot be set up,
             # say so loudly and drive the SAME kernels pass by pass with torch.distributed's RCCL send/recv instead

@@ -218,9 +218,11 @@ typedef struct fluid_stripe_op {
  * logic, no device needed).  ops may be NULL to query *n_ops. */
 int fluid_stripe_plan(int halo, int dye_halo, int iterations, int advect_rows, int advect_dye_rows,
                       fluid_stripe_op *ops, int max_ops, int *n_ops);
-/* rows an advection back-trace may span: dt * max|v| + 2 (default 20: dt <= 1/60, script.js:1191, and |v| <= 1000,
- * script.js:864).  Only that many velocity / dye ghost rows are refreshed before the advection; a longer back-trace
- * is counted and reported by fluid_halo_check (FLUID_ERR_HALO), never silently served from a stale row. */
+/* rows an advection back-trace may span: dt * max|v| + 2.  Default 24: dt <= 1/60 (script.js:1191); the vorticity pass
+ * clamps |v| to 1000 (script.js:864), but the projection that follows overshoots it — 1106 measured on the 4096 x 32768
+ * grid of the 8-rank bench (tools/max_velocity.py) = 18.4 rows; 24 holds up to |v| ~ 1300.  Only that many velocity / dye
+ * ghost rows are refreshed before the advection; a longer back-trace is counted and reported by fluid_halo_check
+ * (FLUID_ERR_HALO), never silently served from a stale row. */
 int fluid_set_reach(fluid_ctx *ctx, int rows);
 int fluid_advect_exchange_rows(const fluid_ctx *ctx, int *velocity_rows, int *dye_rows);
 /* interior-first overlap of the exchanges with the curl/vorticity/divergence and advection kernels (default on) */

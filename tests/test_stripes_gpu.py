@@ -127,7 +127,8 @@ def test_native_group_back_trace_beyond_reach_is_reported(overlap):
 
 
 def test_native_group_default_reach_covers_the_velocity_clamp():
-    """|v| <= 1000 (script.js:864) and dt <= 1/60 (script.js:1191): 16.7 rows + the bilinear footprint < 20"""
+    """|v| <= 1000 at the vorticity clamp (script.js:864), a projection overshoot on top, dt <= 1/60 (script.js:1191): the
+    default reach of 24 rows covers back-traces of up to 22 rows plus the bilinear footprint"""
     import fluid_hip
     from fluid_hip.stripes import StripeGroup
     cfg = {"SIM_RESOLUTION": 256, "DYE_RESOLUTION": 256, "PRESSURE_ITERATIONS": 10, "CURL": 0}
@@ -214,8 +215,8 @@ def test_native_rccl_path_with_several_ranks_bitwise(world, halo, overlap, cfg, 
     assert out["rccl"] == lib
     import fluid_hip
     dye_halo = -(-halo * cfg["DYE_RESOLUTION"] // cfg["SIM_RESOLUTION"])
-    va = min(20 + (0 if cfg["DYE_RESOLUTION"] == cfg["SIM_RESOLUTION"] else 1), halo)
-    plan = fluid_hip._abi.stripe_plan(halo, dye_halo, cfg["PRESSURE_ITERATIONS"], va, min(dye_halo, va if cfg["DYE_RESOLUTION"] == cfg["SIM_RESOLUTION"] else 41))
+    va = min(24 + (0 if cfg["DYE_RESOLUTION"] == cfg["SIM_RESOLUTION"] else 1), halo)       # default reach: 24 rows
+    plan = fluid_hip._abi.stripe_plan(halo, dye_halo, cfg["PRESSURE_ITERATIONS"], va, min(dye_halo, va if cfg["DYE_RESOLUTION"] == cfg["SIM_RESOLUTION"] else 49))
     assert out["exchanges"] == steps * sum(1 for op in plan if op[0] == "exchange")
 
 

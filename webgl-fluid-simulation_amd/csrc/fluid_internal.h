@@ -47,7 +47,7 @@ struct fluid_ctx {
     void* stage[8] = {};                 // 2-D tiles: contiguous staging of the strided column / row blocks, per direction
     size_t stage_bytes[8] = {};
     long exchanges = 0;
-    int reach = 20;                      // rows an advection back-trace may span (dt*|v| + 2); see fluid_set_reach
+    int reach = 24;                      // rows an advection back-trace may span (dt*|v| + 2); see fluid_set_reach
     int overlap = 1;                     // interior-first overlap of exchanges (FLUID_STRIPE_OVERLAP=0 turns it off)
 
     fluid_display_state* display = nullptr;  // bloom pyramid, sunrays, dithering texture, frame (fluid_display.cpp)
