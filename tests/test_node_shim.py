@@ -124,3 +124,40 @@ def test_node_host_drives_a_tile_rank(addon, tmp_path):
         n = want[k].size
         assert np.array_equal(raw[off:off + n].reshape(want[k].shape), want[k]), k
         off += n
+
+
+@pytest.mark.gpu
+@needs_node
+def test_javascript_launcher_runs_a_rank_per_gpu(addon, tmp_path):
+    """addon/launch_tiles.js: fork one Node process per GPU, rank 0 creates the ncclUniqueId, the parent hands it round, every
+    child builds its tile (ncclCommInitRank) and steps it.  One GPU here -> one rank; the result equals the plain context."""
+    import fluid_hip
+    cfg = {"SIM_RESOLUTION": 128, "DYE_RESOLUTION": 128, "PRESSURE_ITERATIONS": 20}
+    args = {"gpus": 1, "canvas": {"width": 512, "height": 512}, "config": cfg, "seed": 31, "randomSplats": 4, "steps": 3, "dt": 0.016666,
+            "out": str(tmp_path / "fields.bin")}
+    out = node("run_launch_tiles.js", args)
+    assert out["ok"], out
+    assert out["results"] == [{"rank": 0, "exchanges": 0, "sim": [128, 128]}]
+    with fluid_hip.FluidSim(canvas=(512, 512), config=cfg, random=fluid_hip.mulberry32(31)) as sim:
+        sim.multipleSplats(4)
+        sim.step(0.016666, 3)
+        want = sim.fields()
+    raw = np.fromfile(args["out"] + ".0", dtype=np.float32)
+    off = 0
+    for k in S.FIELDS:
+        n = want[k].size
+        assert np.array_equal(raw[off:off + n].reshape(want[k].shape), want[k]), k
+        off += n
+
+
+@needs_node
+def test_javascript_launcher_reports_a_failing_rank():
+    """without a GPU the child's createFluid throws: the launcher rejects with that rank's message instead of hanging"""
+    import fluid_hip
+    if fluid_hip.device_count() > 0:
+        pytest.skip("a HIP device is visible")
+    r = subprocess.run([NODE, os.path.join(ROOT, "tests", "node", "run_launch_tiles.js"),
+                        json.dumps({"gpus": 1, "canvas": {"width": 64, "height": 64}, "config": {}, "seed": 1, "randomSplats": 1, "steps": 1,
+                                    "dt": 0.016, "out": "/tmp/unused"})], capture_output=True, text=True, timeout=120)
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert r.returncode == 1 and not out["ok"] and "rank 0" in out["error"]

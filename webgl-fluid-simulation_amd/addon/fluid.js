@@ -121,7 +121,7 @@ function wrap (value, min, max) {
 }
 
 // options: { canvas: {width, height}, config: {...overrides}, device, schedule: 'fused'|'passes', storage: 'f32'|'f16',
-//            random: () => number (defaults to Math.random), backend: <object with the addon's functions>,
+//            random: () => number (defaults to Math.random), seed: number (shorthand for random: mulberry32(seed)), backend: <object with the addon's functions>,
 //            tile: { rank, world, tilesX = 1, halo = 56, commId: Buffer } }
 // `storage`: 'f32' keeps fp32 fields (what the headless reference build keeps); 'f16' keeps half texels like the reference's
 // half-float textures on a real GPU (ext.halfFloatTexType): every pass output is rounded to fp16, a step moves half the bytes.
@@ -132,7 +132,8 @@ function wrap (value, min, max) {
 function createFluid (options) {
     options = options || {};
     const native = options.backend || loadBackend();
-    const random = options.random || Math.random;
+    // `seed` (a number) is the serialisable way to ask for a reproducible Math.random: options.random wins if both are given
+    const random = options.random || (options.seed !== undefined ? mulberry32(options.seed) : Math.random);
     const sim = {};
 
     sim.config = Object.assign(defaultConfig(), options.config || {});
