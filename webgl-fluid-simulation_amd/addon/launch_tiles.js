@@ -4,7 +4,8 @@
 //   const { launchTiles } = require('./launch_tiles.js');
 //   const results = await launchTiles({ gpus: 8, tilesX: 1, halo: 56, worker: '/abs/path/worker.js', args: {...} });
 //
-// The parent forks `gpus` children (HIP_VISIBLE_DEVICES = one GPU each, so every child sees its GPU as device 0).  Rank 0
+// The parent forks `gpus` children; child `rank` drives HIP device `devices[rank]` (default: its rank; every process sees all
+// GPUs, the arrangement RCCL is exercised with most — `isolate: true` hides the others through HIP_VISIBLE_DEVICES).  Rank 0
 // creates the communicator id (ncclGetUniqueId inside libfluid_hip.so) and hands it to the parent, which passes it on to
 // the other ranks; every child then builds its tile with createFluid({ tile: { rank, world, tilesX, halo, commId } }) —
 // a collective ncclCommInitRank — and runs the worker module's exported function `(sim, ctx) => result` on it, where
@@ -30,7 +31,8 @@ function launchTiles (options) {
             reject(err);
         };
         for (let rank = 0; rank < world; rank++) {
-            const env = Object.assign({}, process.env, { HIP_VISIBLE_DEVICES: String(devices[rank]), HSA_ENABLE_IPC_MODE_LEGACY: '0' });
+            const env = Object.assign({}, process.env, { HSA_ENABLE_IPC_MODE_LEGACY: '0' });   // dmabuf IPC: what RCCL across processes needs here
+            if (options.isolate) env.HIP_VISIBLE_DEVICES = String(devices[rank]);
             const child = fork(__filename, ['--tile-child'], { env, stdio: ['ignore', 'inherit', 'inherit', 'ipc'] });
             children.push(child);
             child.on('message', m => {
@@ -44,7 +46,7 @@ function launchTiles (options) {
                 }
             });
             child.on('exit', code => { if (code !== 0 && results[rank] === undefined) fail(new Error('rank ' + rank + ' exited with code ' + code)); });
-            child.send({ type: 'init', rank, world, tilesX, halo: options.halo === undefined ? 56 : options.halo, reach: options.reach,
+            child.send({ type: 'init', rank, world, tilesX, device: options.isolate ? 0 : devices[rank], halo: options.halo === undefined ? 56 : options.halo, reach: options.reach,
                          worker: path.resolve(options.worker), fluid: options.fluid || {}, args: options.args || {} });
         }
     });
@@ -62,7 +64,7 @@ function childMain () {
                 const commId = Buffer.from(m.id, 'base64');
                 const tile = { rank: init.rank, world: init.world, tilesX: init.tilesX, halo: init.world > 1 ? init.halo : 0, commId };
                 if (init.reach !== undefined) tile.reach = init.reach;
-                const sim = fluid.createFluid(Object.assign({}, init.fluid, { tile }));   // every child drives its GPU as device 0
+                const sim = fluid.createFluid(Object.assign({}, init.fluid, { tile, device: init.device }));
                 const work = require(init.worker);
                 const value = await work(sim, { rank: init.rank, world: init.world, tilesX: init.tilesX, args: init.args, fluid });
                 sim.destroy();
