@@ -82,6 +82,19 @@ def run(scenario: Dict[str, Any], timeout: float = 1800.0) -> Dict[str, Any]:
             w, h = (dw, dh) if name == "dye" else (sw, sh)
             dec[name] = np.frombuffer(base64.b64decode(s), np.float32).reshape(h, w, 4).copy()
         res["fields"] = dec
+    if "samples" in res:   # subsampled dump (oracle_plotly.js `sample`): native channel counts
+        (sw, sh), (dw, dh) = res["sim"], res["dye"]
+        nch = {"velocity": 2, "pressure": 1, "divergence": 1, "curl": 1, "dye": 4}
+        dec = {}
+        for name, smp in res["samples"].items():
+            w = dw if name == "dye" else sw
+            nw, nh = smp["size"]
+            sub = np.frombuffer(base64.b64decode(smp["sub"]), np.float32).reshape(nh, nw, 4)[..., :nch[name]]
+            band = np.frombuffer(base64.b64decode(smp["band"]), np.float32).reshape(-1, w, 4)[..., :nch[name]]
+            if nch[name] == 1:
+                sub, band = sub[..., 0], band[..., 0]
+            dec[name] = {"sub": np.ascontiguousarray(sub), "band": np.ascontiguousarray(band), "absmax": float(smp["absmax"])}
+        res["samples"] = dec
     if "frame" in res:   # render scenario: float frame, 8-bit frame (already flipped by normalizeTexture), bloom, sunrays, mask
         fw, fh = res["frameSize"]
         res["frame"] = np.frombuffer(base64.b64decode(res["frame"]), np.float32).reshape(fh, fw, 4).copy()

@@ -17,6 +17,8 @@
 //   passes             ["curl","vorticity",...] run single passes instead of step()
 //   resizeTo           {SIM_RESOLUTION, DYE_RESOLUTION} -> initFramebuffers() again after the steps
 //   steps, dt, timing, noDump
+//   sample             {stride, band: [row0, row1]}: instead of the full dumps, per field every stride-th row / column, the rows of
+//                      the band at full resolution and max |value| (grids too large to return whole, e.g. 4096^2)
 //   render             {config: {SHADING, BLOOM, SUNRAYS, TRANSPARENT, BACK_COLOR, BLOOM_*, SUNRAYS_*, CAPTURE_RESOLUTION},
 //                       dither: {w, h, seed}} -> after the steps: the reference's captureScreenshot() up to the PNG
 //                      (render(target) into a float FBO of getResolution(CAPTURE_RESOLUTION), framebufferToTexture,
@@ -257,7 +259,19 @@
                  maxTex: gl.getParameter(gl.MAX_TEXTURE_SIZE), linear: !!ext.supportLinearFiltering };
       var dbg = gl.getExtension('WEBGL_debug_renderer_info');
       if (dbg) out.gl.renderer = gl.getParameter(dbg.UNMASKED_RENDERER_WEBGL);
-      if (!P.noDump) out.fields = {
+      if (P.sample) {   // grids too large to ship whole: every `stride`-th row and column, rows [band[0], band[1]) in full, max |value|
+        var sampleOf = function (target, nch) {
+          var a = framebufferToTexture(target), w = target.width, h = target.height, S = P.sample.stride;
+          var b0 = P.sample.band[0], b1 = P.sample.band[1];
+          var sw = Math.ceil(w / S), sh = Math.ceil(h / S), sub = new Float32Array(sw * sh * 4), amax = 0, k, i, j;
+          for (j = 0; j < sh; j++) for (i = 0; i < sw; i++) for (k = 0; k < 4; k++) sub[(j * sw + i) * 4 + k] = a[((j * S) * w + i * S) * 4 + k];
+          for (i = 0; i < w * h; i++) for (k = 0; k < nch; k++) { var v = Math.abs(a[i * 4 + k]); if (v > amax) amax = v; }
+          return { sub: b64(sub), size: [sw, sh], band: b64(a.subarray(b0 * w * 4, b1 * w * 4)), absmax: amax };
+        };
+        out.samples = { velocity: sampleOf(velocity.read, 2), pressure: sampleOf(pressure.read, 1), divergence: sampleOf(divergence, 1),
+                        curl: sampleOf(curl, 1), dye: sampleOf(dye.read, 4) };
+      }
+      if (!P.noDump && !P.sample) out.fields = {
         velocity: b64(framebufferToTexture(velocity.read)), pressure: b64(framebufferToTexture(pressure.read)),
         divergence: b64(framebufferToTexture(divergence)), curl: b64(framebufferToTexture(curl)),
         dye: b64(framebufferToTexture(dye.read)) };
