@@ -94,7 +94,8 @@ def test_hip_matches_live_reference_at_1024(schedule):
 # noise floor grows with the width (texcoord jitter ~ W * 2^-22 = 1e-3 at W = 4096); measured
 # restatement-vs-reference: velocity 2.5e-3, pressure 5.0e-4, divergence 6.1e-3, curl 5.1e-3, dye 4.2e-5 of max|field|; the splat list
 # and max|pressure| agree exactly.  The HIP path is additionally held to the restatement at this size (median / 99th percentile / max).
-HUGE_TOL = {"velocity": 5e-3, "pressure": 1.2e-3, "divergence": 1.5e-2, "curl": 1.2e-2, "dye": 1e-4}
+# (curl: 1.3e-2 on the 4096 x 8192 grid, where max|curl| is half as large)
+HUGE_TOL = {"velocity": 5e-3, "pressure": 1.2e-3, "divergence": 1.5e-2, "curl": 2.5e-2, "dye": 1e-4}
 
 
 def _check_huge(out, log, g):
@@ -169,6 +170,32 @@ def test_four_stripes_match_live_reference_at_8192():
     from fluid_hip.stripes import StripeGroup
     g, sc = S.load("big_step2_8192")
     grp = StripeGroup(4, canvas=S.canvas_of(g), config=sc["config"], halo=56, random=fluid_hip.mulberry32(sc["seed"]), reach=32)
+    try:
+        grp.multipleSplats(sc["randomSplats"])
+        grp.step(sc.get("dt", 0.016666), sc["steps"])
+        grp.check_halo()
+        out = {k: grp.read(k) for k in S.FIELDS}
+    finally:
+        grp.close()
+    _check_huge(out, g["splats"], g)
+
+
+# ---- the grid bench.py runs on TWO GPUs (weak scaling: 4096 x 8192, one 4096 x 4096 stripe per rank) through the live reference
+# (oracle/live/make_golden_4096x8192.py; the full-resolution band straddles the border between the two stripes)
+def test_oracle_matches_live_reference_on_the_two_gpu_bench_grid(oracle):
+    g, sc = S.load("big_step2_4096x8192")
+    ad = S.OracleAdapter(oracle, S.canvas_of(g), sc.get("config"), sc.get("seed", 1234))
+    out, log = S.replay(ad, g, sc)
+    _check_huge(out, log, g)
+
+
+@pytest.mark.gpu
+def test_two_stripes_match_live_reference_on_the_two_gpu_bench_grid():
+    """what `bench.py --gpus 2` computes (two row stripes, halo 56, reach 32, native plan, fused schedule) against the reference"""
+    import fluid_hip
+    from fluid_hip.stripes import StripeGroup
+    g, sc = S.load("big_step2_4096x8192")
+    grp = StripeGroup(2, canvas=S.canvas_of(g), config=sc["config"], halo=56, random=fluid_hip.mulberry32(sc["seed"]), reach=32)
     try:
         grp.multipleSplats(sc["randomSplats"])
         grp.step(sc.get("dt", 0.016666), sc["steps"])
