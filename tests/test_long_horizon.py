@@ -164,12 +164,14 @@ def test_hip_matches_live_reference_at_8192(schedule):
 
 
 @pytest.mark.gpu
-def test_four_stripes_match_live_reference_at_8192():
-    """configs[3] as the 4-GPU run decomposes it (four row stripes, halo 56, the native plan) against the reference itself"""
+@pytest.mark.parametrize("tiles_x", [1, 2])
+def test_four_ranks_match_live_reference_at_8192(tiles_x):
+    """configs[3] as a 4-GPU run decomposes it — four row stripes, or 2 x 2 tiles (BASELINE's wording) — halo 56, the native plan,
+    against the reference itself"""
     import fluid_hip
     from fluid_hip.stripes import StripeGroup
     g, sc = S.load("big_step2_8192")
-    grp = StripeGroup(4, canvas=S.canvas_of(g), config=sc["config"], halo=56, random=fluid_hip.mulberry32(sc["seed"]), reach=32)
+    grp = StripeGroup(4, canvas=S.canvas_of(g), config=sc["config"], halo=56, random=fluid_hip.mulberry32(sc["seed"]), reach=32, tiles_x=tiles_x)
     try:
         grp.multipleSplats(sc["randomSplats"])
         grp.step(sc.get("dt", 0.016666), sc["steps"])
