@@ -206,3 +206,42 @@ def test_two_stripes_match_live_reference_on_the_two_gpu_bench_grid():
     finally:
         grp.close()
     _check_huge(out, g["splats"], g)
+
+
+# ---- the headline grid over a longer horizon: 4096^2, 50 iterations, CURL = 0, TEN steps (500 Jacobi iterations, 20 advections) through
+# the live reference (oracle/live/make_golden_4096_curl0.py).  Without the discontinuous vorticity force the trajectory is not chaotic
+# and the comparison stays texel-tight — which also shows that the 1e-3 differences of the CURL = 30 fixtures above come from that
+# force, not from the grid size.  Measured restatement-vs-reference after 10 steps: velocity 9.3e-7, pressure 2.2e-7, divergence 1.1e-5,
+# curl 1.5e-4, dye 5.0e-7 of max|field|.
+CURL0_TOL = {"velocity": 4e-6, "pressure": 1e-6, "divergence": 5e-5, "curl": 6e-4, "dye": 2e-6}
+
+
+def _check_curl0(out, log, g):
+    assert np.array_equal(log, g["splats"])
+    st = int(g["stride"])
+    b0, b1 = (int(x) for x in g["band"])
+    for k in S.FIELDS:
+        scale = float(g["absmax_" + k])
+        a = out[k]
+        assert float(np.abs(a[::st, ::st].astype(np.float64) - g["sub_" + k]).max()) <= CURL0_TOL[k] * scale, (k, float(np.abs(a[::st, ::st].astype(np.float64) - g["sub_" + k]).max()) / scale)
+        assert float(np.abs(a[b0:b1].astype(np.float64) - g["band_" + k]).max()) <= CURL0_TOL[k] * scale, k
+        assert abs(float(np.abs(a).max()) - scale) <= CURL0_TOL[k] * scale, k
+
+
+def test_oracle_matches_live_reference_over_ten_steps_at_4096(oracle):
+    g, sc = S.load("big_step10_curl0_4096")
+    ad = S.OracleAdapter(oracle, S.canvas_of(g), sc.get("config"), sc.get("seed", 1234))
+    out, log = S.replay(ad, g, sc)
+    _check_curl0(out, log, g)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("schedule", ["fused", "passes"])
+def test_hip_matches_live_reference_over_ten_steps_at_4096(schedule):
+    g, sc = S.load("big_step10_curl0_4096")
+    ad = S.HipAdapter(S.canvas_of(g), sc.get("config"), sc.get("seed", 1234), schedule=schedule)
+    try:
+        out, log = S.replay(ad, g, sc)
+    finally:
+        ad.close()
+    _check_curl0(out, log, g)
