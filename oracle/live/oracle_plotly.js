@@ -17,6 +17,8 @@
 //   passes             ["curl","vorticity",...] run single passes instead of step()
 //   resizeTo           {SIM_RESOLUTION, DYE_RESOLUTION} -> initFramebuffers() again after the steps
 //   steps, dt, timing, noDump
+//   halfTargets        true: every draw into a simulation framebuffer is followed by an fp16 round trip of that attachment
+//                      (half-float render targets emulated around the unmodified reference: its shaders, a 16F target's rounding)
 //   sample             {stride, band: [row0, row1]}: instead of the full dumps, per field every stride-th row / column, the rows of
 //                      the band at full resolution and max |value| (grids too large to return whole, e.g. 4096^2)
 //   render             {config: {SHADING, BLOOM, SUNRAYS, TRANSPARENT, BACK_COLOR, BLOOM_*, SUNRAYS_*, CAPTURE_RESOLUTION},
@@ -44,6 +46,28 @@
     var bin = atob(str), u = new Uint8Array(bin.length);
     for (var i = 0; i < bin.length; i++) u[i] = bin.charCodeAt(i);
     return new Float32Array(u.buffer);
+  }
+  // fp32 -> nearest fp16 (ties to even, subnormals kept, overflow to infinity) -> fp32: what a half-float render target keeps
+  var _f = new Float32Array(1), _u = new Uint32Array(_f.buffer);
+  function roundHalf(v) {
+    _f[0] = v;
+    var x = _u[0], sign = x & 0x80000000, h, e, m, shift, r, rem, half;
+    x = x & 0x7fffffff;
+    if (x > 0x7f800000) return v;                                     // NaN
+    if (x >= 0x47800000) { _u[0] = (sign | 0x7f800000) >>> 0; return _f[0]; }   // >= 65536 -> inf
+    if (x >= 0x38800000) {                                            // normal half (may round up to inf at 65520)
+      x = (x + 0xfff + ((x >>> 13) & 1)) >>> 0;
+      x = (x & 0xffffe000) >>> 0;
+      _u[0] = (sign | x) >>> 0;
+      if ((x >>> 0) >= 0x47800000) _u[0] = (sign | 0x7f800000) >>> 0;
+      return _f[0];
+    }
+    if (x <= 0x33000000) { _u[0] = sign >>> 0; return _f[0]; }        // <= 2^-25 -> +-0
+    e = x >>> 23; m = (x & 0x7fffff) | 0x800000; shift = 126 - e;     // subnormal half: unit 2^-24
+    r = m >>> shift; rem = m & ((1 << shift) - 1); half = 1 << (shift - 1);
+    if (rem > half || (rem === half && (r & 1))) r++;
+    h = r * 5.9604644775390625e-08;                                   // r * 2^-24, exact
+    return sign ? -h : h;
   }
   function el(tag, cls, id) {
     var e = document.createElement(tag); if (cls) e.className = cls; if (id) e.id = id;
@@ -73,6 +97,34 @@
     return load(refdir + 'dat.gui.min.js').then(function () { return load(refdir + 'script.js'); }).then(function () {
       var k;
       for (k in (P.config || {})) config[k] = P.config[k];
+      if (P.halfTargets) {
+        // Emulate half-float render targets (what halfFloatTexType gives the reference on a real GPU; SwiftShader keeps fp32):
+        // after EVERY draw of the reference into one of its simulation framebuffers, the attachment is read back, rounded to
+        // fp16 and written back — the reference's own shaders, plus the store rounding of a 16F target.  script.js is untouched:
+        // only the context's drawElements / bindFramebuffer methods are wrapped.
+        var curFbo = null, rawBind = gl.bindFramebuffer.bind(gl), rawDraw = gl.drawElements.bind(gl);
+        gl.bindFramebuffer = function (t, f) { curFbo = f; rawBind(t, f); };
+        gl.drawElements = function (a, b, c, d) {
+          rawDraw(a, b, c, d);
+          if (!curFbo) return;
+          var cands = [[dye && dye.read, 4], [dye && dye.write, 4], [velocity && velocity.read, 2], [velocity && velocity.write, 2],
+                       [pressure && pressure.read, 1], [pressure && pressure.write, 1], [divergence, 1], [curl, 1]], i, t = null, nch = 0;
+          for (i = 0; i < cands.length; i++) if (cands[i][0] && cands[i][0].fbo === curFbo) { t = cands[i][0]; nch = cands[i][1]; }
+          if (!t) return;
+          var w = t.width, h = t.height, px4 = new Float32Array(w * h * 4), d2 = new Float32Array(w * h * nch), n, c2;
+          gl.readPixels(0, 0, w, h, gl.RGBA, gl.FLOAT, px4);
+          for (n = 0; n < w * h; n++) for (c2 = 0; c2 < nch; c2++) d2[n * nch + c2] = roundHalf(px4[n * 4 + c2]);
+          // leave the reference's texture-unit state exactly as it was (step() attaches the divergence texture ONCE in front of
+          // its Jacobi loop, script.js:1261): work on unit 7 and put its binding and the active unit back
+          var act = gl.getParameter(gl.ACTIVE_TEXTURE);
+          gl.activeTexture(gl.TEXTURE7);
+          var was = gl.getParameter(gl.TEXTURE_BINDING_2D);
+          gl.bindTexture(gl.TEXTURE_2D, t.texture);
+          gl.texSubImage2D(gl.TEXTURE_2D, 0, 0, 0, w, h, nch === 1 ? gl.RED : nch === 2 ? gl.RG : gl.RGBA, gl.FLOAT, d2);
+          gl.bindTexture(gl.TEXTURE_2D, was);
+          gl.activeTexture(act);
+        };
+      }
       dye = null; velocity = null; initFramebuffers();
       reseed(); draws.length = 0;
 
