@@ -5,7 +5,8 @@
 // and its render-target write rounds the result back to fp16.  These kernels do exactly that — the per-texel arithmetic
 // is the SAME fp32 code as the fp32-storage kernels (`*_texel` bodies of fluid_math.h), only the loads widen and the
 // stores narrow (round to nearest even, v_cvt_f16_f32) — so a step moves half the bytes of the fp32 mode.
-// Parity target: the oracle restatement with an fp16 round trip after every pass output (oracle/oracle.py storage="f16").
+// Parity: the oracle restatement with an fp16 round trip after every pass output (oracle/oracle.py storage="f16"), and the live
+// reference with half-float render targets emulated around the unmodified page (tests/test_f16_vs_golden.py).
 #include "fluid_kernels.h"
 #include "fluid_math.h"
 
