@@ -40,7 +40,49 @@ def algorithmic_bytes_per_cell(iters: int) -> int:
     return 128 + 12 * iters
 
 
-def cpu_baseline(size: int, iters: int, budget_s: float):
+def cpu_baseline_reference(size: int, iters: int, timeout_s: float):
+    """The reference ITSELF — the unmodified script.js step() (script.js:1231-1294) under Chromium + SwiftShader (software WebGL,
+    kaleido package) — timed on this host's cores on the same workload: 3 warm-up + 5 timed whole steps with a readPixels sync per
+    step (oracle/live/time_reference.py).  The page script is the staged byte-for-byte copy oracle/_ref/ (oracle/stage_reference.sh;
+    /root/reference in the build container).  Runs in its own process group under a timeout; returns (dict | None, reason)."""
+    import signal
+    import subprocess
+    script = os.path.join(ROOT, "oracle", "live", "time_reference.py")
+    if size > 8192:
+        return None, "the reference cannot run above 8192^2 (SwiftShader MAX_TEXTURE_SIZE)"
+    try:
+        import kaleido  # noqa: F401
+    except Exception as ex:
+        return None, "kaleido (Chromium + SwiftShader) is not importable here: %s" % ex
+    have = [d for d in ("/root/reference", os.path.join(ROOT, "oracle", "_ref")) if os.path.exists(os.path.join(d, "script.js"))]
+    if not have:
+        return None, "no reference page script on this box (neither /root/reference nor the staged oracle/_ref/)"
+    p = subprocess.Popen([sys.executable, script, "--size", str(size), "--iters", str(iters), "--warm", "3", "--timed", "5", "--json"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True)
+    try:
+        so, se = p.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)   # exactly the process group started above (python + the browser it spawned)
+        except OSError:
+            pass
+        p.wait()
+        return None, "the live reference did not finish within %.0f s" % timeout_s
+    lines = [l for l in so.decode(errors="replace").splitlines() if l.startswith("{")]
+    if p.returncode != 0 or not lines:
+        return None, "the live reference failed here: " + (se.decode(errors="replace").strip().splitlines() or ["no output"])[-1][:200]
+    r = json.loads(lines[-1])
+    return {"value": r["GLUPS"], "unit": "GLUPS", "steps_per_sec": r["steps_per_sec"], "ms_per_step": r["ms_per_step"],
+            "cores": r["nproc"], "kind": "reference", "cpu_model": r["cpu_model"],
+            "renderer": "%s / %s" % (r["gl"].get("renderer"), r["gl"].get("version")), "user_agent": r["gl"].get("userAgent"),
+            "swiftshader_threads": r["gl"].get("cores"),
+            "sample": "%d whole step(s) of the same %dx%d / %d-iteration workload after %d warm-up steps: the unmodified reference "
+                      "script.js step() under headless Chromium + SwiftShader (software WebGL2), readPixels sync per step; "
+                      "`cores` = host cores available, SwiftShader keeps only a few of them busy"
+                      % (r["timed_steps"], r["sim"][0], r["sim"][1], iters, r["warmup_steps"])}, None
+
+
+def cpu_baseline_port(size: int, iters: int, budget_s: float):
     """The CPU oracle (a port of the reference's algorithm, OpenMP over rows) timed on this host's
     cores on a bounded sample of the same workload: same grid, same splats, whole steps."""
     from oracle import oracle as O
@@ -61,9 +103,28 @@ def cpu_baseline(size: int, iters: int, budget_s: float):
     per = spent / steps if steps else first
     return {"value": round(size * size / per / 1e9, 6), "unit": "GLUPS", "steps_per_sec": round(1.0 / per, 4),
             "cores": O.num_threads(), "kind": "port",
-            "sample": "%d whole step(s) of the same %dx%d / %d-iteration workload after 1 warm-up step, oracle/fluid_oracle.c "
-                      "(OpenMP); the live reference (Chromium+SwiftShader) cannot run here: /root/reference is absent on the GPU box"
+            "sample": "%d whole step(s) of the same %dx%d / %d-iteration workload after 1 warm-up step, oracle/fluid_oracle.c (OpenMP)"
                       % (steps or 1, size, size, iters)}
+
+
+def cpu_baseline(size: int, iters: int, budget_s: float, kind: str = "auto"):
+    """`cpu_baseline` of the JSON line: the live reference when it can run on this box (kind "reference"), else the C/OpenMP port
+    of its algorithm (kind "port") with the reason the reference could not run.  With the reference as the baseline the port's
+    number is still reported beside it (`port`), on a short sample, for the record."""
+    why = None
+    if kind in ("auto", "reference"):
+        ref, why = cpu_baseline_reference(size, iters, timeout_s=max(240.0, 12 * budget_s))
+        if ref is not None:
+            if budget_s > 0:
+                port = cpu_baseline_port(size, iters, min(budget_s, 6.0))
+                ref["port"] = {k: port[k] for k in ("value", "unit", "steps_per_sec", "cores", "sample")}
+            return ref
+        if kind == "reference":
+            return {"value": None, "unit": "GLUPS", "kind": "reference", "cores": os.cpu_count(), "sample": "not measured: " + why}
+    out = cpu_baseline_port(size, iters, budget_s)
+    if why:
+        out["sample"] += "; the live reference could not be timed here: " + why
+    return out
 
 
 def load_traffic():
@@ -94,6 +155,8 @@ def main():
     ap.add_argument("--reach", type=int, default=32, help="N > 1: ghost rows refreshed in front of the advection (rows a back-trace may span); "
                     "the 4096 x 32768 grid of the 8-rank run reaches |v| = 1106 = 18.4 rows (tools/max_velocity.py), the library default is 24")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-oracle work for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-kind", default="auto", choices=["auto", "reference", "port"], help="cpu_baseline: the live reference under "
+                    "SwiftShader when it can run here (auto / reference), or the C/OpenMP port of its algorithm")
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the HIP-event instrumented pass")
     ap.add_argument("--stripes", action="store_true", help="use the multi-GPU stripe driver even at N = 1 (exercises that code path)")
     ap.add_argument("--tiles-x", type=int, default=1, help="N > 1: 2-D decomposition, N // tiles_x row stripes x tiles_x column tiles "
@@ -241,7 +304,7 @@ def main():
         out["pass_ms_per_step"] = per_step
 
     if rank == 0 and N == 1 and args.cpu_budget > 0:
-        out["cpu_baseline"] = cpu_baseline(size, iters, args.cpu_budget)
+        out["cpu_baseline"] = cpu_baseline(size, iters, args.cpu_budget, args.cpu_kind)
 
     if striped:
         out["config"]["exchanges_per_step"] = sim.exchanges / max(args.steps + args.warmup, 1)

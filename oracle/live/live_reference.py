@@ -2,10 +2,12 @@
 headless under Chromium 88 + SwiftShader (software WebGL2) as shipped inside the `kaleido`
 pip package, and returns fp32 dumps of its simulation fields.
 
-Only usable where `/root/reference` exists (the build container).  Used by
+Needs the reference's script.js: `/root/reference` (the build container) or the staged copy `oracle/_ref/`
+(oracle/stage_reference.sh; that is what bench.py's `cpu_baseline` leg finds on the GPU box).  Used by
 `oracle/live/make_golden.py` to generate `tests/golden/*.npz` and by
 `oracle/live/time_reference.py` for the reference-side timing quoted in DESIGN.md.
-Nothing under `tests/ -m gpu`, `bench.py` or `smoke()` imports this module.
+`bench.py` imports it for its `cpu_baseline` leg only (the reference timed on the host cores, beside the GPU number);
+nothing under `tests/ -m gpu` or `smoke()` does.
 
 Protocol: kaleido reads one JSON request per line on stdin and answers one JSON line on
 stdout whose "result" is the string our fake `Plotly.toImage` resolved (oracle_plotly.js).
@@ -21,7 +23,10 @@ from typing import Any, Dict, Optional
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-REFERENCE_DIR = "/root/reference"
+# the reference's page script: the read-only checkout in the build container, or the byte-for-byte staged copy that
+# oracle/stage_reference.sh puts under oracle/_ref/ (git-ignored; travels to the GPU box with the gpurun snapshot)
+_CANDIDATES = tuple(filter(None, (os.environ.get("FLUID_REFERENCE_DIR"), "/root/reference", os.path.join(os.path.dirname(HERE), "_ref"))))
+REFERENCE_DIR = next((d for d in _CANDIDATES if os.path.exists(os.path.join(d, "script.js"))), _CANDIDATES[0])
 
 
 def _kaleido_exe() -> Optional[str]:
@@ -46,8 +51,9 @@ def run(scenario: Dict[str, Any], timeout: float = 1800.0) -> Dict[str, Any]:
     reply["fields"][name] is a float32 array [H, W, 4] (row 0 = bottom)."""
     exe = _kaleido_exe()
     if exe is None or not available():
-        raise RuntimeError("live reference unavailable (needs kaleido and /root/reference)")
+        raise RuntimeError("live reference unavailable (needs kaleido and /root/reference or oracle/_ref)")
     sc = dict(scenario)
+    sc.setdefault("refdir", "file://" + REFERENCE_DIR.rstrip("/") + "/")
     inj = sc.get("inject")
     if inj:
         sc["inject"] = {k: _b64(v) for k, v in inj.items()}

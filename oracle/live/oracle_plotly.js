@@ -308,7 +308,8 @@
       out.splats = splatLog; out.draws = draws.length;
       out.canvas = [canvas.width, canvas.height];
       out.gl = { version: gl.getParameter(gl.VERSION), cores: navigator.hardwareConcurrency,
-                 maxTex: gl.getParameter(gl.MAX_TEXTURE_SIZE), linear: !!ext.supportLinearFiltering };
+                 maxTex: gl.getParameter(gl.MAX_TEXTURE_SIZE), linear: !!ext.supportLinearFiltering,
+                 userAgent: navigator.userAgent };
       var dbg = gl.getExtension('WEBGL_debug_renderer_info');
       if (dbg) out.gl.renderer = gl.getParameter(dbg.UNMASKED_RENDERER_WEBGL);
       if (P.sample) {   // grids too large to ship whole: every `stride`-th row and column, rows [band[0], band[1]) in full, max |value|

@@ -429,7 +429,11 @@ __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb(Win w
     using G = JacobiTB<NW, RY, HX, HY>;
     __shared__ float4 mail[2][NW][2][64];
     int bx, by;
+#ifdef FLUID_TB_REPEAT  // experiment: the grid holds FLUID_TB_REPEAT copies of the tile set (steady-state rate without per-launch tails)
+    tile_of_block((int)blockIdx.x % (nx * ny), nx, ny, remap, bx, by);
+#else
     tile_of_block((int)blockIdx.x, nx, ny, remap, bx, by);
+#endif
     const int x0 = xs + bx * G::VX, y0 = ys + by * G::VY;
     const bool edge = (x0 <= 0) || (x0 + G::TX >= w.W) || (y0 <= 0) || (y0 + G::TY >= w.H);
     if (edge) jacobi_tb_body<NW, RY, HX, HY, true>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
@@ -794,8 +798,13 @@ hipError_t launch_tb(hipStream_t s, Win w, const float* p, const float* div, flo
 {
     using G = JacobiTB<NW, RY, HX, HY>;
     const Axis ax = make_axis(w.x0, w.x1, w.W, G::TX, HX), ay = make_axis(ga, gb, w.H, G::TY, HY);
-    k_jacobi_tb<NW, RY, HX, HY, BPC><<<dim3(ax.n * ay.n, 1, 1), dim3(64, NW, 1), 0, s>>>(w, p, div, p_out, pscale, iters, ga, gb, ax.S, ay.S, ax.n,
-                                                                                 ay.n, xcd_remap());
+#ifdef FLUID_TB_REPEAT
+    const int rep = FLUID_TB_REPEAT;
+#else
+    const int rep = 1;
+#endif
+    k_jacobi_tb<NW, RY, HX, HY, BPC><<<dim3(ax.n * ay.n * rep, 1, 1), dim3(64, NW, 1), 0, s>>>(w, p, div, p_out, pscale, iters, ga, gb, ax.S, ay.S, ax.n,
+                                                                                       ay.n, xcd_remap());
     return hipGetLastError();
 }
 
