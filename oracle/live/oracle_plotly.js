@@ -14,12 +14,17 @@
 //   randomSplats       n -> multipleSplats(n) after the fields are re-created
 //   splats             [[x,y,dx,dy,r,g,b], ...] explicit splat() calls
 //   inject             {velocity|pressure|divergence|curl|dye: base64 fp32} exact state upload
+//   synth              {velocity|pressure|divergence|curl|dye: {seed, noise, amp: [per channel], cx, cy, R2}} exact state generated
+//                      IN THE PAGE (grids too large to upload, 4096^2): texel (i, j), channel c gets
+//                      fround(amp[c] * shape_c(x, y) + (mulberry32_k - 0.5) * noise), x = (i + .5) / W, y = (j + .5) / H,
+//                      shapes: a compact vortex (-(y - cy) g, (x - cx) g, g, x y with g = max(0, 1 - r2 / R2)^2), k = (j W + i) nch + c;
+//                      doubles and + - * / max only, so tests/synth.py reproduces every value bit for bit in numpy
 //   passes             ["curl","vorticity",...] run single passes instead of step()
 //   resizeTo           {SIM_RESOLUTION, DYE_RESOLUTION} -> initFramebuffers() again after the steps
 //   steps, dt, timing, noDump
 //   halfTargets        true: every draw into a simulation framebuffer is followed by an fp16 round trip of that attachment
 //                      (half-float render targets emulated around the unmodified reference: its shaders, a 16F target's rounding)
-//   sample             {stride, band: [row0, row1]}: instead of the full dumps, per field every stride-th row / column, the rows of
+//   sample             {stride, band: [row0, row1], bands: [[row0, row1], ...]}: instead of the full dumps, per field every stride-th row / column, the rows of
 //                      the band at full resolution and max |value| (grids too large to return whole, e.g. 4096^2)
 //   render             {config: {SHADING, BLOOM, SUNRAYS, TRANSPARENT, BACK_COLOR, BLOOM_*, SUNRAYS_*, CAPTURE_RESOLUTION},
 //                       dither: {w, h, seed}} -> after the steps: the reference's captureScreenshot() up to the PNG
@@ -156,6 +161,32 @@
       if (inj.divergence) upload(divergence, 1, unb64(inj.divergence));
       if (inj.curl) upload(curl, 1, unb64(inj.curl));
       if (inj.dye) upload(dye.read, 4, unb64(inj.dye));
+      function synth(target, nch, spec) {
+        var w = target.width, h = target.height, a = new Float32Array(w * h * nch), st = (spec.seed >>> 0), i, j, c, k = 0;
+        var amp = spec.amp || [0, 0, 0, 0], cx = spec.cx === undefined ? 0.5 : spec.cx, cy = spec.cy === undefined ? 0.5 : spec.cy;
+        var R2 = spec.R2 === undefined ? 0.1 : spec.R2, noise = spec.noise || 0;
+        for (j = 0; j < h; j++) {
+          var y = (j + 0.5) / h;
+          for (i = 0; i < w; i++) {
+            var x = (i + 0.5) / w, dx = x - cx, dy = y - cy, r2 = dx * dx + dy * dy, g = Math.max(0, 1 - r2 / R2); g = g * g;
+            for (c = 0; c < nch; c++) {
+              st = (st + 0x6D2B79F5) | 0;
+              var t = Math.imul(st ^ (st >>> 15), 1 | st);
+              t = (t + Math.imul(t ^ (t >>> 7), 61 | t)) ^ t;
+              var r = ((t ^ (t >>> 14)) >>> 0) / 4294967296;
+              var sh = c === 0 ? -dy * g : c === 1 ? dx * g : c === 2 ? g : x * y;
+              a[k++] = amp[c] * sh + (r - 0.5) * noise;
+            }
+          }
+        }
+        upload(target, nch, a);
+      }
+      var syn = P.synth || {};
+      if (syn.velocity) synth(velocity.read, 2, syn.velocity);
+      if (syn.pressure) synth(pressure.read, 1, syn.pressure);
+      if (syn.divergence) synth(divergence, 1, syn.divergence);
+      if (syn.curl) synth(curl, 1, syn.curl);
+      if (syn.dye) synth(dye.read, 4, syn.dye);
 
       if (P.randomSplats) multipleSplats(P.randomSplats);
       (P.splats || []).forEach(function (s) { splat(s[0], s[1], s[2], s[3], { r: s[4], g: s[5], b: s[6] }); });
@@ -315,11 +346,14 @@
       if (P.sample) {   // grids too large to ship whole: every `stride`-th row and column, rows [band[0], band[1]) in full, max |value|
         var sampleOf = function (target, nch) {
           var a = framebufferToTexture(target), w = target.width, h = target.height, S = P.sample.stride;
-          var b0 = P.sample.band[0], b1 = P.sample.band[1];
+          var bands = P.sample.bands || [P.sample.band], parts = [], nb;
+          for (nb = 0; nb < bands.length; nb++) parts.push(a.subarray(bands[nb][0] * w * 4, bands[nb][1] * w * 4));
+          var cat = new Float32Array(parts.reduce(function (n, q) { return n + q.length; }, 0)), off = 0;
+          for (nb = 0; nb < parts.length; nb++) { cat.set(parts[nb], off); off += parts[nb].length; }
           var sw = Math.ceil(w / S), sh = Math.ceil(h / S), sub = new Float32Array(sw * sh * 4), amax = 0, k, i, j;
           for (j = 0; j < sh; j++) for (i = 0; i < sw; i++) for (k = 0; k < 4; k++) sub[(j * sw + i) * 4 + k] = a[((j * S) * w + i * S) * 4 + k];
           for (i = 0; i < w * h; i++) for (k = 0; k < nch; k++) { var v = Math.abs(a[i * 4 + k]); if (v > amax) amax = v; }
-          return { sub: b64(sub), size: [sw, sh], band: b64(a.subarray(b0 * w * 4, b1 * w * 4)), absmax: amax };
+          return { sub: b64(sub), size: [sw, sh], band: b64(cat), absmax: amax };
         };
         out.samples = { velocity: sampleOf(velocity.read, 2), pressure: sampleOf(pressure.read, 1), divergence: sampleOf(divergence, 1),
                         curl: sampleOf(curl, 1), dye: sampleOf(dye.read, 4) };
