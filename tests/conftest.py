@@ -13,6 +13,32 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _gpu_unavailable():
+    """Why the -m gpu tests cannot run here (None if they can): libfluid_hip.so must load and see a HIP device."""
+    try:
+        import fluid_hip
+        n = fluid_hip.device_count()
+    except Exception as ex:  # library not built, or the HIP runtime is unusable
+        return "libfluid_hip.so unavailable: %s" % ex
+    return None if n > 0 else "no HIP device visible (fluid_device_count() == 0)"
+
+
+def pytest_collection_modifyitems(config, items):
+    """A plain `pytest tests` on a box without a GPU skips the gpu-marked tests instead of failing them one by one
+    (the product itself still fails loudly without a device: tests/test_abi.py::test_no_cpu_fallback)."""
+    gpu_items = [it for it in items if it.get_closest_marker("gpu")]
+    if not gpu_items:
+        return
+    expr = (config.getoption("markexpr") or "").strip()
+    if "gpu" in expr and "not gpu" not in expr:
+        return   # `-m gpu` was asked for explicitly (the GPU box): a missing library or device must FAIL there, never skip
+    why = _gpu_unavailable()
+    if why:
+        skip = pytest.mark.skip(reason="needs an MI355X: " + why)
+        for it in gpu_items:
+            it.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as O

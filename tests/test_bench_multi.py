@@ -1,0 +1,65 @@
+"""bench.py's N > 1 branch before hardware runs it: rendezvous, StripeSim set-up, barrier, MAX-over-ranks time, halo check and
+the JSON line, on two CPU ranks over gloo with the CPU oracle injected as the stripe engine through bench.main()'s test hook
+(the command line cannot select an engine: `python bench.py` always measures libfluid_hip.so).  Also: a launch that cannot
+work prints ONE JSON line with `error` instead of dying silently."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank(rank, world, port, out_dir, argv):
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (ROOT, os.path.join(ROOT, "webgl-fluid-simulation_amd"), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    fd = os.open(os.path.join(out_dir, "stdout_%d.txt" % rank), os.O_WRONLY | os.O_CREAT | os.O_TRUNC)
+    os.dup2(fd, 1)     # bench.py writes its one JSON line to the process's stdout descriptor
+    import bench
+    from oracle_engine import OracleStripeEngine
+    bench.main(argv, engine_factory=OracleStripeEngine, backend="gloo")
+
+
+def test_bench_two_ranks_over_gloo(oracle, tmp_path):
+    import torch.multiprocessing as mp
+    argv = ["--gpus", "2", "--size", "64", "--iters", "20", "--steps", "3", "--warmup", "1", "--halo", "8", "--cpu-budget", "0", "--comm-timeout", "100"]
+    mp.spawn(_rank, args=(2, _free_port(), str(tmp_path), argv), nprocs=2, join=True)
+    lines0 = [l for l in open(os.path.join(str(tmp_path), "stdout_0.txt")).read().splitlines() if l.strip()]
+    lines1 = [l for l in open(os.path.join(str(tmp_path), "stdout_1.txt")).read().splitlines() if l.strip()]
+    assert len(lines0) == 1 and not lines1, (lines0, lines1)     # exactly ONE JSON line, from rank 0
+    d = json.loads(lines0[0])
+    assert "error" not in d
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["unit"] == "GLUPS"
+    assert d["config"]["parallelism"] == "stripes2"
+    assert "64x128" in d["config"]["workload"]                   # weak scaling: one 64 x 64 stripe per rank
+    # halo 8: blocks of <= 5 Jacobi iterations -> {velocity, pressure} + 3 further pressure exchanges + {velocity, dye}
+    assert d["config"]["exchanges_per_step"] == 5
+    assert d["config"]["driver"].startswith("hosted")
+    assert d["value"] > 0 and d["ms_per_step"] > 0
+    assert abs(d["value"] - 64 * 128 * d["steps_per_sec"] / 1e9) <= 1e-4   # WHOLE-job cells per second (the line rounds to 1e-4 GLUPS)
+    assert "roofline" not in d and "cpu_baseline" not in d       # rank 0 at N = 1 only
+
+
+def test_bench_reports_a_launch_that_cannot_work():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cpu-budget", "0"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode != 0
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] is None and "torch.distributed.run" in d["error"]

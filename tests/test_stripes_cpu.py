@@ -148,6 +148,7 @@ class _RecordingEngine:
         return contextlib.nullcontext()
 
     def close(self): pass
+    def check_halo(self): pass
     def curl_vorticity_divergence(self, curl, dt, ext): self.log.append(("curl_vorticity_divergence", 0, ext))
     def clear(self, value, ext): self.log.append(("clear", 0, ext))
     def clear_jacobi(self, value, iters, ext): self.log.append(("clear_jacobi", iters, ext))

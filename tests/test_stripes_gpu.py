@@ -99,10 +99,10 @@ def test_native_group_halo_overflow_raises():
     g = StripeGroup(2, canvas=(256, 256), config={"SIM_RESOLUTION": 64, "DYE_RESOLUTION": 64, "PRESSURE_ITERATIONS": 4}, halo=4)
     try:
         g.splat(0.5, 0.5, 0.0, 90000.0, (1, 1, 1))
-        g.step(0.016666)
         with pytest.raises(fluid_hip.FluidError) as e:
-            g.check_halo()
+            g.step(0.016666)     # the step that samples a row / column that was not refreshed fails itself (FLUID_ERR_HALO) ...
         assert e.value.status == -5
+        g.check_halo()           # ... and resets the counter
     finally:
         g.close()
 
@@ -110,7 +110,7 @@ def test_native_group_halo_overflow_raises():
 @pytest.mark.parametrize("overlap", [True, False])
 def test_native_group_back_trace_beyond_reach_is_reported(overlap):
     """only `reach` ghost rows are refreshed before the advection: a longer back-trace must not be served from a stale
-    (or in-flight) row — it is counted, and check_halo raises"""
+    (or in-flight) row — it is counted, and the step raises"""
     import fluid_hip
     from fluid_hip.stripes import StripeGroup
     cfg = {"SIM_RESOLUTION": 256, "DYE_RESOLUTION": 256, "PRESSURE_ITERATIONS": 10}
@@ -118,10 +118,10 @@ def test_native_group_back_trace_beyond_reach_is_reported(overlap):
     try:
         assert g.engines[0].advect_exchange_rows() == (3, 3)
         g.splat(0.5, 0.5, 0.0, 800.0, (1, 1, 1))      # dt * |v| = 13 rows > reach 3, < halo 32
-        g.step(0.016666)
         with pytest.raises(fluid_hip.FluidError) as e:
-            g.check_halo()
+            g.step(0.016666)     # the step that samples a row / column that was not refreshed fails itself (FLUID_ERR_HALO) ...
         assert e.value.status == -5
+        g.check_halo()           # ... and resets the counter
     finally:
         g.close()
 
@@ -265,10 +265,10 @@ def test_native_tile_group_back_trace_beyond_reach_is_reported():
     g = StripeGroup(2, canvas=(256, 256), config=cfg, halo=32, reach=3, tiles_x=2)     # 1 x 2: only ghost columns
     try:
         g.splat(0.5, 0.5, 800.0, 0.0, (1, 1, 1))       # a horizontal jet across the tile border: dt * |v| = 13 columns > 3
-        g.step(0.016666)
         with pytest.raises(fluid_hip.FluidError) as e:
-            g.check_halo()
+            g.step(0.016666)     # the step that samples a row / column that was not refreshed fails itself (FLUID_ERR_HALO) ...
         assert e.value.status == -5
+        g.check_halo()           # ... and resets the counter
     finally:
         g.close()
 

@@ -24,51 +24,29 @@ if [ "$MODE" != "quick" ]; then
   echo "smoke exit $?" | tee -a "$OUT/log.txt"
 fi
 
-echo "== bench (headline) ==" | tee -a "$OUT/log.txt"
-timeout 600 python bench.py >"$OUT/bench.json" 2>"$OUT/bench.err"
+echo "== bench (headline; the PMC traffic passes and the reference baseline run inside it) ==" | tee -a "$OUT/log.txt"
+FLUID_BENCH_KEEP_PMC="$OUT" timeout 1200 python bench.py >"$OUT/bench.json" 2>"$OUT/bench.err"
 echo "bench exit $?" | tee -a "$OUT/log.txt"
 cat "$OUT/bench.json" | tee -a "$OUT/log.txt"
 
+echo "== bench as the driver runs it: --steps 20 --warmup 5 ==" | tee -a "$OUT/log.txt"
+timeout 900 python bench.py --steps 20 --warmup 5 --cpu-budget 0 --no-traffic >"$OUT/bench_driver_flags.json" 2>>"$OUT/bench.err"
+cat "$OUT/bench_driver_flags.json" | tee -a "$OUT/log.txt"
+
 echo "== bench passes schedule ==" | tee -a "$OUT/log.txt"
-timeout 600 python bench.py --schedule passes --cpu-budget 0 >"$OUT/bench_passes.json" 2>>"$OUT/bench.err"
+FLUID_BENCH_KEEP_PMC="$OUT" timeout 900 python bench.py --schedule passes --cpu-budget 0 --no-steady >"$OUT/bench_passes.json" 2>>"$OUT/bench.err"
 cat "$OUT/bench_passes.json" | tee -a "$OUT/log.txt"
 
-echo "== bench --stripes (stripe driver at N=1) ==" | tee -a "$OUT/log.txt"
-timeout 600 python bench.py --stripes --cpu-budget 0 >"$OUT/bench_stripes1.json" 2>>"$OUT/bench.err"
-cat "$OUT/bench_stripes1.json" | tee -a "$OUT/log.txt"
-
 echo "== bench --storage f16 (side mode, SURVEY 8f N4) ==" | tee -a "$OUT/log.txt"
-timeout 600 python bench.py --storage f16 --cpu-budget 0 >"$OUT/bench_f16.json" 2>>"$OUT/bench.err"
+timeout 600 python bench.py --storage f16 --cpu-budget 0 --no-traffic --no-steady >"$OUT/bench_f16.json" 2>>"$OUT/bench.err"
 cat "$OUT/bench_f16.json" | tee -a "$OUT/log.txt"
 
 echo "== rocprofv3 kernel trace ==" | tee -a "$OUT/log.txt"
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o ks -- \
-    python "$GRAFT_REPO_ROOT/bench.py" --cpu-budget 0 >"$OUT/bench_under_rocprof.json" 2>"$OUT/rocprof.err" )
+    python "$GRAFT_REPO_ROOT/bench.py" --cpu-budget 0 --no-traffic --no-steady >"$OUT/bench_under_rocprof.json" 2>"$OUT/rocprof.err" )
 echo "rocprof exit $?" | tee -a "$OUT/log.txt"
-find "$OUT/prof" -name '*kernel_stats*' | head | tee -a "$OUT/log.txt"
 KS=$(find "$OUT/prof" -name '*kernel_stats.csv' | head -1)
 [ -n "$KS" ] && cp "$KS" "$OUT/kernel_stats.csv" && head -12 "$OUT/kernel_stats.csv" | cut -c1-200 | tee -a "$OUT/log.txt"
-
-if [ "$MODE" != "quick" ]; then
-  echo "== PMC passes (separate runs per counter, no tracing domains besides kernel-trace) ==" | tee -a "$OUT/log.txt"
-  for sched in fused passes; do
-    for ctr in FETCH_SIZE WRITE_SIZE; do
-      ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$OUT/pmc_${ctr}_${sched}" -o pmc -- \
-          python "$GRAFT_REPO_ROOT/bench.py" --steps 5 --warmup 0 --cpu-budget 0 --no-profile-pass --schedule $sched >/dev/null 2>>"$OUT/rocprof.err" )
-      F=$(find "$OUT/pmc_${ctr}_${sched}" -name '*counter_collection.csv' | head -1)
-      [ -n "$F" ] && cp "$F" "$OUT/pmc_${ctr}_${sched}.csv"
-      rm -rf "$OUT/pmc_${ctr}_${sched}"
-    done
-  done
-  python tools/pmc_traffic.py "$OUT/pmc_FETCH_SIZE_fused.csv" "$OUT/pmc_WRITE_SIZE_fused.csv" "$OUT/pmc_FETCH_SIZE_passes.csv" \
-      "$OUT/pmc_WRITE_SIZE_passes.csv" 4096 4096 "$OUT/traffic.json" >/dev/null 2>>"$OUT/log.txt"
-  python - "$OUT/traffic.json" <<'EOF' | tee -a "$OUT/log.txt"
-import json, sys
-t = json.load(open(sys.argv[1]))
-for k, v in t["kernels"].items():
-    print("%-28s %6.2f B/texel  (%d dispatches)" % (k, v["bytes_per_texel"], v["dispatches"]))
-EOF
-fi
 # keep the merged-back payload small
 rm -rf "$OUT/prof"
 echo "== done ==" | tee -a "$OUT/log.txt"

@@ -34,6 +34,14 @@
 //   velocity, dye, pressure, divergence, curl  950-954   sim.velocity ... (width/height/texelSize views)
 //
 // There is no CPU path: without the addon / a HIP device, createFluid() throws.
+//
+// Attribution.  The host-side functions in this file that have one natural spelling in JavaScript — the `config` literal, the
+// pointer prototype, updatePointerDownData / MoveData / UpData, correctDeltaX / correctDeltaY, splatPointer, multipleSplats,
+// generateColor, HSVtoRGB, normalizeColor, wrap, getResolution, scaleByPixelRatio and the listener bodies in dispatch() — follow
+// the reference's script.js closely (same names, same statements, `sim.` in front of what were globals) so that the shim is a
+// drop-in; they are
+//     Copyright (c) 2017 Pavel Dobryakov, MIT License
+// and the licence text is reproduced in NOTICE at the repository root.  Everything that talks to the device is original.
 'use strict';
 
 const FIELD = { velocity: 0, pressure: 1, divergence: 2, curl: 3, dye: 4 };

@@ -112,7 +112,7 @@ int check_ext(fluid_ctx* c, int ext, int need_in)
     // every neighbour row a pass reads must exist in the window (rows beyond the domain edge are clamped,
     // and row_range() clips the computed rows to the domain, so a whole-domain context accepts any ext)
     if (ext < 0) return c->fail(FLUID_ERR_INVALID, "negative ext");
-    if (c->desc.parts > 1 && ext + need_in > c->desc.halo)
+    if ((c->desc.parts > 1 || c->desc.parts_x > 1) && ext + need_in > c->desc.halo)  // 1 x N tile sets have ghost columns only: same bound
         return c->fail(FLUID_ERR_INVALID, "ext exceeds the ghost rows available to this pass");
     return FLUID_OK;
 }

@@ -676,7 +676,9 @@ int stripe_step_n(fluid_ctx* c, int n, float dt, const fluid_params* P)
                 CK(rccl_exchange_end(c));
             }
         }
-    return FLUID_OK;
+    // A back-trace longer than the refreshed ghost rows was counted by the advection kernels (Win::v0/v1): report it from the
+    // call that produced it — a caller that never asks fluid_halo_check must not get FLUID_OK with stale rows in its fields.
+    return n > 0 ? fluid_halo_check(c) : FLUID_OK;
 }
 
 void stripes_release(fluid_ctx* c)
@@ -872,6 +874,14 @@ int fluid_group_step_n(fluid_ctx** cs, int n_ctx, int steps, float dt, const flu
                 CK(tiles ? group_exchange_2d_end(cs, n_ctx) : group_exchange_end(cs, n_ctx));
             }
         }
+    if (steps > 0) {  // as in stripe_step_n: a reach violation fails the call that caused it (every stripe is checked and reset)
+        int rc = FLUID_OK;
+        for (int r = 0; r < n_ctx; r++) {
+            const int rc_r = fluid_halo_check(cs[r]);
+            if (rc == FLUID_OK) rc = rc_r;
+        }
+        return rc;
+    }
     return FLUID_OK;
 }
 

@@ -403,6 +403,8 @@ class StripeSim:
             return
         for _ in range(n):
             self._step_hosted(dt)
+        if n > 0:
+            self.engine.check_halo()   # as the native driver does: a reach violation fails the call that caused it
 
     def _step_hosted(self, dt: float):
         c, e, H = self.config, self.engine, self.halo
