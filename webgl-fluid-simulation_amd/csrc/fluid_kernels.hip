@@ -429,11 +429,7 @@ __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb(Win w
     using G = JacobiTB<NW, RY, HX, HY>;
     __shared__ float4 mail[2][NW][2][64];
     int bx, by;
-#ifdef FLUID_TB_REPEAT  // experiment: the grid holds FLUID_TB_REPEAT copies of the tile set (steady-state rate without per-launch tails)
-    tile_of_block((int)blockIdx.x % (nx * ny), nx, ny, remap, bx, by);
-#else
     tile_of_block((int)blockIdx.x, nx, ny, remap, bx, by);
-#endif
     const int x0 = xs + bx * G::VX, y0 = ys + by * G::VY;
     const bool edge = (x0 <= 0) || (x0 + G::TX >= w.W) || (y0 <= 0) || (y0 + G::TY >= w.H);
     if (edge) jacobi_tb_body<NW, RY, HX, HY, true>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
@@ -455,172 +451,6 @@ __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_h(Win
     const bool edge = (x0 <= 0) || (x0 + G::TX >= w.W) || (y0 <= 0) || (y0 + G::TY >= w.H);
     if (edge) jacobi_tb_body<NW, RY, HX, HY, true>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
     else jacobi_tb_body<NW, RY, HX, HY, false>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Streaming, time-pipelined Jacobi: the same iteration, deeper temporal blocking.
-//
-// The register tile above holds a 256 x 80 block at ONE time level, so its depth is bounded by the row apron it can afford
-// (10 of 80 rows per side) and a launch costs its memory time PLUS its arithmetic time (profiles/r02/
-// jacobi_gate_and_nontemporal.txt).  Here the rows of a 256-column strip STREAM through a pipeline of time levels instead.
-// Wave 0 of a workgroup is the FEEDER: it keeps M rows of pressure and divergence in flight from memory (static, unconditional
-// loads: the compiler's partial vmcnt waits keep all of them outstanding) and parks one (pressure, divergence) row pair per step
-// in LDS.  Waves 1 .. NW-1 are STAGES: stage j applies iterations (j-1)K+1 .. jK to every row that comes by, keeping only the
-// three-row window each level needs (two stored rows + the row that just arrived), and hands its output row — with the row's
-// divergence — to the next stage through LDS; the last stage stores.  Level g lags one row behind level g-1, so one STEP of
-// the workgroup takes one new row from memory, moves every level forward by one row and emits one finished row.  A stage
-// holds 2K+2 pressure rows and K+1 divergence rows whatever the length of the stream; the y-apron is not resident, it is merely
-// `iters` extra rows at each end of the stream, and only the x-apron (HX >= iters columns per side) costs width.
-// (NW-1) x K = 28 levels per pass: 50 iterations are two passes through HBM (12 B/texel each) instead of five, and the memory
-// traffic of a pass runs under the arithmetic of the stages.
-//
-// Ring discipline (static register renaming, the step loop is unrolled M = 2K+2 times): at step s a stage's input row enters
-// set s % M; window t-1 (the rows level t reads) is N = set s-2(t-1), B = set s-2(t-1)-1 (centre), A = set s-2(t-1)-2; level t
-// writes its result over A, which makes it the N of window t; the set s-2K leaves the stage at the end of the step.  The
-// divergence row that arrived with input row s sits in D set s % (K+1) and is the centre's divergence of level t at step s+t.
-// Per-level bookkeeping is wave-uniform (scalar): a level skips rows outside the trapezoid that still reaches the segment's
-// output rows after the remaining iterations, and levels beyond `iters` pass their centre row through.
-// Same per-row arithmetic (jacobi_row) as the tile kernel, hence the same bits as `iters` single passes.
-template <int NW, int K, int HX>
-struct JacobiStream {
-    static constexpr int TX = 256, VX = TX - 2 * HX, M = 2 * K + 2, MD = K + 1, DEPTH = (NW - 1) * K;
-    static_assert(HX % 4 == 0 && VX > 0, "column apron must keep float4 alignment");
-    static_assert(M % 2 == 0 && M % MD == 0, "ring periods must divide the unroll factor");
-    static_assert(NW >= 2, "a feeder and at least one stage");
-};
-
-// LDS of one workgroup: the (pressure, divergence) row a wave hands to the next one, double-buffered by step parity
-template <int NW>
-struct StreamLds {
-    float4 slot[2][NW][2][64];
-};
-
-__device__ __forceinline__ void stream_barrier()
-{
-    __syncthreads();
-}
-
-template <int NW, int K, int HX, bool EDGE, class T>
-__device__ __forceinline__ void jacobi_stream_body(const Win& w, const T* __restrict__ p, const T* __restrict__ div, T* __restrict__ p_out,
-                                                   float pscale, int iters, int ga, int gb, int x0, int ya, int yb, StreamLds<NW>& lds)
-{
-    constexpr bool HALF = sizeof(T) == 2;
-    using G = JacobiStream<NW, K, HX>;
-    constexpr int M = G::M, MD = G::MD;
-    const int lane = threadIdx.x;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);  // wave-uniform: all row bookkeeping on the scalar unit
-    const int cx = x0 + 4 * lane;
-    const unsigned cxs = (unsigned)min(max(cx, 0), w.W - 4);
-
-    const int y_lo = max(ya - iters, 0);                          // first input row of the stream
-    const int nsteps = (yb - y_lo) + (NW - 1) * (K + 1);          // until the last stage has emitted row yb - 1
-    auto row_at = [&](int q) -> size_t {                          // clamped: rows outside the window are never used by a live level
-        const int lr = min(max(q - w.g0, 0), w.rows - 1);
-        return (size_t)lr * (size_t)w.W + cxs;
-    };
-
-    if (wv == 0) {
-        // ---- feeder: row y_lo + s is parked at step s; M rows of each field are in flight ahead of it ----
-        const v2f ps = v2f{ pscale, pscale };
-        Quad RP[M], RD[M];
-#pragma unroll
-        for (int k = 0; k < M; k++) {
-            RP[k] = load_quad(p, row_at(y_lo + k));
-            RD[k] = load_quad(div, row_at(y_lo + k));
-        }
-        for (int s0 = 0; s0 < nsteps; s0 += M) {
-#pragma unroll
-            for (int u = 0; u < M; u++) {
-                Quad X = RP[u];
-                X.o = ps * X.o;  // clearShader folded in: value * p, same rounding as the separate pass
-                X.i = ps * X.i;
-                if (HALF) {
-                    X.o = round_half(X.o);
-                    X.i = round_half(X.i);
-                }
-                lds.slot[(u + 1) & 1][0][0][lane] = raw_of(X);
-                lds.slot[(u + 1) & 1][0][1][lane] = raw_of(RD[u]);
-                RP[u] = load_quad(p, row_at(y_lo + s0 + u + M));
-                RD[u] = load_quad(div, row_at(y_lo + s0 + u + M));
-                stream_barrier();
-            }
-        }
-        return;
-    }
-
-    // ---- stage wv: levels (wv-1)K+1 .. wv K; its input row at step s is row qbase + s (handed over by wave wv-1 at step s-1) ----
-    const bool at_left = (cx == 0), at_right = (cx + 3 == w.W - 1);
-    const int qbase = y_lo - 1 - (wv - 1) * (K + 1);
-    Quad P[M], D[MD];
-    const Quad zero = { v2f{ 0.f, 0.f }, v2f{ 0.f, 0.f } };
-#pragma unroll
-    for (int k = 0; k < M; k++) P[k] = zero;
-#pragma unroll
-    for (int k = 0; k < MD; k++) D[k] = zero;
-    int xa, xb;
-    tile_exact(x0, G::TX, HX, w.W, w.x0, w.x1, xa, xb);
-    const bool col_store = (cx >= xa) && (cx < xb);
-    const int out_lo = max(ya, ga), out_hi = min(yb, gb);
-
-    for (int s0 = 0; s0 < nsteps; s0 += M) {
-#pragma unroll
-        for (int u = 0; u < M; u++) {
-            const int q = qbase + s0 + u;
-            P[u] = quad_of_raw(lds.slot[u & 1][wv - 1][0][lane]);       // what wave wv-1 parked at the end of the previous step
-            D[u % MD] = quad_of_raw(lds.slot[u & 1][wv - 1][1][lane]);
-#pragma unroll
-            for (int t = 1; t <= K; t++) {
-                constexpr int MM = 4 * M;
-                const int iN = (u - 2 * (t - 1) + MM) % M, iB = (iN + M - 1) % M, iA = (iN + M - 2) % M;
-                const int g = (wv - 1) * K + t;                // global level of this update
-                const int c = q - t;                           // its centre row
-                const int need = g <= iters ? iters - g : 0;   // iterations still to come: how far beyond [ya, yb) this level matters
-                if (c >= max(ya - need, 0) && c < min(yb + need, w.H)) {
-                    if (g <= iters) P[iA] = jacobi_row<EDGE, HALF>(P[iB], P[iN], P[iA], D[(u - t + MM) % MD], c, w.H, at_left, at_right);
-                    else P[iA] = P[iB];
-                }
-            }
-            const Quad E = P[(u - 2 * K + 4 * M) % M];                  // row q - K after this stage's K levels ...
-            if (wv == NW - 1) {
-                const int r = q - K;
-                if (col_store && r >= out_lo && r < out_hi) store_quad(p_out, (size_t)(r - w.g0) * (size_t)w.W + (unsigned)cx, E);
-            } else {
-                lds.slot[(u + 1) & 1][wv][0][lane] = raw_of(E);
-                lds.slot[(u + 1) & 1][wv][1][lane] = raw_of(D[(u - K + 4 * M) % MD]);   // ... travels with its divergence row
-            }
-            stream_barrier();
-        }
-    }
-}
-
-template <int NW, int K, int HX>
-__global__ void __launch_bounds__(64 * NW, (2 * NW + 3) / 4) k_jacobi_stream(Win w, const float* __restrict__ p, const float* __restrict__ div,
-                                                                            float* __restrict__ p_out, float pscale, int iters, int ga, int gb,
-                                                                            int xs, int nx, int seg, int ny, int remap)
-{
-    using G = JacobiStream<NW, K, HX>;
-    __shared__ StreamLds<NW> lds;
-    int bx, by;
-    tile_of_block((int)blockIdx.x, nx, ny, remap, bx, by);
-    const int x0 = xs + bx * G::VX, ya = ga + by * seg, yb = min(ya + seg, gb);
-    const bool edge = (x0 <= 0) || (x0 + G::TX >= w.W) || (ya - iters <= 0) || (yb + iters >= w.H);
-    if (edge) jacobi_stream_body<NW, K, HX, true>(w, p, div, p_out, pscale, iters, ga, gb, x0, ya, yb, lds);
-    else jacobi_stream_body<NW, K, HX, false>(w, p, div, p_out, pscale, iters, ga, gb, x0, ya, yb, lds);
-}
-
-template <int NW, int K, int HX>
-__global__ void __launch_bounds__(64 * NW, (2 * NW + 3) / 4) k_jacobi_stream_h(Win w, const __half* __restrict__ p, const __half* __restrict__ div,
-                                                                              __half* __restrict__ p_out, float pscale, int iters, int ga, int gb,
-                                                                              int xs, int nx, int seg, int ny, int remap)
-{
-    using G = JacobiStream<NW, K, HX>;
-    __shared__ StreamLds<NW> lds;
-    int bx, by;
-    tile_of_block((int)blockIdx.x, nx, ny, remap, bx, by);
-    const int x0 = xs + bx * G::VX, ya = ga + by * seg, yb = min(ya + seg, gb);
-    const bool edge = (x0 <= 0) || (x0 + G::TX >= w.W) || (ya - iters <= 0) || (yb + iters >= w.H);
-    if (edge) jacobi_stream_body<NW, K, HX, true>(w, p, div, p_out, pscale, iters, ga, gb, x0, ya, yb, lds);
-    else jacobi_stream_body<NW, K, HX, false>(w, p, div, p_out, pscale, iters, ga, gb, x0, ya, yb, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -964,13 +794,8 @@ hipError_t launch_tb(hipStream_t s, Win w, const float* p, const float* div, flo
 {
     using G = JacobiTB<NW, RY, HX, HY>;
     const Axis ax = make_axis(w.x0, w.x1, w.W, G::TX, HX), ay = make_axis(ga, gb, w.H, G::TY, HY);
-#ifdef FLUID_TB_REPEAT
-    const int rep = FLUID_TB_REPEAT;
-#else
-    const int rep = 1;
-#endif
-    k_jacobi_tb<NW, RY, HX, HY, BPC><<<dim3(ax.n * ay.n * rep, 1, 1), dim3(64, NW, 1), 0, s>>>(w, p, div, p_out, pscale, iters, ga, gb, ax.S, ay.S, ax.n,
-                                                                                       ay.n, xcd_remap());
+    k_jacobi_tb<NW, RY, HX, HY, BPC><<<dim3(ax.n * ay.n, 1, 1), dim3(64, NW, 1), 0, s>>>(w, p, div, p_out, pscale, iters, ga, gb, ax.S, ay.S, ax.n,
+                                                                                 ay.n, xcd_remap());
     return hipGetLastError();
 }
 
@@ -1161,79 +986,16 @@ hipError_t launch_curl_vort_div(hipStream_t s, Win w, const __half2* vel, __half
     return hipGetLastError();
 }
 
-// ---- the streaming kernel behind the same launcher interface (launch_jacobi_tb): FLUID_JACOBI_STREAM=0 keeps the register tile ----
-struct StreamShape { int nw, k, hx; };
-constexpr StreamShape kStream[] = {
-    {8, 4, 28},  // 0: default — a feeder + 7 stages x 4 levels: up to 28 iterations per pass (50 = 25 + 25)
-    {8, 3, 20},  // 1: 21 levels
-    {8, 2, 12},  // 2: 14 levels
-};
-constexpr int kNumStream = sizeof(kStream) / sizeof(kStream[0]);
-int stream_variant()  // FLUID_JACOBI_STREAM: -1/0 = off (register tile), 1.. = shape index + 1 (A/B knob, read once)
-{
-    static const int v = [] {
-        const char* e = getenv("FLUID_JACOBI_STREAM");
-        const int k = e ? atoi(e) : 0;  // off until it beats the register tile on the 4096^2 step
-        return (k >= 1 && k <= kNumStream) ? k - 1 : -1;
-    }();
-    return v;
-}
-int stream_target_wgs()  // FLUID_STREAM_WGS: workgroups a launch is cut into (strips x row segments); default two per CU
-{
-    static const int v = [] {
-        const char* e = getenv("FLUID_STREAM_WGS");
-        const int k = e ? atoi(e) : 512;
-        return k > 0 ? k : 512;
-    }();
-    return v;
-}
-
-template <int NW, int K, int HX, class T>
-hipError_t launch_stream(hipStream_t s, Win w, const T* p, const T* div, T* p_out, float pscale, int iters, int ga, int gb)
-{
-    using G = JacobiStream<NW, K, HX>;
-    const Axis ax = make_axis(w.x0, w.x1, w.W, G::TX, HX);
-    const int rows = gb - ga;
-    int ny = stream_target_wgs() / ax.n;  // never more workgroups than asked for: one more than fits is a whole second round
-    if (ny < 1) ny = 1;
-    int seg = (rows + ny - 1) / ny;
-    if (seg < 16) seg = 16;  // a stream shorter than its own pipeline is all fill and flush
-    ny = (rows + seg - 1) / seg;
-    if constexpr (sizeof(T) == 2)
-        k_jacobi_stream_h<NW, K, HX><<<dim3(ax.n * ny, 1, 1), dim3(64, NW, 1), 0, s>>>(w, p, div, p_out, pscale, iters, ga, gb, ax.S, ax.n, seg, ny, xcd_remap());
-    else
-        k_jacobi_stream<NW, K, HX><<<dim3(ax.n * ny, 1, 1), dim3(64, NW, 1), 0, s>>>(w, p, div, p_out, pscale, iters, ga, gb, ax.S, ax.n, seg, ny, xcd_remap());
-    return hipGetLastError();
-}
-
-template <class T>
-hipError_t launch_stream_variant(hipStream_t s, Win w, const T* p, const T* div, T* p_out, float pscale, int iters, int ga, int gb)
-{
-    switch (stream_variant()) {
-    case 0: return launch_stream<8, 4, 28>(s, w, p, div, p_out, pscale, iters, ga, gb);
-    case 1: return launch_stream<8, 3, 20>(s, w, p, div, p_out, pscale, iters, ga, gb);
-    case 2: return launch_stream<8, 2, 12>(s, w, p, div, p_out, pscale, iters, ga, gb);
-    default: return hipErrorInvalidValue;
-    }
-}
-int stream_max_iters()
-{
-    const StreamShape& v = kStream[stream_variant()];
-    const int depth = (v.nw - 1) * v.k;  // wave 0 feeds, the others hold k levels each
-    return v.hx < depth ? v.hx : depth;
-}
-
-int jacobi_tb_max_iters() { return stream_variant() >= 0 ? stream_max_iters() : kTB[tb_variant()].hy; }
+int jacobi_tb_max_iters() { return kTB[tb_variant()].hy; }
 
 // fp16 storage: the default tile shape only (8 waves x 10 rows, apron 12 x 10)
 constexpr int kHalfTB[5] = { 8, 10, 12, 10, 2 };
-int jacobi_tb_max_iters_f16() { return stream_variant() >= 0 ? stream_max_iters() : kHalfTB[3]; }
+int jacobi_tb_max_iters_f16() { return kHalfTB[3]; }
 
 hipError_t launch_jacobi_tb(hipStream_t s, Win w, const __half* p, const __half* div, __half* p_out, float pscale, int iters, int ga, int gb)
 {
     ROWS_OR_RETURN();
     if (iters < 1 || iters > jacobi_tb_max_iters_f16() || !jacobi_tb_supported(w)) return hipErrorInvalidValue;
-    if (stream_variant() >= 0) return launch_stream_variant(s, w, p, div, p_out, pscale, iters, ga, gb);
     constexpr int NW = kHalfTB[0], RY = kHalfTB[1], HX = kHalfTB[2], HY = kHalfTB[3], BPC = kHalfTB[4];
     using G = JacobiTB<NW, RY, HX, HY>;
     const Axis ax = make_axis(w.x0, w.x1, w.W, G::TX, HX), ay = make_axis(ga, gb, w.H, G::TY, HY);
@@ -1249,7 +1011,6 @@ hipError_t launch_jacobi_tb(hipStream_t s, Win w, const float* p, const float* d
 {
     ROWS_OR_RETURN();
     if (iters < 1 || iters > jacobi_tb_max_iters() || !jacobi_tb_supported(w)) return hipErrorInvalidValue;
-    if (stream_variant() >= 0) return launch_stream_variant(s, w, p, div, p_out, pscale, iters, ga, gb);
     switch (tb_variant()) {
 #define TB_CASE(k, NW, RY, HX, HY, BPC)                                                                                         \
     case k:                                                                                                                     \
