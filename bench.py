@@ -362,10 +362,9 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         avg_ms = tm["jacobi_ms"] / launches
         half = 0.5 if args.storage == "f16" else 1.0
         alg_launch = 12.0 * iters * size * size * tm["steps"] / launches * half  # 12 B/cell/iteration, SURVEY.md 8(d)
-        # the kernel that runs the loop: the streaming kernel by default, the register tile with FLUID_JACOBI_STREAM=0 (A/B knob),
-        # one launch per iteration under --schedule passes
+        # the kernel that runs the loop: the temporally blocked register tile, or one launch per iteration under --schedule passes
         if args.schedule == "fused":
-            cands = ["k_jacobi_tb", "k_jacobi_stream"] if os.environ.get("FLUID_JACOBI_STREAM", "1") in ("0", "-1") else ["k_jacobi_stream", "k_jacobi_tb"]
+            cands = ["k_jacobi_tb"]
         else:
             cands = ["k_h_jacobi", "k_jacobi"] if args.storage == "f16" else ["k_jacobi"]
         kname = cands[0]
