@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define FLUID_ABI_VERSION 5
+#define FLUID_ABI_VERSION 6
 
 typedef enum fluid_status {
     FLUID_OK = 0,
@@ -102,6 +102,10 @@ typedef struct fluid_field_info {
     int col0, cols;     /* owned global columns [col0, col0 + cols)      */
     int halo_x;         /* ghost columns each side (0 unless parts_x > 1) */
     int bytes_per_channel; /* 4 (FLUID_STORE_F32) or 2 (FLUID_STORE_F16): element size of the DEVICE array       */
+    /* layout of the device array (fluid_field_device_ptr): array row r = global row row0 - halo + r, array column k = global
+     * column array_col0 + k, `pitch` texels per array row (a multiple of 4 >= the columns held: rows stay 16-byte aligned for
+     * every width; a 2-D tile holds its owned + ghost columns only).  Columns beyond the field's width are padding. */
+    int pitch, array_col0;
 } fluid_field_info;
 
 /* per-pass device time of the last fluid_step*(), filled when timing is enabled */

@@ -27,10 +27,16 @@ def test_fused_equals_passes_bitwise(N):
 
 
 @pytest.mark.parametrize("canvas,res,dye", [((512, 512), 64, 64), ((520, 300), 300, 300), ((1000, 40), 40, 40), ((4096, 128), 128, 128),
-                                            ((256, 3000), 256, 256), ((640, 480), 240, 480), ((250, 130), 130, 130)])
+                                            ((256, 3000), 256, 256), ((640, 480), 240, 480), ((250, 130), 130, 130),
+                                            # widths that are not multiples of 4 (most of what getResolution, script.js:1612-1624, produces):
+                                            # 1001 x 300, 303 x 128 (the 2560 x 1080 canvas at SIM_RESOLUTION 128), 257 x 64 (one tile + 1 column),
+                                            # 1366 x 768 -> 455 x 256 with a 910 x 512 dye grid, and grids narrower than one quad
+                                            ((1001, 300), 300, 300), ((2560, 1080), 128, 128), ((257, 64), 64, 64), ((1366, 768), 256, 512),
+                                            ((3, 64), 3, 3), ((64, 5), 5, 5), ((1, 1), 1, 1)])
 def test_fused_equals_passes_bitwise_odd_shapes(canvas, res, dye):
     """tile-boundary coverage of the fused kernels: widths/heights that are not multiples of the tile, grids
-    smaller than one tile, W % 4 != 0 (falls back to the per-pass kernels), dye grid != sim grid"""
+    smaller than one tile, W % 4 != 0 (the last quad of a row is partly padding), dye grid != sim grid — and the fused
+    schedule really runs its register-tile kernels at every width (launch counts)"""
     import fluid_hip
     cfg = {"SIM_RESOLUTION": res, "DYE_RESOLUTION": dye, "PRESSURE_ITERATIONS": 23}
     sims = [fluid_hip.FluidSim(canvas=canvas, config=cfg, schedule=s, random=fluid_hip.mulberry32(5)) for s in ("passes", "fused")]
@@ -40,6 +46,15 @@ def test_fused_equals_passes_bitwise_odd_shapes(canvas, res, dye):
             s.step(0.016666, 3)
         for k in ("velocity", "pressure", "divergence", "curl", "dye"):
             assert np.array_equal(sims[0].read(k), sims[1].read(k)), k
+        for s, launches in zip(sims, (23, 3)):     # 23 iterations: one launch each, or three temporally blocked launches of <= 10
+            s.set_timing(True)
+            s.step(0.016666, 2)
+            s.sync()
+            t = s.timings()
+            s.set_timing(False)
+            assert t["steps"] == 2 and t["jacobi_launches"] == 2 * launches, (s.schedule if hasattr(s, "schedule") else "", t)
+            if launches == 3:
+                assert t["curl_ms"] == 0 and t["divergence_ms"] == 0     # curl + vorticity + divergence ran as ONE kernel
     finally:
         for s in sims:
             s.close()

@@ -62,15 +62,28 @@ int default_dither(fluid_ctx* c, fluid_display_state* d)
 // fp32 in both modes.
 int dye_texels(fluid_ctx* c, fluid_display_state* d, const float4** read, float4** write)
 {
-    if (c->storage == FLUID_STORE_F32) {
+    const bool dense = c->dye.P == c->dye.W;   // the compositor's kernels take dense W x H images
+    if (c->storage == FLUID_STORE_F32 && dense) {
         *read = (const float4*)c->dyeb[0];
         *write = (float4*)c->dyeb[1];
         return FLUID_OK;
     }
-    for (auto& b : d->dye32) CK(ensure(c, b, c->dye.W, c->dye.H, sizeof(float4)));
-    HIPCK(c, launch_widen(c->stream, (const __half*)c->dyeb[0], (float*)d->dye32[0].p, (size_t)c->dye.W * c->dye.H * 4));
+    for (auto& b : d->dye32) CK(ensure(c, b, c->dye.P, c->dye.H, sizeof(float4)));
+    const float4* src = (const float4*)c->dyeb[0];
+    if (c->storage != FLUID_STORE_F32) {   // widen (exact) into the second scratch image, pitch and all
+        HIPCK(c, launch_widen(c->stream, (const __half*)c->dyeb[0], (float*)d->dye32[1].p, (size_t)c->dye.P * c->dye.H * 4));
+        src = (const float4*)d->dye32[1].p;
+        if (dense) {
+            *read = src;
+            *write = (float4*)d->dye32[0].p;
+            return FLUID_OK;
+        }
+    }
+    // a width that is not a multiple of 4 keeps padding columns in every row (pitch > width): compact it
+    HIPCK(c, hipMemcpy2DAsync(d->dye32[0].p, (size_t)c->dye.W * sizeof(float4), src, (size_t)c->dye.P * sizeof(float4), (size_t)c->dye.W * sizeof(float4),
+                              (size_t)c->dye.H, hipMemcpyDeviceToDevice, c->stream));
     *read = (const float4*)d->dye32[0].p;
-    *write = (float4*)d->dye32[1].p;
+    *write = (float4*)d->dye32[1].p;   // the sunrays mask goes to scratch (the widened copy, if any, is consumed by now)
     return FLUID_OK;
 }
 

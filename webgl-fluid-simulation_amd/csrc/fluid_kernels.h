@@ -6,23 +6,34 @@
 
 namespace fluid {
 
-// A window onto one field: the device array holds `rows` rows of a field whose global size is
+// A window onto one field: the device array holds `rows` rows x P columns of a field whose global size is
 // W x H; array row r is global row g0 + r (g0 < 0 is allowed: ghost rows below the domain are
-// allocated but never addressed).  Whole domain: g0 = 0, rows = H.
+// allocated but never addressed), array column k is global column c0 + k.  Whole domain: g0 = 0, rows = H, c0 = 0.
 struct Win {
     int W, H;
     int g0;
     int rows;
+    // Columns: c0 (a multiple of 4) is the global column of array column 0 and P the pitch — columns per array row, a multiple
+    // of 4 so that every row starts float4-aligned whatever W is.  The array covers global columns [c0, c0 + P); columns
+    // beyond W - 1 (W % 4 != 0) or beyond what a tile needs are padding: loaded by the four-texel lanes, never meaningful.
+    // Whole width: c0 = 0, P = W rounded up to 4.  A 2-D tile: its owned columns + ghost columns only.
+    int c0, P;
     // Global rows [v0, v1) hold data a GATHER (bilinear fetch) may use: the advection / resample kernels count every
     // tap outside as a miss.  Normally the whole window; the stripe driver narrows it to the rows that are fresh at
     // that moment (owned rows while an exchange is in flight, owned + exchanged rows afterwards).
     int v0, v1;
-    // 2-D tile decomposition: the arrays always span the full width W (columns a rank does not own are simply never
-    // touched), a launch writes columns [x0, x1) only, and gathers may use columns [u0, u1).  Whole width: 0, W.
+    // A launch writes columns [x0, x1) only, and gathers may use columns [u0, u1) (2-D tile decomposition; the whole
+    // width otherwise: 0, W).
     int x0, x1;
     int u0, u1;
 };
-inline Win make_win(int W, int H, int g0, int rows) { return Win{ W, H, g0, rows, g0, g0 + rows, 0, W, 0, W }; }
+inline int pitch_of(int cols) { return (cols + 3) & ~3; }
+inline Win make_win(int W, int H, int g0, int rows) { return Win{ W, H, g0, rows, 0, pitch_of(W), g0, g0 + rows, 0, W, 0, W }; }
+// a window that holds global columns [ca, cb) only (ca a multiple of 4): the arrays of a 2-D tile
+inline Win make_win_cols(int W, int H, int g0, int rows, int ca, int cb)
+{
+    return Win{ W, H, g0, rows, ca, pitch_of(cb - ca), g0, g0 + rows, 0, W, 0, W };
+}
 
 // Storage of the fields (fluid_desc.storage): fp32 texels, or half texels (FLUID_STORE_F16: what the reference's
 // half-float textures hold on a real GPU, script.js:138, 145-147).  Arithmetic is fp32 either way; a store to a half
@@ -49,7 +60,7 @@ hipError_t launch_divergence(hipStream_t s, Win w, const float2* vel, float* div
 hipError_t launch_clear(hipStream_t s, Win w, const float* p, float* p_out, float value, int ga, int gb);
 hipError_t launch_jacobi(hipStream_t s, Win w, const float* p, const float* div, float* p_out, int ga, int gb);
 hipError_t launch_gradsub(hipStream_t s, Win w, const float* p, const float2* vel, float2* vel_out, int ga, int gb);
-// the same pass, four texels per lane (needs W % 4 == 0: fused_supported)
+// the same pass, four texels per lane
 hipError_t launch_gradsub4(hipStream_t s, Win w, const float* p, const float2* vel, float2* vel_out, int ga, int gb);
 hipError_t launch_advect_velocity(hipStream_t s, Win w, const float2* vel, float2* out, float dt, float dissipation,
                                   int ga, int gb, unsigned int* miss);
@@ -65,8 +76,23 @@ hipError_t launch_splat_dye(hipStream_t s, Win w, const float4* base, float4* ou
 hipError_t launch_resample(hipStream_t s, Win sw, const float* src, int nc, Win dw, float* dst);
 hipError_t launch_fill(hipStream_t s, float* dst, size_t n_vec, int nc, float v0, float v1, float v2, float v3);
 
+// Strided block copies for the ghost-column exchange of 2-D tiles (fluid_stripes.cpp): up to 8 rectangles — every field and
+// direction of one exchange phase — packed into (or unpacked from) contiguous staging in ONE launch on the comm stream.
+// `unit` = bytes per element moved (the channel size: 4, or 2 with fp16 storage); pitches and lines are multiples of it.
+struct CopyRect {
+    const char* src;
+    char* dst;
+    size_t spitch, dpitch;  // bytes between rows
+    unsigned line_units, nrows;
+};
+struct CopyRects {
+    CopyRect r[8];
+    int n, unit;
+};
+hipError_t launch_copy_rects(hipStream_t s, const CopyRects& R);
+
 // Fused curl -> vorticity -> divergence (K1+K2+K3): reads velocity rows [ga-3, gb+3) (clamped), writes curl,
-// the confined velocity and its divergence for rows [ga, gb).  Requires W % 4 == 0.  Bitwise equal to the three
+// the confined velocity and its divergence for rows [ga, gb).  Any width (the pitch keeps rows float4-aligned).  Bitwise equal to the three
 // single-pass kernels run in turn.
 bool fused_supported(Win w);
 hipError_t launch_curl_vort_div(hipStream_t s, Win w, const float2* vel, float* curl, float2* vel_out, float* div,
@@ -75,7 +101,7 @@ hipError_t launch_curl_vort_div(hipStream_t s, Win w, const float2* vel, float* 
 // Temporally blocked Jacobi: `iters` (<= jacobi_tb_max_iters()) iterations in one launch, every input
 // value scaled by `pscale` on load (pscale = config.PRESSURE folds the clear pass, 1.0f otherwise).
 // Reads p rows [ga - iters, gb + iters) (clamped to the domain), writes p_out rows [ga, gb).
-// Requires W % 4 == 0.  Bitwise equal to `iters` launches of launch_jacobi.
+// Any width.  Bitwise equal to `iters` launches of launch_jacobi.
 int jacobi_tb_max_iters();
 bool jacobi_tb_supported(Win w);
 hipError_t launch_jacobi_tb(hipStream_t s, Win w, const float* p, const float* div, float* p_out, float pscale,

@@ -17,6 +17,7 @@
 #include "fluid_math.h"
 #include "fluid_tiles.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace fluid {
@@ -128,7 +129,7 @@ __device__ __forceinline__ void advect_both_body(const Win& w, const V2* __restr
         on[k] = gj < gb;
         const int gjc = on[k] ? gj : gb - 1;  // a row past the band repeats the last one (loads stay in bounds, nothing stored)
         v[k] = ((float)gjc + 0.5f) / (float)w.H;
-        c[k] = (long)(gjc - w.g0) * w.W + i;
+        c[k] = at(w, gjc, i);
         vv[k] = ld(vel, c[k]);
     }
     Fetch2 f2[ROWS];
@@ -214,6 +215,18 @@ __global__ void __launch_bounds__(BX) k_fill(float* __restrict__ dst, size_t n, 
         for (int k = 0; k < NC; k++) dst[i * NC + k] = vals[k];
 }
 
+// ghost-column blocks of 2-D tiles: strided rectangle -> contiguous staging and back, all rectangles of a phase in one launch
+template <class U>
+__global__ void __launch_bounds__(BX) k_copy_rects(CopyRects R)
+{
+    const CopyRect q = R.r[blockIdx.y];
+    const size_t n = (size_t)q.line_units * q.nrows;
+    for (size_t idx = (size_t)blockIdx.x * BX + threadIdx.x; idx < n; idx += (size_t)gridDim.x * BX) {
+        const size_t row = idx / q.line_units, k = idx - row * q.line_units;
+        reinterpret_cast<U*>(q.dst + row * q.dpitch)[k] = reinterpret_cast<const U*>(q.src + row * q.spitch)[k];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Temporally blocked Jacobi (the hot loop: 82 % of the reference's bytes at 50 iterations).
 //
@@ -295,13 +308,18 @@ __device__ __forceinline__ v2f round_half(v2f v)
 // ((L + R) + B) + T - div) * 0.25): 11 VALU instructions for the lane's four texels.  HALF: the iteration's output goes
 // through fp16, as it does when the reference renders it into a half-float texture.
 template <bool EDGE, bool HALF = false>
-__device__ __forceinline__ Quad jacobi_row(const Quad C, Quad T, Quad B, const Quad D, int gj, int H, bool at_left, bool at_right)
+__device__ __forceinline__ Quad jacobi_row(Quad C, Quad T, Quad B, const Quad D, int gj, int H, bool at_left, int nv)
 {
+    if (EDGE && nv < 4) {  // the quad that holds column W - 1 of a width that is not a multiple of 4 (nv = its texels inside the
+        if (nv < 2) C.i.x = C.o.x;  // domain): CLAMP_TO_EDGE inside the quad — the texels beyond the edge repeat the last one, so
+        if (nv < 3) C.i.y = C.i.x;  // the horizontal sums below see the clamped neighbour (the padding columns hold no data)
+        C.o.y = C.i.y;
+    }
     float L = from_left_lane(C.o.y);   // column 4*lane - 1 = the left lane's c3
     float R = from_right_lane(C.o.x);  // column 4*lane + 4 = the right lane's c0
     if (EDGE) {  // CLAMP_TO_EDGE: an off-domain neighbour is the centre texel
         if (at_left) L = C.o.x;
-        if (at_right) R = C.o.y;
+        if (nv <= 4) R = C.o.y;  // the lane that holds column W - 1 (lanes beyond it only feed texels outside the domain)
         if (gj == 0) B = C;
         if (gj == H - 1) T = C;
     }
@@ -334,7 +352,7 @@ __device__ __forceinline__ Quad jacobi_row(const Quad C, Quad T, Quad B, const Q
 // waves at the barrier and finish the two outer rows — the mailbox round trip hides behind RY - 2 rows of arithmetic.
 template <int NW, int RY, bool EDGE, bool HALF>
 __device__ __forceinline__ void jacobi_sweep(Quad (&P)[RY], const Quad (&D)[RY], float4 (*box)[2][64], int wv, int lane, int gy,
-                                             int H, bool at_left, bool at_right)
+                                             int H, bool at_left, int nv)
 {
     static_assert(RY >= 3, "a wave needs an inner row");
     box[wv][0][lane] = raw_of(P[0]);
@@ -344,15 +362,15 @@ __device__ __forceinline__ void jacobi_sweep(Quad (&P)[RY], const Quad (&D)[RY],
 #pragma unroll
     for (int r = 1; r < RY - 1; r++) {
         const Quad C = P[r];
-        P[r] = jacobi_row<EDGE, HALF>(C, P[r + 1], below, D[r], gy + r, H, at_left, at_right);
+        P[r] = jacobi_row<EDGE, HALF>(C, P[r + 1], below, D[r], gy + r, H, at_left, nv);
         below = C;
     }
     __syncthreads();
     // unconditional b128 reads: the first/last wave reads its own mailbox, which only feeds the stale apron
     const Quad lo = quad_of_raw(box[wv > 0 ? wv - 1 : 0][1][lane]);
     const Quad hi = quad_of_raw(box[wv < NW - 1 ? wv + 1 : NW - 1][0][lane]);
-    P[RY - 1] = jacobi_row<EDGE, HALF>(P[RY - 1], hi, below, D[RY - 1], gy + RY - 1, H, at_left, at_right);
-    P[0] = jacobi_row<EDGE, HALF>(old0, old1, lo, D[0], gy, H, at_left, at_right);
+    P[RY - 1] = jacobi_row<EDGE, HALF>(P[RY - 1], hi, below, D[RY - 1], gy + RY - 1, H, at_left, nv);
+    P[0] = jacobi_row<EDGE, HALF>(old0, old1, lo, D[0], gy, H, at_left, nv);
 }
 
 // T = float (fp32 fields) or __half (fp16 storage: the clear and every iteration round their output to fp16)
@@ -376,12 +394,12 @@ __device__ __forceinline__ void jacobi_tb_body(const Win& w, const T* __restrict
     // and no in-domain texel reads an off-domain neighbour (EDGE selects) or a texel deeper in
     // the apron than `iters`.
     Quad P[RY], D[RY];
-    const unsigned cxs = (unsigned)min(max(cx, 0), w.W - 4);
+    const unsigned cxs = (unsigned)(min(max(cx, w.c0), w.c0 + w.P - 4) - w.c0);  // array column of the lane's quad, kept inside the array
     const v2f ps = v2f{ pscale, pscale };
 #pragma unroll
     for (int r = 0; r < RY; r++) {
         const int lr = min(max(gy + r - w.g0, 0), w.rows - 1);
-        const size_t row = (size_t)lr * (size_t)w.W;  // wave-uniform
+        const size_t row = (size_t)lr * (size_t)w.P;  // wave-uniform
         P[r] = load_quad(p, row + cxs);
         D[r] = load_quad(div, row + cxs);
     }
@@ -395,16 +413,17 @@ __device__ __forceinline__ void jacobi_tb_body(const Win& w, const T* __restrict
         }
     }
 
-    const bool at_left = (cx == 0), at_right = (cx + 3 == w.W - 1);
+    const bool at_left = (cx == 0);
+    const int nv = w.W - cx;  // texels of the lane's quad inside the domain: 4 or more everywhere but in the lane(s) at the right edge
 
     // two iterations per trip: the mailbox slot is a compile-time constant and the register allocator can hand the
     // second sweep's results back to the registers the first one read (no copies on the loop back-edge)
     int it = 0;
     for (; it + 2 <= iters; it += 2) {
-        jacobi_sweep<NW, RY, EDGE, HALF>(P, D, mail[0], wv, lane, gy, w.H, at_left, at_right);
-        jacobi_sweep<NW, RY, EDGE, HALF>(P, D, mail[1], wv, lane, gy, w.H, at_left, at_right);
+        jacobi_sweep<NW, RY, EDGE, HALF>(P, D, mail[0], wv, lane, gy, w.H, at_left, nv);
+        jacobi_sweep<NW, RY, EDGE, HALF>(P, D, mail[1], wv, lane, gy, w.H, at_left, nv);
     }
-    if (it < iters) jacobi_sweep<NW, RY, EDGE, HALF>(P, D, mail[0], wv, lane, gy, w.H, at_left, at_right);
+    if (it < iters) jacobi_sweep<NW, RY, EDGE, HALF>(P, D, mail[0], wv, lane, gy, w.H, at_left, nv);
 
     // store the texels the apron kept exact
     int xa, xb, out_lo, out_hi;
@@ -415,7 +434,7 @@ __device__ __forceinline__ void jacobi_tb_body(const Win& w, const T* __restrict
     for (int r = 0; r < RY; r++) {
         const int gj = gy + r;
         if (col_store && gj >= out_lo && gj < out_hi)
-            store_quad(p_out, (size_t)(gj - w.g0) * (size_t)w.W + (unsigned)cx, P[r]);
+            store_quad(p_out, (size_t)at(w, gj, cx), P[r]);
     }
 }
 
@@ -523,17 +542,24 @@ __device__ __forceinline__ void gradsub4_body(const Win& w, const S1* __restrict
     const int gj = ga + (int)blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y);
     const int cx = w.x0 + (int)blockIdx.x * 256 + 4 * lane;  // x0, x1 multiples of 4 (the launcher rounds them outward)
     if (gj >= gb || cx >= w.x1) return;
-    const size_t rowC = (size_t)(gj - w.g0) * (size_t)w.W;
-    const size_t rowT = (size_t)(min(gj + 1, w.H - 1) - w.g0) * (size_t)w.W;
-    const size_t rowB = (size_t)(max(gj - 1, 0) - w.g0) * (size_t)w.W;
-    const float4 C = load_s4(p, rowC + cx);
-    const float4 T = load_s4(p, rowT + cx);
-    const float4 B = load_s4(p, rowB + cx);
+    const int ax = cx - w.c0;  // array column of the lane's quad
+    const size_t rowC = (size_t)(gj - w.g0) * (size_t)w.P;
+    const size_t rowT = (size_t)(min(gj + 1, w.H - 1) - w.g0) * (size_t)w.P;
+    const size_t rowB = (size_t)(max(gj - 1, 0) - w.g0) * (size_t)w.P;
+    float4 C = load_s4(p, rowC + ax);
+    const float4 T = load_s4(p, rowT + ax);
+    const float4 B = load_s4(p, rowB + ax);
     float4 va, vb;
-    load_v4(vel, rowC + cx, va, vb);
+    load_v4(vel, rowC + ax, va, vb);
+    const int nv = w.W - cx;  // texels of this quad inside the domain (< 4 only in the last quad of a width that is not a multiple of 4)
+    if (nv < 4) {             // CLAMP_TO_EDGE inside the quad: the texels beyond the edge repeat the last one
+        if (nv < 2) C.y = C.x;
+        if (nv < 3) C.z = C.y;
+        C.w = C.z;
+    }
     float L = from_left_lane(C.w), R = from_right_lane(C.x);
-    if (lane == 0) L = cx > 0 ? ld(p, (long)(rowC + cx - 1)) : C.x;                    // CLAMP_TO_EDGE at the domain border
-    if (lane == 63 || cx + 4 >= w.x1) R = cx + 4 < w.W ? ld(p, (long)(rowC + cx + 4)) : C.w;
+    if (lane == 0) L = cx > 0 ? ld(p, (long)(rowC + ax - 1)) : C.x;                    // CLAMP_TO_EDGE at the domain border
+    if (lane == 63 || cx + 4 >= w.x1) R = cx + 4 < w.W ? ld(p, (long)(rowC + ax + 4)) : C.w;
     float4 oa, ob;
     oa.x = va.x - (C.y - L);
     oa.y = va.y - (T.x - B.x);
@@ -543,7 +569,7 @@ __device__ __forceinline__ void gradsub4_body(const Win& w, const S1* __restrict
     ob.y = vb.y - (T.z - B.z);
     ob.z = vb.z - (R - C.z);
     ob.w = vb.w - (T.w - B.w);
-    store_v4(vel_out, rowC + cx, oa, ob);
+    store_v4(vel_out, rowC + ax, oa, ob);
 }
 
 __global__ void __launch_bounds__(256) k_gradsub4(Win w, const float* __restrict__ p, const float2* __restrict__ vel,
@@ -593,8 +619,9 @@ __device__ __forceinline__ void vort_div_body(const Win& w, const V2* __restrict
     const int lane = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(threadIdx.y);  // wave-uniform: row addressing on the SALU
     const int cx = x0 + 4 * lane;
     const int gy = y0 + wv * RY;
-    const int cxs = min(max(cx, 0), w.W - 4);
-    const bool at_left = (cx == 0), at_right = (cx + 3 == w.W - 1);
+    const int cxs = min(max(cx, w.c0), w.c0 + w.P - 4) - w.c0;  // array column of the lane's quad, kept inside the array
+    const int nv = w.W - cx;                                   // texels of this quad inside the domain
+    const bool at_left = (cx == 0), at_right = (nv >= 1 && nv <= 4);  // the lane that holds column W - 1
     const int wb = wv > 0 ? wv - 1 : 0, wa = wv < NW - 1 ? wv + 1 : NW - 1;
 
     // ---- load velocity (unconditional, clamped addresses; see the Jacobi kernel) ----
@@ -603,9 +630,17 @@ __device__ __forceinline__ void vort_div_body(const Win& w, const V2* __restrict
     for (int r = 0; r < RY; r++) {
         const int lr = min(max(gy + r - w.g0, 0), w.rows - 1);
         float4 a, b;
-        load_v4(vel, (size_t)((long)lr * w.W + cxs), a, b);
+        load_v4(vel, (size_t)((long)lr * w.P + cxs), a, b);
         V[r].x[0] = a.x; V[r].y[0] = a.y; V[r].x[1] = a.z; V[r].y[1] = a.w;
         V[r].x[2] = b.x; V[r].y[2] = b.y; V[r].x[3] = b.z; V[r].y[3] = b.w;
+        if (EDGE && nv < 4) {  // width not a multiple of 4: the quad's texels beyond column W - 1 repeat it (CLAMP_TO_EDGE inside the quad)
+#pragma unroll
+            for (int k = 1; k < 4; k++)
+                if (k >= nv) {
+                    V[r].x[k] = V[r].x[k - 1];
+                    V[r].y[k] = V[r].y[k - 1];
+                }
+        }
     }
 
     // ---- stage 1: curl (needs vx of the rows above/below, vy of the columns left/right) ----
@@ -637,6 +672,11 @@ __device__ __forceinline__ void vort_div_body(const Win& w, const V2* __restrict
             }
             const float vort = R - L - T + B;
             C[r][k] = kept(curl_out, 0.5f * vort);  // the vorticity pass reads the curl TEXTURE: fp16 storage rounds it here
+        }
+        if (EDGE && nv < 4) {
+#pragma unroll
+            for (int k = 1; k < 4; k++)
+                if (k >= nv) C[r][k] = C[r][k - 1];
         }
     }
 
@@ -699,14 +739,14 @@ __device__ __forceinline__ void vort_div_body(const Win& w, const V2* __restrict
             float T = ty[k], B = by[k];
             if (EDGE) {  // reflecting walls: an off-domain neighbour is MINUS the centre component (script.js:804-807)
                 if (at_left && k == 0) L = -N[r].x[0];
-                if (at_right && k == 3) R = -N[r].x[3];
+                if (at_right && k == nv - 1) R = -N[r].x[k];  // the texel in column W - 1
                 if (gj == w.H - 1) T = -N[r].y[k];
                 if (gj == 0) B = -N[r].y[k];
             }
             dv[k] = 0.5f * (R - L + T - B);
         }
         if (col_store && gj >= out_lo && gj < out_hi) {
-            const size_t c = (size_t)((long)(gj - w.g0) * w.W + cx);
+            const size_t c = (size_t)at(w, gj, cx);
             store_s4(curl_out, c, make_float4(C[r][0], C[r][1], C[r][2], C[r][3]));
             store_s4(div_out, c, make_float4(dv[0], dv[1], dv[2], dv[3]));
             store_v4(vel_out, c, make_float4(N[r].x[0], N[r].y[0], N[r].x[1], N[r].y[1]), make_float4(N[r].x[2], N[r].y[2], N[r].x[3], N[r].y[3]));
@@ -950,6 +990,19 @@ hipError_t launch_resample(hipStream_t s, Win sw, const float* src, int nc, Win 
     return hipGetLastError();
 }
 
+hipError_t launch_copy_rects(hipStream_t s, const CopyRects& R)
+{
+    if (R.n < 1) return hipSuccess;
+    if (R.n > 8 || (R.unit != 2 && R.unit != 4)) return hipErrorInvalidValue;
+    size_t most = 0;
+    for (int k = 0; k < R.n; k++) most = std::max(most, (size_t)R.r[k].line_units * R.r[k].nrows);
+    if (most == 0) return hipSuccess;
+    const unsigned gx = (unsigned)std::min<size_t>((most + BX - 1) / BX, 2048);
+    if (R.unit == 4) k_copy_rects<unsigned int><<<dim3(gx, R.n, 1), BX, 0, s>>>(R);
+    else k_copy_rects<unsigned short><<<dim3(gx, R.n, 1), BX, 0, s>>>(R);
+    return hipGetLastError();
+}
+
 hipError_t launch_fill(hipStream_t s, float* dst, size_t n, int nc, float v0, float v1, float v2, float v3)
 {
     if (n == 0) return hipSuccess;
@@ -960,7 +1013,7 @@ hipError_t launch_fill(hipStream_t s, float* dst, size_t n, int nc, float v0, fl
     return hipGetLastError();
 }
 
-bool fused_supported(Win w) { return w.W % 4 == 0 && w.W >= 4; }
+bool fused_supported(Win w) { return w.W >= 1 && w.P % 4 == 0 && w.c0 % 4 == 0; }  // any width: the pitch keeps every row float4-aligned
 
 hipError_t launch_curl_vort_div(hipStream_t s, Win w, const float2* vel, float* curl, float2* vel_out, float* div,
                                 float curl_strength, float dt, int ga, int gb)
@@ -1004,7 +1057,7 @@ hipError_t launch_jacobi_tb(hipStream_t s, Win w, const __half* p, const __half*
     return hipGetLastError();
 }
 
-bool jacobi_tb_supported(Win w) { return w.W % 4 == 0 && w.W >= 4; }
+bool jacobi_tb_supported(Win w) { return fused_supported(w); }
 
 hipError_t launch_jacobi_tb(hipStream_t s, Win w, const float* p, const float* div, float* p_out, float pscale, int iters,
                             int ga, int gb)

@@ -44,8 +44,12 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 // array index of the clamped global texel (gj, gi)
 __device__ __forceinline__ long widx(const Win& w, int gj, int gi)
 {
-    return (long)(clampi(gj, 0, w.H - 1) - w.g0) * w.W + clampi(gi, 0, w.W - 1);
+    // CLAMP_TO_EDGE in global coordinates, then into the array (the second clamp only ever acts on texels no valid output reads:
+    // it keeps a launch at the rim of a tile's ghost zone inside the allocation)
+    return (long)(clampi(gj, 0, w.H - 1) - w.g0) * w.P + clampi(clampi(gi, 0, w.W - 1) - w.c0, 0, w.P - 1);
 }
+// array index of the global texel (gj, i) of the window (no clamping: the caller's texel)
+__device__ __forceinline__ long at(const Win& w, int gj, int i) { return (long)(gj - w.g0) * w.P + (i - w.c0); }
 
 // K2 vorticity confinement, one texel — vorticityShader script.js:835-866
 __device__ __forceinline__ float2 vorticity_cell(float L, float R, float T, float B, float C, float2 v, float curl_strength, float dt)
@@ -88,11 +92,12 @@ __device__ __forceinline__ Taps bil_taps(const Win& w, float u, float v)
     const int ja = clampi(j0, 0, w.H - 1), jb = clampi(j0 + 1, 0, w.H - 1);  // CLAMP_TO_EDGE first, in global rows
     t.miss = (ja < w.v0 || ja >= w.v1) + (jb < w.v0 || jb >= w.v1)          // then: is that row fresh in this window?
              + (ia < w.u0 || ia >= w.u1) + (ib < w.u0 || ib >= w.u1);       //       ... and that column (2-D tiles)
-    const int la = clampi(ja - w.g0, 0, w.rows - 1), lb = clampi(jb - w.g0, 0, w.rows - 1);
-    t.a = (long)la * w.W + ia;
-    t.b = (long)la * w.W + ib;
-    t.c = (long)lb * w.W + ia;
-    t.d = (long)lb * w.W + ib;
+    const int la = clampi(ja - w.g0, 0, w.rows - 1), lb = clampi(jb - w.g0, 0, w.rows - 1);  // a miss still loads: keep it inside the array
+    const int ka = clampi(ia - w.c0, 0, w.P - 1), kb = clampi(ib - w.c0, 0, w.P - 1);
+    t.a = (long)la * w.P + ka;
+    t.b = (long)la * w.P + kb;
+    t.c = (long)lb * w.P + ka;
+    t.d = (long)lb * w.P + kb;
     return t;
 }
 
@@ -122,7 +127,7 @@ __device__ __forceinline__ void curl_texel(const Win& w, const V2* __restrict__ 
     const float T = ld(vel, widx(w, gj + 1, i)).x;
     const float B = ld(vel, widx(w, gj - 1, i)).x;
     const float vort = R - L - T + B;
-    st(curl, (long)(gj - w.g0) * w.W + i, 0.5f * vort);
+    st(curl, at(w, gj, i), 0.5f * vort);
 }
 
 // K2 vorticity confinement — vorticityShader script.js:835-866
@@ -130,7 +135,7 @@ template <class V2, class S1>
 __device__ __forceinline__ void vorticity_texel(const Win& w, const V2* __restrict__ vel, const S1* __restrict__ curl, V2* __restrict__ vel_out,
                                                 float curl_strength, float dt, int i, int gj)
 {
-    const long c = (long)(gj - w.g0) * w.W + i;
+    const long c = at(w, gj, i);
     const float L = ld(curl, widx(w, gj, i - 1));
     const float R = ld(curl, widx(w, gj, i + 1));
     const float T = ld(curl, widx(w, gj + 1, i));
@@ -142,7 +147,7 @@ __device__ __forceinline__ void vorticity_texel(const Win& w, const V2* __restri
 template <class V2, class S1>
 __device__ __forceinline__ void divergence_texel(const Win& w, const V2* __restrict__ vel, S1* __restrict__ div, int i, int gj)
 {
-    const long c = (long)(gj - w.g0) * w.W + i;
+    const long c = at(w, gj, i);
     float L = ld(vel, widx(w, gj, i - 1)).x;
     float R = ld(vel, widx(w, gj, i + 1)).x;
     float T = ld(vel, widx(w, gj + 1, i)).y;
@@ -159,7 +164,7 @@ __device__ __forceinline__ void divergence_texel(const Win& w, const V2* __restr
 template <class S1>
 __device__ __forceinline__ void clear_texel(const Win& w, const S1* __restrict__ p, S1* __restrict__ p_out, float value, int i, int gj)
 {
-    const long c = (long)(gj - w.g0) * w.W + i;
+    const long c = at(w, gj, i);
     st(p_out, c, value * ld(p, c));
 }
 
@@ -167,7 +172,7 @@ __device__ __forceinline__ void clear_texel(const Win& w, const S1* __restrict__
 template <class S1>
 __device__ __forceinline__ void jacobi_texel(const Win& w, const S1* __restrict__ p, const S1* __restrict__ div, S1* __restrict__ p_out, int i, int gj)
 {
-    const long c = (long)(gj - w.g0) * w.W + i;
+    const long c = at(w, gj, i);
     const float L = ld(p, widx(w, gj, i - 1));
     const float R = ld(p, widx(w, gj, i + 1));
     const float T = ld(p, widx(w, gj + 1, i));
@@ -179,7 +184,7 @@ __device__ __forceinline__ void jacobi_texel(const Win& w, const S1* __restrict_
 template <class S1, class V2>
 __device__ __forceinline__ void gradsub_texel(const Win& w, const S1* __restrict__ p, const V2* __restrict__ vel, V2* __restrict__ vel_out, int i, int gj)
 {
-    const long c = (long)(gj - w.g0) * w.W + i;
+    const long c = at(w, gj, i);
     const float L = ld(p, widx(w, gj, i - 1));
     const float R = ld(p, widx(w, gj, i + 1));
     const float T = ld(p, widx(w, gj + 1, i));
@@ -218,7 +223,7 @@ __device__ __forceinline__ int advect_velocity_texel(const Win& w, const V2* __r
 {
     const float u = ((float)i + 0.5f) / (float)w.W;
     const float v = ((float)gj + 0.5f) / (float)w.H;
-    const long c = (long)(gj - w.g0) * w.W + i;
+    const long c = at(w, gj, i);
     const float2 vv = ld(vel, c);
     const float cu = u - dt * vv.x * tsx;
     const float cv = v - dt * vv.y * tsy;
@@ -238,13 +243,13 @@ __device__ __forceinline__ int advect_dye_texel(const Win& vw, const V2* __restr
     const float v = ((float)gj + 0.5f) / (float)dw.H;
     int miss = 0;
     float2 vv;
-    if (SAME_RES) vv = ld(vel, (long)(gj - vw.g0) * vw.W + i);
+    if (SAME_RES) vv = ld(vel, at(vw, gj, i));
     else vv = bil2(vw, vel, u, v, miss);
     const float cu = u - dt * vv.x * tsx;
     const float cv = v - dt * vv.y * tsy;
     const float4 r = bil4(dw, dye, cu, cv, miss);
     const float decay = 1.0f + dissipation * dt;
-    st(out, (long)(gj - dw.g0) * dw.W + i, make_float4(r.x / decay, r.y / decay, r.z / decay, r.w / decay));
+    st(out, at(dw, gj, i), make_float4(r.x / decay, r.y / decay, r.z / decay, r.w / decay));
     return miss;
 }
 
@@ -253,7 +258,7 @@ template <class V2>
 __device__ __forceinline__ void splat_velocity_texel(const Win& w, const V2* __restrict__ base, V2* __restrict__ out, float x, float y,
                                                      float aspect, float radius, float c0, float c1, int i, int gj)
 {
-    const long c = (long)(gj - w.g0) * w.W + i;
+    const long c = at(w, gj, i);
     const float g = splat_weight(w, i, gj, x, y, aspect, radius);
     const float2 b = ld(base, c);
     st(out, c, make_float2(b.x + g * c0, b.y + g * c1));
@@ -263,7 +268,7 @@ template <class D4>
 __device__ __forceinline__ void splat_dye_texel(const Win& w, const D4* __restrict__ base, D4* __restrict__ out, float x, float y, float aspect,
                                                 float radius, float c0, float c1, float c2, int i, int gj)
 {
-    const long c = (long)(gj - w.g0) * w.W + i;
+    const long c = at(w, gj, i);
     const float g = splat_weight(w, i, gj, x, y, aspect, radius);
     const float4 b = ld(base, c);
     st(out, c, make_float4(b.x + g * c0, b.y + g * c1, b.z + g * c2, 1.0f));
@@ -278,7 +283,7 @@ __device__ __forceinline__ void resample_texel(const Win& sw, const T* __restric
     const Taps t = bil_taps(sw, u, v);
     for (int k = 0; k < NC; k++) {
         const float a = ld(src, t.a * NC + k), b = ld(src, t.b * NC + k), c = ld(src, t.c * NC + k), d = ld(src, t.d * NC + k);
-        st(dst, ((long)gj * dw.W + i) * NC + k, mixf(mixf(a, b, t.fx), mixf(c, d, t.fx), t.fy));
+        st(dst, at(dw, gj, i) * NC + k, mixf(mixf(a, b, t.fx), mixf(c, d, t.fx), t.fy));
     }
 }
 

@@ -24,7 +24,7 @@ thread_local std::string g_create_error;
 
 namespace {
 
-size_t cells(const Win& w) { return (size_t)w.rows * (size_t)w.W; }
+size_t cells(const Win& w) { return (size_t)w.rows * (size_t)w.P; }  // texels allocated: rows x pitch (padding columns included)
 
 void free_fields(fluid_ctx* c)
 {
@@ -71,8 +71,17 @@ int set_geometry(fluid_ctx* c, int sw, int sh, int dw, int dh)
     c->dye_col0 = d.part_x * c->dye_ncols;
     c->dye_halo_x = d.parts_x > 1 ? (int)(((long)d.halo * dw + sw - 1) / sw) : 0;
     const int sh_halo = d.parts > 1 ? d.halo : 0;
-    c->sim = make_win(sw, sh, c->sim_row0 - sh_halo, c->sim_rows + 2 * sh_halo);
-    c->dye = make_win(dw, dh, c->dye_row0 - c->dye_halo, c->dye_rows + 2 * c->dye_halo);
+    if (d.parts_x > 1) {
+        // a tile holds its owned columns + ghost columns only (clipped to the domain; the origin is float4-aligned because tile
+        // widths are multiples of 4 and the origin is rounded down to one): memory and clears shrink with parts_x
+        const int sa = std::max((c->sim_col0 - d.halo) & ~3, 0), sb = std::min(c->sim_col0 + c->sim_ncols + d.halo, sw);
+        const int da = std::max((c->dye_col0 - c->dye_halo_x) & ~3, 0), db = std::min(c->dye_col0 + c->dye_ncols + c->dye_halo_x, dw);
+        c->sim = make_win_cols(sw, sh, c->sim_row0 - sh_halo, c->sim_rows + 2 * sh_halo, sa, sb);
+        c->dye = make_win_cols(dw, dh, c->dye_row0 - c->dye_halo, c->dye_rows + 2 * c->dye_halo, da, db);
+    } else {
+        c->sim = make_win(sw, sh, c->sim_row0 - sh_halo, c->sim_rows + 2 * sh_halo);
+        c->dye = make_win(dw, dh, c->dye_row0 - c->dye_halo, c->dye_rows + 2 * c->dye_halo);
+    }
     return FLUID_OK;
 }
 
@@ -617,7 +626,7 @@ int fluid_field_info_get(const fluid_ctx* c, int field, fluid_field_info* out)
     if (!c || !out) return FLUID_ERR_INVALID;
     FieldRef f;
     CK(field_ref(const_cast<fluid_ctx*>(c), field, &f));
-    *out = fluid_field_info{ f.win->W, f.win->H, f.nc, f.row0, f.rows, f.halo, f.col0, f.cols, f.halo_x, (int)f.esz };
+    *out = fluid_field_info{ f.win->W, f.win->H, f.nc, f.row0, f.rows, f.halo, f.col0, f.cols, f.halo_x, (int)f.esz, f.win->P, f.win->c0 };
     return FLUID_OK;
 }
 
@@ -637,8 +646,8 @@ int host_block(fluid_ctx* c, int field, size_t bytes, const char* who, HostBlock
     const FieldRef& f = b->f;
     b->line = (size_t)f.cols * f.nc * sizeof(float);
     if (bytes != (size_t)f.rows * b->line) return c->fail(FLUID_ERR_INVALID, std::string(who) + ": byte count does not match the owned rows x columns (fp32)");
-    b->rows_n = (size_t)f.rows * f.win->W * f.nc;
-    b->first_row = (char*)f.ptr + (size_t)(f.row0 - f.win->g0) * f.win->W * f.texel();
+    b->rows_n = (size_t)f.rows * f.win->P * f.nc;
+    b->first_row = (char*)f.ptr + (size_t)(f.row0 - f.win->g0) * f.win->P * f.texel();
     return FLUID_OK;
 }
 
@@ -650,16 +659,17 @@ int fluid_read_field(fluid_ctx* c, int field, float* host, size_t bytes)
     HostBlock b;
     CK(host_block(c, field, bytes, "read_field", &b));
     HIPCK(c, hipSetDevice(c->device));
-    const size_t pitch32 = (size_t)b.f.win->W * b.f.nc * sizeof(float);
+    const size_t pitch32 = (size_t)b.f.win->P * b.f.nc * sizeof(float);
+    const size_t col = (size_t)(b.f.col0 - b.f.win->c0);  // array column of the first owned column
     if (c->storage == FLUID_STORE_F32) {
-        HIPCK(c, hipMemcpy2DAsync(host, b.line, b.first_row + (size_t)b.f.col0 * b.f.texel(), pitch32, b.line, b.f.rows, hipMemcpyDeviceToHost, c->stream));
+        HIPCK(c, hipMemcpy2DAsync(host, b.line, b.first_row + col * b.f.texel(), pitch32, b.line, b.f.rows, hipMemcpyDeviceToHost, c->stream));
         HIPCK(c, hipStreamSynchronize(c->stream));
         return FLUID_OK;
     }
     float* tmp = nullptr;
     HIPCK(c, hipMalloc((void**)&tmp, b.rows_n * sizeof(float)));
     int rc = c->hip(launch_widen(c->stream, (const __half*)b.first_row, tmp, b.rows_n), "widen");
-    if (!rc) rc = c->hip(hipMemcpy2DAsync(host, b.line, (char*)tmp + (size_t)b.f.col0 * b.f.nc * sizeof(float), pitch32, b.line, b.f.rows, hipMemcpyDeviceToHost, c->stream), "copy");
+    if (!rc) rc = c->hip(hipMemcpy2DAsync(host, b.line, (char*)tmp + col * b.f.nc * sizeof(float), pitch32, b.line, b.f.rows, hipMemcpyDeviceToHost, c->stream), "copy");
     if (!rc) rc = c->hip(hipStreamSynchronize(c->stream), "sync");
     (void)hipFree(tmp);
     return rc;
@@ -671,9 +681,10 @@ int fluid_write_field(fluid_ctx* c, int field, const float* host, size_t bytes)
     HostBlock b;
     CK(host_block(c, field, bytes, "write_field", &b));
     HIPCK(c, hipSetDevice(c->device));
-    const size_t pitch32 = (size_t)b.f.win->W * b.f.nc * sizeof(float);
+    const size_t pitch32 = (size_t)b.f.win->P * b.f.nc * sizeof(float);
+    const size_t col = (size_t)(b.f.col0 - b.f.win->c0);  // array column of the first owned column
     if (c->storage == FLUID_STORE_F32) {
-        HIPCK(c, hipMemcpy2DAsync(b.first_row + (size_t)b.f.col0 * b.f.texel(), pitch32, host, b.line, b.line, b.f.rows, hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, hipMemcpy2DAsync(b.first_row + col * b.f.texel(), pitch32, host, b.line, b.line, b.f.rows, hipMemcpyHostToDevice, c->stream));
         HIPCK(c, hipStreamSynchronize(c->stream));
         return FLUID_OK;
     }
@@ -681,8 +692,8 @@ int fluid_write_field(fluid_ctx* c, int field, const float* host, size_t bytes)
     float* tmp = nullptr;
     HIPCK(c, hipMalloc((void**)&tmp, b.rows_n * sizeof(float)));
     int rc = FLUID_OK;
-    if (b.f.cols != b.f.win->W) rc = c->hip(launch_widen(c->stream, (const __half*)b.first_row, tmp, b.rows_n), "widen");
-    if (!rc) rc = c->hip(hipMemcpy2DAsync((char*)tmp + (size_t)b.f.col0 * b.f.nc * sizeof(float), pitch32, host, b.line, b.line, b.f.rows, hipMemcpyHostToDevice, c->stream), "copy");
+    if (b.f.cols != b.f.win->P) rc = c->hip(launch_widen(c->stream, (const __half*)b.first_row, tmp, b.rows_n), "widen");
+    if (!rc) rc = c->hip(hipMemcpy2DAsync((char*)tmp + col * b.f.nc * sizeof(float), pitch32, host, b.line, b.line, b.f.rows, hipMemcpyHostToDevice, c->stream), "copy");
     if (!rc) rc = c->hip(launch_narrow(c->stream, tmp, (__half*)b.first_row, b.rows_n), "narrow");
     if (!rc) rc = c->hip(hipStreamSynchronize(c->stream), "sync");
     (void)hipFree(tmp);
@@ -758,7 +769,7 @@ static int halo_copy(fluid_ctx* c, int field, int side, int nrows, void* buf, bo
     if (nrows < 1 || nrows > f.halo || nrows > f.rows) return c->fail(FLUID_ERR_INVALID, "halo rows out of range");
     if (side != 0 && side != 1) return c->fail(FLUID_ERR_INVALID, "side must be 0 (bottom) or 1 (top)");
     HIPCK(c, hipSetDevice(c->device));
-    const size_t row_bytes = (size_t)f.win->W * f.texel();
+    const size_t row_bytes = (size_t)f.win->P * f.texel();
     int first;  // first array row of the block
     if (pack) first = side == 0 ? f.halo : f.halo + f.rows - nrows;
     else first = side == 0 ? f.halo - nrows : f.halo + f.rows;

@@ -146,7 +146,7 @@ int rows_of(fluid_ctx* c, int field, int n, Rows* r)
     FieldRef f;
     CK(field_ref(c, field, &f));
     if (n < 1 || n > f.halo || n > f.rows) return c->fail(FLUID_ERR_INVALID, "exchange rows exceed the ghost rows / the stripe");
-    const size_t rowf = (size_t)f.win->W * f.texel();  // bytes per row
+    const size_t rowf = (size_t)f.win->P * f.texel();  // bytes per array row (pitch)
     char* base = (char*)f.ptr;
     const int h = f.halo, rr = f.rows;
     r->send_lo = base + (size_t)h * rowf;             // my lowest owned rows   -> lower neighbour's top ghost rows
@@ -331,10 +331,10 @@ int group_exchange_end(fluid_ctx** cs, int n)
 // ---- 2-D tiles (parts_x > 1): ghost COLUMNS as well ---------------------------------------------------------------
 // Rank = part * parts_x + part_x.  An exchange has two phases: A moves ghost columns between left / right neighbours
 // (owned rows only), B then moves ghost rows between lower / upper neighbours over the owned columns PLUS the ghost
-// columns that phase A just filled — so the corner blocks arrive without diagonal messages.  Column blocks are strided
-// in the full-width arrays: they travel through contiguous staging buffers (hipMemcpy2DAsync on the comm stream packs and
-// unpacks them); row blocks that span the whole width go in place.  One message per neighbour and phase carries all the
-// fields of the exchange.  The interior-first overlap works as for stripes, with four strips around the interior.
+// columns that phase A just filled — so the corner blocks arrive without diagonal messages.  The blocks are strided in the
+// tile's arrays (pitch = owned + ghost columns): they travel through contiguous staging buffers, packed and unpacked by ONE
+// kernel launch each per phase (launch_copy_rects: every field and direction of the phase).  One message per neighbour and
+// phase carries all the fields of the exchange.  The interior-first overlap works as for stripes, with four strips around the interior.
 struct Rect {
     char* p;             // first texel
     size_t pitch, line;  // bytes between rows, bytes per row of the block
@@ -362,12 +362,12 @@ int blocks_of(fluid_ctx* c, int field, int n, Blocks* b)
     FieldRef f;
     CK(field_ref(c, field, &f));
     if (n < 1 || (c->desc.parts > 1 && (n > f.halo || n > f.rows))) return c->fail(FLUID_ERR_INVALID, "exchange rows exceed the ghost rows / the tile");
-    const size_t texel = f.texel(), pitch = (size_t)f.win->W * texel;
+    const size_t texel = f.texel(), pitch = (size_t)f.win->P * texel;
     const int nx = col_depth(c, f, n);
     if (nx < 1 || nx > f.cols) return c->fail(FLUID_ERR_INVALID, "exchange columns exceed the ghost columns / the tile");
     const int h = f.halo, R = f.rows, c0 = f.col0, c1 = f.col0 + f.cols;
     auto rect = [&](int arow, int nrows, int col, int ncols) {
-        return Rect{ (char*)f.ptr + (size_t)arow * pitch + (size_t)col * texel, pitch, (size_t)ncols * texel, nrows };
+        return Rect{ (char*)f.ptr + (size_t)arow * pitch + (size_t)(col - f.win->c0) * texel, pitch, (size_t)ncols * texel, nrows };  // col: global
     };
     // phase A: owned rows, columns next to the left / right tile border
     b->send[LEFT] = rect(h, R, c0, nx);
@@ -398,7 +398,11 @@ int neighbour_rank(const fluid_ctx* c, int dir)
 int copy_rect(fluid_ctx* c, const Rect& dst, const Rect& src, hipStream_t s)
 {
     if (dst.line != src.line || dst.nrows != src.nrows) return c->fail(FLUID_ERR_INVALID, "exchange blocks of neighbouring tiles differ in shape");
-    HIPCK(c, hipMemcpy2DAsync(dst.p, dst.pitch, src.p, src.pitch, src.line, src.nrows, hipMemcpyDeviceToDevice, s));
+    fluid::CopyRects one{};
+    one.n = 1;
+    one.unit = (int)c->esz;
+    one.r[0] = { src.p, dst.p, src.pitch, dst.pitch, (unsigned)(src.line / c->esz), (unsigned)src.nrows };
+    HIPCK(c, fluid::launch_copy_rects(s, one));
     return FLUID_OK;
 }
 
@@ -423,23 +427,28 @@ int rccl_exchange_2d_begin(fluid_ctx* c, const fluid_stripe_op& op)
     for (int i = 0; i < op.n_items; i++) CK(blocks_of(c, op.field[i], op.rows[i], &blk[i]));
     HIPCK(c, hipEventRecord(c->ev_ready, c->stream));
     HIPCK(c, hipStreamWaitEvent(c->comm_stream, c->ev_ready, 0));
+    const int unit = (int)c->esz;  // every line, pitch and staging offset is a multiple of the channel size
     for (int phase = 0; phase < 2; phase++) {
         const int dirs[2] = { phase == 0 ? LEFT : DOWN, phase == 0 ? RIGHT : UP };
         size_t total[2] = { 0, 0 };
+        fluid::CopyRects pack{}, unpack{};
+        pack.unit = unpack.unit = unit;
         for (int k = 0; k < 2; k++) {
             if (!has_neighbour(c, dirs[k])) continue;
             for (int i = 0; i < op.n_items; i++) total[k] += blk[i].send[dirs[k]].bytes();
             CK(ensure_stage(c, 2 * dirs[k], total[k]));      // send staging of this direction
             CK(ensure_stage(c, 2 * dirs[k] + 1, total[k]));  // receive staging (the neighbour's block has the same shape)
             size_t off = 0;
-            for (int i = 0; i < op.n_items; i++) {           // pack
+            for (int i = 0; i < op.n_items; i++) {
                 const Rect& sr = blk[i].send[dirs[k]];
-                HIPCK(c, hipMemcpy2DAsync((char*)c->stage[2 * dirs[k]] + off, sr.line, sr.p, sr.pitch, sr.line, sr.nrows, hipMemcpyDeviceToDevice,
-                                          c->comm_stream));
+                const Rect& rr = blk[i].recv[dirs[k]];
+                pack.r[pack.n++] = { sr.p, (char*)c->stage[2 * dirs[k]] + off, sr.pitch, sr.line, (unsigned)(sr.line / unit), (unsigned)sr.nrows };
+                unpack.r[unpack.n++] = { (char*)c->stage[2 * dirs[k] + 1] + off, rr.p, rr.line, rr.pitch, (unsigned)(rr.line / unit), (unsigned)rr.nrows };
                 off += sr.bytes();
             }
         }
         if (!total[0] && !total[1]) continue;
+        HIPCK(c, fluid::launch_copy_rects(c->comm_stream, pack));      // every field and direction of the phase: one launch
         NCCLCK(c, R, R->GroupStart());
         for (int k = 0; k < 2; k++)
             if (total[k]) {
@@ -447,16 +456,7 @@ int rccl_exchange_2d_begin(fluid_ctx* c, const fluid_stripe_op& op)
                 NCCLCK(c, R, R->Recv(c->stage[2 * dirs[k] + 1], total[k], ncclChar, neighbour_rank(c, dirs[k]), comm, c->comm_stream));
             }
         NCCLCK(c, R, R->GroupEnd());
-        for (int k = 0; k < 2; k++)
-            if (total[k]) {
-                size_t off = 0;
-                for (int i = 0; i < op.n_items; i++) {       // unpack
-                    const Rect& rr = blk[i].recv[dirs[k]];
-                    HIPCK(c, hipMemcpy2DAsync(rr.p, rr.pitch, (char*)c->stage[2 * dirs[k] + 1] + off, rr.line, rr.line, rr.nrows,
-                                              hipMemcpyDeviceToDevice, c->comm_stream));
-                    off += rr.bytes();
-                }
-            }
+        HIPCK(c, fluid::launch_copy_rects(c->comm_stream, unpack));
     }
     HIPCK(c, hipEventRecord(c->ev_landed, c->comm_stream));
     c->exchanges++;

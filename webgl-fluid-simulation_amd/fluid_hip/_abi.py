@@ -40,7 +40,7 @@ class Params(C.Structure):
 
 
 class FieldInfo(C.Structure):
-    _fields_ = [(k, C.c_int) for k in ("width", "height", "channels", "row0", "rows", "halo", "col0", "cols", "halo_x", "bytes_per_channel")]
+    _fields_ = [(k, C.c_int) for k in ("width", "height", "channels", "row0", "rows", "halo", "col0", "cols", "halo_x", "bytes_per_channel", "pitch", "array_col0")]
 
 
 class Timings(C.Structure):
@@ -164,7 +164,7 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the header and the library disagree
             fn.restype = res
             fn.argtypes = args
-        if L.fluid_abi_version() != 5:
+        if L.fluid_abi_version() != 6:
             raise FluidError(ERR_UNSUPPORTED, "ABI version mismatch")
         _lib = L
         _point_at_torch_rccl(L)

@@ -106,7 +106,7 @@ class HipStripeEngine:
         t = self._views.get(key)
         if t is None:
             fi = self.info(name)
-            shape = (fi.rows + 2 * fi.halo, fi.width, fi.channels)
+            shape = (fi.rows + 2 * fi.halo, fi.pitch, fi.channels)   # array rows x pitch (>= width: rows stay 16-byte aligned)
 
             class _DeviceArray:  # minimal CUDA-array-interface carrier
                 __cuda_array_interface__ = {"shape": shape, "typestr": "<f%d" % fi.bytes_per_channel, "data": (ptr.value, False), "version": 2}
