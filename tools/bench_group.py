@@ -40,6 +40,13 @@ def main():
                 ms = (time.perf_counter() - t0) / steps * 1e3
                 g.check_halo()
                 out["group%d_%s_ms" % (world, "overlap" if overlap else "sync")] = round(ms, 4)
+                out["group%d_exchanges_per_step" % world] = g.engines[0].exchange_count() / (steps + warm)
+                # device bytes one rank holds: every field array = (rows + 2 halo) x pitch texels; velocity, pressure, dye are double-buffered
+                e, total = g.engines[0], 0
+                for name, bufs in (("velocity", 2), ("pressure", 2), ("divergence", 1), ("curl", 1), ("dye", 2)):
+                    fi = e.info(name)
+                    total += bufs * (fi.rows + 2 * fi.halo) * fi.pitch * fi.channels * fi.bytes_per_channel
+                out["group%d_MB_per_rank" % world] = round(total / 1e6, 1)
             finally:
                 g.close()
     print(json.dumps(out))
