@@ -7,7 +7,8 @@ rasteriser-interpolated texture coordinates carry no jitter, and EVERY pass of t
 state (no splat, hence no exp()).  Everything here is therefore gated with array_equal: the restatement on the CPU, and the HIP
 path in both schedules.  What the whole-step fixtures WITH splats (tests/test_long_horizon.py, HUGE_TOL) allow is the one libm
 difference of the path — exp() in splatShader (script.js:738), an ulp apart between SwiftShader, glibc and ocml — amplified by the
-discontinuous vorticity force (script.js:856-857), not a per-pass error of either implementation.
+discontinuous vorticity force (script.js:856-857), not a per-pass error of either implementation.  (Subnormal results included: the
+reference keeps them, see tests/golden/pass_clear_jacobi3_subnormal_40.)
 
 The sampled rows straddle the Jacobi kernels' tile seams (rows 2406-2413 cover the seam at 2410; full width covers every
 column seam) and the bottom / top four rows are domain-edge tiles."""
