@@ -191,7 +191,10 @@ int fluid_halo_unpack(fluid_ctx *ctx, int field, int side, int nrows, const void
 /* device address of array row 0 (ghost rows included) of the field's CURRENT read buffer, for zero-copy ghost-row
  * send/recv by the stripe driver.  Passes that swap read/write invalidate it: query after each pass. */
 int fluid_field_device_ptr(fluid_ctx *ctx, int field, void **dev_ptr);
-/* synchronises, then returns FLUID_ERR_HALO if any advection tap since the last check fell outside the stripe's rows */
+/* synchronises, then returns FLUID_ERR_HALO if any advection tap since the last check fell outside the stripe's rows.
+ * fluid_step / fluid_step_n / fluid_group_step_n on stripe and tile contexts call it themselves at the end of every call
+ * (the step that sampled a row that was not refreshed fails; the call synchronises), so this entry point only matters to a
+ * driver that runs the passes and exchanges itself (fluid_pass_*). */
 int fluid_halo_check(fluid_ctx *ctx);
 
 /* ---- multi-GPU: one stripe context per GPU, one process per GPU, ghost rows over RCCL (xGMI) ----

@@ -94,6 +94,26 @@ def test_hip_display_defaults_full_size():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_display_of_a_dye_field_whose_rows_are_padded(storage):
+    """a dye width that is not a multiple of 4 (250): the field's rows carry padding columns (pitch 252) and the compositor works on a
+    compacted copy — same frame as the numpy restatement on the texels the host reads back, and dye.read is left alone"""
+    import fluid_hip
+    from oracle import display as D
+    cfg = {"SIM_RESOLUTION": 130, "DYE_RESOLUTION": 130}
+    with fluid_hip.FluidSim(canvas=(250, 130), config=cfg, storage=storage, random=fluid_hip.mulberry32(4)) as sim:
+        assert [sim.dye.width, sim.dye.height] == [250, 130] and sim._info("dye").pitch == 252
+        sim.multipleSplats(6)
+        sim.step(0.016666, 2)
+        dye = sim.read("dye")
+        w, h = D.get_resolution(D.DISPLAY_DEFAULTS["CAPTURE_RESOLUTION"], 250, 130)
+        frame = sim.render(w, h)
+        assert np.array_equal(sim.read("dye"), dye)
+    want = D.capture(dye, (250, 130), dict(D.DISPLAY_DEFAULTS), None)
+    assert rel(frame, want["frame"]) <= 4e-6
+
+
+@pytest.mark.gpu
 def test_node_and_python_hosts_capture_the_same_image(tmp_path):
     """the JavaScript host (the reference's own language) and the Python host drive the same C ABI: same bytes"""
     import os

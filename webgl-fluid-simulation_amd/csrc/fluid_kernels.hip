@@ -307,10 +307,13 @@ __device__ __forceinline__ v2f round_half(v2f v)
 // One texel row of a Jacobi iteration (pressureShader script.js:881-888, operand order of line 887:
 // ((L + R) + B) + T - div) * 0.25): 11 VALU instructions for the lane's four texels.  HALF: the iteration's output goes
 // through fp16, as it does when the reference renders it into a half-float texture.
-template <bool EDGE, bool HALF = false>
+// EDGE: 0 = the tile is interior (no select at all); 1 = it touches the left / right domain border only, at a width that is a
+// multiple of 4 (two selects per row); 2 = everything (bottom / top rows, the partly padded last quad of any other width).  Border
+// tiles are 14 % of the 4096^2 grid and their selects cost arithmetic the kernel is bound by, so the cheap case has its own path.
+template <int EDGE, bool HALF = false>
 __device__ __forceinline__ Quad jacobi_row(Quad C, Quad T, Quad B, const Quad D, int gj, int H, bool at_left, int nv)
 {
-    if (EDGE && nv < 4) {  // the quad that holds column W - 1 of a width that is not a multiple of 4 (nv = its texels inside the
+    if (EDGE == 2 && nv < 4) {  // the quad that holds column W - 1 of a width that is not a multiple of 4 (nv = its texels inside the
         if (nv < 2) C.i.x = C.o.x;  // domain): CLAMP_TO_EDGE inside the quad — the texels beyond the edge repeat the last one, so
         if (nv < 3) C.i.y = C.i.x;  // the horizontal sums below see the clamped neighbour (the padding columns hold no data)
         C.o.y = C.i.y;
@@ -320,6 +323,8 @@ __device__ __forceinline__ Quad jacobi_row(Quad C, Quad T, Quad B, const Quad D,
     if (EDGE) {  // CLAMP_TO_EDGE: an off-domain neighbour is the centre texel
         if (at_left) L = C.o.x;
         if (nv <= 4) R = C.o.y;  // the lane that holds column W - 1 (lanes beyond it only feed texels outside the domain)
+    }
+    if (EDGE == 2) {
         if (gj == 0) B = C;
         if (gj == H - 1) T = C;
     }
@@ -350,7 +355,7 @@ __device__ __forceinline__ Quad jacobi_row(Quad C, Quad T, Quad B, const Quad D,
 // neighbouring waves (LDS mailbox, `box` is this iteration's slot); every other row only needs the wave's own
 // registers.  So: publish, sweep the inner rows (one delay register carries the old row below), THEN meet the other
 // waves at the barrier and finish the two outer rows — the mailbox round trip hides behind RY - 2 rows of arithmetic.
-template <int NW, int RY, bool EDGE, bool HALF>
+template <int NW, int RY, int EDGE, bool HALF>
 __device__ __forceinline__ void jacobi_sweep(Quad (&P)[RY], const Quad (&D)[RY], float4 (*box)[2][64], int wv, int lane, int gy,
                                              int H, bool at_left, int nv)
 {
@@ -374,7 +379,7 @@ __device__ __forceinline__ void jacobi_sweep(Quad (&P)[RY], const Quad (&D)[RY],
 }
 
 // T = float (fp32 fields) or __half (fp16 storage: the clear and every iteration round their output to fp16)
-template <int NW, int RY, int HX, int HY, bool EDGE, class T>
+template <int NW, int RY, int HX, int HY, int EDGE, class T>
 __device__ __forceinline__ void jacobi_tb_body(const Win& w, const T* __restrict__ p, const T* __restrict__ div,
                                                T* __restrict__ p_out, float pscale, int iters, int ga, int gb, int x0,
                                                int y0, float4 (*mail)[NW][2][64])
@@ -450,9 +455,11 @@ __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb(Win w
     int bx, by;
     tile_of_block((int)blockIdx.x, nx, ny, remap, bx, by);
     const int x0 = xs + bx * G::VX, y0 = ys + by * G::VY;
-    const bool edge = (x0 <= 0) || (x0 + G::TX >= w.W) || (y0 <= 0) || (y0 + G::TY >= w.H);
-    if (edge) jacobi_tb_body<NW, RY, HX, HY, true>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
-    else jacobi_tb_body<NW, RY, HX, HY, false>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
+    const bool xedge = (x0 <= 0) || (x0 + G::TX >= w.W), yedge = (y0 <= 0) || (y0 + G::TY >= w.H);
+    const bool ragged = (w.W & 3) != 0 && x0 + G::TX >= w.W;  // the tile holds the partly padded last quad
+    if (yedge || ragged) jacobi_tb_body<NW, RY, HX, HY, 2>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
+    else if (xedge) jacobi_tb_body<NW, RY, HX, HY, 1>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
+    else jacobi_tb_body<NW, RY, HX, HY, 0>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
 }
 
 // the same tile on fp16-storage fields (FLUID_STORE_F16): half the bytes per launch; every iteration's output is rounded to
@@ -467,9 +474,11 @@ __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_h(Win
     int bx, by;
     tile_of_block((int)blockIdx.x, nx, ny, remap, bx, by);
     const int x0 = xs + bx * G::VX, y0 = ys + by * G::VY;
-    const bool edge = (x0 <= 0) || (x0 + G::TX >= w.W) || (y0 <= 0) || (y0 + G::TY >= w.H);
-    if (edge) jacobi_tb_body<NW, RY, HX, HY, true>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
-    else jacobi_tb_body<NW, RY, HX, HY, false>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
+    const bool xedge = (x0 <= 0) || (x0 + G::TX >= w.W), yedge = (y0 <= 0) || (y0 + G::TY >= w.H);
+    const bool ragged = (w.W & 3) != 0 && x0 + G::TX >= w.W;  // the tile holds the partly padded last quad
+    if (yedge || ragged) jacobi_tb_body<NW, RY, HX, HY, 2>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
+    else if (xedge) jacobi_tb_body<NW, RY, HX, HY, 1>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
+    else jacobi_tb_body<NW, RY, HX, HY, 0>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -610,12 +619,14 @@ struct Row4 {  // four texels of one row held by a lane
     float x[4], y[4];
 };
 
-template <int NW, int RY, bool EDGE, class V2, class S1>
+// EDGE: 0 interior, 1 left / right border only (width a multiple of 4), 2 everything — as for the Jacobi kernel
+template <int NW, int RY, int EDGE, class V2, class S1>
 __device__ __forceinline__ void vort_div_body(const Win& w, const V2* __restrict__ vel, S1* __restrict__ curl_out,
                                               V2* __restrict__ vel_out, S1* __restrict__ div_out, float curl_strength,
                                               float dt, int ga, int gb, int x0, int y0, float4 (*mail)[2][2][64])
 {
     using G = VortDiv<NW, RY>;
+    constexpr bool EX = EDGE >= 1, EY = EDGE == 2;  // selects for the left / right border; for the bottom / top rows and the padded quad
     const int lane = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(threadIdx.y);  // wave-uniform: row addressing on the SALU
     const int cx = x0 + 4 * lane;
     const int gy = y0 + wv * RY;
@@ -633,7 +644,7 @@ __device__ __forceinline__ void vort_div_body(const Win& w, const V2* __restrict
         load_v4(vel, (size_t)((long)lr * w.P + cxs), a, b);
         V[r].x[0] = a.x; V[r].y[0] = a.y; V[r].x[1] = a.z; V[r].y[1] = a.w;
         V[r].x[2] = b.x; V[r].y[2] = b.y; V[r].x[3] = b.z; V[r].y[3] = b.w;
-        if (EDGE && nv < 4) {  // width not a multiple of 4: the quad's texels beyond column W - 1 repeat it (CLAMP_TO_EDGE inside the quad)
+        if (EY && nv < 4) {  // width not a multiple of 4: the quad's texels beyond column W - 1 repeat it (CLAMP_TO_EDGE inside the quad)
 #pragma unroll
             for (int k = 1; k < 4; k++)
                 if (k >= nv) {
@@ -653,7 +664,7 @@ __device__ __forceinline__ void vort_div_body(const Win& w, const V2* __restrict
     for (int r = 0; r < RY; r++) {
         const int gj = gy + r;
         float Lq = from_left_lane(V[r].y[3]), Rq = from_right_lane(V[r].y[0]);
-        if (EDGE) {
+        if (EX) {
             if (at_left) Lq = V[r].y[0];
             if (at_right) Rq = V[r].y[3];
         }
@@ -666,14 +677,14 @@ __device__ __forceinline__ void vort_div_body(const Win& w, const V2* __restrict
             const float L = k > 0 ? V[r].y[k - 1] : Lq;
             const float R = k < 3 ? V[r].y[k + 1] : Rq;
             float T = tx[k], B = bx[k];
-            if (EDGE) {
+            if (EY) {
                 if (gj == 0) B = V[r].x[k];
                 if (gj == w.H - 1) T = V[r].x[k];
             }
             const float vort = R - L - T + B;
             C[r][k] = kept(curl_out, 0.5f * vort);  // the vorticity pass reads the curl TEXTURE: fp16 storage rounds it here
         }
-        if (EDGE && nv < 4) {
+        if (EY && nv < 4) {
 #pragma unroll
             for (int k = 1; k < 4; k++)
                 if (k >= nv) C[r][k] = C[r][k - 1];
@@ -690,7 +701,7 @@ __device__ __forceinline__ void vort_div_body(const Win& w, const V2* __restrict
     for (int r = 0; r < RY; r++) {
         const int gj = gy + r;
         float Lq = from_left_lane(C[r][3]), Rq = from_right_lane(C[r][0]);
-        if (EDGE) {
+        if (EX) {
             if (at_left) Lq = C[r][0];
             if (at_right) Rq = C[r][3];
         }
@@ -702,13 +713,13 @@ __device__ __forceinline__ void vort_div_body(const Win& w, const V2* __restrict
             const float L = k > 0 ? C[r][k - 1] : Lq;
             const float R = k < 3 ? C[r][k + 1] : Rq;
             float T = tc[k], B = bc[k];
-            if (EDGE) {
+            if (EY) {
                 if (gj == 0) B = C[r][k];
                 if (gj == w.H - 1) T = C[r][k];
             }
-            const float2 nv = vorticity_cell(L, R, T, B, C[r][k], make_float2(V[r].x[k], V[r].y[k]), curl_strength, dt);
-            N[r].x[k] = kept(vel_out, nv.x);  // likewise the divergence pass reads the stored velocity
-            N[r].y[k] = kept(vel_out, nv.y);
+            const float2 conf = vorticity_cell(L, R, T, B, C[r][k], make_float2(V[r].x[k], V[r].y[k]), curl_strength, dt);
+            N[r].x[k] = kept(vel_out, conf.x);  // likewise the divergence pass reads the stored velocity
+            N[r].y[k] = kept(vel_out, conf.y);
         }
     }
 
@@ -737,9 +748,11 @@ __device__ __forceinline__ void vort_div_body(const Win& w, const V2* __restrict
             float L = k > 0 ? N[r].x[k - 1] : Lq;
             float R = k < 3 ? N[r].x[k + 1] : Rq;
             float T = ty[k], B = by[k];
-            if (EDGE) {  // reflecting walls: an off-domain neighbour is MINUS the centre component (script.js:804-807)
+            if (EX) {  // reflecting walls: an off-domain neighbour is MINUS the centre component (script.js:804-807)
                 if (at_left && k == 0) L = -N[r].x[0];
-                if (at_right && k == nv - 1) R = -N[r].x[k];  // the texel in column W - 1
+                if (at_right && k == (EY ? nv - 1 : 3)) R = -N[r].x[k];  // the texel in column W - 1
+            }
+            if (EY) {
                 if (gj == w.H - 1) T = -N[r].y[k];
                 if (gj == 0) B = -N[r].y[k];
             }
@@ -765,9 +778,11 @@ __global__ void __launch_bounds__(64 * NW, VD_WAVES_PER_EU) k_curl_vort_div(Win 
     int bx, by;
     tile_of_block((int)blockIdx.x, nx, ny, remap, bx, by);
     const int x0 = xs + bx * G::VX, y0 = ys + by * G::VY;
-    const bool edge = (x0 <= 0) || (x0 + G::TX >= w.W) || (y0 <= 0) || (y0 + G::TY >= w.H);
-    if (edge) vort_div_body<NW, RY, true>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
-    else vort_div_body<NW, RY, false>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
+    const bool xedge = (x0 <= 0) || (x0 + G::TX >= w.W), yedge = (y0 <= 0) || (y0 + G::TY >= w.H);
+    const bool ragged = (w.W & 3) != 0 && x0 + G::TX >= w.W;  // the tile holds the partly padded last quad
+    if (yedge || ragged) vort_div_body<NW, RY, 2>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
+    else if (xedge) vort_div_body<NW, RY, 1>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
+    else vort_div_body<NW, RY, 0>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
 }
 
 template <int NW, int RY>
@@ -781,9 +796,11 @@ __global__ void __launch_bounds__(64 * NW, VD_WAVES_PER_EU) k_curl_vort_div_h(Wi
     int bx, by;
     tile_of_block((int)blockIdx.x, nx, ny, remap, bx, by);
     const int x0 = xs + bx * G::VX, y0 = ys + by * G::VY;
-    const bool edge = (x0 <= 0) || (x0 + G::TX >= w.W) || (y0 <= 0) || (y0 + G::TY >= w.H);
-    if (edge) vort_div_body<NW, RY, true>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
-    else vort_div_body<NW, RY, false>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
+    const bool xedge = (x0 <= 0) || (x0 + G::TX >= w.W), yedge = (y0 <= 0) || (y0 + G::TY >= w.H);
+    const bool ragged = (w.W & 3) != 0 && x0 + G::TX >= w.W;  // the tile holds the partly padded last quad
+    if (yedge || ragged) vort_div_body<NW, RY, 2>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
+    else if (xedge) vort_div_body<NW, RY, 1>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
+    else vort_div_body<NW, RY, 0>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
 }
 
 #ifndef VD_NW_

@@ -44,9 +44,10 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 // array index of the clamped global texel (gj, gi)
 __device__ __forceinline__ long widx(const Win& w, int gj, int gi)
 {
-    // CLAMP_TO_EDGE in global coordinates, then into the array (the second clamp only ever acts on texels no valid output reads:
-    // it keeps a launch at the rim of a tile's ghost zone inside the allocation)
-    return (long)(clampi(gj, 0, w.H - 1) - w.g0) * w.P + clampi(clampi(gi, 0, w.W - 1) - w.c0, 0, w.P - 1);
+    // CLAMP_TO_EDGE in global coordinates, folded with the array's own column range (wave-uniform bounds; the array range only
+    // ever cuts texels no valid output reads: it keeps a launch at the rim of a tile's ghost zone inside the allocation)
+    const int lo = max(w.c0, 0), hi = min(w.c0 + w.P, w.W) - 1;
+    return (long)(clampi(gj, 0, w.H - 1) - w.g0) * w.P + (clampi(gi, lo, hi) - w.c0);
 }
 // array index of the global texel (gj, i) of the window (no clamping: the caller's texel)
 __device__ __forceinline__ long at(const Win& w, int gj, int i) { return (long)(gj - w.g0) * w.P + (i - w.c0); }

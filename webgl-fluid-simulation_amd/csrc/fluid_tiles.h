@@ -49,6 +49,9 @@ __device__ __forceinline__ void tile_of_block(int b, int nx, int ny, int remap, 
     if (remap & 2) {  // row-major tile sequence: the tiles in flight together span whole rows of the field
         by = t / nx;
         bx = t - by * nx;
+        // ... starting with the TOP tile row: the tiles on the bottom / top domain border run the instantiation with every
+        // CLAMP_TO_EDGE select (2.6 x the arithmetic of an interior tile) — taken first, they do not end up as the launch's tail
+        by = by == 0 ? ny - 1 : by - 1;
     } else {
         bx = t / ny;
         by = t - bx * ny;
