@@ -17,14 +17,15 @@ NODE = shutil.which("node")
 needs_node = pytest.mark.skipif(NODE is None, reason="node not installed")
 
 
-def node(script, args, attempts=2):
-    """Run a node script and parse its last stdout line.  One retry on a TIMEOUT only: ncclCommInitRank of the system RCCL (the one
-    a node process loads: no torch there) was seen once to sit in its bootstrap for minutes on a freshly started box; a wrong result
-    or a non-zero exit is never retried."""
+def node(script, args, attempts=3):
+    """Run a node script and parse its last stdout line.  Retried on a TIMEOUT only: in two of five runs of the whole GPU suite the
+    one-rank ncclCommInitRank of the system RCCL (the one a node process loads: no torch there) sat for minutes right after its
+    version banner, while the same test passed 5 / 5 alone and after every single other test file (round 2, visits 8-11: not
+    reproducible on demand, nothing of ours is running at that point).  A wrong result or a non-zero exit is never retried."""
     cmd = [NODE, os.path.join(ROOT, "tests", "node", script), json.dumps(args)]
     for k in range(attempts):
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=150)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=100)
             break
         except subprocess.TimeoutExpired:
             if k == attempts - 1:
