@@ -15,6 +15,8 @@ CASES = [
     ((512, 512), {"SIM_RESOLUTION": 128, "DYE_RESOLUTION": 512, "PRESSURE_ITERATIONS": 20}, 16, 4, 2, "fused"),
     ((256, 1024), {"SIM_RESOLUTION": 256, "DYE_RESOLUTION": 256, "PRESSURE_ITERATIONS": 30}, 12, 8, 1, "fused"),
     ((512, 512), {"SIM_RESOLUTION": 1024, "DYE_RESOLUTION": 1024, "PRESSURE_ITERATIONS": 50}, 32, 4, 1, "fused"),
+    # a width that is not a multiple of 4 (250 x 128 with a 500 x 256 dye grid): the ghost rows travel with their padding columns (pitch 252)
+    ((250, 128), {"SIM_RESOLUTION": 128, "DYE_RESOLUTION": 256, "PRESSURE_ITERATIONS": 23}, 16, 2, 2, "fused"),
 ]
 
 
