@@ -131,7 +131,7 @@ int check_ext(fluid_ctx* c, int ext, int need_in)
 namespace fluid_impl {
 
 // The window of a launch that computes the owned columns +- ext (2-D tiles; whole float4 groups, clipped to the
-// domain).  The arrays span the full width in every decomposition, so only the launch's column range changes.
+// domain).  The window already holds the array's own column origin and pitch (set_geometry); only the launch's range changes.
 Win cols_of(Win w, int parts_x, int col0, int cols, int ext)
 {
     if (parts_x > 1) {
@@ -636,8 +636,8 @@ namespace {
 
 struct HostBlock {
     FieldRef f;
-    size_t line, rows_n;  // fp32 bytes per owned row segment, scalars in the owned rows over the full width
-    char* first_row;      // device address of the first owned row (column 0)
+    size_t line, rows_n;  // fp32 bytes per owned row segment, scalars in the owned rows over the whole pitch
+    char* first_row;      // device address of the first owned row (array column 0)
 };
 
 int host_block(fluid_ctx* c, int field, size_t bytes, const char* who, HostBlock* b)
