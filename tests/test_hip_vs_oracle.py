@@ -1,17 +1,17 @@
 """HIP kernels vs the CPU oracle on identical seeded inputs, through the C ABI.
 
-Bar (tests/tolerances.py): bitwise for curl / divergence / clear / Jacobi / gradient-subtract (pure
-add/mul arithmetic in a fixed order, -ffp-contract=off on both sides); a few ulp where sqrt, divide
-or exp are involved (vorticity, advection, splat)."""
+Bar: BITWISE everywhere, at every size — the passes are add / multiply arithmetic in a fixed order (-ffp-contract=off on both
+sides), sqrt and divide (vorticity, advection) are correctly rounded on both sides, and exp (splat) is the same fixed polynomial
+(the reference rasteriser's, tests/tolerances.py); so whole steps with splats agree bit for bit as well."""
 import numpy as np
 import pytest
 
 import scenario as S
-from tolerances import HIP_VS_ORACLE_STEP, HIP_VS_ORACLE_ULP_PASSES
+
 
 pytestmark = pytest.mark.gpu
 
-# (W, H): odd sizes, W % 4 != 0 (per-pass kernels only), tiles smaller/larger than a Jacobi tile
+# (W, H): odd sizes, W % 4 != 0 (the last quad of a row is partly padding), tiles smaller/larger than a Jacobi tile
 SIZES = [(37, 53), (64, 64), (250, 130), (256, 64), (512, 300), (1000, 40), (1024, 1024)]
 
 
@@ -88,15 +88,15 @@ def test_ulp_passes(oracle, W, H):
         load_state(sim, st)
         sim.run_pass("vorticity")
         ref = oracle.vorticity(st["velocity"], st["curl"], np.float32(30), dt)
-        assert S.rel_err(sim.read("velocity"), ref) <= HIP_VS_ORACLE_ULP_PASSES
+        assert np.array_equal(sim.read("velocity"), ref)
         load_state(sim, st)
         sim.run_pass("advect_velocity")
         ref = oracle.advect(st["velocity"], st["velocity"], dt, np.float32(0.2))
-        assert S.rel_err(sim.read("velocity"), ref) <= HIP_VS_ORACLE_ULP_PASSES
+        assert np.array_equal(sim.read("velocity"), ref)
         load_state(sim, st)
         sim.run_pass("advect_dye")
         ref = oracle.advect(st["velocity"], st["dye"], dt, np.float32(1.0))
-        assert S.rel_err(sim.read("dye"), ref) <= HIP_VS_ORACLE_ULP_PASSES
+        assert np.array_equal(sim.read("dye"), ref)
     finally:
         sim.close()
 
@@ -113,7 +113,7 @@ def test_vorticity_clamp(oracle):
     finally:
         sim.close()
     assert np.abs(got).max() == 1000.0
-    assert S.rel_err(got, oracle.vorticity(st["velocity"], st["curl"], np.float32(30), np.float32(0.016666))) <= HIP_VS_ORACLE_ULP_PASSES
+    assert np.array_equal(got, oracle.vorticity(st["velocity"], st["curl"], np.float32(30), np.float32(0.016666)))
 
 
 def test_advect_dye_cross_resolution(oracle):
@@ -127,7 +127,7 @@ def test_advect_dye_cross_resolution(oracle):
     finally:
         sim.close()
     ref = oracle.advect(st["velocity"], st["dye"], np.float32(0.016666), np.float32(1.0))
-    assert S.rel_err(got, ref) <= HIP_VS_ORACLE_ULP_PASSES
+    assert np.array_equal(got, ref)
 
 
 @pytest.mark.parametrize("W,H", [(64, 64), (130, 50), (400, 200)])
@@ -145,8 +145,8 @@ def test_splat(oracle, W, H):
     f = oracle.f32
     rv = oracle.splat(st["velocity"], f(0.31), f(0.72), f(aspect), f(radius), (f(412.5), f(-230.25), 0.0))
     rd = oracle.splat(st["dye"], f(0.31), f(0.72), f(aspect), f(radius), (f(1.2), f(0.3), f(0.05)))
-    assert S.rel_err(gv, rv) <= HIP_VS_ORACLE_ULP_PASSES
-    assert S.rel_err(gd, rd) <= HIP_VS_ORACLE_ULP_PASSES
+    assert np.array_equal(gv, rv)
+    assert np.array_equal(gd, rd)
     assert np.all(gd[..., 3] == 1.0)
 
 
@@ -173,7 +173,7 @@ def test_full_step_vs_oracle(oracle, canvas, cfg, steps, schedule):
     want = ref.fields()
     for k in S.FIELDS:
         assert got[k].shape == want[k].shape
-        assert S.rel_err(got[k], want[k]) <= HIP_VS_ORACLE_STEP * steps, (k, S.rel_err(got[k], want[k]))
+        assert np.array_equal(got[k], want[k]), (k, S.rel_err(got[k], want[k]))   # whole steps, splats included: the same bits
 
 
 def test_resize_preserves_dye_and_velocity(oracle):
@@ -199,7 +199,7 @@ def test_resize_preserves_dye_and_velocity(oracle):
     want = ref.fields()
     assert got["velocity"].shape == (96, 96, 2) and got["dye"].shape == (200, 200, 4)
     for k in ("velocity", "dye"):
-        assert S.rel_err(got[k], want[k]) <= 1e-5
+        assert np.array_equal(got[k], want[k]), k
     for k in ("pressure", "divergence", "curl"):
         assert not got[k].any()
 
@@ -253,7 +253,7 @@ def test_fused_curl_vorticity_divergence(oracle, W, H):
         sim.close()
     want_curl = oracle.curl(st["velocity"])
     assert np.array_equal(crl, want_curl)
-    assert S.rel_err(vel, oracle.vorticity(st["velocity"], want_curl, np.float32(30), dt)) <= HIP_VS_ORACLE_ULP_PASSES
+    assert np.array_equal(vel, oracle.vorticity(st["velocity"], want_curl, np.float32(30), dt))
     assert np.array_equal(div, oracle.divergence(vel))
 
 
@@ -268,6 +268,6 @@ def test_fused_advect(oracle, W, H):
         vel, dye = sim.read("velocity"), sim.read("dye")
     finally:
         sim.close()
-    assert S.rel_err(vel, oracle.advect(st["velocity"], st["velocity"], dt, np.float32(0.2))) <= HIP_VS_ORACLE_ULP_PASSES
+    assert np.array_equal(vel, oracle.advect(st["velocity"], st["velocity"], dt, np.float32(0.2)))
     # the dye back-trace uses the kernel's own new velocity: feed that to the oracle
-    assert S.rel_err(dye, oracle.advect(vel, st["dye"], dt, np.float32(1.0))) <= HIP_VS_ORACLE_ULP_PASSES
+    assert np.array_equal(dye, oracle.advect(vel, st["dye"], dt, np.float32(1.0)))

@@ -104,6 +104,30 @@ __device__ __forceinline__ Taps bil_taps(const Win& w, float u, float v)
 
 __device__ __forceinline__ float mixf(float a, float b, float t) { return a + (b - a) * t; }
 
+// exp() as the reference's GL implementation evaluates it (splatShader, script.js:738, calls the GLSL built-in; the algorithm lives in
+// the rasteriser the reference runs on here: SwiftShader as bundled with Chromium 88, src/Pipeline/ShaderCore.cpp `exponential()` /
+// `exponential2()`): exp(x) = exp2(1.44269504 x), exp2(x) = 2^i * poly5(f), i = round-to-nearest-even(x - 0.5), f = x - i, the integer part
+// written into the exponent field, a degree-5 polynomial for 2^f, every step a separately rounded fp32 multiply or add (the build has
+// -ffp-contract=off).  With it a splat — and therefore every whole step that starts from splats — is bit-identical to the reference at
+// power-of-two grid sizes (tests/test_hip_vs_golden.py); ocml's expf is an ulp away on 40 % of the texels, which the discontinuous
+// vorticity force then amplifies.
+__device__ __forceinline__ float exp_reference(float x)
+{
+    float x0 = 1.44269504f * x;
+    x0 = fminf(x0, __uint_as_float(0x43010000u));  // 129.0
+    x0 = fmaxf(x0, __uint_as_float(0xC2FDFFFFu));  // -126.99999
+    const int i = __float2int_rn(x0 - 0.5f);
+    const float ii = __uint_as_float((unsigned)(i + 127) << 23);
+    const float f = x0 - (float)i;
+    float ff = __uint_as_float(0x3AF61905u);       // 1.8775767e-3
+    ff = ff * f + __uint_as_float(0x3C134806u);    // 8.9893397e-3
+    ff = ff * f + __uint_as_float(0x3D64AA23u);    // 5.5826318e-2
+    ff = ff * f + __uint_as_float(0x3E75EAD4u);    // 2.4015361e-1
+    ff = ff * f + __uint_as_float(0x3F31727Bu);    // 6.9315308e-1
+    ff = ff * f + 1.0f;
+    return ii * ff;
+}
+
 // K8 splat weight — splatShader script.js:726-744
 __device__ __forceinline__ float splat_weight(const Win& w, int i, int gj, float x, float y, float aspect, float radius)
 {
@@ -111,7 +135,7 @@ __device__ __forceinline__ float splat_weight(const Win& w, int i, int gj, float
     const float v = ((float)gj + 0.5f) / (float)w.H;
     const float px = (u - x) * aspect;
     const float py = v - y;
-    return expf(-(px * px + py * py) / radius);
+    return exp_reference(-(px * px + py * py) / radius);
 }
 
 // ================================================================================================================
