@@ -12,7 +12,6 @@ import numpy as np
 import pytest
 
 import scenario as S
-import tolerances as T
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NODE = shutil.which("node")
@@ -96,5 +95,5 @@ def test_hip_replay_matches_reference_fields(schedule):
         assert sim.velocity.width == int(g["sim"][0]) and sim.dye.height == int(g["dye"][1])
     for k in S.FIELDS:
         want = g["out_" + k]
-        err = float(np.abs(got[k].astype(np.float64) - want).max() / max(np.abs(want).max(), 1e-30))
-        assert err <= T.INPUT_REPLAY, (k, err)
+        # canvas 600 x 300 -> sim 64 x 32, dye 128 x 64: powers of two, so the live reference is bit-reproducible (tolerances.py)
+        assert np.array_equal(got[k], want), (k, float(np.abs(got[k].astype(np.float64) - want).max()))

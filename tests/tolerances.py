@@ -18,9 +18,13 @@ BITWISE_FIXTURES = ("splats_only_64", "splat_stream_20", "step1_64", "step5_curl
 BITWISE_SIM_FIELDS = ("step3_wide_64x32_dye96x48",)
 
 
+# single passes on injected state at power-of-two sizes (oracle/live/make_golden_pow2_passes.py): every pass, every field, array_equal
+BITWISE_PASS_SUFFIXES = ("_64", "_128x64")
+
+
 def bitwise_fields(name: str):
     """the fields of a golden that must be bit-identical to the reference"""
-    if name in BITWISE_FIXTURES:
+    if name in BITWISE_FIXTURES or (name.startswith("pass_") and name.endswith(BITWISE_PASS_SUFFIXES)):
         return ("velocity", "pressure", "divergence", "curl", "dye")
     if name in BITWISE_SIM_FIELDS:
         return ("velocity", "pressure", "divergence", "curl")
@@ -29,6 +33,8 @@ def bitwise_fields(name: str):
 
 def golden_tolerance(name: str) -> float:
     if name.startswith("pass_"):
+        if name.endswith(BITWISE_PASS_SUFFIXES):
+            return 0.0
         if "_noise_" in name:
             return 4e-5      # white-noise inputs: jitter leak scales with roughness (measured <= 2.0e-5)
         return 8e-6          # smooth inputs (measured <= 3.4e-6)
@@ -47,24 +53,6 @@ def golden_tolerance(name: str) -> float:
     return table[name]
 
 
-# HIP vs CPU oracle on identical inputs (both restate the same arithmetic; sqrt and divide are correctly rounded on both sides and
-# exp is the same polynomial): every pass is expected bitwise; the allowance below is kept for the sqrt / divide passes only in case a
-# toolchain ever relaxes them.
-HIP_VS_ORACLE_ULP_PASSES = 4e-7
-# one full step, relative to max|field|.  With CURL = 30 the vorticity force f/(|f|+1e-4) is discontinuous
-# where grad|curl| ~ 0 (script.js:856-857), so the 1-ulp exp() difference between ocml and glibc in the splats
-# is amplified locally (measured <= 7.7e-6 at 1024^2); with CURL = 0 the step agrees to ~1e-7.
-HIP_VS_ORACLE_STEP = 3e-5
-
-# input replay (tests/test_input_replay.py): 16 frames, 14 of them stepped, CURL = 30 -> the 10-step regime above
-INPUT_REPLAY = 1e-3
-
-# fp16-storage mode (tests/test_hip_f16.py), HIP vs the oracle's fp16 mode.  A single pass: identical, or one fp16 ulp
-# apart on the few texels whose fp32 results (a libm ulp apart) straddle an fp16 rounding boundary.
-# Measured (tools/f16_measure.py on an MI355X, profiles/r01/f16_parity_and_speed.txt): NO flips at all — the fp16 rounding
-# absorbs the libm ulps, every pass and every 3-step run below is bit-equal to the oracle.  The allowances stay for seeds
-# that do land on a boundary.
-F16_FLIP_FRACTION = 1e-3
-# three steps, relative to max|field|: one flipped fp16 ulp is 2^-11 = 4.9e-4 of a value, and CURL = 30 amplifies it
-F16_STEP_CURL0 = 1e-3
-F16_STEP = 5e-3
+# HIP vs CPU oracle on identical inputs: both restate the same arithmetic (sqrt and divide correctly rounded on both sides, exp the
+# same polynomial), so every comparison in tests/test_hip_vs_oracle.py, test_hip_f16.py, test_long_horizon.py and
+# test_input_replay.py is array_equal — there is no HIP-vs-oracle tolerance any more.
