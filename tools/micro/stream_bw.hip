@@ -1,7 +1,9 @@
 // stream_bw.hip — what this box's memory system sustains for the access mixes of the step kernels (float4 per lane,
 // coalesced): read-only, write-only, copy (1R:1W), 2R:1W, 3R:2W (gradient subtract), and the byte mix of the
 // advection kernel (24 B read, 24 B written per texel).  Buffers of `MB` MiB each (default 256: a 4096^2 float4 field).
-// Build: hipcc --offload-arch=gfx950 -O3 -o stream_bw stream_bw.hip ; run: ./stream_bw [MiB] [reps]
+// Build: hipcc --offload-arch=gfx950 -O3 -o stream_bw stream_bw.hip ; run: ./stream_bw [MiB] [reps] [stagger bytes]
+// `stagger`: buffer k starts k * stagger bytes into its allocation (a multiple of 16) — do streams that sit at the same offset of
+// equally sized, equally aligned arrays collide in the channel / bank mapping?
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -51,13 +53,24 @@ int main(int argc, char** argv)
 {
     const size_t mib = argc > 1 ? atol(argv[1]) : 256;
     const int reps = argc > 2 ? atoi(argv[2]) : 20;
+    const size_t stagger = argc > 3 ? (size_t)atol(argv[3]) & ~(size_t)15 : 0;
     const size_t n = mib * 1024 * 1024 / 16;
     f4* buf[5];
-    for (int k = 0; k < 5; k++) { CK(hipMalloc(&buf[k], n * 16)); CK(hipMemset(buf[k], 0, n * 16)); }
+    for (int k = 0; k < 5; k++) {
+        char* base;
+        CK(hipMalloc(&base, n * 16 + 5 * stagger));
+        CK(hipMemset(base, 0, n * 16 + 5 * stagger));
+        buf[k] = (f4*)(base + k * stagger);
+    }
     float* sink; CK(hipMalloc(&sink, 4));
-    printf("# %zu MiB per buffer, %d launches per row\n", mib, reps);
-    const int grids[] = { 2048, 8192, 65536 };
-    for (int g : grids) {
+    printf("# %zu MiB per buffer, %d launches per row, buffer k staggered by k * %zu bytes\n", mib, reps, stagger);
+    const int grids_all[] = { 2048, 8192, 65536 };
+    const int grids_one[] = { 65536 };
+    const bool brief = argc > 3;
+    const int* grids = brief ? grids_one : grids_all;
+    const int ngrids = brief ? 1 : 3;
+    for (int gi = 0; gi < ngrids; gi++) {
+        const int g = grids[gi];
         run<1, 0, false>("read", buf, n, g, reps, sink);
         run<0, 1, false>("write", buf, n, g, reps, sink);
         run<1, 1, false>("copy 1R:1W", buf, n, g, reps, sink);
