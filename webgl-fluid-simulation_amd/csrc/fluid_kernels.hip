@@ -97,8 +97,10 @@ __global__ void __launch_bounds__(BX) k_advect_dye(Win vw, const float2* __restr
 // advects the dye texel with it — the new velocity is not re-read from HBM (48 B/texel instead of 56).
 // Same per-texel arithmetic as the two kernels above, hence the same bits.
 // ROWS texels per thread (consecutive rows, same column), processed stage by stage so that the ROWS independent
-// gathers of a stage are all in flight together: the kernel is a chain of three dependent memory round trips
-// (velocity -> 4 velocity taps -> 4 dye taps) and is latency-bound at one texel per thread.
+// gathers of a stage are all in flight together (velocity -> 4 velocity taps -> 4 dye taps; two texels per thread measure 6 % faster
+// than one).  Beyond its HBM bytes the kernel pays for the volume of its gathers through the vector L1 — nine loads, 104 B requested
+// per texel for 24 B of new data — not for its arithmetic and not for the dependency chain (DESIGN.md 6.1,
+// profiles/r02/advect_experiments.txt; the variants that established it: tools/experiments/advect_fast_kernel.hip.txt).
 struct Fetch2 {
     float2 a, b, c, d;
     float fx, fy;
