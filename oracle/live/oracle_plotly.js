@@ -335,6 +335,19 @@
         out.mask = b64(framebufferToTexture(dye.write));
         gl.disable(gl.BLEND);
       }
+      if (P.probeCoords) {   // what the rasteriser hands the fragment shaders: the varyings of the reference's own baseVertexShader, per texel
+        var probe = function (expr) {
+          var fs = compileShader(gl.FRAGMENT_SHADER, 'precision highp float; precision highp sampler2D;\n' +
+            'varying highp vec2 vUv; varying highp vec2 vL; varying highp vec2 vR; varying highp vec2 vT; varying highp vec2 vB;\n' +
+            'void main () { gl_FragColor = ' + expr + '; }');
+          var prog = new Program(baseVertexShader, fs);
+          prog.bind();
+          gl.uniform2f(prog.uniforms.texelSize, velocity.texelSizeX, velocity.texelSizeY);
+          blit(dye.write);
+          return b64(framebufferToTexture(dye.write));
+        };
+        out.coords = { a: probe('vec4(vUv.x, vUv.y, vL.x, vR.x)'), b: probe('vec4(vT.y, vB.y, vL.y, vT.x)') };
+      }
       out.ms = ms; out.sim = [velocity.width, velocity.height]; out.dye = [dye.width, dye.height];
       out.splats = splatLog; out.draws = draws.length;
       out.canvas = [canvas.width, canvas.height];
