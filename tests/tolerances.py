@@ -8,6 +8,12 @@ splats, 50 steps with CURL = 30, the 4096^2 headline workload — reproduce bit 
 LINEAR-filtered velocity / dye textures at interpolated coordinates that are an ulp off the formula, which leaks ~W * 2^-22 of the
 neighbour difference into every tap ("texcoord jitter"): those fixtures keep tolerances.  Passes that only read NEAREST textures (clear,
 Jacobi) are bit-reproducible at every size.
+
+The jitter is not a guess: oracle/raster.py restates the rasteriser's interpolation (identified from the varyings the reference's own
+vertex shader produces, tests/golden/raster_varyings.npz) and evaluates the same passes on those coordinates — and then EVERY fixture, at
+every size, is bit-identical to the live reference (tests/test_raster_mode.py).  The tolerances below are therefore exactly the distance
+between two evaluations of the same shaders: on the texel centres the shader text names (the restatement, the HIP kernels) and on the
+coordinates one particular software rasteriser interpolates (the live reference); they coincide at power-of-two sizes.
 """
 
 BITWISE_PASSES = ("clear", "jacobi", "jacobi5")  # golden name fragments gated with array_equal on pressure
