@@ -1,7 +1,6 @@
 /* TEST INFRASTRUCTURE — model check of csrc/fluid_math.h div_uniform: (float)((double)x * (1.0 / (double)d)) against x / d, bit for bit.
  * Host arithmetic is IEEE (SSE2): the same three operations the device executes (v_cvt_f64_f32, v_mul_f64, v_cvt_f32_f64, round to nearest
- * even, denormals kept).  gcc -O2 -ffp-contract=off div_uniform_check.c -lm && ./a.out : 2.5e6 coordinates and 2.4e8 (decay, value) pairs, 0 differ.
- * The kernel that used it is not in the build (advect_fast_kernel.hip.txt). */
+ * even, denormals kept).  Run by tests/test_div_uniform.py. */
 #include <stdio.h>
 #include <stdint.h>
 #include <string.h>

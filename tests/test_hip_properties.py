@@ -60,6 +60,37 @@ def test_fused_equals_passes_bitwise_odd_shapes(canvas, res, dye):
             s.close()
 
 
+@pytest.mark.parametrize("vd,dd,dt", [(0.2, 1.0, 0.016666),      # the defaults: decays 1.003 / 1.017 -> k_advect_both_fast (div_uniform)
+                                      (0.0, 0.0, 0.016666),      # decay exactly 1
+                                      (4.0, 4.0, 0.016666),      # the GUI's maxima
+                                      (59.0, 0.3, 0.016666),     # velocity decay 1.98: still the fast kernel; heavy damping -> subnormal quotients
+                                      (100.0, 1.0, 0.016666),    # decay 2.67: outside [1, 2) -> the general kernel
+                                      (-0.5, -2.0, 0.016666),    # decays below 1 (growth): the general kernel
+                                      (0.2, 1.0, 0.0)])          # dt = 0
+def test_fused_advection_divides_exactly_whatever_the_decay(vd, dd, dt):
+    """the fused advection kernel replaces the IEEE divide by a wave-uniform divisor with a double multiply (fluid_math.h div_uniform)
+    where that is provably exact, and falls back to the general kernel elsewhere: either way the bits of the per-pass kernels, which
+    divide the plain way — incl. tiny values that decay into the subnormal range (dye tails of exp_reference are ~1e-38 from the start)"""
+    import fluid_hip
+    cfg = {"SIM_RESOLUTION": 250, "DYE_RESOLUTION": 250, "PRESSURE_ITERATIONS": 12, "VELOCITY_DISSIPATION": vd, "DENSITY_DISSIPATION": dd}
+    sims = [fluid_hip.FluidSim(canvas=(500, 250), config=cfg, schedule=s, random=fluid_hip.mulberry32(11)) for s in ("passes", "fused")]
+    try:
+        rng = np.random.default_rng(3)
+        H, W = sims[0].velocity.height, sims[0].velocity.width
+        tiny = (rng.normal(0, 1, (H, W, 4)) * rng.choice([1e-44, 1e-40, 1e-38, 1e-30, 1.0], (H, W, 4))).astype(np.float32)
+        for s in sims:
+            s.multipleSplats(5)
+            s.write("dye", np.abs(tiny) + s.read("dye") * (np.abs(tiny) > 0.5))   # mostly subnormal / tiny dye, some ordinary values
+            s.step(dt, 4)
+        for k in ("velocity", "pressure", "divergence", "curl", "dye"):
+            assert np.array_equal(sims[0].read(k), sims[1].read(k)), k
+        d = sims[1].read("dye")
+        assert np.isfinite(d).all() and ((d != 0) & (np.abs(d) < 1.2e-38)).any()          # subnormals really went through the divide
+    finally:
+        for s in sims:
+            s.close()
+
+
 def test_zero_state_is_a_fixed_point_4096():
     s = sim_of(4096, "fused")
     try:

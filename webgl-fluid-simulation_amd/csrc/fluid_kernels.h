@@ -28,6 +28,8 @@ struct Win {
     int u0, u1;
 };
 inline int pitch_of(int cols) { return (cols + 3) & ~3; }
+inline double udiv_recip(float d) { return 1.0 / (double)d; }
+inline bool udiv_decay_ok(float d) { return d >= 1.0f && d < 2.0f; }
 inline Win make_win(int W, int H, int g0, int rows) { return Win{ W, H, g0, rows, 0, pitch_of(W), g0, g0 + rows, 0, W, 0, W }; }
 // a window that holds global columns [ca, cb) only (ca a multiple of 4): the arrays of a 2-D tile
 inline Win make_win_cols(int W, int H, int g0, int rows, int ca, int cb)

@@ -98,9 +98,7 @@ __global__ void __launch_bounds__(BX) k_advect_dye(Win vw, const float2* __restr
 // Same per-texel arithmetic as the two kernels above, hence the same bits.
 // ROWS texels per thread (consecutive rows, same column), processed stage by stage so that the ROWS independent
 // gathers of a stage are all in flight together (velocity -> 4 velocity taps -> 4 dye taps; two texels per thread measure 6 % faster
-// than one).  Beyond its HBM bytes the kernel pays for the volume of its gathers through the vector L1 — nine loads, 104 B requested
-// per texel for 24 B of new data — not for its arithmetic and not for the dependency chain (DESIGN.md 6.1,
-// profiles/r02/advect_experiments.txt; the variants that established it: tools/experiments/advect_fast_kernel.hip.txt).
+// than one).  advect_both_body is the GENERAL form (any array size, any decay); k_advect_both_fast below is what normally runs.
 struct Fetch2 {
     float2 a, b, c, d;
     float fx, fy;
@@ -167,6 +165,195 @@ __device__ __forceinline__ void advect_both_body(const Win& w, const V2* __restr
     }
     if (miss) atomicAdd(miss_out, (unsigned)miss);
 }
+
+// ---- csrc/fluid_kernels.hip ----
+// ---- the same kernel with everything that is not the reference's arithmetic taken off the VALU, and fewer tap loads ----
+// advect_both_body spends 540 VALU instructions per two texels, of which the reference's own arithmetic (back-trace, filter weights,
+// mixes) is a fifth: 15 IEEE divides (150 instructions) although every divisor is wave-uniform (W, H, the two decays) -> div_uniform (3
+// each, bit-exact); CLAMP_TO_EDGE, array-range and freshness clamps on every tap of every fetch (~25 per fetch) although all but the border
+// waves are interior -> one unsigned range test per axis on the first tap and a branch (the clamped path stays, per lane, for the texels
+// that need it); 64-bit tap addresses (~14 per fetch) -> 32-bit byte offsets from one base (saddr + voffset loads).  259 instructions.
+// Beyond its HBM bytes the kernel pays for the volume of its gathers through the vector L1 (nine loads, 104 B requested per texel for
+// 24 B of new data: timing probes in profiles/r02/advect_experiments.txt), so the two horizontally adjacent velocity taps of a row —
+// 16 contiguous bytes wherever no clamp intervenes — come in ONE load (gather_taps).  Measured inside the step at 4096^2, interleaved
+// A/B: 170.0 us (general, two texels per thread) -> 159.2 (VALU) -> 157.1 (+ paired velocity taps) -> 145.5 us with four texels per
+// thread, which the lighter kernel can afford (98 VGPRs); 1880 -> 1950 steps/s.
+// Launched when the dye array fits 32-bit byte offsets (<= 4 GiB: holds up to BASELINE's 16384^2) and both decay divisors are in [1, 2);
+// otherwise the general kernel.  Same fp32 operations in the same order on the same values, hence the same bits (tests: fused == per-pass
+// kernels — which divide and clamp the plain way — array_equal on every shape, stripes and tiles with misses included).
+struct TapBox {
+    int xlo, ylo;
+    unsigned nx, ny;
+};
+// the first taps (i0, j0) of a fetch whose four taps all lie inside the domain (no CLAMP_TO_EDGE), inside the array and inside the part of
+// the window that is fresh (no miss)
+__device__ __forceinline__ TapBox tap_box(const Win& w)
+{
+    const int xlo = max(max(w.u0, w.c0), 0), xhi = min(min(w.u1, w.c0 + w.P), w.W) - 2;
+    const int ylo = max(max(w.v0, w.g0), 0), yhi = min(min(w.v1, w.g0 + w.rows), w.H) - 2;
+    return TapBox{ xlo, ylo, (unsigned)max(xhi - xlo + 1, 0), (unsigned)max(yhi - ylo + 1, 0) };
+}
+struct Tap4 {
+    unsigned a, b, c, d;  // BYTE offsets of the four taps from the field's base pointer
+    float fx, fy;
+    int miss;
+};
+// SZ = bytes per texel of the field fetched from
+template <unsigned SZ>
+__device__ __forceinline__ Tap4 taps32(const Win& w, const TapBox& B, float u, float v)
+{
+    const float x = u * (float)w.W - 0.5f;
+    const float y = v * (float)w.H - 0.5f;
+    const float fi = floorf(x), fj = floorf(y);
+    Tap4 t;
+    t.fx = x - fi;
+    t.fy = y - fj;
+    const int i0 = (int)fi, j0 = (int)fj;
+    if ((unsigned)(i0 - B.xlo) < B.nx && (unsigned)(j0 - B.ylo) < B.ny) {
+        // ((j0 - g0) P + (i0 - c0)) SZ with the uniform part on the scalar unit; j0 >= 0 and P SZ < 2^24 here: a 24-bit multiply-add
+        const unsigned row_bytes = (unsigned)w.P * SZ;
+        const unsigned k = 0u - (unsigned)(w.g0 * w.P + w.c0) * SZ;
+        t.a = __umul24((unsigned)j0, row_bytes) + k + (unsigned)i0 * SZ;
+        t.b = t.a + SZ;
+        t.c = t.a + row_bytes;
+        t.d = t.c + SZ;
+        t.miss = 0;
+    } else {  // bil_taps, fluid_math.h
+        const int ia = clampi(i0, 0, w.W - 1), ib = clampi(i0 + 1, 0, w.W - 1);
+        const int ja = clampi(j0, 0, w.H - 1), jb = clampi(j0 + 1, 0, w.H - 1);
+        t.miss = (ja < w.v0 || ja >= w.v1) + (jb < w.v0 || jb >= w.v1) + (ia < w.u0 || ia >= w.u1) + (ib < w.u0 || ib >= w.u1);
+        const int la = clampi(ja - w.g0, 0, w.rows - 1), lb = clampi(jb - w.g0, 0, w.rows - 1);
+        const int ka = clampi(ia - w.c0, 0, w.P - 1), kb = clampi(ib - w.c0, 0, w.P - 1);
+        t.a = (unsigned)(la * w.P + ka) * SZ;
+        t.b = (unsigned)(la * w.P + kb) * SZ;
+        t.c = (unsigned)(lb * w.P + ka) * SZ;
+        t.d = (unsigned)(lb * w.P + kb) * SZ;
+    }
+    return t;
+}
+// the texel at a 32-bit byte offset from the (uniform) base pointer
+template <class T>
+__device__ __forceinline__ const T* at_byte(const T* p, unsigned o)
+{
+    return reinterpret_cast<const T*>(reinterpret_cast<const char*>(p) + (size_t)o);
+}
+template <class T>
+__device__ __forceinline__ T* at_byte(T* p, unsigned o)
+{
+    return reinterpret_cast<T*>(reinterpret_cast<char*>(p) + (size_t)o);
+}
+
+
+// two horizontally adjacent fp32 velocity texels in one 16-byte load (8-byte aligned: global loads only need dword alignment)
+typedef float pair_f2 __attribute__((ext_vector_type(4), aligned(8)));
+__device__ __forceinline__ void load_pair(const float2* F, unsigned o, float2& a, float2& b)
+{
+    const pair_f2 v = *reinterpret_cast<const pair_f2*>(reinterpret_cast<const char*>(F) + (size_t)o);
+    a = make_float2(v.x, v.y);
+    b = make_float2(v.z, v.w);
+}
+// f[k].a .. f[k].d = the texels at byte offsets t[k].a .. t[k].d of field F
+template <int ROWS, class T, class FT>
+__device__ __forceinline__ void gather_taps(const T* __restrict__ F, const Tap4 (&t)[ROWS], FT (&f)[ROWS])
+{
+#pragma unroll
+    for (int k = 0; k < ROWS; k++) {
+        bool paired = false;
+        if constexpr (sizeof(T) == sizeof(float2) && sizeof(f[k].a) == sizeof(float2)) {   // fp32 velocity
+            paired = t[k].b == t[k].a + 8u && t[k].d == t[k].c + 8u;                       // no clamp between the two taps of a row
+            if (paired) {
+                load_pair(reinterpret_cast<const float2*>(F), t[k].a, f[k].a, f[k].b);
+                load_pair(reinterpret_cast<const float2*>(F), t[k].c, f[k].c, f[k].d);
+            }
+        }
+        if (!paired) {
+            f[k].a = ld(at_byte(F, t[k].a), 0); f[k].b = ld(at_byte(F, t[k].b), 0); f[k].c = ld(at_byte(F, t[k].c), 0); f[k].d = ld(at_byte(F, t[k].d), 0);
+        }
+        f[k].fx = t[k].fx;
+        f[k].fy = t[k].fy;
+    }
+}
+
+template <int ROWS, class V2, class D4>
+__device__ __forceinline__ void advect_both_fast_body(const Win& w, const V2* __restrict__ vel, V2* __restrict__ vel_out,
+                                                      const D4* __restrict__ dye, D4* __restrict__ dye_out, float dt, double rW, double rH,
+                                                      double rvd, double rdd, float tsx, float tsy, int ga, int gb,
+                                                      unsigned int* __restrict__ miss_out)
+{
+    // a lane past the last column repeats it (loads stay in bounds, nothing stored, nothing counted), like a row past the band
+    const int lane_i = w.x0 + blockIdx.x * BX + threadIdx.x;
+    const bool live = lane_i < w.x1;
+    const int i = live ? lane_i : w.x1 - 1;
+    const int gj0 = ga + blockIdx.y * ROWS;
+    const TapBox B = tap_box(w);
+    const float u = div_uniform((float)i + 0.5f, rW);
+    int miss = 0;
+    bool on[ROWS];
+    unsigned c[ROWS];  // texel index: the velocity and the dye arrays have different texel sizes
+    float v[ROWS];
+    float2 vv[ROWS], nv[ROWS];
+#pragma unroll
+    for (int k = 0; k < ROWS; k++) {
+        const int gj = gj0 + k;
+        on[k] = live && gj < gb;
+        const int gjc = gj < gb ? gj : gb - 1;  // a row past the band repeats the last one
+        v[k] = div_uniform((float)gjc + 0.5f, rH);
+        c[k] = (unsigned)((gjc - w.g0) * w.P + (i - w.c0));
+        vv[k] = ld(at_byte(vel, c[k] * (unsigned)sizeof(V2)), 0);
+    }
+    Tap4 t[ROWS];
+    Fetch2 f2[ROWS];
+#pragma unroll
+    for (int k = 0; k < ROWS; k++) {
+        t[k] = taps32<sizeof(V2)>(w, B, u - dt * vv[k].x * tsx, v[k] - dt * vv[k].y * tsy);
+        if (on[k]) miss += t[k].miss;
+    }
+    gather_taps<ROWS>(vel, t, f2);
+#pragma unroll
+    for (int k = 0; k < ROWS; k++) {
+        const Fetch2& f = f2[k];
+        const float rx = mixf(mixf(f.a.x, f.b.x, f.fx), mixf(f.c.x, f.d.x, f.fx), f.fy);
+        const float ry = mixf(mixf(f.a.y, f.b.y, f.fx), mixf(f.c.y, f.d.y, f.fx), f.fy);
+        // the dye pass reads the velocity TEXTURE the velocity pass wrote: with fp16 storage that is the rounded value
+        nv[k] = make_float2(kept(vel_out, div_uniform(rx, rvd)), kept(vel_out, div_uniform(ry, rvd)));
+        if (on[k]) st(at_byte(vel_out, c[k] * (unsigned)sizeof(V2)), 0, nv[k]);
+        t[k] = taps32<sizeof(D4)>(w, B, u - dt * nv[k].x * tsx, v[k] - dt * nv[k].y * tsy);
+        if (on[k]) miss += t[k].miss;
+    }
+    Fetch4 f4[ROWS];
+    gather_taps<ROWS>(dye, t, f4);
+#pragma unroll
+    for (int k = 0; k < ROWS; k++) {
+        const Fetch4& f = f4[k];
+        const float4 d = make_float4(mixf(mixf(f.a.x, f.b.x, f.fx), mixf(f.c.x, f.d.x, f.fx), f.fy),
+                                     mixf(mixf(f.a.y, f.b.y, f.fx), mixf(f.c.y, f.d.y, f.fx), f.fy),
+                                     mixf(mixf(f.a.z, f.b.z, f.fx), mixf(f.c.z, f.d.z, f.fx), f.fy),
+                                     mixf(mixf(f.a.w, f.b.w, f.fx), mixf(f.c.w, f.d.w, f.fx), f.fy));
+        if (on[k])
+            st(at_byte(dye_out, c[k] * (unsigned)sizeof(D4)), 0,
+               make_float4(div_uniform(d.x, rdd), div_uniform(d.y, rdd), div_uniform(d.z, rdd), div_uniform(d.w, rdd)));
+    }
+    if (miss) atomicAdd(miss_out, (unsigned)miss);
+}
+
+template <int ROWS>
+__global__ void __launch_bounds__(BX) k_advect_both_fast(Win w, const float2* __restrict__ vel, float2* __restrict__ vel_out,
+                                                          const float4* __restrict__ dye, float4* __restrict__ dye_out, float dt, double rW,
+                                                          double rH, double rvd, double rdd, float tsx, float tsy, int ga, int gb,
+                                                          unsigned int* __restrict__ miss_out)
+{
+    advect_both_fast_body<ROWS>(w, vel, vel_out, dye, dye_out, dt, rW, rH, rvd, rdd, tsx, tsy, ga, gb, miss_out);
+}
+
+template <int ROWS>
+__global__ void __launch_bounds__(BX) k_advect_both_fast_h(Win w, const __half2* __restrict__ vel, __half2* __restrict__ vel_out,
+                                                            const half4* __restrict__ dye, half4* __restrict__ dye_out, float dt, double rW,
+                                                            double rH, double rvd, double rdd, float tsx, float tsy, int ga, int gb,
+                                                            unsigned int* __restrict__ miss_out)
+{
+    advect_both_fast_body<ROWS>(w, vel, vel_out, dye, dye_out, dt, rW, rH, rvd, rdd, tsx, tsy, ga, gb, miss_out);
+}
+
 
 template <int ROWS>
 __global__ void __launch_bounds__(BX) k_advect_both(Win w, const float2* __restrict__ vel, float2* __restrict__ vel_out,
@@ -951,20 +1138,51 @@ hipError_t launch_advect_dye(hipStream_t s, Win vw, const float2* vel, Win dw, c
     return hipGetLastError();
 }
 
+// k_advect_both_fast serves when the dye array fits 32-bit byte offsets and both decay divisors are in [1, 2) (div_uniform);
+// FLUID_ADVECT_FAST=0 keeps the general kernel (A/B knob)
+static bool advect_fast_ok(const Win& w, size_t dye_texel_bytes, float vdecay, float ddecay)
+{
+    static const bool enabled = [] {
+        const char* e = getenv("FLUID_ADVECT_FAST");
+        return !(e && atoi(e) == 0);
+    }();
+    return enabled && udiv_decay_ok(vdecay) && udiv_decay_ok(ddecay) && (size_t)w.rows * (size_t)w.P * dye_texel_bytes <= (1ull << 32) &&
+           (size_t)w.P * dye_texel_bytes < (1u << 24) && w.H < (1 << 24);
+}
+
+// texels per thread of the fast kernel (FLUID_ADVECT_ROWS / FLUID_ADVECT_ROWS_F16: A/B knobs); the general kernel runs with two
+static int advect_rows(const char* env, int dflt)
+{
+    const char* e = getenv(env);
+    const int k = e ? atoi(e) : dflt;
+    return (k == 1 || k == 2 || k == 3 || k == 4 || k == 6 || k == 8) ? k : dflt;
+}
+#define ADVECT_FAST_CASE(K, R)                                                                                                        \
+    case R:                                                                                                                           \
+        K<R><<<dim3(gx, (gb - ga + R - 1) / R, 1), BX, 0, s>>>(w, vel, vel_out, dye, dye_out, dt, rW, rH, rvd, rdd, tsx, tsy, ga, gb, miss); \
+        break;
+
 hipError_t launch_advect_both(hipStream_t s, Win w, const float2* vel, float2* vel_out, const float4* dye, float4* dye_out,
                               float dt, float vel_dissipation, float dye_dissipation, int ga, int gb, unsigned int* miss)
 {
     ROWS_OR_RETURN();
-    static const int rows_per_thread = [] {  // FLUID_ADVECT_ROWS: 1, 2 or 4 texels per thread (A/B knob)
-        const char* e = getenv("FLUID_ADVECT_ROWS");
-        const int k = e ? atoi(e) : 2;
-        return (k == 1 || k == 2 || k == 4) ? k : 2;
-    }();
+    static const int rows = advect_rows("FLUID_ADVECT_ROWS", 4);
     const float tsx = (float)(1.0 / w.W), tsy = (float)(1.0 / w.H);
-    const dim3 g((w.x1 - w.x0 + BX - 1) / BX, (gb - ga + rows_per_thread - 1) / rows_per_thread, 1);
-    if (rows_per_thread == 1) k_advect_both<1><<<g, BX, 0, s>>>(w, vel, vel_out, dye, dye_out, dt, vel_dissipation, dye_dissipation, tsx, tsy, ga, gb, miss);
-    else if (rows_per_thread == 2) k_advect_both<2><<<g, BX, 0, s>>>(w, vel, vel_out, dye, dye_out, dt, vel_dissipation, dye_dissipation, tsx, tsy, ga, gb, miss);
-    else k_advect_both<4><<<g, BX, 0, s>>>(w, vel, vel_out, dye, dye_out, dt, vel_dissipation, dye_dissipation, tsx, tsy, ga, gb, miss);
+    const unsigned gx = (w.x1 - w.x0 + BX - 1) / BX;
+    const float vdecay = 1.0f + vel_dissipation * dt, ddecay = 1.0f + dye_dissipation * dt;
+    if (advect_fast_ok(w, sizeof(float4), vdecay, ddecay)) {
+        const double rW = udiv_recip((float)w.W), rH = udiv_recip((float)w.H), rvd = udiv_recip(vdecay), rdd = udiv_recip(ddecay);
+        switch (rows) {
+            ADVECT_FAST_CASE(k_advect_both_fast, 1)
+            ADVECT_FAST_CASE(k_advect_both_fast, 2)
+            ADVECT_FAST_CASE(k_advect_both_fast, 3)
+            ADVECT_FAST_CASE(k_advect_both_fast, 4)
+            ADVECT_FAST_CASE(k_advect_both_fast, 6)
+            ADVECT_FAST_CASE(k_advect_both_fast, 8)
+        }
+        return hipGetLastError();
+    }
+    k_advect_both<2><<<dim3(gx, (gb - ga + 1) / 2, 1), BX, 0, s>>>(w, vel, vel_out, dye, dye_out, dt, vel_dissipation, dye_dissipation, tsx, tsy, ga, gb, miss);
     return hipGetLastError();
 }
 
@@ -972,17 +1190,26 @@ hipError_t launch_advect_both(hipStream_t s, Win w, const __half2* vel, __half2*
                               float vel_dissipation, float dye_dissipation, int ga, int gb, unsigned int* miss)
 {
     ROWS_OR_RETURN();
-    static const int rows = [] {  // FLUID_ADVECT_ROWS_F16: 2 or 4 texels per thread (A/B knob)
-        const char* e = getenv("FLUID_ADVECT_ROWS_F16");
-        const int k = e ? atoi(e) : 2;
-        return (k == 2 || k == 4) ? k : 2;
-    }();
+    static const int rows = advect_rows("FLUID_ADVECT_ROWS_F16", 4);
     const float tsx = (float)(1.0 / w.W), tsy = (float)(1.0 / w.H);
-    const dim3 g((w.x1 - w.x0 + BX - 1) / BX, (gb - ga + rows - 1) / rows, 1);
-    if (rows == 2) k_advect_both_h<2><<<g, BX, 0, s>>>(w, vel, vel_out, dye, dye_out, dt, vel_dissipation, dye_dissipation, tsx, tsy, ga, gb, miss);
-    else k_advect_both_h<4><<<g, BX, 0, s>>>(w, vel, vel_out, dye, dye_out, dt, vel_dissipation, dye_dissipation, tsx, tsy, ga, gb, miss);
+    const unsigned gx = (w.x1 - w.x0 + BX - 1) / BX;
+    const float vdecay = 1.0f + vel_dissipation * dt, ddecay = 1.0f + dye_dissipation * dt;
+    if (advect_fast_ok(w, sizeof(half4), vdecay, ddecay)) {
+        const double rW = udiv_recip((float)w.W), rH = udiv_recip((float)w.H), rvd = udiv_recip(vdecay), rdd = udiv_recip(ddecay);
+        switch (rows) {
+            ADVECT_FAST_CASE(k_advect_both_fast_h, 1)
+            ADVECT_FAST_CASE(k_advect_both_fast_h, 2)
+            ADVECT_FAST_CASE(k_advect_both_fast_h, 3)
+            ADVECT_FAST_CASE(k_advect_both_fast_h, 4)
+            ADVECT_FAST_CASE(k_advect_both_fast_h, 6)
+            ADVECT_FAST_CASE(k_advect_both_fast_h, 8)
+        }
+        return hipGetLastError();
+    }
+    k_advect_both_h<2><<<dim3(gx, (gb - ga + 1) / 2, 1), BX, 0, s>>>(w, vel, vel_out, dye, dye_out, dt, vel_dissipation, dye_dissipation, tsx, tsy, ga, gb, miss);
     return hipGetLastError();
 }
+#undef ADVECT_FAST_CASE
 
 hipError_t launch_splat_velocity(hipStream_t s, Win w, const float2* base, float2* out, float x, float y, float aspect,
                                  float radius, float c0, float c1, int ga, int gb)

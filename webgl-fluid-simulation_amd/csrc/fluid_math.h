@@ -104,6 +104,23 @@ __device__ __forceinline__ Taps bil_taps(const Win& w, float u, float v)
 
 __device__ __forceinline__ float mixf(float a, float b, float t) { return a + (b - a) * t; }
 
+// ---- csrc/fluid_math.h ----
+// x / d for a WAVE-UNIFORM divisor d, with r = 1.0 / (double)d rounded to double (host: udiv_recip): the fp32 quotient, CORRECTLY
+// ROUNDED — bit for bit `x / d` — in three full-rate instructions (v_cvt_f64_f32, v_mul_f64, v_cvt_f32_f64) instead of the 10-instruction
+// IEEE divide sequence (v_div_scale x 2, v_rcp, 5 fma, v_div_fmas, v_div_fixup: 14 fma-issue-slots on this chip,
+// tools/micro/valu_rate2.hip).  Why it is exact: the product carries a relative error <= 2^-52 (r and the multiply, 2^-53 each), while a
+// quotient of two 24-bit significands that is not itself a rounding boundary stays >= 2^-49 (relative) away from every boundary
+// (midpoint of two neighbouring floats: a 25-bit significand M; |x/d - M| = |x - d M| / d and x - d M is a non-zero multiple of the product
+// of their last places), and it never IS a boundary: d M would need >= 26 significant bits unless d is a power of two, where r is exact.
+// Results in the subnormal range (a decaying dye does get there, and the reference keeps subnormals): the boundaries are coarser, the
+// margin is 2^-48, and an exact tie would need d * (odd) to be an even multiple of the input's last place — impossible for 1 <= d < 2,
+// which is what the callers guarantee for the divisors whose quotients can underflow (udiv_decay_ok).  Zeros keep their sign, infinities
+// and NaNs propagate (a multiply by a positive finite number).  Checked against `x / d` on 2.4e8 (d, x) pairs of every class and on
+// every (i + .5) / W, W <= 2200 and the BASELINE widths (tests/test_div_uniform.py).
+__device__ __forceinline__ float div_uniform(float x, double r) { return (float)((double)x * r); }
+
+
+
 // exp() as the reference's GL implementation evaluates it (splatShader, script.js:738, calls the GLSL built-in; the algorithm lives in
 // the rasteriser the reference runs on here: SwiftShader as bundled with Chromium 88, src/Pipeline/ShaderCore.cpp `exponential()` /
 // `exponential2()`): exp(x) = exp2(1.44269504 x), exp2(x) = 2^i * poly5(f), i = round-to-nearest-even(x - 0.5), f = x - i, the integer part
