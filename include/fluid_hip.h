@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define FLUID_ABI_VERSION 6
+#define FLUID_ABI_VERSION 7
 
 typedef enum fluid_status {
     FLUID_OK = 0,
@@ -114,6 +114,8 @@ typedef struct fluid_timings {
     float total_ms;
     int jacobi_launches;   /* kernel launches the Jacobi loop took (ITERS, or fewer when temporally blocked) */
     int steps;             /* steps the sums cover */
+    int folded_launches;   /* how many of jacobi_launches also carried the gradient subtract (fused schedule: the last launch of a
+                            * step's loop).  Their time is in gradsub_ms; jacobi_ms covers the other jacobi_launches - folded_launches */
 } fluid_timings;
 
 typedef struct fluid_ctx fluid_ctx;

@@ -480,6 +480,8 @@ static napi_value n_get_timings(napi_env env, napi_callback_info info)
     NAPI_OK(napi_set_named_property(env, obj, "jacobiLaunches", v));
     NAPI_OK(napi_create_int32(env, t.steps, &v));
     NAPI_OK(napi_set_named_property(env, obj, "steps", v));
+    NAPI_OK(napi_create_int32(env, t.folded_launches, &v));
+    NAPI_OK(napi_set_named_property(env, obj, "foldedLaunches", v));
     return obj;
 }
 

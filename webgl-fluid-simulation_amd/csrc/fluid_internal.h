@@ -36,7 +36,7 @@ struct fluid_ctx {
     hipEvent_t ev[P_COUNT + 1] = {};
     double acc_ms[P_COUNT] = {};
     double acc_total = 0;
-    int acc_steps = 0, acc_jacobi_launches = 0;
+    int acc_steps = 0, acc_jacobi_launches = 0, acc_folded_launches = 0;
 
     // stripe driver (fluid_stripes.cpp): RCCL communicator of the stripe set, exchange bookkeeping
     void* comm = nullptr;                // ncclComm_t, rank == desc.part, nranks == desc.parts
@@ -122,8 +122,10 @@ int pass_vorticity(fluid_ctx* c, float curl, float dt, int ext);
 int pass_divergence(fluid_ctx* c, int ext);
 int pass_curl_vort_div(fluid_ctx* c, float curl, float dt, int ext, Timer* t);
 int pass_clear(fluid_ctx* c, float value, int ext);
-int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launches);
-int pass_clear_jacobi(fluid_ctx* c, float value, int iters, int ext_out, int* launches);
+struct Timer;
+int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launches, bool* gradsub, Timer* t);
+bool gradsub_fold_enabled();
+int pass_clear_jacobi(fluid_ctx* c, float value, int iters, int ext_out, int* launches, bool* gradsub);
 int pass_gradsub(fluid_ctx* c, int ext);
 int pass_advect_velocity(fluid_ctx* c, float dt, float dissipation, int ext);
 int pass_advect_dye(fluid_ctx* c, float dt, float dissipation);

@@ -108,6 +108,14 @@ int jacobi_tb_max_iters();
 bool jacobi_tb_supported(Win w);
 hipError_t launch_jacobi_tb(hipStream_t s, Win w, const float* p, const float* div, float* p_out, float pscale,
                             int iters, int ga, int gb);
+// The same launch with K6 (gradient subtract) folded in — for the LAST block of a step's loop: runs `iters` iterations, writes p_out rows
+// [ga, gb) AND vel_out = vel - grad(p_out) for the same texels (the tile carries one more apron ring, so the pressure neighbours of every
+// stored texel are exact in registers).  Reads p rows [ga - iters - 1, gb + iters + 1).  Bitwise equal to launch_jacobi_tb + launch_gradsub.
+bool jacobi_tb_gradsub_supported(Win w, int ga, int gb);
+hipError_t launch_jacobi_tb_gradsub(hipStream_t s, Win w, const float* p, const float* div, float* p_out, const float2* vel, float2* vel_out,
+                                    float pscale, int iters, int ga, int gb);
+hipError_t launch_jacobi_tb_gradsub(hipStream_t s, Win w, const __half* p, const __half* div, __half* p_out, const __half2* vel,
+                                    __half2* vel_out, float pscale, int iters, int ga, int gb);
 // the fused kernels on fp16-storage fields: every intermediate the reference would have rendered to a half-float texture
 // between two of the fused passes (curl, the confined velocity, the advected velocity) is rounded to fp16 in registers,
 // so each is bitwise equal to its single-pass half kernels run in turn

@@ -493,6 +493,63 @@ __device__ __forceinline__ v2f round_half(v2f v)
     return __builtin_convertvector(__builtin_convertvector(v, v2h), v2f);  // fptrunc (RTNE: one v_cvt_pk_f16_f32 on gfx950) + fpext
 }
 
+// ------------------------------------------------------------------------------------------------
+// Four consecutive texels of a lane, to / from fp32 or fp16 fields (the register-tile kernels below are templated on the
+// storage type; the fp32 instantiations are the kernels the headline runs, the half ones serve FLUID_STORE_F16).
+// (`kept(field, v)`, fluid_math.h: what a field of that storage keeps of v — applied to every intermediate the reference
+// would have written to a texture between two of the fused passes.)
+
+__device__ __forceinline__ float4 load_s4(const float* p, size_t idx) { return *reinterpret_cast<const float4*>(p + idx); }
+__device__ __forceinline__ float4 load_s4(const __half* p, size_t idx)
+{
+    const half4 h = *reinterpret_cast<const half4*>(p + idx);
+    const float2 a = __half22float2(h.lo), b = __half22float2(h.hi);
+    return make_float4(a.x, a.y, b.x, b.y);
+}
+__device__ __forceinline__ void store_s4(float* p, size_t idx, float4 v) { *reinterpret_cast<float4*>(p + idx) = v; }
+__device__ __forceinline__ void store_s4(__half* p, size_t idx, float4 v)
+{
+    half4 h;
+    h.lo = __float22half2_rn(make_float2(v.x, v.y));
+    h.hi = __float22half2_rn(make_float2(v.z, v.w));
+    *reinterpret_cast<half4*>(p + idx) = h;
+}
+// four velocity texels as two (x0 y0 x1 y1) groups
+__device__ __forceinline__ void load_v4(const float2* vel, size_t idx, float4& a, float4& b)
+{
+    const float4* src = reinterpret_cast<const float4*>(vel + idx);
+    a = src[0];
+    b = src[1];
+}
+__device__ __forceinline__ void load_v4(const __half2* vel, size_t idx, float4& a, float4& b)
+{
+    struct alignas(16) H8 {
+        __half2 t[4];
+    };
+    const H8 h = *reinterpret_cast<const H8*>(vel + idx);
+    const float2 t0 = __half22float2(h.t[0]), t1 = __half22float2(h.t[1]), t2 = __half22float2(h.t[2]), t3 = __half22float2(h.t[3]);
+    a = make_float4(t0.x, t0.y, t1.x, t1.y);
+    b = make_float4(t2.x, t2.y, t3.x, t3.y);
+}
+__device__ __forceinline__ void store_v4(float2* vel, size_t idx, float4 a, float4 b)
+{
+    float4* dst = reinterpret_cast<float4*>(vel + idx);
+    dst[0] = a;
+    dst[1] = b;
+}
+__device__ __forceinline__ void store_v4(__half2* vel, size_t idx, float4 a, float4 b)
+{
+    struct alignas(16) H8 {
+        __half2 t[4];
+    };
+    H8 h;
+    h.t[0] = __float22half2_rn(make_float2(a.x, a.y));
+    h.t[1] = __float22half2_rn(make_float2(a.z, a.w));
+    h.t[2] = __float22half2_rn(make_float2(b.x, b.y));
+    h.t[3] = __float22half2_rn(make_float2(b.z, b.w));
+    *reinterpret_cast<H8*>(vel + idx) = h;
+}
+
 // One texel row of a Jacobi iteration (pressureShader script.js:881-888, operand order of line 887:
 // ((L + R) + B) + T - div) * 0.25): 11 VALU instructions for the lane's four texels.  HALF: the iteration's output goes
 // through fp16, as it does when the reference renders it into a half-float texture.
@@ -568,10 +625,11 @@ __device__ __forceinline__ void jacobi_sweep(Quad (&P)[RY], const Quad (&D)[RY],
 }
 
 // T = float (fp32 fields) or __half (fp16 storage: the clear and every iteration round their output to fp16)
-template <int NW, int RY, int HX, int HY, int EDGE, class T>
+template <int NW, int RY, int HX, int HY, int EDGE, class T, bool GS = false, class V2 = float2>
 __device__ __forceinline__ void jacobi_tb_body(const Win& w, const T* __restrict__ p, const T* __restrict__ div,
                                                T* __restrict__ p_out, float pscale, int iters, int ga, int gb, int x0,
-                                               int y0, float4 (*mail)[NW][2][64])
+                                               int y0, float4 (*mail)[NW][2][64], const V2* __restrict__ vel = nullptr,
+                                               V2* __restrict__ vel_out = nullptr)
 {
     constexpr bool HALF = sizeof(T) == 2;
     using G = JacobiTB<NW, RY, HX, HY>;
@@ -630,6 +688,67 @@ __device__ __forceinline__ void jacobi_tb_body(const Win& w, const T* __restrict
         if (col_store && gj >= out_lo && gj < out_hi)
             store_quad(p_out, (size_t)at(w, gj, cx), P[r]);
     }
+
+    // K6 folded into the LAST launch of the loop (gradientSubtractShader script.js:895-913): the tile still holds the final pressure,
+    // exact one ring beyond what it stores (the launcher gives this instantiation an apron of iters + 1 rows, HX >= iters + 1 columns),
+    // so velocity -= (R - L, T - B) needs no second trip of the pressure through HBM and no launch of its own: the step moves
+    // 16 B/texel here (velocity in and out) instead of 20 in k_gradsub4 + the kernel boundary.  Same subtraction per texel as
+    // gradsub_texel / gradsub4_body, hence the same bits.
+    if constexpr (GS) {
+        float4 (*box)[2][64] = mail[iters & 1];  // the slot the NEXT sweep would use: every wave is past the barrier behind its last readers
+        box[wv][0][lane] = raw_of(P[0]);
+        box[wv][1][lane] = raw_of(P[RY - 1]);
+        __syncthreads();
+        const Quad lo = quad_of_raw(box[wv > 0 ? wv - 1 : 0][1][lane]);
+        const Quad hi = quad_of_raw(box[wv < NW - 1 ? wv + 1 : NW - 1][0][lane]);
+        constexpr int CH = RY >= 8 ? (RY + 1) / 2 : RY;  // velocity rows in flight together (8 registers each)
+#pragma unroll
+        for (int r0 = 0; r0 < RY; r0 += CH) {
+            float4 va[CH], vb[CH];
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                const int r = r0 + k, gj = gy + r;
+                if (r < RY && gj >= out_lo && gj < out_hi) {  // wave-uniform
+                    if (col_store) load_v4(vel, (size_t)at(w, gj, cx), va[k], vb[k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                const int r = r0 + k, gj = gy + r;
+                if (r < RY && gj >= out_lo && gj < out_hi) {
+                    Quad C = P[r];
+                    Quad Tq = r < RY - 1 ? P[r + 1] : hi;
+                    Quad Bq = r > 0 ? P[r - 1] : lo;
+                    if (EDGE == 2 && nv < 4) {  // CLAMP_TO_EDGE inside the partly padded last quad, as in jacobi_row
+                        if (nv < 2) C.i.x = C.o.x;
+                        if (nv < 3) C.i.y = C.i.x;
+                        C.o.y = C.i.y;
+                    }
+                    float L = from_left_lane(C.o.y), R = from_right_lane(C.o.x);  // all lanes active here: the shifts see every neighbour
+                    if (EDGE) {
+                        if (at_left) L = C.o.x;
+                        if (nv <= 4) R = C.o.y;
+                    }
+                    if (EDGE == 2) {
+                        if (gj == 0) Bq = C;
+                        if (gj == w.H - 1) Tq = C;
+                    }
+                    if (col_store) {
+                        float4 oa, ob;
+                        oa.x = va[k].x - (C.i.x - L);
+                        oa.y = va[k].y - (Tq.o.x - Bq.o.x);
+                        oa.z = va[k].z - (C.i.y - C.o.x);
+                        oa.w = va[k].w - (Tq.i.x - Bq.i.x);
+                        ob.x = vb[k].x - (C.o.y - C.i.x);
+                        ob.y = vb[k].y - (Tq.i.y - Bq.i.y);
+                        ob.z = vb[k].z - (R - C.i.y);
+                        ob.w = vb[k].w - (Tq.o.y - Bq.o.y);
+                        store_v4(vel_out, (size_t)at(w, gj, cx), oa, ob);
+                    }
+                }
+            }
+        }
+    }
 }
 
 // BPC = workgroups that must fit on a CU together (their load / compute / store phases overlap each other):
@@ -651,6 +770,44 @@ __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb(Win w
     else jacobi_tb_body<NW, RY, HX, HY, 0>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
 }
 
+// The LAST launch of a step's loop with the gradient subtract folded in (jacobi_tb_body, GS): the row apron is HY + 1 so that `iters`
+// <= HY iterations leave the pressure exact one ring beyond the texels the tile stores; reads and writes the velocity for those texels.
+template <int NW, int RY, int HX, int HY, int BPC>
+__global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_gs(Win w, const float* __restrict__ p, const float* __restrict__ div,
+                                                           float* __restrict__ p_out, const float2* __restrict__ vel,
+                                                           float2* __restrict__ vel_out, float pscale, int iters, int ga, int gb, int xs,
+                                                           int ys, int nx, int ny, int remap)
+{
+    using G = JacobiTB<NW, RY, HX, HY + 1>;
+    __shared__ float4 mail[2][NW][2][64];
+    int bx, by;
+    tile_of_block((int)blockIdx.x, nx, ny, remap, bx, by);
+    const int x0 = xs + bx * G::VX, y0 = ys + by * G::VY;
+    const bool xedge = (x0 <= 0) || (x0 + G::TX >= w.W), yedge = (y0 <= 0) || (y0 + G::TY >= w.H);
+    const bool ragged = (w.W & 3) != 0 && x0 + G::TX >= w.W;
+    if (yedge || ragged) jacobi_tb_body<NW, RY, HX, HY + 1, 2, float, true>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail, vel, vel_out);
+    else if (xedge) jacobi_tb_body<NW, RY, HX, HY + 1, 1, float, true>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail, vel, vel_out);
+    else jacobi_tb_body<NW, RY, HX, HY + 1, 0, float, true>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail, vel, vel_out);
+}
+
+template <int NW, int RY, int HX, int HY, int BPC>
+__global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_gs_h(Win w, const __half* __restrict__ p, const __half* __restrict__ div,
+                                                             __half* __restrict__ p_out, const __half2* __restrict__ vel,
+                                                             __half2* __restrict__ vel_out, float pscale, int iters, int ga, int gb, int xs,
+                                                             int ys, int nx, int ny, int remap)
+{
+    using G = JacobiTB<NW, RY, HX, HY + 1>;
+    __shared__ float4 mail[2][NW][2][64];
+    int bx, by;
+    tile_of_block((int)blockIdx.x, nx, ny, remap, bx, by);
+    const int x0 = xs + bx * G::VX, y0 = ys + by * G::VY;
+    const bool xedge = (x0 <= 0) || (x0 + G::TX >= w.W), yedge = (y0 <= 0) || (y0 + G::TY >= w.H);
+    const bool ragged = (w.W & 3) != 0 && x0 + G::TX >= w.W;
+    if (yedge || ragged) jacobi_tb_body<NW, RY, HX, HY + 1, 2, __half, true>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail, vel, vel_out);
+    else if (xedge) jacobi_tb_body<NW, RY, HX, HY + 1, 1, __half, true>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail, vel, vel_out);
+    else jacobi_tb_body<NW, RY, HX, HY + 1, 0, __half, true>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail, vel, vel_out);
+}
+
 // the same tile on fp16-storage fields (FLUID_STORE_F16): half the bytes per launch; every iteration's output is rounded to
 // fp16 in registers, exactly where the reference's per-iteration render into a half-float texture rounds it
 template <int NW, int RY, int HX, int HY, int BPC>
@@ -668,63 +825,6 @@ __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_h(Win
     if (yedge || ragged) jacobi_tb_body<NW, RY, HX, HY, 2>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
     else if (xedge) jacobi_tb_body<NW, RY, HX, HY, 1>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
     else jacobi_tb_body<NW, RY, HX, HY, 0>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Four consecutive texels of a lane, to / from fp32 or fp16 fields (the register-tile kernels below are templated on the
-// storage type; the fp32 instantiations are the kernels the headline runs, the half ones serve FLUID_STORE_F16).
-// (`kept(field, v)`, fluid_math.h: what a field of that storage keeps of v — applied to every intermediate the reference
-// would have written to a texture between two of the fused passes.)
-
-__device__ __forceinline__ float4 load_s4(const float* p, size_t idx) { return *reinterpret_cast<const float4*>(p + idx); }
-__device__ __forceinline__ float4 load_s4(const __half* p, size_t idx)
-{
-    const half4 h = *reinterpret_cast<const half4*>(p + idx);
-    const float2 a = __half22float2(h.lo), b = __half22float2(h.hi);
-    return make_float4(a.x, a.y, b.x, b.y);
-}
-__device__ __forceinline__ void store_s4(float* p, size_t idx, float4 v) { *reinterpret_cast<float4*>(p + idx) = v; }
-__device__ __forceinline__ void store_s4(__half* p, size_t idx, float4 v)
-{
-    half4 h;
-    h.lo = __float22half2_rn(make_float2(v.x, v.y));
-    h.hi = __float22half2_rn(make_float2(v.z, v.w));
-    *reinterpret_cast<half4*>(p + idx) = h;
-}
-// four velocity texels as two (x0 y0 x1 y1) groups
-__device__ __forceinline__ void load_v4(const float2* vel, size_t idx, float4& a, float4& b)
-{
-    const float4* src = reinterpret_cast<const float4*>(vel + idx);
-    a = src[0];
-    b = src[1];
-}
-__device__ __forceinline__ void load_v4(const __half2* vel, size_t idx, float4& a, float4& b)
-{
-    struct alignas(16) H8 {
-        __half2 t[4];
-    };
-    const H8 h = *reinterpret_cast<const H8*>(vel + idx);
-    const float2 t0 = __half22float2(h.t[0]), t1 = __half22float2(h.t[1]), t2 = __half22float2(h.t[2]), t3 = __half22float2(h.t[3]);
-    a = make_float4(t0.x, t0.y, t1.x, t1.y);
-    b = make_float4(t2.x, t2.y, t3.x, t3.y);
-}
-__device__ __forceinline__ void store_v4(float2* vel, size_t idx, float4 a, float4 b)
-{
-    float4* dst = reinterpret_cast<float4*>(vel + idx);
-    dst[0] = a;
-    dst[1] = b;
-}
-__device__ __forceinline__ void store_v4(__half2* vel, size_t idx, float4 a, float4 b)
-{
-    struct alignas(16) H8 {
-        __half2 t[4];
-    };
-    H8 h;
-    h.t[0] = __float22half2_rn(make_float2(a.x, a.y));
-    h.t[1] = __float22half2_rn(make_float2(a.z, a.w));
-    h.t[2] = __float22half2_rn(make_float2(b.x, b.y));
-    h.t[3] = __float22half2_rn(make_float2(b.z, b.w));
-    *reinterpret_cast<H8*>(vel + idx) = h;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1001,20 +1101,28 @@ __global__ void __launch_bounds__(64 * NW, VD_WAVES_PER_EU) k_curl_vort_div_h(Wi
 constexpr int VD_NW = VD_NW_, VD_RY = VD_RY_;
 
 // tile-shape variants (NW waves x RY rows per wave, apron HX columns x HY rows, BPC workgroups per CU); FLUID_TB_VARIANT picks one (tuning knob,
-// read once); the default is the shape that measured best on MI355X at 4096^2 (profiles/)
-struct TBVariant { int nw, ry, hx, hy, bpc; };
+// read once).  Without the knob the shape follows the grid (tb_variant_for): the 8 x 10 tile measured best on MI355X at 4096^2 and above
+// (profiles/), but a 1024^2 launch is only 90 such tiles on 512 workgroup slots and each of them runs its ten iterations latency-bound
+// (15.8 us per launch, profiles/r02/pass_time_vs_grid_size.txt) — small grids take tiles with fewer rows per wave: more workgroups, a
+// shorter per-iteration chain.  `gs`: the shape has a gradient-subtract instantiation (k_jacobi_tb_gs: needs HX >= HY + 1).
+struct TBVariant { int nw, ry, hx, hy, bpc; bool gs; };
 constexpr TBVariant kTB[] = {
-    {8, 10, 12, 10, 2},  // 0: default — 112 VGPRs, two workgroups per CU, 50 iterations in 5 launches
-    {8, 8, 8, 8, 2},     // 1: shallow apron, 7 launches (the round's first shape)
-    {8, 11, 12, 10, 2},  // 2
-    {8, 12, 12, 10, 2},  // 3
-    {8, 12, 16, 13, 2},  // 4: 4 launches, 128 VGPRs
-    {8, 16, 20, 17, 1},  // 5: 3 launches, one workgroup per CU
-    {16, 12, 20, 17, 1}, // 6: 3 launches, 16-wave workgroup
-    {4, 24, 16, 13, 2},  // 7: 4 waves x 24 rows
+    {8, 10, 12, 10, 2, true},   // 0: default at >= 4096^2 — 126 VGPRs, two workgroups per CU, 50 iterations in 5 launches
+    {8, 8, 8, 8, 2, false},     // 1: shallow apron, 7 launches (round 1's first shape)
+    {8, 11, 12, 10, 2, false},  // 2
+    {8, 12, 12, 10, 2, true},   // 3: 972 tiles at 4096^2 instead of 1242
+    {8, 12, 16, 13, 2, false},  // 4: 4 launches, 128 VGPRs
+    {8, 16, 20, 17, 1, false},  // 5: 3 launches, one workgroup per CU
+    {16, 12, 20, 17, 1, false}, // 6: 3 launches, 16-wave workgroup
+    {4, 24, 16, 13, 2, false},  // 7: 4 waves x 24 rows
+    {8, 5, 12, 10, 2, true},    // 8: small grids: 40-row tile
+    {8, 6, 12, 10, 2, true},    // 9: 48-row tile
+    {8, 7, 12, 10, 2, true},    // 10: 56-row tile
+    {8, 4, 12, 10, 3, true},    // 11: 32-row tile, three workgroups per CU
 };
 constexpr int kNumTB = sizeof(kTB) / sizeof(kTB[0]);
 constexpr int kDefaultTB = 0;  // measured best of the table at 4096^2 (profiles/r01/jacobi_variants.txt, there listed as "8x10 h12/10")
+constexpr int kTBIters = 10;   // every shape the grid-driven choice may take runs up to this many iterations per launch (pass_jacobi's split)
 
 int cvd_remap()  // FLUID_CVD_REMAP: tile order of the fused curl/vorticity/divergence kernel (same encoding)
 {
@@ -1025,14 +1133,39 @@ int cvd_remap()  // FLUID_CVD_REMAP: tile order of the fused curl/vorticity/dive
     return v;
 }
 
-int tb_variant()
+int tb_variant_env()  // FLUID_TB_VARIANT, or -1
 {
     static const int v = [] {
         const char* e = getenv("FLUID_TB_VARIANT");
-        const int k = e ? atoi(e) : kDefaultTB;
-        return (k >= 0 && k < kNumTB) ? k : kDefaultTB;
+        const int k = e ? atoi(e) : -1;
+        return (k >= 0 && k < kNumTB) ? k : -1;
     }();
     return v;
+}
+
+// FLUID_TB_SMALL="a,b": texel counts below which the grid-driven choice takes variant 8 / variant 10 (A/B knob for the thresholds)
+void tb_thresholds(long& t8, long& t10)
+{
+    static const struct Th { long a, b; } th = [] {
+        Th t{ 1536l * 1536l, 3072l * 3072l };
+        if (const char* e = getenv("FLUID_TB_SMALL")) {
+            long a = 0, b = 0;
+            if (sscanf(e, "%ld,%ld", &a, &b) == 2) t = Th{ a, b };
+        }
+        return t;
+    }();
+    t8 = th.a;
+    t10 = th.b;
+}
+
+// the tile shape for a launch over `texels` output texels
+int tb_variant_for(long texels)
+{
+    const int e = tb_variant_env();
+    if (e >= 0) return e;
+    long t8, t10;
+    tb_thresholds(t8, t10);
+    return texels < t8 ? 8 : texels < t10 ? 10 : kDefaultTB;
 }
 
 template <int NW, int RY, int HX, int HY, int BPC>
@@ -1042,6 +1175,39 @@ hipError_t launch_tb(hipStream_t s, Win w, const float* p, const float* div, flo
     const Axis ax = make_axis(w.x0, w.x1, w.W, G::TX, HX), ay = make_axis(ga, gb, w.H, G::TY, HY);
     k_jacobi_tb<NW, RY, HX, HY, BPC><<<dim3(ax.n * ay.n, 1, 1), dim3(64, NW, 1), 0, s>>>(w, p, div, p_out, pscale, iters, ga, gb, ax.S, ay.S, ax.n,
                                                                                  ay.n, xcd_remap());
+    return hipGetLastError();
+}
+
+template <int NW, int RY, int HX, int HY, int BPC>
+hipError_t launch_tb(hipStream_t s, Win w, const __half* p, const __half* div, __half* p_out, float pscale, int iters, int ga, int gb)
+{
+    using G = JacobiTB<NW, RY, HX, HY>;
+    const Axis ax = make_axis(w.x0, w.x1, w.W, G::TX, HX), ay = make_axis(ga, gb, w.H, G::TY, HY);
+    k_jacobi_tb_h<NW, RY, HX, HY, BPC><<<dim3(ax.n * ay.n, 1, 1), dim3(64, NW, 1), 0, s>>>(w, p, div, p_out, pscale, iters, ga, gb, ax.S, ay.S,
+                                                                                   ax.n, ay.n, xcd_remap());
+    return hipGetLastError();
+}
+
+// the last launch with the gradient subtract folded in: the same shape with a row apron of HY + 1
+template <int NW, int RY, int HX, int HY, int BPC>
+hipError_t launch_tb_gs(hipStream_t s, Win w, const float* p, const float* div, float* p_out, const float2* vel, float2* vel_out, float pscale,
+                        int iters, int ga, int gb)
+{
+    using G = JacobiTB<NW, RY, HX, HY + 1>;
+    const Axis ax = make_axis(w.x0, w.x1, w.W, G::TX, HX), ay = make_axis(ga, gb, w.H, G::TY, HY + 1);
+    k_jacobi_tb_gs<NW, RY, HX, HY, BPC><<<dim3(ax.n * ay.n, 1, 1), dim3(64, NW, 1), 0, s>>>(w, p, div, p_out, vel, vel_out, pscale, iters, ga, gb,
+                                                                                    ax.S, ay.S, ax.n, ay.n, xcd_remap());
+    return hipGetLastError();
+}
+
+template <int NW, int RY, int HX, int HY, int BPC>
+hipError_t launch_tb_gs(hipStream_t s, Win w, const __half* p, const __half* div, __half* p_out, const __half2* vel, __half2* vel_out,
+                        float pscale, int iters, int ga, int gb)
+{
+    using G = JacobiTB<NW, RY, HX, HY + 1>;
+    const Axis ax = make_axis(w.x0, w.x1, w.W, G::TX, HX), ay = make_axis(ga, gb, w.H, G::TY, HY + 1);
+    k_jacobi_tb_gs_h<NW, RY, HX, HY, BPC><<<dim3(ax.n * ay.n, 1, 1), dim3(64, NW, 1), 0, s>>>(w, p, div, p_out, vel, vel_out, pscale, iters, ga,
+                                                                                      gb, ax.S, ay.S, ax.n, ay.n, xcd_remap());
     return hipGetLastError();
 }
 
@@ -1285,47 +1451,102 @@ hipError_t launch_curl_vort_div(hipStream_t s, Win w, const __half2* vel, __half
     return hipGetLastError();
 }
 
-int jacobi_tb_max_iters() { return kTB[tb_variant()].hy; }
-
-// fp16 storage: the default tile shape only (8 waves x 10 rows, apron 12 x 10)
-constexpr int kHalfTB[5] = { 8, 10, 12, 10, 2 };
-int jacobi_tb_max_iters_f16() { return kHalfTB[3]; }
-
-hipError_t launch_jacobi_tb(hipStream_t s, Win w, const __half* p, const __half* div, __half* p_out, float pscale, int iters, int ga, int gb)
+// iterations one launch may run: the forced variant's apron, or what every grid-driven shape supports
+int jacobi_tb_max_iters()
 {
-    ROWS_OR_RETURN();
-    if (iters < 1 || iters > jacobi_tb_max_iters_f16() || !jacobi_tb_supported(w)) return hipErrorInvalidValue;
-    constexpr int NW = kHalfTB[0], RY = kHalfTB[1], HX = kHalfTB[2], HY = kHalfTB[3], BPC = kHalfTB[4];
-    using G = JacobiTB<NW, RY, HX, HY>;
-    const Axis ax = make_axis(w.x0, w.x1, w.W, G::TX, HX), ay = make_axis(ga, gb, w.H, G::TY, HY);
-    k_jacobi_tb_h<NW, RY, HX, HY, BPC><<<dim3(ax.n * ay.n, 1, 1), dim3(64, NW, 1), 0, s>>>(w, p, div, p_out, pscale, iters, ga, gb, ax.S, ay.S,
-                                                                                        ax.n, ay.n, xcd_remap());
-    return hipGetLastError();
+    const int e = tb_variant_env();
+    return e >= 0 ? kTB[e].hy : kTBIters;
 }
+int jacobi_tb_max_iters_f16() { return kTBIters; }
 
 bool jacobi_tb_supported(Win w) { return fused_supported(w); }
 
-hipError_t launch_jacobi_tb(hipStream_t s, Win w, const float* p, const float* div, float* p_out, float pscale, int iters,
-                            int ga, int gb)
+// whether the launch over this window has a gradient-subtract instantiation (a forced variant may not)
+bool jacobi_tb_gradsub_supported(Win w, int ga, int gb)
+{
+    return fused_supported(w) && kTB[tb_variant_for((long)(w.x1 - w.x0) * (gb - ga))].gs;
+}
+
+#define TB_VARIANTS(X)      \
+    X(0, 8, 10, 12, 10, 2)  \
+    X(1, 8, 8, 8, 8, 2)     \
+    X(2, 8, 11, 12, 10, 2)  \
+    X(3, 8, 12, 12, 10, 2)  \
+    X(4, 8, 12, 16, 13, 2)  \
+    X(5, 8, 16, 20, 17, 1)  \
+    X(6, 16, 12, 20, 17, 1) \
+    X(7, 4, 24, 16, 13, 2)  \
+    X(8, 8, 5, 12, 10, 2)   \
+    X(9, 8, 6, 12, 10, 2)   \
+    X(10, 8, 7, 12, 10, 2)  \
+    X(11, 8, 4, 12, 10, 3)
+#define TB_GS_VARIANTS(X)  \
+    X(0, 8, 10, 12, 10, 2) \
+    X(3, 8, 12, 12, 10, 2) \
+    X(8, 8, 5, 12, 10, 2)  \
+    X(9, 8, 6, 12, 10, 2)  \
+    X(10, 8, 7, 12, 10, 2) \
+    X(11, 8, 4, 12, 10, 3)
+#define TB_CHECK(k, NW, RY, HX, HY, BPC) \
+    static_assert(kTB[k].nw == NW && kTB[k].ry == RY && kTB[k].hx == HX && kTB[k].hy == HY && kTB[k].bpc == BPC, "variant table");
+TB_VARIANTS(TB_CHECK)
+#define TB_GS_CHECK(k, NW, RY, HX, HY, BPC) TB_CHECK(k, NW, RY, HX, HY, BPC) static_assert(kTB[k].gs && HX >= HY + 1, "gs variant");
+TB_GS_VARIANTS(TB_GS_CHECK)
+static_assert(kTB[8].hy == kTBIters && kTB[10].hy == kTBIters && kTB[kDefaultTB].hy == kTBIters, "grid-driven shapes share the iteration depth");
+
+template <class T>
+hipError_t launch_jacobi_tb_any(hipStream_t s, Win w, const T* p, const T* div, T* p_out, float pscale, int iters, int ga, int gb)
 {
     ROWS_OR_RETURN();
-    if (iters < 1 || iters > jacobi_tb_max_iters() || !jacobi_tb_supported(w)) return hipErrorInvalidValue;
-    switch (tb_variant()) {
-#define TB_CASE(k, NW, RY, HX, HY, BPC)                                                                                         \
-    case k:                                                                                                                     \
-        static_assert(kTB[k].nw == NW && kTB[k].ry == RY && kTB[k].hx == HX && kTB[k].hy == HY && kTB[k].bpc == BPC, "table"); \
-        return launch_tb<NW, RY, HX, HY, BPC>(s, w, p, div, p_out, pscale, iters, ga, gb)
-    TB_CASE(0, 8, 10, 12, 10, 2);
-    TB_CASE(1, 8, 8, 8, 8, 2);
-    TB_CASE(2, 8, 11, 12, 10, 2);
-    TB_CASE(3, 8, 12, 12, 10, 2);
-    TB_CASE(4, 8, 12, 16, 13, 2);
-    TB_CASE(5, 8, 16, 20, 17, 1);
-    TB_CASE(6, 16, 12, 20, 17, 1);
-    TB_CASE(7, 4, 24, 16, 13, 2);
+    if (!jacobi_tb_supported(w)) return hipErrorInvalidValue;
+    const int v = tb_variant_for((long)(w.x1 - w.x0) * (gb - ga));
+    if (iters < 1 || iters > kTB[v].hy) return hipErrorInvalidValue;
+    switch (v) {
+#define TB_CASE(k, NW, RY, HX, HY, BPC) \
+    case k: return launch_tb<NW, RY, HX, HY, BPC>(s, w, p, div, p_out, pscale, iters, ga, gb);
+        TB_VARIANTS(TB_CASE)
 #undef TB_CASE
     default: return hipErrorInvalidValue;
     }
+}
+
+template <class T, class V2>
+hipError_t launch_jacobi_tb_gradsub_any(hipStream_t s, Win w, const T* p, const T* div, T* p_out, const V2* vel, V2* vel_out, float pscale,
+                                        int iters, int ga, int gb)
+{
+    ROWS_OR_RETURN();
+    if (!jacobi_tb_gradsub_supported(w, ga, gb)) return hipErrorInvalidValue;
+    const int v = tb_variant_for((long)(w.x1 - w.x0) * (gb - ga));
+    if (iters < 1 || iters > kTB[v].hy) return hipErrorInvalidValue;
+    w.x0 &= ~3;  // whole float4 groups, as launch_gradsub4
+    w.x1 = (w.x1 + 3) & ~3;
+    if (w.x1 > w.W) w.x1 = w.W;
+    switch (v) {
+#define TB_CASE(k, NW, RY, HX, HY, BPC) \
+    case k: return launch_tb_gs<NW, RY, HX, HY, BPC>(s, w, p, div, p_out, vel, vel_out, pscale, iters, ga, gb);
+        TB_GS_VARIANTS(TB_CASE)
+#undef TB_CASE
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_jacobi_tb(hipStream_t s, Win w, const float* p, const float* div, float* p_out, float pscale, int iters, int ga, int gb)
+{
+    return launch_jacobi_tb_any(s, w, p, div, p_out, pscale, iters, ga, gb);
+}
+hipError_t launch_jacobi_tb(hipStream_t s, Win w, const __half* p, const __half* div, __half* p_out, float pscale, int iters, int ga, int gb)
+{
+    return launch_jacobi_tb_any(s, w, p, div, p_out, pscale, iters, ga, gb);
+}
+hipError_t launch_jacobi_tb_gradsub(hipStream_t s, Win w, const float* p, const float* div, float* p_out, const float2* vel, float2* vel_out,
+                                    float pscale, int iters, int ga, int gb)
+{
+    return launch_jacobi_tb_gradsub_any(s, w, p, div, p_out, vel, vel_out, pscale, iters, ga, gb);
+}
+hipError_t launch_jacobi_tb_gradsub(hipStream_t s, Win w, const __half* p, const __half* div, __half* p_out, const __half2* vel,
+                                    __half2* vel_out, float pscale, int iters, int ga, int gb)
+{
+    return launch_jacobi_tb_gradsub_any(s, w, p, div, p_out, vel, vel_out, pscale, iters, ga, gb);
 }
 
 }  // namespace fluid

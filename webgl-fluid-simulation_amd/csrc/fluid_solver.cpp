@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -202,12 +203,18 @@ int pass_clear(fluid_ctx* c, float value, int ext)
     return FLUID_OK;
 }
 
-// `iters` Jacobi iterations; pscale != 1 folds the clear pass into the first load (FUSED only)
-int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launches)
+// `iters` Jacobi iterations; pscale != 1 folds the clear pass into the first load (FUSED only).
+// `gradsub` (in: fold K6 into the last launch if that launch has the instantiation; out: whether it was): the last block then writes
+// the pressure AND velocity - grad(pressure) for the owned rows / columns (ext 0), and the caller skips pass_gradsub.  The blocks in
+// front of it leave the pressure valid one ring further out (ext_out >= 1), which is what the separate pass needs as well.
+int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launches, bool* gradsub, Timer* t)
 {
     if (iters < 0) return c->fail(FLUID_ERR_INVALID, "negative iteration count");
-    CK(check_ext(c, ext_out, iters));
     const bool tb = jacobi_tb_applies(c);
+    bool fold = gradsub && *gradsub && tb && iters > 0 && gradsub_fold_enabled();
+    if (gradsub) *gradsub = false;
+    if (fold && ext_out < 1) ext_out = 1;
+    CK(check_ext(c, ext_out, iters));
     int done = 0;
     if (!tb && pscale != 1.0f) return c->fail(FLUID_ERR_INVALID, "pscale needs the fused schedule");
     // balanced blocks: ceil(iters / max) launches of nearly equal depth (50 with max 8 -> 8,7,7,7,7,7,7)
@@ -218,6 +225,22 @@ int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launche
         if (tb) {
             const int k = (iters - done + launches_left - 1) / launches_left;
             launches_left--;
+            const bool last = done + k == iters;
+            if (last && fold) {
+                row_range(c->sim, c->sim_row0, c->sim_rows, 0, ga, gb);
+                const Win w = sim_cols(c, 0);
+                if (jacobi_tb_gradsub_supported(w, ga, gb)) {
+                    if (t) t->mark(P_JACOBI);  // the launches so far; this one is timed as P_GRADSUB by the caller
+                    CK(c->hip(STORE_CALL(c, launch_jacobi_tb_gradsub(c->stream, w, (const S::T1*)c->prs[0], (const S::T1*)c->div, (S::T1*)c->prs[1],
+                                                                     (const S::T2*)c->vel[0], (S::T2*)c->vel[1], done == 0 ? pscale : 1.0f, k, ga, gb)),
+                              "jacobi_tb_gradsub"));
+                    std::swap(c->prs[0], c->prs[1]);
+                    std::swap(c->vel[0], c->vel[1]);
+                    if (launches) (*launches)++;
+                    *gradsub = true;
+                    return FLUID_OK;
+                }
+            }
             row_range(c->sim, c->sim_row0, c->sim_rows, ext_out + (iters - done - k), ga, gb);
             CK(c->hip(STORE_CALL(c, launch_jacobi_tb(c->stream, sim_cols(c, ext_out + (iters - done - k)), (const S::T1*)c->prs[0], (const S::T1*)c->div,
                                                      (S::T1*)c->prs[1], done == 0 ? pscale : 1.0f, k, ga, gb)),
@@ -236,13 +259,14 @@ int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launche
 }
 
 // K4 + K5 x iters; the clear rides on the first temporally blocked launch when that kernel applies
-int pass_clear_jacobi(fluid_ctx* c, float value, int iters, int ext_out, int* launches)
+int pass_clear_jacobi(fluid_ctx* c, float value, int iters, int ext_out, int* launches, bool* gradsub)
 {
     if (iters < 0) return c->fail(FLUID_ERR_INVALID, "negative iteration count");
     const bool fold = jacobi_tb_applies(c) && iters > 0;
-    if (fold) return pass_jacobi(c, iters, ext_out, value, launches);
+    if (fold) return pass_jacobi(c, iters, ext_out, value, launches, gradsub, nullptr);
+    if (gradsub) *gradsub = false;
     CK(pass_clear(c, value, ext_out + iters));
-    return pass_jacobi(c, iters, ext_out, 1.0f, launches);
+    return pass_jacobi(c, iters, ext_out, 1.0f, launches, nullptr, nullptr);
 }
 
 int pass_gradsub(fluid_ctx* c, int ext)
@@ -305,6 +329,16 @@ int pass_advect(fluid_ctx* c, float dt, float vel_diss, float dye_diss, Timer* t
 // ---- band forms for the stripe driver: one row band of a single-kernel pass, WITHOUT the ping-pong swap, so that a
 //      pass can run as "interior rows while the ghost rows are in flight, then the strips next to them" ----
 // the temporally blocked Jacobi kernel exists for both storage types
+// FLUID_FOLD_GRADSUB=0: keep K6 as its own launch (A/B knob; same bits either way)
+bool gradsub_fold_enabled()
+{
+    static const bool on = [] {
+        const char* e = getenv("FLUID_FOLD_GRADSUB");
+        return !(e && atoi(e) == 0);
+    }();
+    return on;
+}
+
 bool jacobi_tb_applies(const fluid_ctx* c) { return c->desc.schedule == FLUID_SCHED_FUSED && jacobi_tb_supported(c->sim); }
 
 bool fused_cvd_applies(const fluid_ctx* c) { return c->desc.schedule == FLUID_SCHED_FUSED && fused_supported(c->sim); }
@@ -358,14 +392,18 @@ int step_once(fluid_ctx* c, float dt, const fluid_params* P)
         CK(pass_clear(c, P->pressure, 0));
         t.mark(P_CLEAR);
     }
-    CK(pass_jacobi(c, P->iterations, 0, fold_clear ? P->pressure : 1.0f, &launches));
-    t.mark(P_JACOBI);
-    CK(pass_gradsub(c, 0));
+    bool gradsub_done = true;  // ask for K6 inside the last Jacobi launch
+    CK(pass_jacobi(c, P->iterations, 0, fold_clear ? P->pressure : 1.0f, &launches, &gradsub_done, &t));
+    if (!gradsub_done) {
+        t.mark(P_JACOBI);
+        CK(pass_gradsub(c, 0));
+    }
     t.mark(P_GRADSUB);
     CK(pass_advect(c, dt, P->velocity_dissipation, P->density_dissipation, &t));
     if (c->timing) {
         c->acc_steps++;
         c->acc_jacobi_launches += launches;
+        c->acc_folded_launches += gradsub_done ? 1 : 0;
     }
     return FLUID_OK;
 }
@@ -732,12 +770,12 @@ int fluid_pass_clear(fluid_ctx* c, float value, int ext)
 int fluid_pass_jacobi(fluid_ctx* c, int iters, int ext_out)
 {
     PASS_PROLOGUE();
-    return pass_jacobi(c, iters, ext_out, 1.0f, nullptr);
+    return pass_jacobi(c, iters, ext_out, 1.0f, nullptr, nullptr, nullptr);
 }
 int fluid_pass_clear_jacobi(fluid_ctx* c, float value, int iters, int ext_out)
 {
     PASS_PROLOGUE();
-    return pass_clear_jacobi(c, value, iters, ext_out, nullptr);
+    return pass_clear_jacobi(c, value, iters, ext_out, nullptr, nullptr);
 }
 int fluid_pass_gradsub(fluid_ctx* c, int ext)
 {
@@ -817,7 +855,7 @@ int fluid_set_timing(fluid_ctx* c, int enabled)
     c->timing = enabled != 0;
     std::fill(std::begin(c->acc_ms), std::end(c->acc_ms), 0.0);
     c->acc_total = 0;
-    c->acc_steps = c->acc_jacobi_launches = 0;
+    c->acc_steps = c->acc_jacobi_launches = c->acc_folded_launches = 0;
     return FLUID_OK;
 }
 
@@ -835,6 +873,7 @@ int fluid_get_timings(fluid_ctx* c, fluid_timings* out)
     out->total_ms = (float)c->acc_total;
     out->jacobi_launches = c->acc_jacobi_launches;
     out->steps = c->acc_steps;
+    out->folded_launches = c->acc_folded_launches;
     return FLUID_OK;
 }
 

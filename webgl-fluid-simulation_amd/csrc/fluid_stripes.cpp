@@ -127,12 +127,28 @@ int run_pass(fluid_ctx* c, const fluid_stripe_op& op, float dt, const fluid_para
     switch (op.kind) {
     case FLUID_OP_CURL_VORT_DIV: return pass_curl_vort_div(c, P->curl, dt, op.ext, nullptr);
     case FLUID_OP_CLEAR: return pass_clear(c, P->pressure, op.ext);
-    case FLUID_OP_CLEAR_JACOBI: return pass_clear_jacobi(c, P->pressure, op.iters, op.ext, nullptr);
-    case FLUID_OP_JACOBI: return pass_jacobi(c, op.iters, op.ext, 1.0f, nullptr);
+    case FLUID_OP_CLEAR_JACOBI: return pass_clear_jacobi(c, P->pressure, op.iters, op.ext, nullptr, nullptr);
+    case FLUID_OP_JACOBI: return pass_jacobi(c, op.iters, op.ext, 1.0f, nullptr, nullptr, nullptr);
     case FLUID_OP_GRADSUB: return pass_gradsub(c, op.ext);
     case FLUID_OP_ADVECT: return pass_advect(c, dt, P->velocity_dissipation, P->density_dissipation, nullptr);
     default: return c->fail(FLUID_ERR_INVALID, "unknown stripe op");
     }
+}
+
+// The last pressure block followed by the gradient subtract (plan: ... JACOBI(d, e = 1), GRADSUB(0)): K6 rides on the block's last
+// launch where that launch has the instantiation (pass_jacobi), otherwise the two ops run in turn.  Same bits either way.
+bool folds_gradsub(const std::vector<fluid_stripe_op>& ops, size_t i)
+{
+    return (ops[i].kind == FLUID_OP_CLEAR_JACOBI || ops[i].kind == FLUID_OP_JACOBI) && ops[i].iters > 0 && i + 1 < ops.size() &&
+           ops[i + 1].kind == FLUID_OP_GRADSUB && ops[i + 1].ext == 0 && ops[i].ext >= 1;
+}
+
+int run_block_and_gradsub(fluid_ctx* c, const fluid_stripe_op& op, const fluid_stripe_op& gs, const fluid_params* P)
+{
+    bool folded = true;
+    if (op.kind == FLUID_OP_CLEAR_JACOBI) CK(pass_clear_jacobi(c, P->pressure, op.iters, op.ext, nullptr, &folded));
+    else CK(pass_jacobi(c, op.iters, op.ext, 1.0f, nullptr, &folded, nullptr));
+    return folded ? (int)FLUID_OK : pass_gradsub(c, gs.ext);
 }
 
 // ghost / owned row blocks of one exchange item: addresses and bytes (fp32 or fp16 texels: the exchange moves bytes)
@@ -662,6 +678,11 @@ int stripe_step_n(fluid_ctx* c, int n, float dt, const fluid_params* P)
         for (size_t i = 0; i < ops.size(); i++) {
             const fluid_stripe_op& op = ops[i];
             if (op.kind != FLUID_OP_EXCHANGE) {
+                if (folds_gradsub(ops, i)) {
+                    CK(run_block_and_gradsub(c, op, ops[i + 1], P));
+                    i++;
+                    continue;
+                }
                 CK(pass_whole(c, op, dt, P));
                 continue;
             }
@@ -858,6 +879,12 @@ int fluid_group_step_n(fluid_ctx** cs, int n_ctx, int steps, float dt, const flu
         for (size_t i = 0; i < ops.size(); i++) {
             const fluid_stripe_op& op = ops[i];
             if (op.kind != FLUID_OP_EXCHANGE) {
+                if (folds_gradsub(ops, i)) {
+                    const fluid_stripe_op& gs = ops[i + 1];
+                    CK(each([&](fluid_ctx* c) { return run_block_and_gradsub(c, op, gs, P); }));
+                    i++;
+                    continue;
+                }
                 CK(each([&](fluid_ctx* c) { return pass_whole(c, op, dt, P); }));
                 continue;
             }

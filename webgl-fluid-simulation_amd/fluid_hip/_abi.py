@@ -46,7 +46,7 @@ class FieldInfo(C.Structure):
 class Timings(C.Structure):
     _fields_ = [(k, C.c_float) for k in ("curl_ms", "vorticity_ms", "divergence_ms", "clear_ms", "jacobi_ms", "gradsub_ms",
                                          "advect_velocity_ms", "advect_dye_ms", "total_ms")] + \
-               [("jacobi_launches", C.c_int), ("steps", C.c_int)]
+               [("jacobi_launches", C.c_int), ("steps", C.c_int), ("folded_launches", C.c_int)]
 
 
 class DisplayParams(C.Structure):
@@ -164,7 +164,7 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the header and the library disagree
             fn.restype = res
             fn.argtypes = args
-        if L.fluid_abi_version() != 6:
+        if L.fluid_abi_version() != 7:
             raise FluidError(ERR_UNSUPPORTED, "ABI version mismatch")
         _lib = L
         _point_at_torch_rccl(L)
