@@ -30,7 +30,8 @@ for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E peak (spec), /opt/skills/guides/MI355X_MICROARCH.md
+HBM_ATTAINABLE_GBPS = 6290.0  # the same guide: measured float4 copy, 79 % of the peak
 DT = 0.016666           # the reference's dt clamp, script.js:1191
 
 
@@ -107,13 +108,13 @@ def cpu_baseline_port(size: int, iters: int, budget_s: float):
                       % (steps or 1, size, size, iters)}
 
 
-def cpu_baseline(size: int, iters: int, budget_s: float, kind: str = "auto"):
+def cpu_baseline(size: int, iters: int, budget_s: float, kind: str = "auto", max_wait: float = 1e9):
     """`cpu_baseline` of the JSON line: the live reference when it can run on this box (kind "reference"), else the C/OpenMP port
     of its algorithm (kind "port") with the reason the reference could not run.  With the reference as the baseline the port's
     number is still reported beside it (`port`), on a short sample, for the record."""
     why = None
     if kind in ("auto", "reference"):
-        ref, why = cpu_baseline_reference(size, iters, timeout_s=max(240.0, 12 * budget_s))
+        ref, why = cpu_baseline_reference(size, iters, timeout_s=min(max(240.0, 12 * budget_s), max(30.0, max_wait - 10.0)))
         if ref is not None:
             if budget_s > 0:
                 port = cpu_baseline_port(size, iters, min(budget_s, 6.0))
@@ -127,37 +128,61 @@ def cpu_baseline(size: int, iters: int, budget_s: float, kind: str = "auto"):
     return out
 
 
-def collect_traffic(args, steps_under_profiler: int = 4):
-    """HBM bytes per launch of every step kernel, measured IN THIS RUN: two short child runs of this very script under
-    `rocprofv3 --kernel-trace --pmc <counter>` (FETCH_SIZE and WRITE_SIZE in separate passes, as the guide's HBM section
-    prescribes; no other tracing domain), corrected as tools/pmc_traffic.py documents (KiB units, x2 on FETCH_SIZE for gfx950,
-    WRITE_SIZE calibrated to 1.0 on k_clear in profiles/r01).  Returns {kernel: {...}} + per-step totals, or (None, reason)."""
+class Deadline:
+    """The extras behind the timed section (PMC child runs, steady timing, the CPU baseline) share one budget (--extras-budget): the
+    headline line must not wait for a slow rocprofv3 or SwiftShader; an extra that no longer fits is skipped and says so."""
+
+    def __init__(self, seconds):
+        self.t_end = time.monotonic() + seconds
+
+    def left(self):
+        return self.t_end - time.monotonic()
+
+
+def pmc_pass(args, counters, deadline, steps_under_profiler=4):
+    """One child run of this very script under `rocprofv3 --kernel-trace --pmc <counters>` (no other tracing domain): average counter
+    value per dispatch of every kernel -> ({kernel: {counter: (avg, dispatches)}}, None) or (None, reason)."""
     import shutil
     import subprocess
     import tempfile
     exe = shutil.which("rocprofv3")
     if not exe:
         return None, "rocprofv3 is not on PATH"
+    limit = min(240.0, deadline.left())
+    if limit < 45:
+        return None, "extras budget spent before the %s pass" % "+".join(counters)
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pmc_traffic
+    with tempfile.TemporaryDirectory(prefix="fluid_pmc_", dir="/tmp") as d:
+        cmd = [exe, "--kernel-trace", "--pmc"] + list(counters) + ["--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
+               os.path.abspath(__file__), "--steps", str(steps_under_profiler - 1), "--warmup", "1", "--cpu-budget", "0", "--no-profile-pass",
+               "--no-traffic", "--no-steady", "--no-parity", "--size", str(args.size), "--iters", str(args.iters), "--schedule", args.schedule,
+               "--storage", args.storage]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=limit)
+        except subprocess.TimeoutExpired:
+            return None, "rocprofv3 --pmc %s did not finish within %.0f s" % (" ".join(counters), limit)
+        files = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith("counter_collection.csv")]
+        if r.returncode != 0 or not files:
+            return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (" ".join(counters), r.returncode, (r.stderr.decode(errors="replace").strip().splitlines() or [""])[-1][:160])
+        out = pmc_traffic.per_kernel_counters(files[0])
+        keep = os.environ.get("FLUID_BENCH_KEEP_PMC")   # tools/gpu_round.sh: keep the raw counter CSVs for profiles/
+        if keep:
+            shutil.copy(files[0], os.path.join(keep, "pmc_%s_%s.csv" % ("_".join(counters)[:40], args.schedule)))
+        return out, None
+
+
+def collect_traffic(args, deadline, steps_under_profiler: int = 4):
+    """HBM bytes per launch of every step kernel, measured IN THIS RUN: two short child runs under `rocprofv3 --kernel-trace --pmc`
+    (FETCH_SIZE and WRITE_SIZE in separate passes, as the guide's HBM section prescribes), corrected as tools/pmc_traffic.py documents
+    (KiB units, x2 on FETCH_SIZE for gfx950, WRITE_SIZE calibrated to 1.0 on k_clear in profiles/r01).
+    Returns ({kernels, bytes_per_step}, None) or (None, reason)."""
     per = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-        with tempfile.TemporaryDirectory(prefix="fluid_pmc_", dir="/tmp") as d:
-            cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
-                   os.path.abspath(__file__), "--steps", str(steps_under_profiler - 1), "--warmup", "1", "--cpu-budget", "0", "--no-profile-pass",
-                   "--no-traffic", "--no-steady", "--size", str(args.size), "--iters", str(args.iters), "--schedule", args.schedule,
-                   "--storage", args.storage]
-            try:
-                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
-            except subprocess.TimeoutExpired:
-                return None, "rocprofv3 --pmc %s did not finish within 420 s" % ctr
-            files = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith("counter_collection.csv")]
-            if r.returncode != 0 or not files:
-                return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (ctr, r.returncode, (r.stderr.decode(errors="replace").strip().splitlines() or [""])[-1][:160])
-            per[ctr] = pmc_traffic.per_kernel(files[0])
-            keep = os.environ.get("FLUID_BENCH_KEEP_PMC")   # tools/gpu_round.sh: keep the raw counter CSVs for profiles/
-            if keep:
-                shutil.copy(files[0], os.path.join(keep, "pmc_%s_%s.csv" % (ctr, args.schedule)))
+        got, why = pmc_pass(args, [ctr], deadline, steps_under_profiler)
+        if got is None:
+            return None, why
+        per[ctr] = {k: v[ctr] for k, v in got.items() if ctr in v}
     kernels, step_bytes = {}, 0.0
     for k in sorted(set(per["FETCH_SIZE"]) & set(per["WRITE_SIZE"])):
         if not k.startswith("k_") or k.startswith("k_fill") or k.startswith("k_splat"):
@@ -168,6 +193,32 @@ def collect_traffic(args, steps_under_profiler: int = 4):
         kernels[k] = {"read_bytes": int(rd), "write_bytes": int(wr), "bytes_per_launch": int(rd + wr), "launches_per_step": n / steps_under_profiler}
         step_bytes += (rd + wr) * n / steps_under_profiler
     return {"kernels": kernels, "bytes_per_step": int(step_bytes)}, None
+
+
+N_SIMD = 256 * 4   # MI355X: 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
+
+
+def collect_valu(args, deadline, kernel_prefixes):
+    """What the dominant kernel's VALU pipes did, from one more counter pass in this run: SQ_INSTS_VALU (wave-instructions),
+    SQ_ACTIVE_INST_VALU (quad-cycles a wave spent issuing VALU, summed over waves; x4 = cycles), SQ_WAVE_CYCLES, SQ_BUSY_CU_CYCLES and
+    GRBM_GUI_ACTIVE (the dispatch's duration in shader-clock cycles).  valu_busy_frac = the average SIMD's VALU-issuing cycles / the
+    dispatch's cycles: the fraction of the launch during which the kernel was paying for arithmetic, whatever else it overlapped with."""
+    got, why = pmc_pass(args, ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE"], deadline)
+    if got is None:
+        return None, why
+    for pre in kernel_prefixes:
+        for k, v in got.items():
+            if k.startswith(pre) and "SQ_ACTIVE_INST_VALU" in v:
+                insts, active = v["SQ_INSTS_VALU"][0], v["SQ_ACTIVE_INST_VALU"][0]
+                gui = v.get("GRBM_GUI_ACTIVE", (0, 0))[0]
+                out = {"kernel": k, "insts_per_launch": int(insts), "active_quad_cycles_per_launch": int(active),
+                       "wave_cycles_per_launch": int(v.get("SQ_WAVE_CYCLES", (0, 0))[0]), "gui_active_cycles_per_launch": int(gui),
+                       "cycles_per_inst": round(4.0 * active / max(insts, 1), 3),
+                       "simd_valu_cycles_per_launch": int(4.0 * active / N_SIMD)}
+                if gui > 0:
+                    out["busy_frac"] = round(4.0 * active / N_SIMD / gui, 4)
+                return out, None
+    return None, "no %s dispatch in the SQ counter pass" % kernel_prefixes[0]
 
 
 class Watchdog:
@@ -196,6 +247,58 @@ class Watchdog:
         self.done.set()
 
 
+def parity_in_run(fluid_hip, size, iters, device, storage, deadline):
+    """Parity checked in the same run as the number, BEFORE the warm-up steps:
+      (a) HIP == the CPU oracle bit for bit on a small case (256^2 sim / 512^2 dye, 20 iterations, 6 seeded splats, 2 steps, both
+          schedules) — the oracle is the checker here, never the thing timed;
+      (b) at the benchmark's own size: the fused schedule (what is timed) == the one-kernel-per-reference-pass schedule, every field,
+          compared on the device after 3 steps from the same seeded splats.
+    Returns a dict for the JSON line; a mismatch is an error of the run, not a footnote."""
+    import numpy as np
+    import torch
+    out = {}
+    t0 = time.perf_counter()
+    try:
+        from oracle import oracle as O
+        cfg = {"SIM_RESOLUTION": 256, "DYE_RESOLUTION": 512, "PRESSURE_ITERATIONS": 20}
+        ref = O.RefSim(canvas=(512, 512), config=cfg, seed=4321, storage=storage) if storage == "f16" else O.RefSim(canvas=(512, 512), config=cfg, seed=4321)
+        ref.multiple_splats(6)
+        ref.step(DT, 2)
+        want = ref.fields()
+        ok = True
+        for schedule in ("passes", "fused"):
+            with fluid_hip.FluidSim(canvas=(512, 512), config=cfg, device=device, schedule=schedule, random=fluid_hip.mulberry32(4321),
+                                    storage=storage) as sim:
+                sim.multipleSplats(6)
+                sim.step(DT, 2)
+                got = sim.fields()
+            ok = ok and all(np.array_equal(got[k], w) for k, w in want.items())
+        out["hip_vs_oracle_256"] = "bitwise equal, both schedules" if ok else "MISMATCH"
+    except Exception as ex:   # the oracle library may be absent on a box: say so, the on-device check below does not need it
+        out["hip_vs_oracle_256"] = "not run: %s" % str(ex)[:120]
+    cfg = {"SIM_RESOLUTION": size, "DYE_RESOLUTION": size, "PRESSURE_ITERATIONS": iters}
+    sims = []
+    try:
+        for schedule in ("passes", "fused"):
+            sim = fluid_hip.FluidSim(canvas=(size, size), config=cfg, device=device, schedule=schedule, random=fluid_hip.mulberry32(1234),
+                                     storage=storage)
+            sim.multipleSplats(20)
+            sim.step(DT, 3)
+            sim.sync()
+            sims.append(sim)
+        same = True
+        for k in ("velocity", "pressure", "divergence", "curl", "dye"):
+            same = same and bool(torch.equal(sims[0].device_view(k), sims[1].device_view(k)))
+        torch.cuda.synchronize()
+        out["fused_vs_passes_%d" % size] = "bitwise equal, all five fields after 3 steps" if same else "MISMATCH"
+    finally:
+        for sim in sims:
+            sim.close()
+    out["seconds"] = round(time.perf_counter() - t0, 2)
+    out["ok"] = "MISMATCH" not in json.dumps(out)
+    return out
+
+
 def main(argv=None, engine_factory=None, backend="nccl"):
     """`engine_factory` / `backend` are the hooks of tests/test_bench_multi.py: the N > 1 branch of THIS function — rendezvous,
     StripeSim set-up, barrier, max-over-ranks timing, the JSON line — runs on CPU ranks over gloo with an injected stripe engine.
@@ -219,13 +322,20 @@ def main(argv=None, engine_factory=None, backend="nccl"):
     ap.add_argument("--cpu-kind", default="auto", choices=["auto", "reference", "port"], help="cpu_baseline: the live reference under "
                     "SwiftShader when it can run here (auto / reference), or the C/OpenMP port of its algorithm")
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the HIP-event instrumented pass")
-    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure HBM bytes per launch")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child runs (HBM bytes per launch, VALU counters)")
     ap.add_argument("--no-steady", action="store_true", help="skip the long (>= 2000 steps) steady-state timing appended to the line")
+    ap.add_argument("--no-parity", action="store_true", help="N = 1: skip the in-run parity check in front of the warm-up")
+    ap.add_argument("--extras-budget", type=float, default=600.0, help="seconds everything BEHIND the timed section may take in total "
+                    "(counter passes, steady timing, CPU baseline); an extra that no longer fits is skipped and says so in the line")
     ap.add_argument("--tiles-x", type=int, default=1, help="N > 1: 2-D decomposition, N // tiles_x row stripes x tiles_x column tiles "
                                                            "(global grid size*tiles_x x size*N/tiles_x); default 1 = row stripes")
     ap.add_argument("--strong", action="store_true", help="N > 1: strong scaling — the global grid stays --size x --size and is cut into N "
                                                           "stripes / tiles (BASELINE configs[3]: --size 8192 --tiles-x 2 on 4 GPUs; configs[4]: "
                                                           "--size 16384 --iters 200 on 8 GPUs); default: weak scaling, --size x --size per GPU")
+    ap.add_argument("--extra-config", action="append", default=None, metavar="SIZE,ITERS,TILES_X[,STEPS]",
+                    help="N > 1: after the weak-scaling measurement also time this STRONG-scaling configuration (global SIZE^2 cut into N "
+                         "stripes, or N/TILES_X x TILES_X tiles) and report it under `extra_configs`.  Default: BASELINE.json's own multi-GPU "
+                         "configurations when N matches — N = 4: 8192,50,2 (configs[3]); N = 8: 16384,200,1 (configs[4]); 'none' disables")
     ap.add_argument("--hosted", action="store_true", help="N > 1: drive the passes from Python with torch.distributed send/recv "
                                                           "instead of the native plan + RCCL inside libfluid_hip.so")
     ap.add_argument("--comm-timeout", type=float, default=120.0, help="N > 1: seconds the communicator set-up and the warm-up steps may take "
@@ -265,8 +375,22 @@ def main(argv=None, engine_factory=None, backend="nccl"):
     dev_sync = (lambda: None) if on_cpu else torch.cuda.synchronize
     cfg = {"SIM_RESOLUTION": size, "DYE_RESOLUTION": size, "PRESSURE_ITERATIONS": iters}
     dog = None
+    dist = None
+    parity = None
+
+    def make_stripes(gw, gh, its, tx):
+        from fluid_hip.stripes import StripeSim
+        c = dict(cfg, SIM_RESOLUTION=min(gw, gh), DYE_RESOLUTION=min(gw, gh), PRESSURE_ITERATIONS=its)
+        kw = dict(engine_factory=engine_factory) if on_cpu else dict(native=not args.hosted, tiles_x=tx, storage=args.storage,
+                                                                    reach=min(args.reach, args.halo))
+        return StripeSim(canvas=(gw, gh), config=c, halo=args.halo, schedule=args.schedule, random=fluid_hip.mulberry32(1234),
+                         device=local_rank, **kw)
 
     if N == 1:
+        if not args.no_parity and not on_cpu:
+            parity = parity_in_run(fluid_hip, size, iters, local_rank, args.storage, None)
+            if not parity["ok"]:
+                fail("in-run parity check failed: %s" % json.dumps(parity), code=6)
         sim = fluid_hip.FluidSim(canvas=(size, size), config=cfg, device=local_rank, schedule=args.schedule,
                                  random=fluid_hip.mulberry32(1234), storage=args.storage)
         sim.multipleSplats(20)
@@ -274,7 +398,6 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         grid_w, grid_h = size, size
     else:
         import torch.distributed as dist
-        from fluid_hip.stripes import StripeSim
         dog = Watchdog(real_stdout, args.comm_timeout, base)
         dog.at("torch.distributed rendezvous (init_process_group, backend %s)" % backend)
         if not dist.is_initialized():
@@ -286,13 +409,9 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         # (--tiles-x T: size * T columns x size * N / T rows, every rank still owns size x size texels)
         tx = max(1, args.tiles_x)
         gw, gh = (size, size) if args.strong else (size * tx, size * N // tx)
-        cfg = dict(cfg, SIM_RESOLUTION=min(gw, gh), DYE_RESOLUTION=min(gw, gh))
         dog.at("communicator set-up (ncclGetUniqueId on rank 0, broadcast, ncclCommInitRank inside libfluid_hip.so)")
         try:
-            kw = dict(engine_factory=engine_factory) if on_cpu else dict(native=not args.hosted, tiles_x=tx, storage=args.storage,
-                                                                        reach=min(args.reach, args.halo))
-            sim = StripeSim(canvas=(gw, gh), config=cfg, halo=args.halo, schedule=args.schedule, random=fluid_hip.mulberry32(1234),
-                            device=local_rank, **kw)
+            sim = make_stripes(gw, gh, iters, tx)
         except Exception as ex:   # no silent switch to another driver: say what failed, on every rank, and stop
             dog.stop()
             fail("stripe driver set-up failed on rank %d: %s" % (rank, ex), code=4)
@@ -300,37 +419,70 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         barrier = dist.barrier
         grid_w, grid_h = gw, gh
 
+    def agree(err):
+        """N > 1: a failure on ONE rank (a reach violation is counted per rank) must end EVERY rank — the others would sit in the next
+        exchange or collective until the RCCL timeout.  Every rank contributes its flag; all of them fail together."""
+        if N == 1:
+            return err
+        flag = torch.tensor([1.0 if err else 0.0], dtype=torch.float64, device="cpu" if on_cpu else "cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if float(flag.item()) > 0 and not err:
+            return "another rank failed (see its message on stderr)"
+        return err
+
+    def measure(sm, warmup, steps, label):
+        """`warmup` untimed steps, then EXACTLY `steps` steps bracketed by sync + barrier + sync; MAX over ranks"""
+        def sync():
+            sm.sync()
+            dev_sync()
+        err = None
+        if dog:
+            dog.at("%s: warm-up, %d steps (the first ghost-row exchanges over RCCL / xGMI)" % (label, warmup))
+        try:
+            sm.step(DT, warmup)   # N > 1, native driver: the plan and its RCCL exchanges run inside libfluid_hip.so
+            sync(); barrier(); sync()
+            if dog:
+                dog.at("%s: the timed %d steps" % (label, steps))
+            t0 = time.perf_counter()
+            sm.step(DT, steps)
+            sync(); barrier(); sync()
+            elapsed = time.perf_counter() - t0
+            if N > 1:
+                sm.check_halo()
+        except fluid_hip.FluidError as ex:
+            err, elapsed = "step failed on rank %d: %s" % (rank, ex), 0.0
+        err = agree(err)
+        if err:
+            if dog:
+                dog.stop()
+            fail(err, code=5)
+        if N > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if on_cpu else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed
+
     def run(k):
-        sim.step(DT, k)   # N > 1, native driver: the plan and its RCCL exchanges run inside libfluid_hip.so
+        sim.step(DT, k)
 
     def sync():
         sim.sync()
         dev_sync()
 
-    if dog:
-        dog.at("warm-up: %d steps (the first ghost-row exchanges over RCCL / xGMI)" % args.warmup)
-    try:
-        run(args.warmup)
-        sync(); barrier(); sync()
-        if dog:
-            dog.stop()
-        t0 = time.perf_counter()
-        run(args.steps)
-        sync(); barrier(); sync()
-        elapsed = time.perf_counter() - t0
-    except fluid_hip.FluidError as ex:
-        if dog:
-            dog.stop()
-        fail("step failed on rank %d: %s" % (rank, ex), code=5)
-    if N > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if on_cpu else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        sim.check_halo()
+    elapsed = measure(sim, args.warmup, args.steps, "headline")
 
     steps_per_s = args.steps / elapsed
     glups = grid_w * grid_h * steps_per_s / 1e9
-    alg_step_bytes = algorithmic_bytes_per_cell(iters) * grid_w * grid_h * (0.5 if args.storage == "f16" else 1.0)
+    half = 0.5 if args.storage == "f16" else 1.0
+    alg_step_bytes = algorithmic_bytes_per_cell(iters) * grid_w * grid_h * half
+    txn = max(1, args.tiles_x)
+    if N == 1:
+        which = {(4096, 50): "configs[2]", (1024, 50): "configs[1]"}.get((size, iters), "a side size, not a BASELINE config")
+        workload = "%s: %dx%d sim = dye grid, %d Jacobi iters/step, dt=%.6f, 20 splats mulberry32(1234), defaults otherwise" % (which, grid_w, grid_h, iters, DT)
+    else:
+        workload = ("%s scaling of configs[2]'s per-GPU grid: %dx%d global sim = dye grid as %d ranks of %dx%d (halo %d), %d Jacobi iters/step, "
+                    "dt=%.6f, 20 splats mulberry32(1234), defaults otherwise"
+                    % ("strong" if args.strong else "weak", grid_w, grid_h, N, grid_w // txn, grid_h * txn // N, args.halo, iters, DT))
     out = dict(base)
     out.update({
         "value": round(glups, 4),
@@ -339,17 +491,69 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         "scaling": "strong" if (args.strong and N > 1) else "weak", "vs_baseline": None,
         "dtype": "f32" if args.storage == "f32" else "f32 arithmetic on f16-stored fields (side measurement, not the headline)",
         "data": "synthetic",
-        "config": {"workload": "configs[2]: %dx%d sim = dye grid%s, %d Jacobi iters/step, dt=%.6f, 20 splats mulberry32(1234), defaults otherwise"
-                               % (grid_w, grid_h, "" if N == 1 else " (%d ranks of %dx%d, halo %d)" % (N, grid_w // max(1, args.tiles_x), grid_h * max(1, args.tiles_x) // N, args.halo), iters, DT),
-                   "schedule": args.schedule, "storage": args.storage,
+        "config": {"workload": workload, "schedule": args.schedule, "storage": args.storage,
                    "parallelism": "single" if N == 1 else ("stripes%d" % N if args.tiles_x <= 1 else "tiles%dx%d" % (N // args.tiles_x, args.tiles_x))},
         # what the reference's pass structure would have to move for this many steps per second (SURVEY 8d's byte model): with
         # temporal blocking this is a speed-up figure, NOT a fraction of the HBM roofline — the bounded fractions are below
         "speedup_vs_pass_structure": {"algorithmic_GBps": round(alg_step_bytes * steps_per_s / 1e9, 1),
                                       "x_hbm_peak": round(alg_step_bytes * steps_per_s / 1e9 / (HBM_PEAK_GBPS * N), 4)},
     })
+    if parity:
+        out["parity_in_run"] = parity
     if on_cpu:
         out["config"]["engine"] = "injected stripe engine on CPU ranks over %s (launcher-path test, not a measurement)" % backend
+    if N > 1:
+        out["config"]["exchanges_per_step"] = sim.exchanges / max(args.steps + args.warmup, 1)
+        out["config"]["driver"] = "native plan + ncclSend/ncclRecv inside libfluid_hip.so" if sim.native else "hosted: torch.distributed batch_isend_irecv"
+        if sim.native:
+            out["config"]["advect_exchange_rows"] = list(sim.engine.advect_exchange_rows())
+
+    # ---- N > 1: BASELINE.json's own multi-GPU configurations, strong scaling, after the weak-scaling measurement (`value` above is
+    #      untouched: the driver's scaling curve is computed from it) ----
+    if N > 1:
+        plans = args.extra_config
+        if plans is None:
+            plans = {4: ["8192,50,2"], 8: ["16384,200,1"]}.get(N, [])
+        plans = [] if plans == ["none"] else plans
+        extra = []
+        for spec in plans:
+            f = [int(x) for x in spec.split(",")]
+            esize, eiters, etx = f[0], f[1], max(1, f[2] if len(f) > 2 else 1)
+            esteps = f[3] if len(f) > 3 else max(10, min(args.steps, int(2e10 / (float(esize) * esize * (128 + 12 * eiters) / 728.0 / N * 50))))
+            name = {(8192, 50, 2): "configs[3]", (16384, 200, 1): "configs[4]"}.get((esize, eiters, etx), "extra")
+            label = "%s: %dx%d sim = dye grid, %d Jacobi iters/step, strong scaling over %d ranks as %s" % (
+                name, esize, esize, eiters, N, "%d stripes" % N if etx == 1 else "%dx%d tiles" % (N // etx, etx))
+            entry = {"config": label, "steps": esteps, "warmup": max(2, esteps // 5)}
+            sim.close()
+            try:
+                sim = make_stripes(esize, esize, eiters, etx)
+                sim.multipleSplats(20)
+                problem = None
+            except Exception as ex:
+                problem = "set-up failed on rank %d: %s" % (rank, str(ex)[:200])
+            problem = agree(problem)
+            if problem:
+                entry["error"] = problem
+                extra.append(entry)
+                if problem.startswith("set-up failed"):
+                    sim = None
+                break
+            el = measure(sim, entry["warmup"], esteps, name)
+            sps = esteps / el
+            eb = algorithmic_bytes_per_cell(eiters) * float(esize) * esize * half
+            entry.update({"value": round(float(esize) * esize * sps / 1e9, 4), "unit": "GLUPS", "steps_per_sec": round(sps, 3),
+                          "ms_per_step": round(1e3 * el / esteps, 4), "scaling": "strong",
+                          "speedup_vs_pass_structure": {"algorithmic_GBps": round(eb * sps / 1e9, 1),
+                                                        "x_hbm_peak": round(eb * sps / 1e9 / (HBM_PEAK_GBPS * N), 4)},
+                          "exchanges_per_step": sim.exchanges / max(esteps + entry["warmup"], 1)})
+            extra.append(entry)
+        if plans:
+            out["extra_configs"] = extra
+    if dog:
+        dog.stop()
+
+    deadline = Deadline(args.extras_budget)
+    skipped = {}
 
     # ---- the dominant kernel (the Jacobi loop): launch time from HIP events on the solver's own stream, HBM bytes from PMC passes ----
     if rank == 0 and N == 1 and not args.no_profile_pass:
@@ -362,7 +566,6 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         # schedule: k_jacobi_tb_gs, timed under gradsub_ms)
         launches = max(tm["jacobi_launches"] - tm.get("folded_launches", 0), 1)
         avg_ms = tm["jacobi_ms"] / launches
-        half = 0.5 if args.storage == "f16" else 1.0
         alg_launch = 12.0 * iters * size * size * tm["steps"] / max(tm["jacobi_launches"], 1) * half  # 12 B/cell/iteration, SURVEY.md 8(d)
         # the kernel that runs the loop: the temporally blocked register tile, or one launch per iteration under --schedule passes
         if args.schedule == "fused":
@@ -370,7 +573,7 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         else:
             cands = ["k_h_jacobi", "k_jacobi"] if args.storage == "f16" else ["k_jacobi"]
         kname = cands[0]
-        traffic, why = (None, "--no-traffic") if args.no_traffic else collect_traffic(args)
+        traffic, why = (None, "--no-traffic") if args.no_traffic else collect_traffic(args, deadline)
         entry = None
         if traffic:
             for c in cands:
@@ -385,43 +588,80 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         else:   # the least a launch must move: pressure in, divergence in, pressure out (no apron re-reads counted)
             bytes_launch, source = int(12.0 * size * size * half), "model: compulsory 12 B/texel per launch (PMC pass unavailable: %s)" % why
         achieved = bytes_launch / (avg_ms * 1e-3) / 1e9
-        out["roofline"] = {
+        roof = {
             "kernel": kname, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": bytes_launch, "traffic_source": source,
+            "attainable": HBM_ATTAINABLE_GBPS, "frac_of_attainable": round(achieved / HBM_ATTAINABLE_GBPS, 4),
             "avg_launch_ms": round(avg_ms, 5), "launches_per_step": launches / max(tm["steps"], 1),
             "iterations_per_launch": iters * tm["steps"] / max(tm["jacobi_launches"], 1),
             "algorithmic_bytes_per_launch": int(alg_launch),
             "algorithmic_GBps": round(alg_launch / (avg_ms * 1e-3) / 1e9, 1),
             "note": "achieved = HBM bytes one launch really moves / its measured duration (bounded by the peak); "
                     "algorithmic_* = the reference's 12 B/cell/iteration for the iterations this launch performs (a speed-up over the "
-                    "pass structure, may exceed the peak)",
+                    "pass structure, may exceed the peak); bound = the larger of the memory term (frac_of_attainable: achieved / the "
+                    "guide's measured 6.29 TB/s streaming ceiling) and the arithmetic term (valu.busy_frac: the average SIMD's "
+                    "VALU-issuing cycles / the launch's cycles, SQ counters of this run)",
         }
+        # the two phases of a temporally blocked launch, timed in this run: ONE iteration (the tile's loads and stores: the memory
+        # phase) against the full depth (each further iteration is arithmetic on registers)
+        if args.schedule == "fused" and iters >= 2:
+            kfull = int(round(roof["iterations_per_launch"]))
+            t1, tk = time_jacobi_launch(sim, 1), time_jacobi_launch(sim, kfull)
+            roof["mem_phase_ms"] = round(t1, 5)
+            roof["valu_phase_ms"] = round(max(tk - t1, 0.0) * kfull / max(kfull - 1, 1), 5)
+            roof["phase_note"] = ("launch of 1 iteration / extra time of a launch of %d iterations scaled to %d (standalone launches on "
+                                  "random-free state; they overlap partly inside a step, so mem + valu > avg_launch_ms is expected)" % (kfull, kfull))
+        if not args.no_traffic and args.schedule == "fused":
+            valu, vwhy = collect_valu(args, deadline, cands)
+            if valu:
+                valu["busy_ms_at_max_clock"] = round(valu["simd_valu_cycles_per_launch"] / 2.4e6, 5)   # 2.4 GHz: a lower bound on the time
+                gui = valu.get("gui_active_cycles_per_launch", 0)
+                if gui:   # the counter may come summed over the 8 XCDs: its value per millisecond tells (the clock is 1.8-2.4 GHz)
+                    inst = 8 if gui / (avg_ms * 1e6) > 4.8 else 1
+                    valu["gui_instances_assumed"] = inst
+                    valu["busy_frac"] = round(valu["simd_valu_cycles_per_launch"] / (gui / inst), 4)
+                    valu["effective_clock_GHz"] = round(gui / inst / (avg_ms * 1e6), 3)
+                else:
+                    valu["busy_frac"] = round(valu["busy_ms_at_max_clock"] / avg_ms, 4)
+                roof["valu"] = valu
+                if valu["busy_frac"] > roof["frac_of_attainable"]:
+                    roof["bound"] = "valu"
+            else:
+                roof["valu"] = {"busy_frac": None, "why": vwhy}
+        out["roofline"] = roof
         if traffic:
             out["step_hbm"] = {"bytes_per_step": traffic["bytes_per_step"], "GBps": round(traffic["bytes_per_step"] * steps_per_s / 1e9, 1),
                                "frac": round(traffic["bytes_per_step"] * steps_per_s / 1e9 / HBM_PEAK_GBPS, 4),
+                               "frac_of_attainable": round(traffic["bytes_per_step"] * steps_per_s / 1e9 / HBM_ATTAINABLE_GBPS, 4),
                                "kernels": {k: {"bytes_per_launch": v["bytes_per_launch"], "launches_per_step": v["launches_per_step"]}
                                            for k, v in traffic["kernels"].items()}}
         per_step = {k: round(v / max(tm["steps"], 1), 4) for k, v in tm.items() if k.endswith("_ms")}
         out["pass_ms_per_step"] = per_step
+        if tm.get("folded_launches", 0):
+            out["pass_ms_note"] = "gradsub_ms = the last Jacobi launch of the step with the gradient subtract folded in (k_jacobi_tb_gs); jacobi_ms = the other launches"
 
     # ---- the same loop well inside steady clocks: the contract's K steps may be as few as 20 (11 ms), inside the clock ramp ----
     if rank == 0 and N == 1 and not args.no_steady:
         n_long = max(2000, args.steps)
-        sync()
-        t0 = time.perf_counter()
-        run(n_long)
-        sync()
-        out["steady_ms_per_step"] = round(1e3 * (time.perf_counter() - t0) / n_long, 4)
-        out["steady_steps"] = n_long
+        if deadline.left() > 20:
+            sync()
+            t0 = time.perf_counter()
+            run(n_long)
+            sync()
+            out["steady_ms_per_step"] = round(1e3 * (time.perf_counter() - t0) / n_long, 4)
+            out["steady_steps"] = n_long
+        else:
+            skipped["steady_ms_per_step"] = "extras budget spent"
 
     if rank == 0 and N == 1 and args.cpu_budget > 0:
-        out["cpu_baseline"] = cpu_baseline(size, iters, args.cpu_budget, args.cpu_kind)
+        if deadline.left() > 30:
+            out["cpu_baseline"] = cpu_baseline(size, iters, min(args.cpu_budget, deadline.left() / 12.0), args.cpu_kind, max_wait=deadline.left())
+        else:
+            out["cpu_baseline"] = {"value": None, "unit": "GLUPS", "kind": "reference", "cores": os.cpu_count(),
+                                   "sample": "not measured: the extras budget (--extras-budget) was spent by the counter passes"}
+    if skipped:
+        out["skipped"] = skipped
 
-    if N > 1:
-        out["config"]["exchanges_per_step"] = sim.exchanges / max(args.steps + args.warmup, 1)
-        out["config"]["driver"] = "native plan + ncclSend/ncclRecv inside libfluid_hip.so" if sim.native else "hosted: torch.distributed batch_isend_irecv"
-        if sim.native:
-            out["config"]["advect_exchange_rows"] = list(sim.engine.advect_exchange_rows())
     if rank == 0:
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     os.dup2(real_stdout, 1)
@@ -430,6 +670,18 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         dist.barrier()
         dist.destroy_process_group()
     return out
+
+
+def time_jacobi_launch(sim, k, reps=20):
+    """milliseconds of one standalone temporally blocked launch of k iterations on the bench's own fields (fluid_pass_jacobi)"""
+    for _ in range(3):
+        sim.run_pass("jacobi", iters=k)
+    sim.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        sim.run_pass("jacobi", iters=k)
+    sim.sync()
+    return 1e3 * (time.perf_counter() - t0) / reps
 
 
 if __name__ == "__main__":

@@ -39,6 +39,21 @@ def per_kernel(path):
     return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
 
 
+def per_kernel_counters(path):
+    """{kernel: {counter: (average value per dispatch, dispatches)}} for a CSV that holds one or several counters"""
+    per_dispatch = defaultdict(float)
+    names = {}
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            key = (row["Dispatch_Id"], row["Counter_Name"])
+            per_dispatch[key] += float(row["Counter_Value"])
+            names[row["Dispatch_Id"]] = short(row["Kernel_Name"])
+    agg = defaultdict(lambda: defaultdict(list))
+    for (d, c), v in per_dispatch.items():
+        agg[names[d]][c].append(v)
+    return {k: {c: (sum(v) / len(v), len(v)) for c, v in cs.items()} for k, cs in agg.items()}
+
+
 def main(a):
     ff, wf, fp, wp = (per_kernel(p) for p in a[:4])
     W, H = int(a[4]), int(a[5])

@@ -124,7 +124,7 @@ int pass_curl_vort_div(fluid_ctx* c, float curl, float dt, int ext, Timer* t);
 int pass_clear(fluid_ctx* c, float value, int ext);
 struct Timer;
 int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launches, bool* gradsub, Timer* t);
-bool gradsub_fold_enabled();
+bool gradsub_fold_enabled(long owned_texels);
 int pass_clear_jacobi(fluid_ctx* c, float value, int iters, int ext_out, int* launches, bool* gradsub);
 int pass_gradsub(fluid_ctx* c, int ext);
 int pass_advect_velocity(fluid_ctx* c, float dt, float dissipation, int ext);

@@ -100,22 +100,25 @@ bool fused_supported(Win w);
 hipError_t launch_curl_vort_div(hipStream_t s, Win w, const float2* vel, float* curl, float2* vel_out, float* div,
                                 float curl_strength, float dt, int ga, int gb);
 
-// Temporally blocked Jacobi: `iters` (<= jacobi_tb_max_iters()) iterations in one launch, every input
+// Temporally blocked Jacobi: `iters` (<= jacobi_tb_depth(shape)) iterations in one launch, every input
 // value scaled by `pscale` on load (pscale = config.PRESSURE folds the clear pass, 1.0f otherwise).
 // Reads p rows [ga - iters, gb + iters) (clamped to the domain), writes p_out rows [ga, gb).
-// Any width.  Bitwise equal to `iters` launches of launch_jacobi.
-int jacobi_tb_max_iters();
+// Any width.  Bitwise equal to `iters` launches of launch_jacobi.  `shape`: the register tile's geometry, picked ONCE per pass from the
+// number of owned texels (jacobi_tb_pick: small grids take smaller, deeper tiles; FLUID_TB_VARIANT forces one).
+int jacobi_tb_pick(long owned_texels);
+int jacobi_tb_depth(int shape);
+bool jacobi_tb_has_gradsub(int shape);
 bool jacobi_tb_supported(Win w);
 hipError_t launch_jacobi_tb(hipStream_t s, Win w, const float* p, const float* div, float* p_out, float pscale,
-                            int iters, int ga, int gb);
+                            int iters, int ga, int gb, int shape);
 // The same launch with K6 (gradient subtract) folded in — for the LAST block of a step's loop: runs `iters` iterations, writes p_out rows
 // [ga, gb) AND vel_out = vel - grad(p_out) for the same texels (the tile carries one more apron ring, so the pressure neighbours of every
 // stored texel are exact in registers).  Reads p rows [ga - iters - 1, gb + iters + 1).  Bitwise equal to launch_jacobi_tb + launch_gradsub.
-bool jacobi_tb_gradsub_supported(Win w, int ga, int gb);
+// Only shapes with jacobi_tb_has_gradsub().
 hipError_t launch_jacobi_tb_gradsub(hipStream_t s, Win w, const float* p, const float* div, float* p_out, const float2* vel, float2* vel_out,
-                                    float pscale, int iters, int ga, int gb);
+                                    float pscale, int iters, int ga, int gb, int shape);
 hipError_t launch_jacobi_tb_gradsub(hipStream_t s, Win w, const __half* p, const __half* div, __half* p_out, const __half2* vel,
-                                    __half2* vel_out, float pscale, int iters, int ga, int gb);
+                                    __half2* vel_out, float pscale, int iters, int ga, int gb, int shape);
 // the fused kernels on fp16-storage fields: every intermediate the reference would have rendered to a half-float texture
 // between two of the fused passes (curl, the confined velocity, the advected velocity) is rounded to fp16 in registers,
 // so each is bitwise equal to its single-pass half kernels run in turn
@@ -126,9 +129,8 @@ hipError_t launch_advect_both(hipStream_t s, Win w, const __half2* vel, __half2*
                               float vel_dissipation, float dye_dissipation, int ga, int gb, unsigned int* miss);
 // the same on fp16-storage fields: the clear (pscale) and every iteration round their output to fp16, so the launch is
 // bitwise equal to `iters` launches of the half launch_jacobi
-int jacobi_tb_max_iters_f16();
 hipError_t launch_jacobi_tb(hipStream_t s, Win w, const __half* p, const __half* div, __half* p_out, float pscale, int iters, int ga,
-                            int gb);
+                            int gb, int shape);
 
 
 // ---- the same passes on fp16-storage fields (fluid_kernels_f16.hip): one kernel per reference pass ----

@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 namespace fluid {
 
@@ -354,6 +355,121 @@ __global__ void __launch_bounds__(BX) k_advect_both_fast_h(Win w, const __half2*
     advect_both_fast_body<ROWS>(w, vel, vel_out, dye, dye_out, dt, rW, rH, rvd, rdd, tsx, tsy, ga, gb, miss_out);
 }
 
+
+// ---- dye grid != sim grid (the reference's shipping defaults: SIM_RESOLUTION 128, DYE_RESOLUTION 1024, script.js:60-66): K7a and K7b stay
+// two launches (the dye pass samples the NEW velocity bilinearly, script.js:1287-1293), each with the same treatment as the fused kernel:
+// uniform divides as double multiplies, the interior tap fast path, 32-bit offsets, paired velocity taps, ROWS texels per thread.  Same
+// fp32 operations in the same order as advect_velocity_texel / advect_dye_texel<false>, hence the same bits.
+template <int ROWS, class V2>
+__device__ __forceinline__ void advect_velocity_fast_body(const Win& w, const V2* __restrict__ vel, V2* __restrict__ vel_out, float dt, double rW,
+                                                          double rH, double rvd, float tsx, float tsy, int ga, int gb,
+                                                          unsigned int* __restrict__ miss_out)
+{
+    const int lane_i = w.x0 + blockIdx.x * BX + threadIdx.x;
+    const bool live = lane_i < w.x1;
+    const int i = live ? lane_i : w.x1 - 1;
+    const int gj0 = ga + blockIdx.y * ROWS;
+    const TapBox B = tap_box(w);
+    const float u = div_uniform((float)i + 0.5f, rW);
+    int miss = 0;
+    bool on[ROWS];
+    unsigned c[ROWS];
+    float v[ROWS];
+    float2 vv[ROWS];
+#pragma unroll
+    for (int k = 0; k < ROWS; k++) {
+        const int gj = gj0 + k;
+        on[k] = live && gj < gb;
+        const int gjc = gj < gb ? gj : gb - 1;
+        v[k] = div_uniform((float)gjc + 0.5f, rH);
+        c[k] = (unsigned)((gjc - w.g0) * w.P + (i - w.c0));
+        vv[k] = ld(at_byte(vel, c[k] * (unsigned)sizeof(V2)), 0);
+    }
+    Tap4 t[ROWS];
+    Fetch2 f2[ROWS];
+#pragma unroll
+    for (int k = 0; k < ROWS; k++) {
+        t[k] = taps32<sizeof(V2)>(w, B, u - dt * vv[k].x * tsx, v[k] - dt * vv[k].y * tsy);
+        if (on[k]) miss += t[k].miss;
+    }
+    gather_taps<ROWS>(vel, t, f2);
+#pragma unroll
+    for (int k = 0; k < ROWS; k++) {
+        const Fetch2& f = f2[k];
+        const float rx = mixf(mixf(f.a.x, f.b.x, f.fx), mixf(f.c.x, f.d.x, f.fx), f.fy);
+        const float ry = mixf(mixf(f.a.y, f.b.y, f.fx), mixf(f.c.y, f.d.y, f.fx), f.fy);
+        if (on[k]) st(at_byte(vel_out, c[k] * (unsigned)sizeof(V2)), 0, make_float2(div_uniform(rx, rvd), div_uniform(ry, rvd)));
+    }
+    if (miss) atomicAdd(miss_out, (unsigned)miss);
+}
+
+template <int ROWS, class V2, class D4>
+__device__ __forceinline__ void advect_dye_fast_body(const Win& vw, const V2* __restrict__ vel, const Win& dw, const D4* __restrict__ dye,
+                                                     D4* __restrict__ dye_out, float dt, double rW, double rH, double rdd, float tsx, float tsy,
+                                                     int ga, int gb, unsigned int* __restrict__ miss_out)
+{
+    const int lane_i = dw.x0 + blockIdx.x * BX + threadIdx.x;
+    const bool live = lane_i < dw.x1;
+    const int i = live ? lane_i : dw.x1 - 1;
+    const int gj0 = ga + blockIdx.y * ROWS;
+    const TapBox Bv = tap_box(vw), Bd = tap_box(dw);
+    const float u = div_uniform((float)i + 0.5f, rW);
+    int miss = 0;
+    bool on[ROWS];
+    unsigned c[ROWS];
+    float v[ROWS];
+    Tap4 t[ROWS];
+#pragma unroll
+    for (int k = 0; k < ROWS; k++) {
+        const int gj = gj0 + k;
+        on[k] = live && gj < gb;
+        const int gjc = gj < gb ? gj : gb - 1;
+        v[k] = div_uniform((float)gjc + 0.5f, rH);
+        c[k] = (unsigned)((gjc - dw.g0) * dw.P + (i - dw.c0));
+        t[k] = taps32<sizeof(V2)>(vw, Bv, u, v[k]);  // uVelocity sampled at vUv: a LINEAR fetch on the sim grid
+        if (on[k]) miss += t[k].miss;
+    }
+    Fetch2 f2[ROWS];
+    gather_taps<ROWS>(vel, t, f2);
+#pragma unroll
+    for (int k = 0; k < ROWS; k++) {
+        const Fetch2& f = f2[k];
+        const float vx = mixf(mixf(f.a.x, f.b.x, f.fx), mixf(f.c.x, f.d.x, f.fx), f.fy);
+        const float vy = mixf(mixf(f.a.y, f.b.y, f.fx), mixf(f.c.y, f.d.y, f.fx), f.fy);
+        t[k] = taps32<sizeof(D4)>(dw, Bd, u - dt * vx * tsx, v[k] - dt * vy * tsy);
+        if (on[k]) miss += t[k].miss;
+    }
+    Fetch4 f4[ROWS];
+    gather_taps<ROWS>(dye, t, f4);
+#pragma unroll
+    for (int k = 0; k < ROWS; k++) {
+        const Fetch4& f = f4[k];
+        const float4 d = make_float4(mixf(mixf(f.a.x, f.b.x, f.fx), mixf(f.c.x, f.d.x, f.fx), f.fy),
+                                     mixf(mixf(f.a.y, f.b.y, f.fx), mixf(f.c.y, f.d.y, f.fx), f.fy),
+                                     mixf(mixf(f.a.z, f.b.z, f.fx), mixf(f.c.z, f.d.z, f.fx), f.fy),
+                                     mixf(mixf(f.a.w, f.b.w, f.fx), mixf(f.c.w, f.d.w, f.fx), f.fy));
+        if (on[k])
+            st(at_byte(dye_out, c[k] * (unsigned)sizeof(D4)), 0,
+               make_float4(div_uniform(d.x, rdd), div_uniform(d.y, rdd), div_uniform(d.z, rdd), div_uniform(d.w, rdd)));
+    }
+    if (miss) atomicAdd(miss_out, (unsigned)miss);
+}
+
+template <int ROWS, class V2>
+__global__ void __launch_bounds__(BX) k_advect_velocity_fast(Win w, const V2* __restrict__ vel, V2* __restrict__ vel_out, float dt, double rW,
+                                                              double rH, double rvd, float tsx, float tsy, int ga, int gb,
+                                                              unsigned int* __restrict__ miss_out)
+{
+    advect_velocity_fast_body<ROWS>(w, vel, vel_out, dt, rW, rH, rvd, tsx, tsy, ga, gb, miss_out);
+}
+
+template <int ROWS, class V2, class D4>
+__global__ void __launch_bounds__(BX) k_advect_dye_fast(Win vw, const V2* __restrict__ vel, Win dw, const D4* __restrict__ dye,
+                                                         D4* __restrict__ dye_out, float dt, double rW, double rH, double rdd, float tsx,
+                                                         float tsy, int ga, int gb, unsigned int* __restrict__ miss_out)
+{
+    advect_dye_fast_body<ROWS>(vw, vel, dw, dye, dye_out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss_out);
+}
 
 template <int ROWS>
 __global__ void __launch_bounds__(BX) k_advect_both(Win w, const float2* __restrict__ vel, float2* __restrict__ vel_out,
@@ -1107,11 +1223,11 @@ constexpr int VD_NW = VD_NW_, VD_RY = VD_RY_;
 // shorter per-iteration chain.  `gs`: the shape has a gradient-subtract instantiation (k_jacobi_tb_gs: needs HX >= HY + 1).
 struct TBVariant { int nw, ry, hx, hy, bpc; bool gs; };
 constexpr TBVariant kTB[] = {
-    {8, 10, 12, 10, 2, true},   // 0: default at >= 4096^2 — 126 VGPRs, two workgroups per CU, 50 iterations in 5 launches
+    {8, 10, 12, 10, 2, true},   // 0: default at >= 3072^2 — 126 VGPRs, two workgroups per CU, 50 iterations in 5 launches
     {8, 8, 8, 8, 2, false},     // 1: shallow apron, 7 launches (round 1's first shape)
-    {8, 11, 12, 10, 2, false},  // 2
-    {8, 12, 12, 10, 2, true},   // 3: 972 tiles at 4096^2 instead of 1242
-    {8, 12, 16, 13, 2, false},  // 4: 4 launches, 128 VGPRs
+    {8, 11, 12, 10, 2, false},  // 2: (spills)
+    {8, 12, 12, 10, 2, true},   // 3: 972 tiles at 4096^2 instead of 1242 (spills: 0.78 ms per step against 0.50)
+    {8, 12, 16, 13, 2, false},  // 4: 4 launches, 128 VGPRs (spills)
     {8, 16, 20, 17, 1, false},  // 5: 3 launches, one workgroup per CU
     {16, 12, 20, 17, 1, false}, // 6: 3 launches, 16-wave workgroup
     {4, 24, 16, 13, 2, false},  // 7: 4 waves x 24 rows
@@ -1119,10 +1235,13 @@ constexpr TBVariant kTB[] = {
     {8, 6, 12, 10, 2, true},    // 9: 48-row tile
     {8, 7, 12, 10, 2, true},    // 10: 56-row tile
     {8, 4, 12, 10, 3, true},    // 11: 32-row tile, three workgroups per CU
+    {8, 7, 20, 17, 2, true},    // 12: small grids, deeper: 56-row tile with a 17-row apron — 50 iterations in 3 launches
+    {8, 8, 28, 25, 2, true},    // 13: 64-row tile with a 25-row apron — 2 launches
+    {8, 6, 20, 17, 2, true},    // 14: 48-row tile, 17-row apron
+    {16, 6, 28, 25, 1, true},   // 15: 16 waves x 6 rows, 25-row apron — 2 launches
 };
 constexpr int kNumTB = sizeof(kTB) / sizeof(kTB[0]);
 constexpr int kDefaultTB = 0;  // measured best of the table at 4096^2 (profiles/r01/jacobi_variants.txt, there listed as "8x10 h12/10")
-constexpr int kTBIters = 10;   // every shape the grid-driven choice may take runs up to this many iterations per launch (pass_jacobi's split)
 
 int cvd_remap()  // FLUID_CVD_REMAP: tile order of the fused curl/vorticity/divergence kernel (same encoding)
 {
@@ -1143,29 +1262,31 @@ int tb_variant_env()  // FLUID_TB_VARIANT, or -1
     return v;
 }
 
-// FLUID_TB_SMALL="a,b": texel counts below which the grid-driven choice takes variant 8 / variant 10 (A/B knob for the thresholds)
-void tb_thresholds(long& t8, long& t10)
+// FLUID_TB_SMALL="texels:shape,texels:shape,...": grids below `texels` owned texels take `shape` (first match; A/B knob for the
+// grid-driven choice).  Default: below 3072^2 the 40-row tile (profiles/r03/jacobi_shapes_small_grids.txt).
+struct TBRule { long below; int shape; };
+const std::vector<TBRule>& tb_rules()
 {
-    static const struct Th { long a, b; } th = [] {
-        Th t{ 1536l * 1536l, 3072l * 3072l };
+    static const std::vector<TBRule> rules = [] {
+        std::vector<TBRule> r;
         if (const char* e = getenv("FLUID_TB_SMALL")) {
-            long a = 0, b = 0;
-            if (sscanf(e, "%ld,%ld", &a, &b) == 2) t = Th{ a, b };
+            const char* p = e;
+            while (*p) {
+                char* q = nullptr;
+                const long t = strtol(p, &q, 10);
+                if (q == p || *q != ':') break;
+                p = q + 1;
+                const long sh = strtol(p, &q, 10);
+                if (q == p) break;
+                if (sh >= 0 && sh < kNumTB) r.push_back({ t, (int)sh });
+                p = *q == ',' ? q + 1 : q;
+            }
+        } else {
+            r.push_back({ 3072l * 3072l, 8 });
         }
-        return t;
+        return r;
     }();
-    t8 = th.a;
-    t10 = th.b;
-}
-
-// the tile shape for a launch over `texels` output texels
-int tb_variant_for(long texels)
-{
-    const int e = tb_variant_env();
-    if (e >= 0) return e;
-    long t8, t10;
-    tb_thresholds(t8, t10);
-    return texels < t8 ? 8 : texels < t10 ? 10 : kDefaultTB;
+    return rules;
 }
 
 template <int NW, int RY, int HX, int HY, int BPC>
@@ -1284,10 +1405,64 @@ hipError_t launch_gradsub4(hipStream_t s, Win w, const __half* p, const __half2*
     return hipGetLastError();
 }
 
+// whether the fast advection kernels apply to a field of `texel_bytes` per texel held in window w, decaying by `decay`
+// (32-bit byte offsets, 24-bit row multiply, divisor in [1, 2) for div_uniform); FLUID_ADVECT_FAST=0 keeps the general kernels (A/B knob)
+static bool advect_fast_ok(const Win& w, size_t texel_bytes, float decay_a, float decay_b)
+{
+    static const bool enabled = [] {
+        const char* e = getenv("FLUID_ADVECT_FAST");
+        return !(e && atoi(e) == 0);
+    }();
+    return enabled && udiv_decay_ok(decay_a) && udiv_decay_ok(decay_b) && (size_t)w.rows * (size_t)w.P * texel_bytes <= (1ull << 32) &&
+           (size_t)w.P * texel_bytes < (1u << 24) && w.H < (1 << 24);
+}
+
+// texels per thread of the separate fast kernels: four, or fewer on small grids so that the launch still spreads over the chip
+static int split_advect_rows(long texels) { return texels >= (1l << 22) ? 4 : texels >= (1l << 20) ? 2 : 1; }
+
+template <class V2>
+hipError_t launch_advect_velocity_any(hipStream_t s, Win w, const V2* vel, V2* out, float dt, float dissipation, int ga, int gb, unsigned int* miss)
+{
+    ROWS_OR_RETURN();
+    const float tsx = (float)(1.0 / w.W), tsy = (float)(1.0 / w.H), decay = 1.0f + dissipation * dt;
+    if (advect_fast_ok(w, sizeof(V2), decay, decay)) {
+        const double rW = udiv_recip((float)w.W), rH = udiv_recip((float)w.H), rvd = udiv_recip(decay);
+        const unsigned gx = (w.x1 - w.x0 + BX - 1) / BX;
+        switch (split_advect_rows((long)(w.x1 - w.x0) * (gb - ga))) {
+        case 4: k_advect_velocity_fast<4><<<dim3(gx, (gb - ga + 3) / 4, 1), BX, 0, s>>>(w, vel, out, dt, rW, rH, rvd, tsx, tsy, ga, gb, miss); break;
+        case 2: k_advect_velocity_fast<2><<<dim3(gx, (gb - ga + 1) / 2, 1), BX, 0, s>>>(w, vel, out, dt, rW, rH, rvd, tsx, tsy, ga, gb, miss); break;
+        default: k_advect_velocity_fast<1><<<dim3(gx, gb - ga, 1), BX, 0, s>>>(w, vel, out, dt, rW, rH, rvd, tsx, tsy, ga, gb, miss); break;
+        }
+        return hipGetLastError();
+    }
+    return hipErrorNotReady;  // the caller launches the general per-texel kernel
+}
+
+template <class V2, class D4>
+hipError_t launch_advect_dye_any(hipStream_t s, Win vw, const V2* vel, Win dw, const D4* dye, D4* out, float dt, float dissipation, int ga, int gb,
+                                 unsigned int* miss)
+{
+    ROWS_OR_RETURN();
+    const float tsx = (float)(1.0 / vw.W), tsy = (float)(1.0 / vw.H), decay = 1.0f + dissipation * dt;
+    if (!(vw.W == dw.W && vw.H == dw.H) && advect_fast_ok(dw, sizeof(D4), decay, decay) && advect_fast_ok(vw, sizeof(V2), decay, decay)) {
+        const double rW = udiv_recip((float)dw.W), rH = udiv_recip((float)dw.H), rdd = udiv_recip(decay);
+        const unsigned gx = (dw.x1 - dw.x0 + BX - 1) / BX;
+        switch (split_advect_rows((long)(dw.x1 - dw.x0) * (gb - ga))) {
+        case 4: k_advect_dye_fast<4><<<dim3(gx, (gb - ga + 3) / 4, 1), BX, 0, s>>>(vw, vel, dw, dye, out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss); break;
+        case 2: k_advect_dye_fast<2><<<dim3(gx, (gb - ga + 1) / 2, 1), BX, 0, s>>>(vw, vel, dw, dye, out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss); break;
+        default: k_advect_dye_fast<1><<<dim3(gx, gb - ga, 1), BX, 0, s>>>(vw, vel, dw, dye, out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss); break;
+        }
+        return hipGetLastError();
+    }
+    return hipErrorNotReady;
+}
+
 hipError_t launch_advect_velocity(hipStream_t s, Win w, const float2* vel, float2* out, float dt, float dissipation, int ga,
                                   int gb, unsigned int* miss)
 {
     ROWS_OR_RETURN();
+    const hipError_t e = launch_advect_velocity_any(s, w, vel, out, dt, dissipation, ga, gb, miss);
+    if (e != hipErrorNotReady) return e;
     k_advect_velocity<<<row_grid(w, ga, gb), BX, 0, s>>>(w, vel, out, dt, dissipation, (float)(1.0 / w.W), (float)(1.0 / w.H), ga, miss);
     return hipGetLastError();
 }
@@ -1296,6 +1471,8 @@ hipError_t launch_advect_dye(hipStream_t s, Win vw, const float2* vel, Win dw, c
                              float dissipation, int ga, int gb, unsigned int* miss)
 {
     ROWS_OR_RETURN();
+    const hipError_t e = launch_advect_dye_any(s, vw, vel, dw, dye, out, dt, dissipation, ga, gb, miss);
+    if (e != hipErrorNotReady) return e;
     const float tsx = (float)(1.0 / vw.W), tsy = (float)(1.0 / vw.H);  // velocity.texelSizeX/Y, script.js:1061-1062, 1276
     if (vw.W == dw.W && vw.H == dw.H)
         k_advect_dye<true><<<row_grid(dw, ga, gb), BX, 0, s>>>(vw, vel, dw, dye, out, dt, dissipation, tsx, tsy, ga, miss);
@@ -1304,18 +1481,7 @@ hipError_t launch_advect_dye(hipStream_t s, Win vw, const float2* vel, Win dw, c
     return hipGetLastError();
 }
 
-// k_advect_both_fast serves when the dye array fits 32-bit byte offsets and both decay divisors are in [1, 2) (div_uniform);
-// FLUID_ADVECT_FAST=0 keeps the general kernel (A/B knob)
-static bool advect_fast_ok(const Win& w, size_t dye_texel_bytes, float vdecay, float ddecay)
-{
-    static const bool enabled = [] {
-        const char* e = getenv("FLUID_ADVECT_FAST");
-        return !(e && atoi(e) == 0);
-    }();
-    return enabled && udiv_decay_ok(vdecay) && udiv_decay_ok(ddecay) && (size_t)w.rows * (size_t)w.P * dye_texel_bytes <= (1ull << 32) &&
-           (size_t)w.P * dye_texel_bytes < (1u << 24) && w.H < (1 << 24);
-}
-
+// k_advect_both_fast serves when advect_fast_ok (above) holds for the dye array and both decay divisors; otherwise the general kernel
 // texels per thread of the fast kernel (FLUID_ADVECT_ROWS / FLUID_ADVECT_ROWS_F16: A/B knobs); the general kernel runs with two
 static int advect_rows(const char* env, int dflt)
 {
@@ -1451,21 +1617,19 @@ hipError_t launch_curl_vort_div(hipStream_t s, Win w, const __half2* vel, __half
     return hipGetLastError();
 }
 
-// iterations one launch may run: the forced variant's apron, or what every grid-driven shape supports
-int jacobi_tb_max_iters()
+// the tile shape for a pass over `texels` owned texels: the forced one (FLUID_TB_VARIANT), or by grid size
+int jacobi_tb_pick(long texels)
 {
     const int e = tb_variant_env();
-    return e >= 0 ? kTB[e].hy : kTBIters;
+    if (e >= 0) return e;
+    for (const TBRule& r : tb_rules())
+        if (texels < r.below) return r.shape;
+    return kDefaultTB;
 }
-int jacobi_tb_max_iters_f16() { return kTBIters; }
+int jacobi_tb_depth(int shape) { return kTB[shape].hy; }
+bool jacobi_tb_has_gradsub(int shape) { return kTB[shape].gs; }
 
 bool jacobi_tb_supported(Win w) { return fused_supported(w); }
-
-// whether the launch over this window has a gradient-subtract instantiation (a forced variant may not)
-bool jacobi_tb_gradsub_supported(Win w, int ga, int gb)
-{
-    return fused_supported(w) && kTB[tb_variant_for((long)(w.x1 - w.x0) * (gb - ga))].gs;
-}
 
 #define TB_VARIANTS(X)      \
     X(0, 8, 10, 12, 10, 2)  \
@@ -1479,27 +1643,33 @@ bool jacobi_tb_gradsub_supported(Win w, int ga, int gb)
     X(8, 8, 5, 12, 10, 2)   \
     X(9, 8, 6, 12, 10, 2)   \
     X(10, 8, 7, 12, 10, 2)  \
-    X(11, 8, 4, 12, 10, 3)
+    X(11, 8, 4, 12, 10, 3)  \
+    X(12, 8, 7, 20, 17, 2)  \
+    X(13, 8, 8, 28, 25, 2)  \
+    X(14, 8, 6, 20, 17, 2)  \
+    X(15, 16, 6, 28, 25, 1)
 #define TB_GS_VARIANTS(X)  \
     X(0, 8, 10, 12, 10, 2) \
     X(3, 8, 12, 12, 10, 2) \
     X(8, 8, 5, 12, 10, 2)  \
     X(9, 8, 6, 12, 10, 2)  \
     X(10, 8, 7, 12, 10, 2) \
-    X(11, 8, 4, 12, 10, 3)
+    X(11, 8, 4, 12, 10, 3) \
+    X(12, 8, 7, 20, 17, 2) \
+    X(13, 8, 8, 28, 25, 2) \
+    X(14, 8, 6, 20, 17, 2) \
+    X(15, 16, 6, 28, 25, 1)
 #define TB_CHECK(k, NW, RY, HX, HY, BPC) \
     static_assert(kTB[k].nw == NW && kTB[k].ry == RY && kTB[k].hx == HX && kTB[k].hy == HY && kTB[k].bpc == BPC, "variant table");
 TB_VARIANTS(TB_CHECK)
 #define TB_GS_CHECK(k, NW, RY, HX, HY, BPC) TB_CHECK(k, NW, RY, HX, HY, BPC) static_assert(kTB[k].gs && HX >= HY + 1, "gs variant");
 TB_GS_VARIANTS(TB_GS_CHECK)
-static_assert(kTB[8].hy == kTBIters && kTB[10].hy == kTBIters && kTB[kDefaultTB].hy == kTBIters, "grid-driven shapes share the iteration depth");
 
 template <class T>
-hipError_t launch_jacobi_tb_any(hipStream_t s, Win w, const T* p, const T* div, T* p_out, float pscale, int iters, int ga, int gb)
+hipError_t launch_jacobi_tb_any(hipStream_t s, Win w, const T* p, const T* div, T* p_out, float pscale, int iters, int ga, int gb, int v)
 {
     ROWS_OR_RETURN();
-    if (!jacobi_tb_supported(w)) return hipErrorInvalidValue;
-    const int v = tb_variant_for((long)(w.x1 - w.x0) * (gb - ga));
+    if (!jacobi_tb_supported(w) || v < 0 || v >= kNumTB) return hipErrorInvalidValue;
     if (iters < 1 || iters > kTB[v].hy) return hipErrorInvalidValue;
     switch (v) {
 #define TB_CASE(k, NW, RY, HX, HY, BPC) \
@@ -1512,11 +1682,10 @@ hipError_t launch_jacobi_tb_any(hipStream_t s, Win w, const T* p, const T* div, 
 
 template <class T, class V2>
 hipError_t launch_jacobi_tb_gradsub_any(hipStream_t s, Win w, const T* p, const T* div, T* p_out, const V2* vel, V2* vel_out, float pscale,
-                                        int iters, int ga, int gb)
+                                        int iters, int ga, int gb, int v)
 {
     ROWS_OR_RETURN();
-    if (!jacobi_tb_gradsub_supported(w, ga, gb)) return hipErrorInvalidValue;
-    const int v = tb_variant_for((long)(w.x1 - w.x0) * (gb - ga));
+    if (!jacobi_tb_supported(w) || v < 0 || v >= kNumTB || !kTB[v].gs) return hipErrorInvalidValue;
     if (iters < 1 || iters > kTB[v].hy) return hipErrorInvalidValue;
     w.x0 &= ~3;  // whole float4 groups, as launch_gradsub4
     w.x1 = (w.x1 + 3) & ~3;
@@ -1530,23 +1699,23 @@ hipError_t launch_jacobi_tb_gradsub_any(hipStream_t s, Win w, const T* p, const 
     }
 }
 
-hipError_t launch_jacobi_tb(hipStream_t s, Win w, const float* p, const float* div, float* p_out, float pscale, int iters, int ga, int gb)
+hipError_t launch_jacobi_tb(hipStream_t s, Win w, const float* p, const float* div, float* p_out, float pscale, int iters, int ga, int gb, int shape)
 {
-    return launch_jacobi_tb_any(s, w, p, div, p_out, pscale, iters, ga, gb);
+    return launch_jacobi_tb_any(s, w, p, div, p_out, pscale, iters, ga, gb, shape);
 }
-hipError_t launch_jacobi_tb(hipStream_t s, Win w, const __half* p, const __half* div, __half* p_out, float pscale, int iters, int ga, int gb)
+hipError_t launch_jacobi_tb(hipStream_t s, Win w, const __half* p, const __half* div, __half* p_out, float pscale, int iters, int ga, int gb, int shape)
 {
-    return launch_jacobi_tb_any(s, w, p, div, p_out, pscale, iters, ga, gb);
+    return launch_jacobi_tb_any(s, w, p, div, p_out, pscale, iters, ga, gb, shape);
 }
 hipError_t launch_jacobi_tb_gradsub(hipStream_t s, Win w, const float* p, const float* div, float* p_out, const float2* vel, float2* vel_out,
-                                    float pscale, int iters, int ga, int gb)
+                                    float pscale, int iters, int ga, int gb, int shape)
 {
-    return launch_jacobi_tb_gradsub_any(s, w, p, div, p_out, vel, vel_out, pscale, iters, ga, gb);
+    return launch_jacobi_tb_gradsub_any(s, w, p, div, p_out, vel, vel_out, pscale, iters, ga, gb, shape);
 }
 hipError_t launch_jacobi_tb_gradsub(hipStream_t s, Win w, const __half* p, const __half* div, __half* p_out, const __half2* vel,
-                                    __half2* vel_out, float pscale, int iters, int ga, int gb)
+                                    __half2* vel_out, float pscale, int iters, int ga, int gb, int shape)
 {
-    return launch_jacobi_tb_gradsub_any(s, w, p, div, p_out, vel, vel_out, pscale, iters, ga, gb);
+    return launch_jacobi_tb_gradsub_any(s, w, p, div, p_out, vel, vel_out, pscale, iters, ga, gb, shape);
 }
 
 }  // namespace fluid

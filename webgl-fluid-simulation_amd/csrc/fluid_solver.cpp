@@ -211,39 +211,38 @@ int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launche
 {
     if (iters < 0) return c->fail(FLUID_ERR_INVALID, "negative iteration count");
     const bool tb = jacobi_tb_applies(c);
-    bool fold = gradsub && *gradsub && tb && iters > 0 && gradsub_fold_enabled();
+    const long owned = (long)c->sim_ncols * c->sim_rows;
+    const int shape = tb ? jacobi_tb_pick(owned) : 0;  // one tile geometry for every launch of this pass
+    bool fold = gradsub && *gradsub && tb && iters > 0 && jacobi_tb_has_gradsub(shape) && gradsub_fold_enabled(owned);
     if (gradsub) *gradsub = false;
     if (fold && ext_out < 1) ext_out = 1;
     CK(check_ext(c, ext_out, iters));
     int done = 0;
     if (!tb && pscale != 1.0f) return c->fail(FLUID_ERR_INVALID, "pscale needs the fused schedule");
     // balanced blocks: ceil(iters / max) launches of nearly equal depth (50 with max 8 -> 8,7,7,7,7,7,7)
-    const int tb_max = c->storage == FLUID_STORE_F16 ? jacobi_tb_max_iters_f16() : jacobi_tb_max_iters();
+    const int tb_max = tb ? jacobi_tb_depth(shape) : 1;
     int launches_left = tb ? (iters + tb_max - 1) / tb_max : iters;
     while (done < iters) {
         int ga, gb;
         if (tb) {
             const int k = (iters - done + launches_left - 1) / launches_left;
             launches_left--;
-            const bool last = done + k == iters;
-            if (last && fold) {
+            if (done + k == iters && fold) {
                 row_range(c->sim, c->sim_row0, c->sim_rows, 0, ga, gb);
-                const Win w = sim_cols(c, 0);
-                if (jacobi_tb_gradsub_supported(w, ga, gb)) {
-                    if (t) t->mark(P_JACOBI);  // the launches so far; this one is timed as P_GRADSUB by the caller
-                    CK(c->hip(STORE_CALL(c, launch_jacobi_tb_gradsub(c->stream, w, (const S::T1*)c->prs[0], (const S::T1*)c->div, (S::T1*)c->prs[1],
-                                                                     (const S::T2*)c->vel[0], (S::T2*)c->vel[1], done == 0 ? pscale : 1.0f, k, ga, gb)),
-                              "jacobi_tb_gradsub"));
-                    std::swap(c->prs[0], c->prs[1]);
-                    std::swap(c->vel[0], c->vel[1]);
-                    if (launches) (*launches)++;
-                    *gradsub = true;
-                    return FLUID_OK;
-                }
+                if (t) t->mark(P_JACOBI);  // the launches so far; this one is timed as P_GRADSUB by the caller
+                CK(c->hip(STORE_CALL(c, launch_jacobi_tb_gradsub(c->stream, sim_cols(c, 0), (const S::T1*)c->prs[0], (const S::T1*)c->div,
+                                                                 (S::T1*)c->prs[1], (const S::T2*)c->vel[0], (S::T2*)c->vel[1],
+                                                                 done == 0 ? pscale : 1.0f, k, ga, gb, shape)),
+                          "jacobi_tb_gradsub"));
+                std::swap(c->prs[0], c->prs[1]);
+                std::swap(c->vel[0], c->vel[1]);
+                if (launches) (*launches)++;
+                *gradsub = true;
+                return FLUID_OK;
             }
             row_range(c->sim, c->sim_row0, c->sim_rows, ext_out + (iters - done - k), ga, gb);
             CK(c->hip(STORE_CALL(c, launch_jacobi_tb(c->stream, sim_cols(c, ext_out + (iters - done - k)), (const S::T1*)c->prs[0], (const S::T1*)c->div,
-                                                     (S::T1*)c->prs[1], done == 0 ? pscale : 1.0f, k, ga, gb)),
+                                                     (S::T1*)c->prs[1], done == 0 ? pscale : 1.0f, k, ga, gb, shape)),
                       "jacobi_tb"));
             done += k;
         } else {
@@ -329,14 +328,16 @@ int pass_advect(fluid_ctx* c, float dt, float vel_diss, float dye_diss, Timer* t
 // ---- band forms for the stripe driver: one row band of a single-kernel pass, WITHOUT the ping-pong swap, so that a
 //      pass can run as "interior rows while the ghost rows are in flight, then the strips next to them" ----
 // the temporally blocked Jacobi kernel exists for both storage types
-// FLUID_FOLD_GRADSUB=0: keep K6 as its own launch (A/B knob; same bits either way)
-bool gradsub_fold_enabled()
+// K6 inside the last Jacobi launch?  FLUID_FOLD_GRADSUB=0 / 1 forces it off / on (A/B knob; same bits either way).  Default: on small
+// grids only, where a step is a chain of latency-bound launches and one launch fewer is worth 4-8 %; at 4096^2 the folded launch saves
+// 12 us of pass time and the step is not faster for it (profiles/r03/gradsub_fold_ab.txt)
+bool gradsub_fold_enabled(long owned_texels)
 {
-    static const bool on = [] {
+    static const int mode = [] {
         const char* e = getenv("FLUID_FOLD_GRADSUB");
-        return !(e && atoi(e) == 0);
+        return e ? (atoi(e) != 0 ? 1 : 0) : -1;
     }();
-    return on;
+    return mode >= 0 ? mode == 1 : owned_texels < 3072l * 3072l;
 }
 
 bool jacobi_tb_applies(const fluid_ctx* c) { return c->desc.schedule == FLUID_SCHED_FUSED && jacobi_tb_supported(c->sim); }

@@ -449,6 +449,21 @@ class FluidSim:
     def fields(self) -> Dict[str, np.ndarray]:
         return {k: self.read(k) for k in FIELD_IDS}
 
+    def device_view(self, name: str):
+        """torch tensor [rows, width, channels] aliasing the field's CURRENT read buffer on the device (zero copy through
+        __cuda_array_interface__; the padding columns of the pitch are sliced off).  Valid until the next call that swaps the
+        field's ping-pong buffers; the caller orders its torch work against the solver stream (sim.sync())."""
+        import torch
+        ptr = C.c_void_p()
+        self._check(self._lib.fluid_field_device_ptr(self._ctx, FIELD_IDS[name], C.byref(ptr)))
+        fi = self._info(name)
+        shape = (fi.rows + 2 * fi.halo, fi.pitch, fi.channels)
+
+        class _DeviceArray:  # minimal CUDA-array-interface carrier
+            __cuda_array_interface__ = {"shape": shape, "typestr": "<f%d" % fi.bytes_per_channel, "data": (ptr.value, False), "version": 2}
+
+        return torch.as_tensor(_DeviceArray(), device="cuda:%d" % self._device)[:, :fi.width]
+
     # -- single passes (test / stripe-driver port) -------------------------------------------------
     def run_pass(self, name: str, dt: float = 0.016666, iters: int = 1, ext: int = 0):
         L, c, P = self._lib, self._ctx, self.params()
