@@ -26,10 +26,6 @@ def _gpu_unavailable():
 def pytest_collection_modifyitems(config, items):
     """A plain `pytest tests` on a box without a GPU skips the gpu-marked tests instead of failing them one by one
     (the product itself still fails loudly without a device: tests/test_abi.py::test_no_cpu_fallback)."""
-    # the two node tests that bring up the system RCCL go first: its bootstrap was seen to hang only late in a long session
-    first = [it for it in items if "tile_rank" in it.nodeid or "launcher_runs_a_rank" in it.nodeid]
-    if first:
-        items[:] = first + [it for it in items if it not in first]
     gpu_items = [it for it in items if it.get_closest_marker("gpu")]
     if not gpu_items:
         return

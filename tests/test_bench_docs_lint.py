@@ -1,5 +1,5 @@
-"""The bench line's contract, checked on the committed output of the last GPU visit (profiles/r02/bench_4096_50.json is what
-`python bench.py` printed there): the keys the driver reads, a roofline that is a fraction of a physical peak (<= 1, = achieved / peak,
+"""DOCS LINT, not a test of bench.py (that is tests/test_bench_live.py, which runs it): the bench lines COMMITTED under profiles/ — the
+numbers DESIGN.md quotes — are well-formed lines of the contract (profiles/r02/bench_4096_50.json is what `python bench.py` printed there): the keys the driver reads, a roofline that is a fraction of a physical peak (<= 1, = achieved / peak,
 achieved = measured HBM bytes per launch / measured launch time), the CPU baseline of the same run and what kind it is."""
 import json
 import os

@@ -1,0 +1,62 @@
+"""bench.py run for real on the GPU (a small grid so that it takes seconds): ONE JSON line, the keys the driver reads, a roofline that is a
+fraction of a physical peak and follows from the numbers beside it, traffic measured in the run (or a stated reason), the in-run parity
+check, and the extras budget honoured.  This is the test that fails when bench.py regresses; tests/test_bench_docs_lint.py only lints
+the lines committed under profiles/."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*argv, timeout=900):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-800:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines          # exactly ONE JSON line on stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_line_is_live_and_consistent():
+    d = run_bench("--steps", "5", "--warmup", "2", "--size", "1024", "--cpu-budget", "0")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "parity_in_run"):
+        assert k in d, k
+    assert d["unit"] == "GLUPS" and d["higher_is_better"] is True and d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f32" and d["scaling"] == "weak"
+    assert "1024x1024" in d["config"]["workload"] and "50 Jacobi" in d["config"]["workload"] and "configs[1]" in d["config"]["workload"]
+    assert "model" not in d["config"]
+    assert abs(d["value"] - 1024 * 1024 * 1e3 / d["ms_per_step"] / 1e9) <= 2e-3 * d["value"]    # value is what the timing says
+    p = d["parity_in_run"]
+    assert p["ok"] and "bitwise" in p["fused_vs_passes_1024"] and "MISMATCH" not in json.dumps(p)
+    r = d["roofline"]
+    assert r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["attainable"] == 6290.0 and r["kernel"].startswith("k_jacobi_tb<")
+    assert 0 < r["frac"] <= 1.0 and 0 < r["frac_of_attainable"] <= 1.3
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-3
+    assert abs(r["achieved"] - r["traffic"] / (r["avg_launch_ms"] * 1e-3) / 1e9) <= 2e-3 * r["achieved"]   # bytes per launch / launch time
+    assert "PMC" in r["traffic_source"] or "unavailable" in r["traffic_source"]       # measured in this run, or the reason why not
+    if "PMC" in r["traffic_source"]:
+        assert 0.5 * 12 * 1024 * 1024 <= r["traffic"] <= 3.0 * 12 * 1024 * 1024
+        s = d["step_hbm"]
+        assert 0 < s["frac"] <= 1.0 and abs(s["frac"] - s["GBps"] / 8000.0) <= 1e-3
+    v = r.get("valu")
+    assert v is not None and ("why" in v or 0 < v["busy_frac"] <= 1.0)
+    assert r["bound"] in ("hbm", "valu")
+    if v.get("busy_frac"):
+        assert r["bound"] == ("valu" if v["busy_frac"] > r["frac_of_attainable"] else "hbm")
+    assert r["mem_phase_ms"] > 0 and r["valu_phase_ms"] >= 0
+    assert d["steady_ms_per_step"] > 0 and d["speedup_vs_pass_structure"]["x_hbm_peak"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_extras_budget_is_honoured():
+    """with no budget left for the extras the line still comes, at once, and says what it skipped"""
+    d = run_bench("--steps", "3", "--warmup", "1", "--size", "512", "--cpu-budget", "5", "--extras-budget", "1", "--no-parity")
+    assert d["value"] > 0 and "roofline" in d
+    assert "model" in d["roofline"]["traffic_source"] and "budget" in d["roofline"]["traffic_source"]
+    assert d["cpu_baseline"]["value"] is None and "budget" in d["cpu_baseline"]["sample"]
+    assert d["skipped"]["steady_ms_per_step"]

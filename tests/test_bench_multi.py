@@ -54,6 +54,24 @@ def test_bench_two_ranks_over_gloo(oracle, tmp_path):
     assert "roofline" not in d and "cpu_baseline" not in d       # rank 0 at N = 1 only
 
 
+def test_bench_extra_config_is_strong_scaling_and_leaves_the_headline_alone(oracle, tmp_path):
+    """the N > 1 line also carries BASELINE.json's own multi-GPU configurations (N = 4: configs[3], N = 8: configs[4]) under
+    `extra_configs`; here the mechanism with a small stand-in: the global 64 x 64 grid cut into two stripes, strong scaling"""
+    import torch.multiprocessing as mp
+    argv = ["--gpus", "2", "--size", "64", "--iters", "20", "--steps", "3", "--warmup", "1", "--halo", "8", "--cpu-budget", "0", "--comm-timeout", "100",
+            "--extra-config", "64,10,1,2"]
+    mp.spawn(_rank, args=(2, _free_port(), str(tmp_path), argv), nprocs=2, join=True)
+    lines0 = [l for l in open(os.path.join(str(tmp_path), "stdout_0.txt")).read().splitlines() if l.strip()]
+    assert len(lines0) == 1
+    d = json.loads(lines0[0])
+    assert "error" not in d and d["scaling"] == "weak" and "64x128" in d["config"]["workload"] and "weak scaling" in d["config"]["workload"]
+    assert abs(d["value"] - 64 * 128 * d["steps_per_sec"] / 1e9) <= 1e-4          # the headline is the weak-scaling number, untouched
+    (e,) = d["extra_configs"]
+    assert "error" not in e and e["scaling"] == "strong" and e["steps"] == 2 and "64x64" in e["config"] and "2 stripes" in e["config"]
+    assert e["value"] > 0 and abs(e["value"] - 64 * 64 * e["steps_per_sec"] / 1e9) <= 1e-4
+    assert e["exchanges_per_step"] == 3   # 10 iterations with halo 8: {velocity, pressure}, one more pressure block, {velocity, dye}
+
+
 def test_bench_reports_a_launch_that_cannot_work():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cpu-budget", "0"], env=env,

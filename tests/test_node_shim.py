@@ -17,27 +17,50 @@ NODE = shutil.which("node")
 needs_node = pytest.mark.skipif(NODE is None, reason="node not installed")
 
 
-def node(script, args, attempts=2, rccl=False):
+def node(script, args, rccl=False):
     """Run a node script and parse its last stdout line.  `rccl`: the script initialises a one-rank communicator with the SYSTEM RCCL
-    (a node process has no torch).  On this GPU pool that ncclCommInitRank intermittently never returns — in 3 of 8 runs of the whole
-    suite, always right after RCCL's version banner, on every retry of that session, while the same test passed 5 / 5 alone and after
-    every other test file, and the same entry points pass through torch's RCCL in tests/test_stripes_gpu.py (round 2, visits 8-11; not
-    reproducible on demand, nothing of ours is executing at that point).  Such a hang is reported as a SKIP with that reason; a wrong
-    result or a non-zero exit is never retried or skipped."""
+    (a node process has no torch).  On this GPU pool that ncclCommInitRank was seen to never return in some sessions (round 2: 3 of 8
+    full-suite runs; round 3: tools/rccl_init_probe.py, the same call from 40 lines of C, returned 6 / 6 — profiles/r03/).  The child runs
+    with FLUID_TRACE_COMM (fluid.js prints a marker before and after commInit) and NCCL_DEBUG=INFO; if it does not finish, every thread's
+    kernel-side state is dumped from /proc into gpurun_out/ before the process group is killed, and the verdict is:
+      * the markers show the process INSIDE commInit (begin without done)  -> XFAIL with the dump's path: RCCL's bootstrap on this box,
+        nothing of ours is executing;
+      * anything else (no marker, or past `commInit done`)                 -> FAIL: that would be a hang of this library.
+    A wrong result or a non-zero exit is never retried, skipped or xfailed."""
     cmd = [NODE, os.path.join(ROOT, "tests", "node", script), json.dumps(args)]
-    for k in range(attempts):
-        try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=60 if rccl else 300)
-            break
-        except subprocess.TimeoutExpired as ex:
-            banner_only = "RCCL version" in (ex.stdout.decode() if isinstance(ex.stdout, bytes) else (ex.stdout or "")) 
-            if k == attempts - 1:
-                if rccl and banner_only:
-                    pytest.skip("the system RCCL's one-rank ncclCommInitRank did not return within %d x 60 s on this box (intermittent on this "
-                                "pool; the same entry points are exercised through torch's RCCL in tests/test_stripes_gpu.py)" % attempts)
-                raise
-    assert r.returncode == 0, r.stderr
-    return json.loads(r.stdout.strip().splitlines()[-1])
+    if not rccl:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    import signal
+    import sys
+    import time
+    env = dict(os.environ, FLUID_TRACE_COMM="1", NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,BOOTSTRAP,ENV")
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, start_new_session=True)
+    try:
+        so, se = p.communicate(timeout=90)
+    except subprocess.TimeoutExpired:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from rccl_init_probe import thread_dump
+        kids = subprocess.run(["pgrep", "-g", str(p.pid)], capture_output=True, text=True).stdout.split()   # exactly the group started above
+        dump = "\n".join("pid %s\n%s" % (k, thread_dump(int(k))) for k in kids)
+        os.killpg(p.pid, signal.SIGKILL)
+        so, se = p.communicate()
+        text = "== %s did not finish within 90 s ==\n-- stderr --\n%s\n-- stdout --\n%s\n-- threads at the time of the kill --\n%s\n" % (
+            script, se.decode(errors="replace")[-6000:], so.decode(errors="replace")[-2000:], dump)
+        out_dir = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out_dir, exist_ok=True)
+        path = os.path.join(out_dir, "node_rccl_hang_%s_%d.txt" % (script.replace(".js", ""), int(time.time())))
+        with open(path, "w") as f:
+            f.write(text)
+        err = se.decode(errors="replace")
+        inside = "commInit begin" in err and "commInit done" not in err
+        assert inside, "node %s hung OUTSIDE ncclCommInitRank (markers: %r): a hang of this library\n%s" % (
+            script, [l for l in err.splitlines() if l.startswith("[fluid.js]")], text[-3000:])
+        pytest.xfail("the system RCCL's one-rank ncclCommInitRank did not return within 90 s on this box (process inside commInit per the "
+                     "markers; thread dump + NCCL_DEBUG trace in %s)" % path)
+    assert p.returncode == 0, se.decode(errors="replace")
+    return json.loads(so.decode().strip().splitlines()[-1])
 
 
 @pytest.fixture(scope="module")

@@ -196,7 +196,12 @@ function createFluid (options) {
             handle = native.createTile(simRes.width, simRes.height, dyeRes.width, dyeRes.height, device, schedule,
                 Math.floor(t.rank / tilesX), t.world / tilesX, t.rank % tilesX, tilesX, t.halo === undefined ? 56 : t.halo, storage);
             if (t.reach !== undefined) native.setReach(handle, t.reach);
+            // FLUID_TRACE_COMM: marker lines on stderr around the one call that talks to RCCL (ncclCommInitRank), so that a wedged
+            // communicator bootstrap on a box can be told from a hang in this library (tests/test_node_shim.py)
+            const trace = !!process.env.FLUID_TRACE_COMM;
+            if (trace) process.stderr.write('[fluid.js] commInit begin rank ' + t.rank + '/' + t.world + '\n');
             native.commInit(handle, t.commId);          // collective: every rank of the run calls it
+            if (trace) process.stderr.write('[fluid.js] commInit done rank ' + t.rank + '\n');
         } else if (handle == null) handle = native.create(simRes.width, simRes.height, dyeRes.width, dyeRes.height, device, schedule, storage);
         else native.resize(handle, simRes.width, simRes.height, dyeRes.width, dyeRes.height);
     };

@@ -972,8 +972,10 @@ __device__ __forceinline__ void gradsub4_body(const Win& w, const S1* __restrict
         C.w = C.z;
     }
     float L = from_left_lane(C.w), R = from_right_lane(C.x);
-    if (lane == 0) L = cx > 0 ? ld(p, (long)(rowC + ax - 1)) : C.x;                    // CLAMP_TO_EDGE at the domain border
-    if (lane == 63 || cx + 4 >= w.x1) R = cx + 4 < w.W ? ld(p, (long)(rowC + ax + 4)) : C.w;
+    // the two lanes at the segment ends fetch their outside neighbour: CLAMP_TO_EDGE at the domain border, and never outside the array
+    // (a tile array holds owned + ghost columns only; a launch that starts at its first column has no valid output there anyway)
+    if (lane == 0) L = (cx > 0 && ax > 0) ? ld(p, (long)(rowC + ax - 1)) : C.x;
+    if (lane == 63 || cx + 4 >= w.x1) R = (cx + 4 < w.W && ax + 4 < w.P) ? ld(p, (long)(rowC + ax + 4)) : C.w;
     float4 oa, ob;
     oa.x = va.x - (C.y - L);
     oa.y = va.y - (T.x - B.x);

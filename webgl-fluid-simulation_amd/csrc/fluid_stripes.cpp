@@ -411,9 +411,16 @@ int neighbour_rank(const fluid_ctx* c, int dir)
     return dir == LEFT ? r - 1 : dir == RIGHT ? r + 1 : dir == DOWN ? r - c->desc.parts_x : r + c->desc.parts_x;
 }
 
-int copy_rect(fluid_ctx* c, const Rect& dst, const Rect& src, hipStream_t s)
+// `from`: the context that owns the source block.  On the same device the copy is one k_copy_rects launch on c's comm stream; a
+// neighbour on ANOTHER device is not dereferenced from a kernel (nothing here enables peer access): the runtime's 2-D copy moves the
+// block, with or without peer access between the two GPUs.
+int copy_rect(fluid_ctx* c, const fluid_ctx* from, const Rect& dst, const Rect& src, hipStream_t s)
 {
     if (dst.line != src.line || dst.nrows != src.nrows) return c->fail(FLUID_ERR_INVALID, "exchange blocks of neighbouring tiles differ in shape");
+    if (from->device != c->device) {
+        HIPCK(c, hipMemcpy2DAsync(dst.p, dst.pitch, src.p, src.pitch, src.line, (size_t)src.nrows, hipMemcpyDeviceToDevice, s));
+        return FLUID_OK;
+    }
     fluid::CopyRects one{};
     one.n = 1;
     one.unit = (int)c->esz;
@@ -504,8 +511,8 @@ int group_exchange_2d_begin(fluid_ctx** cs, int n, const fluid_stripe_op& op)
         HIPCK(c, hipStreamWaitEvent(c->comm_stream, c->ev_ready, 0));
         CK(wait_neighbours(r, c->comm_stream, false));
         for (int i = 0; i < op.n_items; i++) {
-            if (has_neighbour(c, LEFT)) CK(copy_rect(c, blk[(size_t)r * 2 + i].recv[LEFT], blk[(size_t)(r - 1) * 2 + i].send[RIGHT], c->comm_stream));
-            if (has_neighbour(c, RIGHT)) CK(copy_rect(c, blk[(size_t)r * 2 + i].recv[RIGHT], blk[(size_t)(r + 1) * 2 + i].send[LEFT], c->comm_stream));
+            if (has_neighbour(c, LEFT)) CK(copy_rect(c, cs[r - 1], blk[(size_t)r * 2 + i].recv[LEFT], blk[(size_t)(r - 1) * 2 + i].send[RIGHT], c->comm_stream));
+            if (has_neighbour(c, RIGHT)) CK(copy_rect(c, cs[r + 1], blk[(size_t)r * 2 + i].recv[RIGHT], blk[(size_t)(r + 1) * 2 + i].send[LEFT], c->comm_stream));
         }
         HIPCK(c, hipEventRecord(c->ev_mid, c->comm_stream));
     }
@@ -514,8 +521,8 @@ int group_exchange_2d_begin(fluid_ctx** cs, int n, const fluid_stripe_op& op)
         HIPCK(c, hipSetDevice(c->device));
         CK(wait_neighbours(r, c->comm_stream, true));
         for (int i = 0; i < op.n_items; i++) {
-            if (has_neighbour(c, DOWN)) CK(copy_rect(c, blk[(size_t)r * 2 + i].recv[DOWN], blk[(size_t)(r - px) * 2 + i].send[UP], c->comm_stream));
-            if (has_neighbour(c, UP)) CK(copy_rect(c, blk[(size_t)r * 2 + i].recv[UP], blk[(size_t)(r + px) * 2 + i].send[DOWN], c->comm_stream));
+            if (has_neighbour(c, DOWN)) CK(copy_rect(c, cs[r - px], blk[(size_t)r * 2 + i].recv[DOWN], blk[(size_t)(r - px) * 2 + i].send[UP], c->comm_stream));
+            if (has_neighbour(c, UP)) CK(copy_rect(c, cs[r + px], blk[(size_t)r * 2 + i].recv[UP], blk[(size_t)(r + px) * 2 + i].send[DOWN], c->comm_stream));
         }
         HIPCK(c, hipEventRecord(c->ev_landed, c->comm_stream));
         c->exchanges++;
