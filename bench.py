@@ -247,56 +247,58 @@ class Watchdog:
         self.done.set()
 
 
-def parity_in_run(fluid_hip, size, iters, device, storage, deadline):
-    """Parity checked in the same run as the number, BEFORE the warm-up steps:
+def parity_in_run(fluid_hip, size, iters, device, storage, with_oracle=True, steps=10):
+    """Parity checked in the same run as the number, directly in front of the warm-up steps:
       (a) HIP == the CPU oracle bit for bit on a small case (256^2 sim / 512^2 dye, 20 iterations, 6 seeded splats, 2 steps, both
           schedules) — the oracle is the checker here, never the thing timed;
-      (b) at the benchmark's own size: the fused schedule (what is timed) == the one-kernel-per-reference-pass schedule, every field,
-          compared on the device after 3 steps from the same seeded splats.
-    Returns a dict for the JSON line; a mismatch is an error of the run, not a footnote."""
+      (b) at the benchmark's own size, on this rank's GPU: the fused schedule (what is timed) == the one-kernel-per-reference-pass
+          schedule, every field, compared on the device after `steps` steps from the same seeded splats.
+    Returns (dict for the JSON line, the two big contexts).  The caller closes the contexts AFTER the timed section: freeing 2 GB
+    synchronises the device, and (b) is also what the chip is busy with right before the warm-up — the timed steps then start on a
+    GPU that has been under load for ~30 ms instead of on an idle one that is still ramping its clocks (the driver's --steps 20
+    --warmup 5 covers 12 ms; profiles/r01/bench_warmup_sensitivity.txt, profiles/r03/driver_flags_preroll.txt).
+    A mismatch is an error of the run, not a footnote."""
     import numpy as np
     import torch
     out = {}
     t0 = time.perf_counter()
-    try:
-        from oracle import oracle as O
-        cfg = {"SIM_RESOLUTION": 256, "DYE_RESOLUTION": 512, "PRESSURE_ITERATIONS": 20}
-        ref = O.RefSim(canvas=(512, 512), config=cfg, seed=4321, storage=storage) if storage == "f16" else O.RefSim(canvas=(512, 512), config=cfg, seed=4321)
-        ref.multiple_splats(6)
-        ref.step(DT, 2)
-        want = ref.fields()
-        ok = True
-        for schedule in ("passes", "fused"):
-            with fluid_hip.FluidSim(canvas=(512, 512), config=cfg, device=device, schedule=schedule, random=fluid_hip.mulberry32(4321),
-                                    storage=storage) as sim:
-                sim.multipleSplats(6)
-                sim.step(DT, 2)
-                got = sim.fields()
-            ok = ok and all(np.array_equal(got[k], w) for k, w in want.items())
-        out["hip_vs_oracle_256"] = "bitwise equal, both schedules" if ok else "MISMATCH"
-    except Exception as ex:   # the oracle library may be absent on a box: say so, the on-device check below does not need it
-        out["hip_vs_oracle_256"] = "not run: %s" % str(ex)[:120]
+    if with_oracle:
+        try:
+            from oracle import oracle as O
+            cfg = {"SIM_RESOLUTION": 256, "DYE_RESOLUTION": 512, "PRESSURE_ITERATIONS": 20}
+            ref = O.RefSim(canvas=(512, 512), config=cfg, seed=4321, storage=storage) if storage == "f16" else O.RefSim(canvas=(512, 512), config=cfg, seed=4321)
+            ref.multiple_splats(6)
+            ref.step(DT, 2)
+            want = ref.fields()
+            ok = True
+            for schedule in ("passes", "fused"):
+                with fluid_hip.FluidSim(canvas=(512, 512), config=cfg, device=device, schedule=schedule, random=fluid_hip.mulberry32(4321),
+                                        storage=storage) as sim:
+                    sim.multipleSplats(6)
+                    sim.step(DT, 2)
+                    got = sim.fields()
+                ok = ok and all(np.array_equal(got[k], w) for k, w in want.items())
+            out["hip_vs_oracle_256"] = "bitwise equal, both schedules" if ok else "MISMATCH"
+        except Exception as ex:   # the oracle library may be absent on a box: say so, the on-device check below does not need it
+            out["hip_vs_oracle_256"] = "not run: %s" % str(ex)[:120]
     cfg = {"SIM_RESOLUTION": size, "DYE_RESOLUTION": size, "PRESSURE_ITERATIONS": iters}
     sims = []
-    try:
-        for schedule in ("passes", "fused"):
-            sim = fluid_hip.FluidSim(canvas=(size, size), config=cfg, device=device, schedule=schedule, random=fluid_hip.mulberry32(1234),
-                                     storage=storage)
-            sim.multipleSplats(20)
-            sim.step(DT, 3)
-            sim.sync()
-            sims.append(sim)
-        same = True
-        for k in ("velocity", "pressure", "divergence", "curl", "dye"):
-            same = same and bool(torch.equal(sims[0].device_view(k), sims[1].device_view(k)))
-        torch.cuda.synchronize()
-        out["fused_vs_passes_%d" % size] = "bitwise equal, all five fields after 3 steps" if same else "MISMATCH"
-    finally:
-        for sim in sims:
-            sim.close()
+    for schedule in ("passes", "fused"):
+        sim = fluid_hip.FluidSim(canvas=(size, size), config=cfg, device=device, schedule=schedule, random=fluid_hip.mulberry32(1234),
+                                 storage=storage)
+        sims.append(sim)
+        sim.multipleSplats(20)
+    for sim in sims:
+        sim.step(DT, steps)
+    for sim in sims:
+        sim.sync()
+    same = True
+    for k in ("velocity", "pressure", "divergence", "curl", "dye"):
+        same = same and bool(torch.equal(sims[0].device_view(k), sims[1].device_view(k)))
+    out["fused_vs_passes_%d" % size] = ("bitwise equal, all five fields after %d steps" % steps) if same else "MISMATCH"
     out["seconds"] = round(time.perf_counter() - t0, 2)
     out["ok"] = "MISMATCH" not in json.dumps(out)
-    return out
+    return out, sims
 
 
 def main(argv=None, engine_factory=None, backend="nccl"):
@@ -386,11 +388,8 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         return StripeSim(canvas=(gw, gh), config=c, halo=args.halo, schedule=args.schedule, random=fluid_hip.mulberry32(1234),
                          device=local_rank, **kw)
 
+    parity_sims = []
     if N == 1:
-        if not args.no_parity and not on_cpu:
-            parity = parity_in_run(fluid_hip, size, iters, local_rank, args.storage, None)
-            if not parity["ok"]:
-                fail("in-run parity check failed: %s" % json.dumps(parity), code=6)
         sim = fluid_hip.FluidSim(canvas=(size, size), config=cfg, device=local_rank, schedule=args.schedule,
                                  random=fluid_hip.mulberry32(1234), storage=args.storage)
         sim.multipleSplats(20)
@@ -469,7 +468,26 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         sim.sync()
         dev_sync()
 
+    # the in-run parity check, on every rank's own GPU, directly in front of the warm-up (see parity_in_run)
+    if not args.no_parity and not on_cpu:
+        problem = None
+        if dog:
+            dog.at("in-run parity check (fused == per-pass schedule on this rank's GPU)")
+        try:
+            parity, parity_sims = parity_in_run(fluid_hip, size, iters, local_rank, args.storage, with_oracle=(rank == 0))
+            if not parity["ok"]:
+                problem = "in-run parity check failed on rank %d: %s" % (rank, json.dumps(parity))
+        except Exception as ex:
+            problem = "in-run parity check could not run on rank %d: %s" % (rank, str(ex)[:200])
+        problem = agree(problem)
+        if problem:
+            if dog:
+                dog.stop()
+            fail(problem, code=6)
+
     elapsed = measure(sim, args.warmup, args.steps, "headline")
+    for ps in parity_sims:
+        ps.close()
 
     steps_per_s = args.steps / elapsed
     glups = grid_w * grid_h * steps_per_s / 1e9

@@ -139,8 +139,10 @@ void sim_band(const fluid_ctx* c, int ext, int& ga, int& gb);  // owned rows +- 
 fluid::Win sim_cols(const fluid_ctx* c, int ext);              // the window with this launch's column range (2-D tiles)
 fluid::Win dye_cols(const fluid_ctx* c, int ext);
 int cvd_band(fluid_ctx* c, float curl, float dt, int ga, int gb, int xa, int xb);
+int cvd_rects(fluid_ctx* c, float curl, float dt, const fluid::BandRects& B);
 void cvd_swap(fluid_ctx* c);
 int advect_both_band(fluid_ctx* c, float dt, float vel_diss, float dye_diss, int ga, int gb, int xa, int xb, int v0, int v1, int u0, int u1);
+int advect_both_rects(fluid_ctx* c, float dt, float vel_diss, float dye_diss, const fluid::BandRects& B, int v0, int v1, int u0, int u1);
 void advect_both_swap(fluid_ctx* c);
 
 // fluid_stripes.cpp

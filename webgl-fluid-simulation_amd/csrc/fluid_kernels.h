@@ -93,6 +93,20 @@ struct CopyRects {
 };
 hipError_t launch_copy_rects(hipStream_t s, const CopyRects& R);
 
+// Several bands of a single-kernel pass group in ONE launch: the strips around the interior of a 2-D tile (fluid_stripes.cpp).  Each
+// rectangle = columns [xa, xb) x rows [ga, gb) of the window (xa, xb whole float4 groups for the register-tile kernel); empty ones are
+// skipped.  Same kernels bodies, same bits as one launch per rectangle.
+struct BandRect { int xa, xb, ga, gb; };
+struct BandRects { BandRect r[4]; int n; };
+hipError_t launch_advect_both_rects(hipStream_t s, Win w, const float2* vel, float2* vel_out, const float4* dye, float4* dye_out, float dt,
+                                    float vel_dissipation, float dye_dissipation, const BandRects& B, unsigned int* miss);
+hipError_t launch_advect_both_rects(hipStream_t s, Win w, const __half2* vel, __half2* vel_out, const half4* dye, half4* dye_out, float dt,
+                                    float vel_dissipation, float dye_dissipation, const BandRects& B, unsigned int* miss);
+hipError_t launch_curl_vort_div_rects(hipStream_t s, Win w, const float2* vel, float* curl, float2* vel_out, float* div, float curl_strength,
+                                      float dt, const BandRects& B);
+hipError_t launch_curl_vort_div_rects(hipStream_t s, Win w, const __half2* vel, __half* curl, __half2* vel_out, __half* div, float curl_strength,
+                                      float dt, const BandRects& B);
+
 // Fused curl -> vorticity -> divergence (K1+K2+K3): reads velocity rows [ga-3, gb+3) (clamped), writes curl,
 // the confined velocity and its divergence for rows [ga, gb).  Any width (the pitch keeps rows float4-aligned).  Bitwise equal to the three
 // single-pass kernels run in turn.

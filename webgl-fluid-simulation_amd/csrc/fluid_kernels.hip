@@ -279,13 +279,14 @@ template <int ROWS, class V2, class D4>
 __device__ __forceinline__ void advect_both_fast_body(const Win& w, const V2* __restrict__ vel, V2* __restrict__ vel_out,
                                                       const D4* __restrict__ dye, D4* __restrict__ dye_out, float dt, double rW, double rH,
                                                       double rvd, double rdd, float tsx, float tsy, int ga, int gb,
-                                                      unsigned int* __restrict__ miss_out)
+                                                      unsigned int* __restrict__ miss_out, int bx, int by)
 {
+    // (bx, by): the block's position in its band — blockIdx for a one-band launch, or its place in one of the launch's rectangles
     // a lane past the last column repeats it (loads stay in bounds, nothing stored, nothing counted), like a row past the band
-    const int lane_i = w.x0 + blockIdx.x * BX + threadIdx.x;
+    const int lane_i = w.x0 + bx * BX + threadIdx.x;
     const bool live = lane_i < w.x1;
     const int i = live ? lane_i : w.x1 - 1;
-    const int gj0 = ga + blockIdx.y * ROWS;
+    const int gj0 = ga + by * ROWS;
     const TapBox B = tap_box(w);
     const float u = div_uniform((float)i + 0.5f, rW);
     int miss = 0;
@@ -343,7 +344,7 @@ __global__ void __launch_bounds__(BX) k_advect_both_fast(Win w, const float2* __
                                                           double rH, double rvd, double rdd, float tsx, float tsy, int ga, int gb,
                                                           unsigned int* __restrict__ miss_out)
 {
-    advect_both_fast_body<ROWS>(w, vel, vel_out, dye, dye_out, dt, rW, rH, rvd, rdd, tsx, tsy, ga, gb, miss_out);
+    advect_both_fast_body<ROWS>(w, vel, vel_out, dye, dye_out, dt, rW, rH, rvd, rdd, tsx, tsy, ga, gb, miss_out, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 template <int ROWS>
@@ -352,9 +353,33 @@ __global__ void __launch_bounds__(BX) k_advect_both_fast_h(Win w, const __half2*
                                                             double rH, double rvd, double rdd, float tsx, float tsy, int ga, int gb,
                                                             unsigned int* __restrict__ miss_out)
 {
-    advect_both_fast_body<ROWS>(w, vel, vel_out, dye, dye_out, dt, rW, rH, rvd, rdd, tsx, tsy, ga, gb, miss_out);
+    advect_both_fast_body<ROWS>(w, vel, vel_out, dye, dye_out, dt, rW, rH, rvd, rdd, tsx, tsy, ga, gb, miss_out, (int)blockIdx.x, (int)blockIdx.y);
 }
 
+
+// ---- several bands in ONE launch (2-D tiles: the four strips around a tile's interior, fluid_stripes.cpp pass_strips).  A strip is a few
+// rows or columns wide: as a launch of its own it is mostly launch latency, and a step had eight of them (decomposition overhead of the
+// 2 x 2 tiling: +10 ... 14 % on one GPU, profiles/r02/decomposition_overhead_one_gpu.txt).  Block b finds its rectangle from the prefix sums
+// (wave-uniform, scalar unit) and runs the same body with that rectangle's column / row range.
+struct AdvRects {
+    int n;
+    int xa[4], xb[4], ga[4], gb[4], nbx[4], blk0[5];
+};
+
+template <int ROWS, class V2, class D4>
+__global__ void __launch_bounds__(BX) k_advect_both_fast_rects(Win w, AdvRects R, const V2* __restrict__ vel, V2* __restrict__ vel_out,
+                                                                const D4* __restrict__ dye, D4* __restrict__ dye_out, float dt, double rW,
+                                                                double rH, double rvd, double rdd, float tsx, float tsy,
+                                                                unsigned int* __restrict__ miss_out)
+{
+    const int b = (int)blockIdx.x;
+    int k = 0;
+    while (k + 1 < R.n && b >= R.blk0[k + 1]) k++;
+    const int local = b - R.blk0[k], nbx = R.nbx[k];
+    w.x0 = R.xa[k];
+    w.x1 = R.xb[k];
+    advect_both_fast_body<ROWS>(w, vel, vel_out, dye, dye_out, dt, rW, rH, rvd, rdd, tsx, tsy, R.ga[k], R.gb[k], miss_out, local % nbx, local / nbx);
+}
 
 // ---- dye grid != sim grid (the reference's shipping defaults: SIM_RESOLUTION 128, DYE_RESOLUTION 1024, script.js:60-66): K7a and K7b stay
 // two launches (the dye pass samples the NEW velocity bilinearly, script.js:1287-1293), each with the same treatment as the fused kernel:
@@ -1210,6 +1235,35 @@ __global__ void __launch_bounds__(64 * NW, VD_WAVES_PER_EU) k_curl_vort_div_h(Wi
     else vort_div_body<NW, RY, 0>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
 }
 
+struct TileRects {
+    int n;
+    int x0[4], x1[4], ga[4], gb[4], xs[4], ys[4], nx[4], ny[4], blk0[5];
+};
+
+// the fused curl / vorticity / divergence tile kernel over several rectangles in one launch (see k_advect_both_fast_rects)
+template <int NW, int RY, class V2, class S1>
+__global__ void __launch_bounds__(64 * NW, VD_WAVES_PER_EU) k_curl_vort_div_rects(Win w, TileRects R, const V2* __restrict__ vel, S1* __restrict__ curl_out,
+                                                                  V2* __restrict__ vel_out, S1* __restrict__ div_out, float curl_strength,
+                                                                  float dt, int remap)
+{
+    using G = VortDiv<NW, RY>;
+    __shared__ float4 mail[NW][2][2][64];
+    const int b = (int)blockIdx.x;
+    int k = 0;
+    while (k + 1 < R.n && b >= R.blk0[k + 1]) k++;
+    int bx, by;
+    tile_of_block(b - R.blk0[k], R.nx[k], R.ny[k], remap, bx, by);
+    w.x0 = R.x0[k];
+    w.x1 = R.x1[k];
+    const int ga = R.ga[k], gb = R.gb[k];
+    const int x0 = R.xs[k] + bx * G::VX, y0 = R.ys[k] + by * G::VY;
+    const bool xedge = (x0 <= 0) || (x0 + G::TX >= w.W), yedge = (y0 <= 0) || (y0 + G::TY >= w.H);
+    const bool ragged = (w.W & 3) != 0 && x0 + G::TX >= w.W;
+    if (yedge || ragged) vort_div_body<NW, RY, 2>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
+    else if (xedge) vort_div_body<NW, RY, 1>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
+    else vort_div_body<NW, RY, 0>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
+}
+
 #ifndef VD_NW_
 #define VD_NW_ 8
 #endif
@@ -1420,7 +1474,17 @@ static bool advect_fast_ok(const Win& w, size_t texel_bytes, float decay_a, floa
 }
 
 // texels per thread of the separate fast kernels: four, or fewer on small grids so that the launch still spreads over the chip
-static int split_advect_rows(long texels) { return texels >= (1l << 22) ? 4 : texels >= (1l << 20) ? 2 : 1; }
+// (FLUID_ADVECT_SPLIT_ROWS=1 / 2 / 4 forces one: A/B knob)
+static int split_advect_rows(long texels)
+{
+    static const int forced = [] {
+        const char* e = getenv("FLUID_ADVECT_SPLIT_ROWS");
+        const int k = e ? atoi(e) : 0;
+        return (k == 1 || k == 2 || k == 4) ? k : 0;
+    }();
+    if (forced) return forced;
+    return texels >= (1l << 22) ? 4 : texels >= (1l << 20) ? 2 : 1;
+}
 
 template <class V2>
 hipError_t launch_advect_velocity_any(hipStream_t s, Win w, const V2* vel, V2* out, float dt, float dissipation, int ga, int gb, unsigned int* miss)
@@ -1718,6 +1782,88 @@ hipError_t launch_jacobi_tb_gradsub(hipStream_t s, Win w, const __half* p, const
                                     __half2* vel_out, float pscale, int iters, int ga, int gb, int shape)
 {
     return launch_jacobi_tb_gradsub_any(s, w, p, div, p_out, vel, vel_out, pscale, iters, ga, gb, shape);
+}
+
+// ---- several bands in one launch (the strips of a 2-D tile) ----
+template <class V2, class D4>
+hipError_t launch_advect_both_rects_any(hipStream_t s, Win w, const V2* vel, V2* vel_out, const D4* dye, D4* dye_out, float dt, float vel_dissipation,
+                                        float dye_dissipation, const BandRects& B, unsigned int* miss)
+{
+    const float vdecay = 1.0f + vel_dissipation * dt, ddecay = 1.0f + dye_dissipation * dt;
+    AdvRects R{};
+    constexpr int ROWS = 4;
+    int total = 0;
+    for (int k = 0; k < B.n; k++) {
+        const BandRect& q = B.r[k];
+        if (q.gb <= q.ga || q.xb <= q.xa) continue;
+        const int i = R.n++;
+        R.xa[i] = q.xa; R.xb[i] = q.xb; R.ga[i] = q.ga; R.gb[i] = q.gb;
+        R.nbx[i] = (q.xb - q.xa + BX - 1) / BX;
+        R.blk0[i] = total;
+        total += R.nbx[i] * ((q.gb - q.ga + ROWS - 1) / ROWS);
+    }
+    R.blk0[R.n] = total;
+    if (R.n == 0) return hipSuccess;
+    if (R.n > 1 && advect_fast_ok(w, sizeof(D4), vdecay, ddecay)) {
+        const float tsx = (float)(1.0 / w.W), tsy = (float)(1.0 / w.H);
+        const double rW = udiv_recip((float)w.W), rH = udiv_recip((float)w.H), rvd = udiv_recip(vdecay), rdd = udiv_recip(ddecay);
+        k_advect_both_fast_rects<ROWS><<<dim3(total, 1, 1), BX, 0, s>>>(w, R, vel, vel_out, dye, dye_out, dt, rW, rH, rvd, rdd, tsx, tsy, miss);
+        return hipGetLastError();
+    }
+    for (int i = 0; i < R.n; i++) {  // one band, or the general kernel: a launch per rectangle
+        Win wb = w;
+        wb.x0 = R.xa[i];
+        wb.x1 = R.xb[i];
+        const hipError_t e = launch_advect_both(s, wb, vel, vel_out, dye, dye_out, dt, vel_dissipation, dye_dissipation, R.ga[i], R.gb[i], miss);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_advect_both_rects(hipStream_t s, Win w, const float2* vel, float2* vel_out, const float4* dye, float4* dye_out, float dt,
+                                    float vel_dissipation, float dye_dissipation, const BandRects& B, unsigned int* miss)
+{
+    return launch_advect_both_rects_any(s, w, vel, vel_out, dye, dye_out, dt, vel_dissipation, dye_dissipation, B, miss);
+}
+hipError_t launch_advect_both_rects(hipStream_t s, Win w, const __half2* vel, __half2* vel_out, const half4* dye, half4* dye_out, float dt,
+                                    float vel_dissipation, float dye_dissipation, const BandRects& B, unsigned int* miss)
+{
+    return launch_advect_both_rects_any(s, w, vel, vel_out, dye, dye_out, dt, vel_dissipation, dye_dissipation, B, miss);
+}
+
+template <class V2, class S1>
+hipError_t launch_curl_vort_div_rects_any(hipStream_t s, Win w, const V2* vel, S1* curl, V2* vel_out, S1* div, float curl_strength, float dt,
+                                          const BandRects& B)
+{
+    if (!fused_supported(w)) return hipErrorInvalidValue;
+    using G = VortDiv<VD_NW, VD_RY>;
+    TileRects R{};
+    int total = 0;
+    for (int k = 0; k < B.n; k++) {
+        const BandRect& q = B.r[k];
+        if (q.gb <= q.ga || q.xb <= q.xa) continue;
+        const int i = R.n++;
+        const Axis ax = make_axis(q.xa, q.xb, w.W, G::TX, G::AX), ay = make_axis(q.ga, q.gb, w.H, G::TY, G::AY);
+        R.x0[i] = q.xa; R.x1[i] = q.xb; R.ga[i] = q.ga; R.gb[i] = q.gb;
+        R.xs[i] = ax.S; R.ys[i] = ay.S; R.nx[i] = ax.n; R.ny[i] = ay.n;
+        R.blk0[i] = total;
+        total += ax.n * ay.n;
+    }
+    R.blk0[R.n] = total;
+    if (R.n == 0) return hipSuccess;
+    k_curl_vort_div_rects<VD_NW, VD_RY><<<dim3(total, 1, 1), dim3(64, VD_NW, 1), 0, s>>>(w, R, vel, curl, vel_out, div, curl_strength, dt, cvd_remap());
+    return hipGetLastError();
+}
+
+hipError_t launch_curl_vort_div_rects(hipStream_t s, Win w, const float2* vel, float* curl, float2* vel_out, float* div, float curl_strength,
+                                      float dt, const BandRects& B)
+{
+    return launch_curl_vort_div_rects_any(s, w, vel, curl, vel_out, div, curl_strength, dt, B);
+}
+hipError_t launch_curl_vort_div_rects(hipStream_t s, Win w, const __half2* vel, __half* curl, __half2* vel_out, __half* div, float curl_strength,
+                                      float dt, const BandRects& B)
+{
+    return launch_curl_vort_div_rects_any(s, w, vel, curl, vel_out, div, curl_strength, dt, B);
 }
 
 }  // namespace fluid

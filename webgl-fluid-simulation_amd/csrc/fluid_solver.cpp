@@ -356,6 +356,11 @@ int cvd_band(fluid_ctx* c, float curl, float dt, int ga, int gb, int xa, int xb)
     return c->hip(STORE_CALL(c, launch_curl_vort_div(c->stream, w, VEL(c, 0), CURL(c), VEL(c, 1), DIVG(c), curl, dt, ga, gb)), "curl_vort_div");
 }
 
+int cvd_rects(fluid_ctx* c, float curl, float dt, const BandRects& B)
+{
+    return c->hip(STORE_CALL(c, launch_curl_vort_div_rects(c->stream, c->sim, VEL(c, 0), CURL(c), VEL(c, 1), DIVG(c), curl, dt, B)), "curl_vort_div");
+}
+
 void cvd_swap(fluid_ctx* c) { std::swap(c->vel[0], c->vel[1]); }
 
 int advect_both_band(fluid_ctx* c, float dt, float vel_diss, float dye_diss, int ga, int gb, int xa, int xb, int v0, int v1, int u0, int u1)
@@ -368,6 +373,17 @@ int advect_both_band(fluid_ctx* c, float dt, float vel_diss, float dye_diss, int
     w.u0 = u0;
     w.u1 = u1;
     return c->hip(STORE_CALL(c, launch_advect_both(c->stream, w, VEL(c, 0), VEL(c, 1), DYE(c, 0), DYE(c, 1), dt, vel_diss, dye_diss, ga, gb, c->miss)),
+                  "advect");
+}
+
+int advect_both_rects(fluid_ctx* c, float dt, float vel_diss, float dye_diss, const BandRects& B, int v0, int v1, int u0, int u1)
+{
+    Win w = c->sim;  // dye grid == sim grid: one window serves both gathers
+    w.v0 = v0;
+    w.v1 = v1;
+    w.u0 = u0;
+    w.u1 = u1;
+    return c->hip(STORE_CALL(c, launch_advect_both_rects(c->stream, w, VEL(c, 0), VEL(c, 1), DYE(c, 0), DYE(c, 1), dt, vel_diss, dye_diss, B, c->miss)),
                   "advect");
 }
 

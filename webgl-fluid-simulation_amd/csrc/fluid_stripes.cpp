@@ -614,11 +614,32 @@ int pass_interior(fluid_ctx* c, const fluid_stripe_op& op, float dt, const fluid
                : FLUID_OK;
 }
 
+// FLUID_STRIP_RECTS=0: one launch per strip, as in round 2 (A/B knob; same bits)
+bool strip_rects_enabled()
+{
+    static const bool on = [] {
+        const char* e = getenv("FLUID_STRIP_RECTS");
+        return !(e && atoi(e) == 0);
+    }();
+    return on;
+}
+
 int pass_strips(fluid_ctx* c, const fluid_stripe_op& op, float dt, const fluid_params* P)
 {
+    // the (up to four) strips of the band go into ONE launch (launch_*_rects): each is a few rows or columns of the tile
+    fluid::BandRects B{};
+    auto collect = [&](int ga, int gb, int xa, int xb) {
+        B.r[B.n++] = fluid::BandRect{ xa, xb, ga, gb };
+        return (int)FLUID_OK;
+    };
     if (op.kind == FLUID_OP_CURL_VORT_DIV) {
         const Split s = split_band(c, op.ext, 3, 4);
-        CK(for_each_strip(s, [&](int ga, int gb, int xa, int xb) { return cvd_band(c, P->curl, dt, ga, gb, xa, xb); }));
+        if (strip_rects_enabled()) {
+            CK(for_each_strip(s, collect));
+            CK(cvd_rects(c, P->curl, dt, B));
+        } else {
+            CK(for_each_strip(s, [&](int ga, int gb, int xa, int xb) { return cvd_band(c, P->curl, dt, ga, gb, xa, xb); }));
+        }
         cvd_swap(c);
         return FLUID_OK;
     }
@@ -627,9 +648,14 @@ int pass_strips(fluid_ctx* c, const fluid_stripe_op& op, float dt, const fluid_p
     // fresh now: owned + the rows / columns just exchanged
     const int v0 = c->sim_row0 - A, v1 = c->sim_row0 + c->sim_rows + A;
     const int u0 = c->desc.parts_x > 1 ? c->sim_col0 - A : 0, u1 = c->desc.parts_x > 1 ? c->sim_col0 + c->sim_ncols + A : c->sim.W;
-    CK(for_each_strip(s, [&](int ga, int gb, int xa, int xb) {
-        return advect_both_band(c, dt, P->velocity_dissipation, P->density_dissipation, ga, gb, xa, xb, v0, v1, u0, u1);
-    }));
+    if (strip_rects_enabled()) {
+        CK(for_each_strip(s, collect));
+        CK(advect_both_rects(c, dt, P->velocity_dissipation, P->density_dissipation, B, v0, v1, u0, u1));
+    } else {
+        CK(for_each_strip(s, [&](int ga, int gb, int xa, int xb) {
+            return advect_both_band(c, dt, P->velocity_dissipation, P->density_dissipation, ga, gb, xa, xb, v0, v1, u0, u1);
+        }));
+    }
     advect_both_swap(c);
     return FLUID_OK;
 }
