@@ -219,12 +219,8 @@ def test_every_knob_of_the_fused_schedule_yields_the_same_bits():
     import subprocess
     import sys
     pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "webgl-fluid-simulation_amd")
-    # K6 on the fly inside the advection is the default where it applies (same grids, fp32): the fold / own-pass variants of K6 are
-    # reached with FLUID_PROJECT_ADVECT=0 there, and as they are where the dye grid differs
-    settings = [{}] + [{"FLUID_TB_VARIANT": str(v), "FLUID_FOLD_GRADSUB": f, "FLUID_PROJECT_ADVECT": "0"}
-                       for v in (0, 8, 9, 10, 11, 12, 13, 14, 15) for f in ("0", "1")]
-    settings += [{"FLUID_PROJECT_ROWS": r} for r in ("1", "2", "3")]
-    settings += [{"FLUID_ADVECT_FAST": "0"}, {"FLUID_ADVECT_FAST": "0", "FLUID_PROJECT_ADVECT": "0"}, {"FLUID_ADVECT_SPLIT_ROWS": "4"},
+    settings = [{}] + [{"FLUID_TB_VARIANT": str(v), "FLUID_FOLD_GRADSUB": f} for v in (0, 8, 9, 10, 11, 12, 13, 14, 15) for f in ("0", "1")]
+    settings += [{"FLUID_ADVECT_FAST": "0"}, {"FLUID_ADVECT_SPLIT_ROWS": "4"}, {"FLUID_ADVECT_SPLIT_ROWS": "1"}, {"FLUID_ADVECT_ROWS": "2"},
                  {"FLUID_TB_VARIANT": "1", "FLUID_FOLD_GRADSUB": "1"}, {"FLUID_TB_VARIANT": "5"}]
     ref = None
     for env in settings:

@@ -133,7 +133,6 @@ int pass_advect(fluid_ctx* c, float dt, float vel_diss, float dye_diss, Timer* t
 
 // band forms (no ping-pong swap) of the single-kernel passes, for interior-first overlap in the stripe driver
 bool jacobi_tb_applies(const fluid_ctx* c);
-bool project_advect_applies(const fluid_ctx* c);
 bool fused_cvd_applies(const fluid_ctx* c);
 bool fused_advect_applies(const fluid_ctx* c);
 void sim_band(const fluid_ctx* c, int ext, int& ga, int& gb);  // owned rows +- ext, clipped to domain and window

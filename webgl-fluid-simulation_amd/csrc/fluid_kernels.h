@@ -93,12 +93,6 @@ struct CopyRects {
 };
 hipError_t launch_copy_rects(hipStream_t s, const CopyRects& R);
 
-// K6 + K7a + K7b in one kernel: the advection of `vel` MINUS the gradient of `prs`, evaluated on the fly at the texel and at every
-// tap (fp32 storage, dye grid == sim grid, whole rows [ga, gb)); bitwise equal to launch_gradsub followed by launch_advect_both.
-// hipErrorNotReady: the fast-path conditions do not hold, nothing was launched.
-hipError_t launch_project_advect(hipStream_t s, Win w, const float2* vel, const float* prs, float2* vel_out, const float4* dye, float4* dye_out,
-                                 float dt, float vel_dissipation, float dye_dissipation, int ga, int gb, unsigned int* miss);
-
 // Several bands of a single-kernel pass group in ONE launch: the strips around the interior of a 2-D tile (fluid_stripes.cpp).  Each
 // rectangle = columns [xa, xb) x rows [ga, gb) of the window (xa, xb whole float4 groups for the register-tile kernel); empty ones are
 // skipped.  Same kernels bodies, same bits as one launch per rectangle.

@@ -357,161 +357,6 @@ __global__ void __launch_bounds__(BX) k_advect_both_fast_h(Win w, const __half2*
 }
 
 
-// ---- K6 + K7a + K7b: the gradient subtract evaluated ON THE FLY inside the advection (whole-domain fp32 contexts) ----
-// The projected velocity (gradientSubtractShader, script.js:892-913) is consumed by the two advection passes only and then overwritten:
-// as a pass of its own it costs 20 B/texel (pressure and velocity in, velocity out) plus a launch, and the advection reads its output
-// straight back.  Here every velocity the advection touches — the texel's own (the back-trace direction) and the four taps of the
-// LINEAR fetch — is computed as v - (p_R - p_L, p_T - p_B) from the UNPROJECTED velocity and the final pressure, the very
-// subtraction K6 performs per texel, so the result has the same bits as K6 followed by the fused advection; the projected field never
-// exists in HBM (-16 B/texel, one launch fewer).  Price: the pressure around each tap block — two 16-byte and two 8-byte gathers per
-// texel on a 4 B/texel field (few cache lines per wave) — and the texel's own four neighbours (coalesced 4-byte loads).
-typedef float f4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-typedef float f2_a4 __attribute__((ext_vector_type(2), aligned(4)));
-
-// K6 at one texel, general form: CLAMP_TO_EDGE on the pressure neighbours (same expression as gradsub_texel)
-__device__ __forceinline__ float2 projected_at(const Win& w, const float2* __restrict__ vel, const float* __restrict__ p, int gi, int gj)
-{
-    const float L = ld(p, widx(w, gj, gi - 1)), R = ld(p, widx(w, gj, gi + 1));
-    const float T = ld(p, widx(w, gj + 1, gi)), B = ld(p, widx(w, gj - 1, gi));
-    const float2 v = ld(vel, widx(w, gj, gi));
-    return make_float2(v.x - (R - L), v.y - (T - B));
-}
-
-template <int ROWS>
-__device__ __forceinline__ void project_advect_body(const Win& w, const float2* __restrict__ vel, const float* __restrict__ prs,
-                                                    float2* __restrict__ vel_out, const float4* __restrict__ dye, float4* __restrict__ dye_out,
-                                                    float dt, double rW, double rH, double rvd, double rdd, float tsx, float tsy, int ga, int gb,
-                                                    unsigned int* __restrict__ miss_out, int bx, int by)
-{
-    const int lane_i = w.x0 + bx * BX + threadIdx.x;
-    const bool live = lane_i < w.x1;
-    const int i = live ? lane_i : w.x1 - 1;
-    const int gj0 = ga + by * ROWS;
-    const TapBox B = tap_box(w);
-    // velocity taps whose whole pressure neighbourhood (one texel further out on every side) needs no clamp either
-    const TapBox Bp = TapBox{ B.xlo + 1, B.ylo + 1, B.nx > 2 ? B.nx - 2 : 0u, B.ny > 2 ? B.ny - 2 : 0u };
-    const float u = div_uniform((float)i + 0.5f, rW);
-    const unsigned P = (unsigned)w.P;
-    int miss = 0;
-    bool on[ROWS];
-    unsigned c[ROWS];
-    float v[ROWS];
-    float2 pv[ROWS], nv[ROWS];
-    // ---- stage 1: the texel's own projected velocity (K6 at (i, gj)) ----
-    {
-        const int il = max(i - 1, max(w.c0, 0)), ir = min(i + 1, min(w.c0 + w.P, w.W) - 1);  // CLAMP_TO_EDGE, folded with the array's columns (widx)
-        float2 vr[ROWS];
-        float pc[ROWS + 2], pl[ROWS], pr[ROWS];
-#pragma unroll
-        for (int k = 0; k < ROWS + 2; k++) {  // the pressure column of the texel, one row beyond the thread's rows on both sides
-            const int gj = min(max(min(gj0 + k - 1, gb), 0), w.H - 1);  // rows past the band repeat (never used for a store), CLAMP_TO_EDGE
-            pc[k] = ld(at_byte(prs, ((unsigned)(gj - w.g0) * P + (unsigned)(i - w.c0)) * 4u), 0);
-        }
-#pragma unroll
-        for (int k = 0; k < ROWS; k++) {
-            const int gj = gj0 + k;
-            on[k] = live && gj < gb;
-            const int gjc = gj < gb ? gj : gb - 1;
-            v[k] = div_uniform((float)gjc + 0.5f, rH);
-            c[k] = (unsigned)(gjc - w.g0) * P + (unsigned)(i - w.c0);
-            vr[k] = ld(at_byte(vel, c[k] * 8u), 0);
-            const unsigned row = (unsigned)(gjc - w.g0) * P;
-            pl[k] = ld(at_byte(prs, (row + (unsigned)(il - w.c0)) * 4u), 0);
-            pr[k] = ld(at_byte(prs, (row + (unsigned)(ir - w.c0)) * 4u), 0);
-        }
-#pragma unroll
-        for (int k = 0; k < ROWS; k++) {
-            // pc[k + 1] is the texel's own row (gj0 + k) unless that row is past the band (then the values are never used)
-            pv[k] = make_float2(vr[k].x - (pr[k] - pl[k]), vr[k].y - (pc[k + 2] - pc[k]));
-        }
-    }
-    // ---- stage 2: the four taps of the velocity fetch, each projected ----
-    // Tap positions first; then ONE branch per thread: all of its fetches interior (everything but the texels within a back-trace of
-    // the border) -> the 6 * ROWS gathers are issued back to back, no control flow between them; otherwise the plain clamped form per tap.
-    float tfx[ROWS], tfy[ROWS];
-    int ti0[ROWS], tj0[ROWS];
-    float2 ta[ROWS], tb[ROWS], tc[ROWS], td[ROWS];
-    bool interior = true;
-#pragma unroll
-    for (int k = 0; k < ROWS; k++) {
-        const float x = (u - dt * pv[k].x * tsx) * (float)w.W - 0.5f;
-        const float y = (v[k] - dt * pv[k].y * tsy) * (float)w.H - 0.5f;
-        const float fi = floorf(x), fj = floorf(y);
-        tfx[k] = x - fi;
-        tfy[k] = y - fj;
-        ti0[k] = (int)fi;
-        tj0[k] = (int)fj;
-        interior = interior && (unsigned)(ti0[k] - Bp.xlo) < Bp.nx && (unsigned)(tj0[k] - Bp.ylo) < Bp.ny;
-    }
-    if (interior) {
-        float2 a[ROWS], bq[ROWS], cq[ROWS], d[ROWS];
-        f4_a4 r0[ROWS], r1[ROWS];
-        f2_a4 rm[ROWS], rp[ROWS];
-#pragma unroll
-        for (int k = 0; k < ROWS; k++) {
-            const unsigned o = __umul24((unsigned)(tj0[k] - w.g0), P) + (unsigned)(ti0[k] - w.c0);  // texel index of tap a
-            load_pair(vel, o * 8u, a[k], bq[k]);
-            load_pair(vel, (o + P) * 8u, cq[k], d[k]);
-            r0[k] = *reinterpret_cast<const f4_a4*>(reinterpret_cast<const char*>(prs) + (size_t)((o - 1u) * 4u));      // p(i0-1 .. i0+2, j0)
-            r1[k] = *reinterpret_cast<const f4_a4*>(reinterpret_cast<const char*>(prs) + (size_t)((o + P - 1u) * 4u));  // row j0 + 1
-            rm[k] = *reinterpret_cast<const f2_a4*>(reinterpret_cast<const char*>(prs) + (size_t)((o - P) * 4u));       // p(i0, i0+1, j0-1)
-            rp[k] = *reinterpret_cast<const f2_a4*>(reinterpret_cast<const char*>(prs) + (size_t)((o + 2u * P) * 4u));  // row j0 + 2
-        }
-#pragma unroll
-        for (int k = 0; k < ROWS; k++) {
-            ta[k] = make_float2(a[k].x - (r0[k].z - r0[k].x), a[k].y - (r1[k].y - rm[k].x));
-            tb[k] = make_float2(bq[k].x - (r0[k].w - r0[k].y), bq[k].y - (r1[k].z - rm[k].y));
-            tc[k] = make_float2(cq[k].x - (r1[k].z - r1[k].x), cq[k].y - (rp[k].x - r0[k].y));
-            td[k] = make_float2(d[k].x - (r1[k].w - r1[k].y), d[k].y - (rp[k].y - r0[k].z));
-        }
-    } else {  // a tap on or next to the domain border (or outside the fresh part of a window): clamp, count, project the plain way
-#pragma unroll
-        for (int k = 0; k < ROWS; k++) {
-            const int ia = clampi(ti0[k], 0, w.W - 1), ib = clampi(ti0[k] + 1, 0, w.W - 1);
-            const int ja = clampi(tj0[k], 0, w.H - 1), jb = clampi(tj0[k] + 1, 0, w.H - 1);
-            if (on[k]) miss += (ja < w.v0 || ja >= w.v1) + (jb < w.v0 || jb >= w.v1) + (ia < w.u0 || ia >= w.u1) + (ib < w.u0 || ib >= w.u1);
-            ta[k] = projected_at(w, vel, prs, ia, ja);
-            tb[k] = projected_at(w, vel, prs, ib, ja);
-            tc[k] = projected_at(w, vel, prs, ia, jb);
-            td[k] = projected_at(w, vel, prs, ib, jb);
-        }
-    }
-    Tap4 t[ROWS];
-#pragma unroll
-    for (int k = 0; k < ROWS; k++) {
-        const float rx = mixf(mixf(ta[k].x, tb[k].x, tfx[k]), mixf(tc[k].x, td[k].x, tfx[k]), tfy[k]);
-        const float ry = mixf(mixf(ta[k].y, tb[k].y, tfx[k]), mixf(tc[k].y, td[k].y, tfx[k]), tfy[k]);
-        nv[k] = make_float2(div_uniform(rx, rvd), div_uniform(ry, rvd));
-        if (on[k]) st(at_byte(vel_out, c[k] * 8u), 0, nv[k]);
-        t[k] = taps32<sizeof(float4)>(w, B, u - dt * nv[k].x * tsx, v[k] - dt * nv[k].y * tsy);
-        if (on[k]) miss += t[k].miss;
-    }
-    // ---- stage 3: the dye, as in advect_both_fast_body ----
-    Fetch4 f4[ROWS];
-    gather_taps<ROWS>(dye, t, f4);
-#pragma unroll
-    for (int k = 0; k < ROWS; k++) {
-        const Fetch4& f = f4[k];
-        const float4 d = make_float4(mixf(mixf(f.a.x, f.b.x, f.fx), mixf(f.c.x, f.d.x, f.fx), f.fy),
-                                     mixf(mixf(f.a.y, f.b.y, f.fx), mixf(f.c.y, f.d.y, f.fx), f.fy),
-                                     mixf(mixf(f.a.z, f.b.z, f.fx), mixf(f.c.z, f.d.z, f.fx), f.fy),
-                                     mixf(mixf(f.a.w, f.b.w, f.fx), mixf(f.c.w, f.d.w, f.fx), f.fy));
-        if (on[k])
-            st(at_byte(dye_out, c[k] * 16u), 0,
-               make_float4(div_uniform(d.x, rdd), div_uniform(d.y, rdd), div_uniform(d.z, rdd), div_uniform(d.w, rdd)));
-    }
-    if (miss) atomicAdd(miss_out, (unsigned)miss);
-}
-
-template <int ROWS>
-__global__ void __launch_bounds__(BX) k_project_advect(Win w, const float2* __restrict__ vel, const float* __restrict__ prs,
-                                                        float2* __restrict__ vel_out, const float4* __restrict__ dye, float4* __restrict__ dye_out,
-                                                        float dt, double rW, double rH, double rvd, double rdd, float tsx, float tsy, int ga,
-                                                        int gb, unsigned int* __restrict__ miss_out)
-{
-    project_advect_body<ROWS>(w, vel, prs, vel_out, dye, dye_out, dt, rW, rH, rvd, rdd, tsx, tsy, ga, gb, miss_out, (int)blockIdx.x, (int)blockIdx.y);
-}
-
 // ---- several bands in ONE launch (2-D tiles: the four strips around a tile's interior, fluid_stripes.cpp pass_strips).  A strip is a few
 // rows or columns wide: as a launch of its own it is mostly launch latency, and a step had eight of them (decomposition overhead of the
 // 2 x 2 tiling: +10 ... 14 % on one GPU, profiles/r02/decomposition_overhead_one_gpu.txt).  Block b finds its rectangle from the prefix sums
@@ -1937,36 +1782,6 @@ hipError_t launch_jacobi_tb_gradsub(hipStream_t s, Win w, const __half* p, const
                                     __half2* vel_out, float pscale, int iters, int ga, int gb, int shape)
 {
     return launch_jacobi_tb_gradsub_any(s, w, p, div, p_out, vel, vel_out, pscale, iters, ga, gb, shape);
-}
-
-// K6 + K7a + K7b in one kernel (fp32 storage, dye grid == sim grid).  Returns hipErrorNotReady when the fast-path conditions do not hold
-// (the caller then runs the gradient subtract and the fused advection in turn).
-static int project_rows()
-{
-    static const int r = [] {
-        const char* e = getenv("FLUID_PROJECT_ROWS");
-        const int k = e ? atoi(e) : 4;
-        return (k == 1 || k == 2 || k == 3 || k == 4) ? k : 4;
-    }();
-    return r;
-}
-
-hipError_t launch_project_advect(hipStream_t s, Win w, const float2* vel, const float* prs, float2* vel_out, const float4* dye, float4* dye_out,
-                                 float dt, float vel_dissipation, float dye_dissipation, int ga, int gb, unsigned int* miss)
-{
-    ROWS_OR_RETURN();
-    const float vdecay = 1.0f + vel_dissipation * dt, ddecay = 1.0f + dye_dissipation * dt;
-    if (!advect_fast_ok(w, sizeof(float4), vdecay, ddecay)) return hipErrorNotReady;
-    const float tsx = (float)(1.0 / w.W), tsy = (float)(1.0 / w.H);
-    const double rW = udiv_recip((float)w.W), rH = udiv_recip((float)w.H), rvd = udiv_recip(vdecay), rdd = udiv_recip(ddecay);
-    const unsigned gx = (w.x1 - w.x0 + BX - 1) / BX;
-    switch (project_rows()) {
-#define PA_CASE(R) \
-    case R: k_project_advect<R><<<dim3(gx, (gb - ga + R - 1) / R, 1), BX, 0, s>>>(w, vel, prs, vel_out, dye, dye_out, dt, rW, rH, rvd, rdd, tsx, tsy, ga, gb, miss); break;
-        PA_CASE(1) PA_CASE(2) PA_CASE(3) PA_CASE(4)
-#undef PA_CASE
-    }
-    return hipGetLastError();
 }
 
 // ---- several bands in one launch (the strips of a 2-D tile) ----

@@ -344,16 +344,6 @@ bool jacobi_tb_applies(const fluid_ctx* c) { return c->desc.schedule == FLUID_SC
 
 bool fused_cvd_applies(const fluid_ctx* c) { return c->desc.schedule == FLUID_SCHED_FUSED && fused_supported(c->sim); }
 
-// FLUID_PROJECT_ADVECT=0: K6 stays a pass (or rides on the last Jacobi launch), as before (A/B knob; same bits)
-bool project_advect_applies(const fluid_ctx* c)
-{
-    static const bool on = [] {
-        const char* e = getenv("FLUID_PROJECT_ADVECT");
-        return !(e && atoi(e) == 0);
-    }();
-    return on && fused_advect_applies(c) && c->storage == FLUID_STORE_F32 && c->desc.parts == 1 && c->desc.parts_x == 1 && fused_supported(c->sim);
-}
-
 bool fused_advect_applies(const fluid_ctx* c) { return c->desc.schedule == FLUID_SCHED_FUSED && c->sim.W == c->dye.W && c->sim.H == c->dye.H; }
 
 void sim_band(const fluid_ctx* c, int ext, int& ga, int& gb) { row_range(c->sim, c->sim_row0, c->sim_rows, ext, ga, gb); }
@@ -419,35 +409,14 @@ int step_once(fluid_ctx* c, float dt, const fluid_params* P)
         CK(pass_clear(c, P->pressure, 0));
         t.mark(P_CLEAR);
     }
-    // K6 rides either on the advection (evaluated on the fly, whole-domain fp32 contexts: project_advect_applies) or on the last
-    // Jacobi launch (small grids), or runs as its own pass
-    const bool on_the_fly = project_advect_applies(c);
-    bool gradsub_done = !on_the_fly;  // ask for K6 inside the last Jacobi launch unless the advection takes it
+    bool gradsub_done = true;  // ask for K6 inside the last Jacobi launch (taken on small grids: pass_jacobi)
     CK(pass_jacobi(c, P->iterations, 0, fold_clear ? P->pressure : 1.0f, &launches, &gradsub_done, &t));
-    bool advected = false;
-    if (on_the_fly) {
+    if (!gradsub_done) {
         t.mark(P_JACOBI);
-        int ga, gb;
-        row_range(c->sim, c->sim_row0, c->sim_rows, 0, ga, gb);
-        const hipError_t e = launch_project_advect(c->stream, c->sim, (const float2*)c->vel[0], (const float*)c->prs[0], (float2*)c->vel[1],
-                                                   (const float4*)c->dyeb[0], (float4*)c->dyeb[1], dt, P->velocity_dissipation,
-                                                   P->density_dissipation, ga, gb, c->miss);
-        if (e != hipErrorNotReady) {
-            CK(c->hip(e, "project_advect"));
-            std::swap(c->vel[0], c->vel[1]);
-            std::swap(c->dyeb[0], c->dyeb[1]);
-            t.mark(P_ADVD);
-            advected = true;
-        }
+        CK(pass_gradsub(c, 0));
     }
-    if (!advected) {
-        if (!gradsub_done) {
-            t.mark(P_JACOBI);
-            CK(pass_gradsub(c, 0));
-        }
-        t.mark(P_GRADSUB);
-        CK(pass_advect(c, dt, P->velocity_dissipation, P->density_dissipation, &t));
-    }
+    t.mark(P_GRADSUB);
+    CK(pass_advect(c, dt, P->velocity_dissipation, P->density_dissipation, &t));
     if (c->timing) {
         c->acc_steps++;
         c->acc_jacobi_launches += launches;
