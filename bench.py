@@ -248,16 +248,14 @@ class Watchdog:
 
 
 def parity_in_run(fluid_hip, size, iters, device, storage, with_oracle=True, steps=10):
-    """Parity checked in the same run as the number, directly in front of the warm-up steps:
+    """Parity checked in the same run as the number, after the timed steps:
       (a) HIP == the CPU oracle bit for bit on a small case (256^2 sim / 512^2 dye, 20 iterations, 6 seeded splats, 2 steps, both
           schedules) — the oracle is the checker here, never the thing timed;
       (b) at the benchmark's own size, on this rank's GPU: the fused schedule (what is timed) == the one-kernel-per-reference-pass
           schedule, every field, compared on the device after `steps` steps from the same seeded splats.
-    Returns (dict for the JSON line, the two big contexts).  The caller closes the contexts AFTER the timed section: freeing 2 GB
-    synchronises the device, and (b) is also what the chip is busy with right before the warm-up — the timed steps then start on a
-    GPU that has been under load for ~30 ms instead of on an idle one that is still ramping its clocks (the driver's --steps 20
-    --warmup 5 covers 12 ms; profiles/r01/bench_warmup_sensitivity.txt, profiles/r03/driver_flags_preroll.txt).
-    A mismatch is an error of the run, not a footnote."""
+    It runs BEHIND the timed section: in front of it, it made the driver's `--steps 20 --warmup 5` read 3-4 % slower (three contexts of
+    1 GB alive and 30 ms of load straight before the warm-up; profiles/r03/driver_flags_preroll.txt) — the gap between that figure and the
+    steady one is not a clock ramp that prior load removes.  A mismatch is an error of the run, not a footnote."""
     import numpy as np
     import torch
     out = {}
@@ -296,9 +294,11 @@ def parity_in_run(fluid_hip, size, iters, device, storage, with_oracle=True, ste
     for k in ("velocity", "pressure", "divergence", "curl", "dye"):
         same = same and bool(torch.equal(sims[0].device_view(k), sims[1].device_view(k)))
     out["fused_vs_passes_%d" % size] = ("bitwise equal, all five fields after %d steps" % steps) if same else "MISMATCH"
+    for sim in sims:
+        sim.close()
     out["seconds"] = round(time.perf_counter() - t0, 2)
     out["ok"] = "MISMATCH" not in json.dumps(out)
-    return out, sims
+    return out
 
 
 def main(argv=None, engine_factory=None, backend="nccl"):
@@ -388,7 +388,6 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         return StripeSim(canvas=(gw, gh), config=c, halo=args.halo, schedule=args.schedule, random=fluid_hip.mulberry32(1234),
                          device=local_rank, **kw)
 
-    parity_sims = []
     if N == 1:
         sim = fluid_hip.FluidSim(canvas=(size, size), config=cfg, device=local_rank, schedule=args.schedule,
                                  random=fluid_hip.mulberry32(1234), storage=args.storage)
@@ -468,13 +467,15 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         sim.sync()
         dev_sync()
 
-    # the in-run parity check, on every rank's own GPU, directly in front of the warm-up (see parity_in_run)
+    elapsed = measure(sim, args.warmup, args.steps, "headline")
+
+    # the in-run parity check, on every rank's own GPU, BEHIND the timed section (see parity_in_run): a mismatch replaces the line by an error
     if not args.no_parity and not on_cpu:
         problem = None
         if dog:
             dog.at("in-run parity check (fused == per-pass schedule on this rank's GPU)")
         try:
-            parity, parity_sims = parity_in_run(fluid_hip, size, iters, local_rank, args.storage, with_oracle=(rank == 0))
+            parity = parity_in_run(fluid_hip, size, iters, local_rank, args.storage, with_oracle=(rank == 0))
             if not parity["ok"]:
                 problem = "in-run parity check failed on rank %d: %s" % (rank, json.dumps(parity))
         except Exception as ex:
@@ -484,10 +485,6 @@ def main(argv=None, engine_factory=None, backend="nccl"):
             if dog:
                 dog.stop()
             fail(problem, code=6)
-
-    elapsed = measure(sim, args.warmup, args.steps, "headline")
-    for ps in parity_sims:
-        ps.close()
 
     steps_per_s = args.steps / elapsed
     glups = grid_w * grid_h * steps_per_s / 1e9
