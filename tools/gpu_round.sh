@@ -15,7 +15,7 @@ python -c "import sys; sys.path.insert(0,'webgl-fluid-simulation_amd'); import f
 
 if [ "$MODE" != "quick" ]; then
   echo "== pytest -m gpu ==" | tee -a "$OUT/log.txt"
-  timeout 1500 python -m pytest tests -m gpu -x -q >"$OUT/pytest_gpu.txt" 2>&1
+  timeout 1500 python -m pytest tests -m gpu -x -q -rsx >"$OUT/pytest_gpu.txt" 2>&1
   echo "pytest exit $?" | tee -a "$OUT/log.txt"
   tail -5 "$OUT/pytest_gpu.txt" | tee -a "$OUT/log.txt"
 
@@ -30,7 +30,7 @@ echo "bench exit $?" | tee -a "$OUT/log.txt"
 cat "$OUT/bench.json" | tee -a "$OUT/log.txt"
 
 echo "== bench as the driver runs it: --steps 20 --warmup 5 ==" | tee -a "$OUT/log.txt"
-timeout 900 python bench.py --steps 20 --warmup 5 --cpu-budget 0 --no-traffic >"$OUT/bench_driver_flags.json" 2>>"$OUT/bench.err"
+timeout 900 python bench.py --steps 20 --warmup 5 >"$OUT/bench_driver_flags.json" 2>>"$OUT/bench.err"
 cat "$OUT/bench_driver_flags.json" | tee -a "$OUT/log.txt"
 
 echo "== bench passes schedule ==" | tee -a "$OUT/log.txt"
@@ -43,10 +43,14 @@ cat "$OUT/bench_f16.json" | tee -a "$OUT/log.txt"
 
 echo "== rocprofv3 kernel trace ==" | tee -a "$OUT/log.txt"
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o ks -- \
-    python "$GRAFT_REPO_ROOT/bench.py" --cpu-budget 0 --no-traffic --no-steady >"$OUT/bench_under_rocprof.json" 2>"$OUT/rocprof.err" )
+    python "$GRAFT_REPO_ROOT/bench.py" --cpu-budget 0 --no-traffic --no-steady --no-parity >"$OUT/bench_under_rocprof.json" 2>"$OUT/rocprof.err" )
 echo "rocprof exit $?" | tee -a "$OUT/log.txt"
 KS=$(find "$OUT/prof" -name '*kernel_stats.csv' | head -1)
 [ -n "$KS" ] && cp "$KS" "$OUT/kernel_stats.csv" && head -12 "$OUT/kernel_stats.csv" | cut -c1-200 | tee -a "$OUT/log.txt"
 # keep the merged-back payload small
 rm -rf "$OUT/prof"
+echo "== other sizes, shipping defaults, SQ counters ==" | tee -a "$OUT/log.txt"
+bash tools/other_sizes.sh "$TAG" >>"$OUT/log.txt" 2>&1
+timeout 600 python tools/bench_shipping.py >"$OUT/bench_shipping_defaults.json" 2>>"$OUT/bench.err"
+bash tools/pmc_sq.sh "$TAG/sq" >/dev/null 2>&1; cp "$OUT/sq/sq_summary.txt" "$OUT/sq_counters_step_kernels.txt" 2>/dev/null
 echo "== done ==" | tee -a "$OUT/log.txt"

@@ -12,9 +12,9 @@ print('size %5d iters %3d: %9.2f steps/s  %6.2f GLUPS  %8.4f ms/step | %s %.1f u
     'PMC' if 'PMC' in r['traffic_source'] else 'model', r['frac'], s.get('bytes_per_step', 0) / 1e9, s.get('frac', 0)))
 "; }
 echo "# bench.py --size N --iters I on one MI355X (fused schedule, dye grid = sim grid), HBM bytes from PMC passes inside each run" | tee $OUT/bench_other_sizes.txt
-timeout 300 python bench.py --size 1024 --iters 50 --steps 2000 --warmup 200 --cpu-budget 0 --no-steady 2>>$OUT/err.txt | line 1024 50 | tee -a $OUT/bench_other_sizes.txt
-timeout 300 python bench.py --size 2048 --iters 50 --steps 800 --warmup 100 --cpu-budget 0 --no-steady 2>>$OUT/err.txt | line 2048 50 | tee -a $OUT/bench_other_sizes.txt
-timeout 400 python bench.py --size 8192 --iters 50 --steps 100 --warmup 20 --cpu-budget 0 --no-steady 2>>$OUT/err.txt | line 8192 50 | tee -a $OUT/bench_other_sizes.txt
-timeout 600 python bench.py --size 16384 --iters 200 --steps 20 --warmup 4 --cpu-budget 0 --no-steady 2>>$OUT/err.txt | line 16384 200 | tee -a $OUT/bench_other_sizes.txt
+timeout 300 python bench.py --size 1024 --iters 50 --steps 2000 --warmup 200 --cpu-budget 0 --no-steady --no-parity 2>>$OUT/err.txt | line 1024 50 | tee -a $OUT/bench_other_sizes.txt
+timeout 300 python bench.py --size 2048 --iters 50 --steps 800 --warmup 100 --cpu-budget 0 --no-steady --no-parity 2>>$OUT/err.txt | line 2048 50 | tee -a $OUT/bench_other_sizes.txt
+timeout 400 python bench.py --size 8192 --iters 50 --steps 100 --warmup 20 --cpu-budget 0 --no-steady --no-parity 2>>$OUT/err.txt | line 8192 50 | tee -a $OUT/bench_other_sizes.txt
+timeout 600 python bench.py --size 16384 --iters 200 --steps 20 --warmup 4 --cpu-budget 0 --no-steady --no-parity 2>>$OUT/err.txt | line 16384 200 | tee -a $OUT/bench_other_sizes.txt
 echo "== soak ==" | tee $OUT/soak.txt
-timeout 600 python tools/soak.py 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tee -a $OUT/soak.txt
+timeout 400 python tools/soak.py 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tee -a $OUT/soak.txt

@@ -2,7 +2,7 @@
 # Copies what one tools/gpu_round.sh visit produced (gpurun_out/<tag>/) into the tracked profiles/<round>/ files.
 # Usage: bash tools/publish_profiles.sh <tag> [round dir, default r02]
 set -e
-F=gpurun_out/$1; R=profiles/${2:-r02}
+F=gpurun_out/$1; R=profiles/${2:-r03}
 mkdir -p $R
 cp $F/bench.json $R/bench_4096_50.json
 cp $F/bench_driver_flags.json $R/bench_4096_50_steps20_warmup5.json
@@ -15,5 +15,7 @@ for s in fused passes; do
   [ -f $F/pmc_FETCH_SIZE_$s.csv ] && cp $F/pmc_FETCH_SIZE_$s.csv $R/pmc_fetch_$s.csv
   [ -f $F/pmc_WRITE_SIZE_$s.csv ] && cp $F/pmc_WRITE_SIZE_$s.csv $R/pmc_write_$s.csv
 done
-grep -h "passed" $F/pytest_gpu.txt | tail -1 > $R/pytest_gpu.txt
+for f in $F/pmc_SQ_*_fused.csv; do [ -f "$f" ] && cp "$f" $R/pmc_sq_valu_fused.csv; done
+for f in bench_shipping_defaults.json bench_other_sizes.txt soak.txt sq_counters_step_kernels.txt; do [ -f $F/$f ] && cp $F/$f $R/$f; done
+tail -15 $F/pytest_gpu.txt > $R/pytest_gpu.txt
 echo "published $F -> $R"
