@@ -326,7 +326,7 @@ def main(argv=None, engine_factory=None, backend="nccl"):
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the HIP-event instrumented pass")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child runs (HBM bytes per launch, VALU counters)")
     ap.add_argument("--no-steady", action="store_true", help="skip the long (>= 2000 steps) steady-state timing appended to the line")
-    ap.add_argument("--no-parity", action="store_true", help="N = 1: skip the in-run parity check in front of the warm-up")
+    ap.add_argument("--no-parity", action="store_true", help="skip the in-run parity check (fused == per-pass schedule at the bench size, HIP == oracle on a small case) that follows the timed sections")
     ap.add_argument("--extras-budget", type=float, default=600.0, help="seconds everything BEHIND the timed section may take in total "
                     "(counter passes, steady timing, CPU baseline); an extra that no longer fits is skipped and says so in the line")
     ap.add_argument("--tiles-x", type=int, default=1, help="N > 1: 2-D decomposition, N // tiles_x row stripes x tiles_x column tiles "
@@ -469,23 +469,6 @@ def main(argv=None, engine_factory=None, backend="nccl"):
 
     elapsed = measure(sim, args.warmup, args.steps, "headline")
 
-    # the in-run parity check, on every rank's own GPU, BEHIND the timed section (see parity_in_run): a mismatch replaces the line by an error
-    if not args.no_parity and not on_cpu:
-        problem = None
-        if dog:
-            dog.at("in-run parity check (fused == per-pass schedule on this rank's GPU)")
-        try:
-            parity = parity_in_run(fluid_hip, size, iters, local_rank, args.storage, with_oracle=(rank == 0))
-            if not parity["ok"]:
-                problem = "in-run parity check failed on rank %d: %s" % (rank, json.dumps(parity))
-        except Exception as ex:
-            problem = "in-run parity check could not run on rank %d: %s" % (rank, str(ex)[:200])
-        problem = agree(problem)
-        if problem:
-            if dog:
-                dog.stop()
-            fail(problem, code=6)
-
     steps_per_s = args.steps / elapsed
     glups = grid_w * grid_h * steps_per_s / 1e9
     half = 0.5 if args.storage == "f16" else 1.0
@@ -513,8 +496,6 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         "speedup_vs_pass_structure": {"algorithmic_GBps": round(alg_step_bytes * steps_per_s / 1e9, 1),
                                       "x_hbm_peak": round(alg_step_bytes * steps_per_s / 1e9 / (HBM_PEAK_GBPS * N), 4)},
     })
-    if parity:
-        out["parity_in_run"] = parity
     if on_cpu:
         out["config"]["engine"] = "injected stripe engine on CPU ranks over %s (launcher-path test, not a measurement)" % backend
     if N > 1:
@@ -667,6 +648,27 @@ def main(argv=None, engine_factory=None, backend="nccl"):
             out["steady_steps"] = n_long
         else:
             skipped["steady_ms_per_step"] = "extras budget spent"
+
+    # the in-run parity check, on every rank's own GPU, BEHIND every timed section of this run (see parity_in_run): a mismatch replaces
+    # the line by an error
+    if not args.no_parity and not on_cpu:
+        problem = None
+        if dog:
+            dog.at("in-run parity check (fused == per-pass schedule on this rank's GPU)")
+        try:
+            parity = parity_in_run(fluid_hip, size, iters, local_rank, args.storage, with_oracle=(rank == 0))
+            if not parity["ok"]:
+                problem = "in-run parity check failed on rank %d: %s" % (rank, json.dumps(parity))
+        except Exception as ex:
+            problem = "in-run parity check could not run on rank %d: %s" % (rank, str(ex)[:200])
+        problem = agree(problem)
+        if problem:
+            if dog:
+                dog.stop()
+            fail(problem, code=6)
+
+    if parity:
+        out["parity_in_run"] = parity
 
     if rank == 0 and N == 1 and args.cpu_budget > 0:
         if deadline.left() > 30:
