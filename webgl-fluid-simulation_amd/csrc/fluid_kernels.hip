@@ -1295,6 +1295,10 @@ constexpr TBVariant kTB[] = {
     {8, 8, 28, 25, 2, true},    // 13: 64-row tile with a 25-row apron — 2 launches
     {8, 6, 20, 17, 2, true},    // 14: 48-row tile, 17-row apron
     {16, 6, 28, 25, 1, true},   // 15: 16 waves x 6 rows, 25-row apron — 2 launches
+    {4, 10, 12, 10, 4, false},  // 16: the 40-row tile as FOUR waves x 10 rows (one wave per SIMD: a 4-wave barrier)
+    {4, 16, 12, 10, 2, false},  // 17: 4 waves x 16 rows
+    {2, 20, 12, 10, 4, false},  // 18: the 40-row tile as TWO waves x 20 rows
+    {16, 3, 12, 10, 1, false},  // 19: 16 waves x 3 rows (48-row tile)      (16-19: profiles/r03/jacobi_iter_cost.txt)
 };
 constexpr int kNumTB = sizeof(kTB) / sizeof(kTB[0]);
 constexpr int kDefaultTB = 0;  // measured best of the table at 4096^2 (profiles/r01/jacobi_variants.txt, there listed as "8x10 h12/10")
@@ -1713,7 +1717,11 @@ bool jacobi_tb_supported(Win w) { return fused_supported(w); }
     X(12, 8, 7, 20, 17, 2)  \
     X(13, 8, 8, 28, 25, 2)  \
     X(14, 8, 6, 20, 17, 2)  \
-    X(15, 16, 6, 28, 25, 1)
+    X(15, 16, 6, 28, 25, 1) \
+    X(16, 4, 10, 12, 10, 4) \
+    X(17, 4, 16, 12, 10, 2) \
+    X(18, 2, 20, 12, 10, 4) \
+    X(19, 16, 3, 12, 10, 1)
 #define TB_GS_VARIANTS(X)  \
     X(0, 8, 10, 12, 10, 2) \
     X(3, 8, 12, 12, 10, 2) \
