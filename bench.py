@@ -521,6 +521,8 @@ def main(argv=None, engine_factory=None, backend="nccl"):
                 name, esize, esize, eiters, N, "%d stripes" % N if etx == 1 else "%dx%d tiles" % (N // etx, etx))
             entry = {"config": label, "steps": esteps, "warmup": max(2, esteps // 5)}
             sim.close()
+            if dog:
+                dog.at("%s: communicator and field set-up" % name)
             try:
                 sim = make_stripes(esize, esize, eiters, etx)
                 sim.multipleSplats(20)
