@@ -911,6 +911,47 @@ __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb(Win w
     else jacobi_tb_body<NW, RY, HX, HY, 0>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
 }
 
+// A launch whose FIRST and / or LAST tiles are smaller (round 3).  The time of a launch is its bytes over the bandwidth plus the latency of
+// the last tiles' iterations, which nothing overlaps any more (4096-wide grids of every height: 18.5 us + 8.2 ns per row for ten iterations
+// against 3.3 us + 7.1 ns per row for one, tools/jacobi_tail_probe.py): the bulk of the rows takes the big tile (least apron traffic), the
+// last rows a tile with fewer rows per wave, whose ten iterations drain sooner.  Up to three row segments, each tiled with the big (RYA) or
+// the small (RYB) shape — so many band launches in one, dispatched in that order.
+struct MixSegs {
+    int n;
+    int g[4];      // segment k covers rows [g[k], g[k + 1])
+    int small[3];  // tiled with RYB (1) or RYA (0) rows per wave
+    int ys[3], ny[3], blk0[4];
+};
+
+template <int NW, int RY, int HX, int HY, class T>
+__device__ __forceinline__ void jacobi_tb_tile(const Win& w, const T* __restrict__ p, const T* __restrict__ div, T* __restrict__ p_out, float pscale,
+                                               int iters, int ga, int gb, int xs, int ys, int nx, int ny, int b, int remap,
+                                               float4 (*mail)[NW][2][64])
+{
+    using G = JacobiTB<NW, RY, HX, HY>;
+    int bx, by;
+    tile_of_block(b, nx, ny, remap, bx, by);
+    const int x0 = xs + bx * G::VX, y0 = ys + by * G::VY;
+    const bool xedge = (x0 <= 0) || (x0 + G::TX >= w.W), yedge = (y0 <= 0) || (y0 + G::TY >= w.H);
+    const bool ragged = (w.W & 3) != 0 && x0 + G::TX >= w.W;
+    if (yedge || ragged) jacobi_tb_body<NW, RY, HX, HY, 2>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
+    else if (xedge) jacobi_tb_body<NW, RY, HX, HY, 1>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
+    else jacobi_tb_body<NW, RY, HX, HY, 0>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
+}
+
+template <int NW, int RYA, int RYB, int HX, int HY, int BPC>
+__global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_mix(Win w, const float* __restrict__ p, const float* __restrict__ div,
+                                                            float* __restrict__ p_out, float pscale, int iters, MixSegs S, int xs, int nx,
+                                                            int remap)
+{
+    __shared__ float4 mail[2][NW][2][64];
+    const int b = (int)blockIdx.x;
+    int k = 0;
+    while (k + 1 < S.n && b >= S.blk0[k + 1]) k++;
+    if (S.small[k]) jacobi_tb_tile<NW, RYB, HX, HY>(w, p, div, p_out, pscale, iters, S.g[k], S.g[k + 1], xs, S.ys[k], nx, S.ny[k], b - S.blk0[k], remap, mail);
+    else jacobi_tb_tile<NW, RYA, HX, HY>(w, p, div, p_out, pscale, iters, S.g[k], S.g[k + 1], xs, S.ys[k], nx, S.ny[k], b - S.blk0[k], remap, mail);
+}
+
 // The LAST launch of a step's loop with the gradient subtract folded in (jacobi_tb_body, GS): the row apron is HY + 1 so that `iters`
 // <= HY iterations leave the pressure exact one ring beyond the texels the tile stores; reads and writes the velocity for those texels.
 template <int NW, int RY, int HX, int HY, int BPC>
@@ -1349,9 +1390,68 @@ const std::vector<TBRule>& tb_rules()
     return rules;
 }
 
+// FLUID_TB_TAIL="head,tail,ry": the first `head` and the last `tail` rows of a launch of the default shape take tiles of `ry` (5 / 6 / 7)
+// rows per wave (k_jacobi_tb_mix); 0,0 = one shape per launch (A/B knob).  Default 366 / 666 rows of 8 x 7 tiles: at 4096^2 the launch goes
+// from 46.3-47.2 to 43.0-43.4 us and the step from 0.502-0.514 to 0.490-0.498 ms (two boxes, interleaved; heads of 200-400 rows and tails of
+// 300-666 rows of 5-, 6- or 7-row tiles are within 0.5 % of each other, heads beyond ~500 rows lose): profiles/r03/jacobi_small_tile_head_tail.txt
+struct TBTail { int head, tail, ry; };
+inline TBTail tb_tail()
+{
+    static const TBTail t = [] {
+        TBTail r{ 366, 666, 7 };
+        if (const char* e = getenv("FLUID_TB_TAIL")) {
+            r = TBTail{ 0, 0, 7 };
+            sscanf(e, "%d,%d,%d", &r.head, &r.tail, &r.ry);
+        }
+        if (r.ry != 5 && r.ry != 6 && r.ry != 7) r.head = r.tail = 0;
+        return r;
+    }();
+    return t;
+}
+
+template <int NW, int RYA, int RYB, int HX, int HY, int BPC>
+hipError_t launch_tb_mix(hipStream_t s, Win w, const float* p, const float* div, float* p_out, float pscale, int iters, int ga, int gb, int head, int tail)
+{
+    using GA = JacobiTB<NW, RYA, HX, HY>;
+    using GB = JacobiTB<NW, RYB, HX, HY>;
+    const Axis ax = make_axis(w.x0, w.x1, w.W, GA::TX, HX);
+    MixSegs S{};
+    int total = 0;
+    auto seg = [&](int a, int b, int small) {
+        if (b <= a) return;
+        const Axis ay = small ? make_axis(a, b, w.H, GB::TY, HY) : make_axis(a, b, w.H, GA::TY, HY);
+        const int k = S.n++;
+        S.g[k] = a; S.g[k + 1] = b; S.small[k] = small; S.ys[k] = ay.S; S.ny[k] = ay.n; S.blk0[k] = total;
+        total += ax.n * ay.n;
+    };
+    // big tile b of the middle segment stores rows up to S + (TY - HY) + b VY (S = its first tile's origin): the cut in front of the tail
+    // snaps down to such a boundary, so that no big tile is launched for a few rows
+    const int lo = ga + head;
+    int gmid = gb - tail;
+    if (tail > 0) {
+        const int base = (lo - HY > 0 ? lo - HY : 0) + GA::TY - HY;
+        if (gmid > base) gmid = base + (gmid - base) / GA::VY * GA::VY;
+    }
+    if (gmid < lo) gmid = lo;
+    seg(ga, lo, 1);
+    seg(lo, gmid, 0);
+    seg(gmid, gb, 1);
+    S.blk0[S.n] = total;
+    k_jacobi_tb_mix<NW, RYA, RYB, HX, HY, BPC><<<dim3(total, 1, 1), dim3(64, NW, 1), 0, s>>>(w, p, div, p_out, pscale, iters, S, ax.S, ax.n, xcd_remap());
+    return hipGetLastError();
+}
+
 template <int NW, int RY, int HX, int HY, int BPC>
 hipError_t launch_tb(hipStream_t s, Win w, const float* p, const float* div, float* p_out, float pscale, int iters, int ga, int gb)
 {
+    if constexpr (NW == 8 && RY == 10 && HX == 12 && HY == 10) {  // the default shape: with small tiles for the launch's first / last rows
+        const TBTail t = tb_tail();
+        if (t.head + t.tail > 0 && gb - ga >= 3 * (t.head + t.tail)) {
+            if (t.ry == 5) return launch_tb_mix<NW, RY, 5, HX, HY, BPC>(s, w, p, div, p_out, pscale, iters, ga, gb, t.head, t.tail);
+            if (t.ry == 6) return launch_tb_mix<NW, RY, 6, HX, HY, BPC>(s, w, p, div, p_out, pscale, iters, ga, gb, t.head, t.tail);
+            return launch_tb_mix<NW, RY, 7, HX, HY, BPC>(s, w, p, div, p_out, pscale, iters, ga, gb, t.head, t.tail);
+        }
+    }
     using G = JacobiTB<NW, RY, HX, HY>;
     const Axis ax = make_axis(w.x0, w.x1, w.W, G::TX, HX), ay = make_axis(ga, gb, w.H, G::TY, HY);
     k_jacobi_tb<NW, RY, HX, HY, BPC><<<dim3(ax.n * ay.n, 1, 1), dim3(64, NW, 1), 0, s>>>(w, p, div, p_out, pscale, iters, ga, gb, ax.S, ay.S, ax.n,
