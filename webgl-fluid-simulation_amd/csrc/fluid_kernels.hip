@@ -1305,6 +1305,39 @@ __global__ void __launch_bounds__(64 * NW, VD_WAVES_PER_EU) k_curl_vort_div_rect
     else vort_div_body<NW, RY, 0>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
 }
 
+// the same kernel with smaller tiles for a launch's first and last rows (see k_jacobi_tb_mix: a launch is its bytes over the bandwidth
+// plus the fill / drain latency of its first / last tiles, and a tile of this kernel is 1400 VALU instructions per wave)
+template <int NW, int RYA, int RYB>
+__global__ void __launch_bounds__(64 * NW, VD_WAVES_PER_EU) k_curl_vort_div_mix(Win w, MixSegs S, const float2* __restrict__ vel, float* __restrict__ curl_out,
+                                                                float2* __restrict__ vel_out, float* __restrict__ div_out, float curl_strength,
+                                                                float dt, int xs, int nx, int remap)
+{
+    __shared__ float4 mail[NW][2][2][64];
+    const int b = (int)blockIdx.x;
+    int k = 0;
+    while (k + 1 < S.n && b >= S.blk0[k + 1]) k++;
+    int bx, by;
+    tile_of_block(b - S.blk0[k], nx, S.ny[k], remap, bx, by);
+    const int ga = S.g[k], gb = S.g[k + 1];
+    if (S.small[k]) {
+        using G = VortDiv<NW, RYB>;
+        const int x0 = xs + bx * G::VX, y0 = S.ys[k] + by * G::VY;
+        const bool xedge = (x0 <= 0) || (x0 + G::TX >= w.W), yedge = (y0 <= 0) || (y0 + G::TY >= w.H);
+        const bool ragged = (w.W & 3) != 0 && x0 + G::TX >= w.W;
+        if (yedge || ragged) vort_div_body<NW, RYB, 2>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
+        else if (xedge) vort_div_body<NW, RYB, 1>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
+        else vort_div_body<NW, RYB, 0>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
+    } else {
+        using G = VortDiv<NW, RYA>;
+        const int x0 = xs + bx * G::VX, y0 = S.ys[k] + by * G::VY;
+        const bool xedge = (x0 <= 0) || (x0 + G::TX >= w.W), yedge = (y0 <= 0) || (y0 + G::TY >= w.H);
+        const bool ragged = (w.W & 3) != 0 && x0 + G::TX >= w.W;
+        if (yedge || ragged) vort_div_body<NW, RYA, 2>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
+        else if (xedge) vort_div_body<NW, RYA, 1>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
+        else vort_div_body<NW, RYA, 0>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
+    }
+}
+
 #ifndef VD_NW_
 #define VD_NW_ 8
 #endif
@@ -1763,11 +1796,53 @@ hipError_t launch_fill(hipStream_t s, float* dst, size_t n, int nc, float v0, fl
 
 bool fused_supported(Win w) { return w.W >= 1 && w.P % 4 == 0 && w.c0 % 4 == 0; }  // any width: the pitch keeps every row float4-aligned
 
+// FLUID_CVD_TAIL="head,tail": rows at the start / end of a launch that take 8 x 3-row tiles (k_curl_vort_div_mix); 0,0 = one shape (A/B knob).
+// Default 378 / 378: the pass goes from 83-84 to 75 us at 4096^2 (it is the HEAD that pays: the first tiles no longer finish loading together),
+// the step -1.1 % (profiles/r03/cvd_small_tile_head_tail.txt)
+struct CvdTail { int head, tail; };
+static CvdTail cvd_tail()
+{
+    static const CvdTail t = [] {
+        CvdTail r{ 378, 378 };
+        if (const char* e = getenv("FLUID_CVD_TAIL")) sscanf(e, "%d,%d", &r.head, &r.tail);
+        return r;
+    }();
+    return t;
+}
+
 hipError_t launch_curl_vort_div(hipStream_t s, Win w, const float2* vel, float* curl, float2* vel_out, float* div,
                                 float curl_strength, float dt, int ga, int gb)
 {
     ROWS_OR_RETURN();
     if (!fused_supported(w)) return hipErrorInvalidValue;
+    const CvdTail t = cvd_tail();
+    if (VD_NW == 8 && VD_RY == 5 && t.head + t.tail > 0 && gb - ga >= 3 * (t.head + t.tail)) {
+        using GA = VortDiv<8, 5>;
+        using GB = VortDiv<8, 3>;
+        const Axis ax = make_axis(w.x0, w.x1, w.W, GA::TX, GA::AX);
+        MixSegs S{};
+        int total = 0;
+        auto seg = [&](int a, int b, int small) {
+            if (b <= a) return;
+            const Axis ay = small ? make_axis(a, b, w.H, GB::TY, GB::AY) : make_axis(a, b, w.H, GA::TY, GA::AY);
+            const int k = S.n++;
+            S.g[k] = a; S.g[k + 1] = b; S.small[k] = small; S.ys[k] = ay.S; S.ny[k] = ay.n; S.blk0[k] = total;
+            total += ax.n * ay.n;
+        };
+        const int lo = ga + t.head;
+        int gmid = gb - t.tail;
+        if (t.tail > 0) {
+            const int base = (lo - GA::AY > 0 ? lo - GA::AY : 0) + GA::TY - GA::AY;
+            if (gmid > base) gmid = base + (gmid - base) / GA::VY * GA::VY;
+        }
+        if (gmid < lo) gmid = lo;
+        seg(ga, lo, 1);
+        seg(lo, gmid, 0);
+        seg(gmid, gb, 1);
+        S.blk0[S.n] = total;
+        k_curl_vort_div_mix<8, 5, 3><<<dim3(total, 1, 1), dim3(64, 8, 1), 0, s>>>(w, S, vel, curl, vel_out, div, curl_strength, dt, ax.S, ax.n, cvd_remap());
+        return hipGetLastError();
+    }
     using G = VortDiv<VD_NW, VD_RY>;
     const Axis ax = make_axis(w.x0, w.x1, w.W, G::TX, G::AX), ay = make_axis(ga, gb, w.H, G::TY, G::AY);
     k_curl_vort_div<VD_NW, VD_RY><<<dim3(ax.n * ay.n, 1, 1), dim3(64, VD_NW, 1), 0, s>>>(w, vel, curl, vel_out, div, curl_strength, dt,
