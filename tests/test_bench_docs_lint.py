@@ -1,5 +1,5 @@
 """DOCS LINT, not a test of bench.py (that is tests/test_bench_live.py, which runs it): the bench lines COMMITTED under profiles/ — the
-numbers DESIGN.md quotes — are well-formed lines of the contract (profiles/r02/bench_4096_50.json is what `python bench.py` printed there): the keys the driver reads, a roofline that is a fraction of a physical peak (<= 1, = achieved / peak,
+numbers DESIGN.md quotes — are well-formed lines of the contract (profiles/r03/bench_4096_50.json is what `python bench.py` printed there): the keys the driver reads, a roofline that is a fraction of a physical peak (<= 1, = achieved / peak,
 achieved = measured HBM bytes per launch / measured launch time), the CPU baseline of the same run and what kind it is."""
 import json
 import os
@@ -11,7 +11,7 @@ FILES = ["bench_4096_50.json", "bench_4096_50_steps20_warmup5.json", "bench_4096
 
 
 def load(name):
-    with open(os.path.join(ROOT, "profiles", "r02", name)) as f:
+    with open(os.path.join(ROOT, "profiles", "r03", name)) as f:
         lines = [ln for ln in f.read().splitlines() if ln.strip()]
     assert len(lines) == 1, "bench.py prints ONE JSON line"
     return json.loads(lines[0])

@@ -1424,22 +1424,25 @@ const std::vector<TBRule>& tb_rules()
 }
 
 // FLUID_TB_TAIL="head,tail,ry": the first `head` and the last `tail` rows of a launch of the default shape take tiles of `ry` (5 / 6 / 7)
-// rows per wave (k_jacobi_tb_mix); 0,0 = one shape per launch (A/B knob).  Default 366 / 666 rows of 8 x 7 tiles: at 4096^2 the launch goes
-// from 46.3-47.2 to 43.0-43.4 us and the step from 0.502-0.514 to 0.490-0.498 ms (two boxes, interleaved; heads of 200-400 rows and tails of
-// 300-666 rows of 5-, 6- or 7-row tiles are within 0.5 % of each other, heads beyond ~500 rows lose): profiles/r03/jacobi_small_tile_head_tail.txt
+// rows per wave (k_jacobi_tb_mix); 0,0 = one shape per launch (A/B knob).  Default: 300 / 600 rows of 8 x 5 tiles, 366 / 666 rows of 8 x 7
+// tiles for bands of more than 6144 rows.  At 4096^2 the launch goes from 46.3-47.2 to 43.0-43.6 us and the step from 0.502-0.514 to
+// 0.482-0.498 ms (four boxes, interleaved; heads of 200-400 rows and tails of 300-666 rows of 5-, 6- or 7-row tiles are within 0.5 % of
+// each other there, heads beyond ~500 rows lose); at 3072^2 the 5-row tiles are 3.6 % ahead of the 7-row ones, at 8192^2 the 7-row tiles
+// 1-3 %: profiles/r03/jacobi_small_tile_head_tail.txt
 struct TBTail { int head, tail, ry; };
-inline TBTail tb_tail()
+inline TBTail tb_tail(int rows)
 {
-    static const TBTail t = [] {
-        TBTail r{ 366, 666, 7 };
+    static const TBTail forced = [] {
+        TBTail r{ -1, -1, 7 };
         if (const char* e = getenv("FLUID_TB_TAIL")) {
             r = TBTail{ 0, 0, 7 };
             sscanf(e, "%d,%d,%d", &r.head, &r.tail, &r.ry);
+            if (r.ry != 5 && r.ry != 6 && r.ry != 7) r.head = r.tail = 0;
         }
-        if (r.ry != 5 && r.ry != 6 && r.ry != 7) r.head = r.tail = 0;
         return r;
     }();
-    return t;
+    if (forced.head >= 0) return forced;
+    return rows > 6144 ? TBTail{ 366, 666, 7 } : TBTail{ 300, 600, 5 };
 }
 
 template <int NW, int RYA, int RYB, int HX, int HY, int BPC>
@@ -1478,8 +1481,14 @@ template <int NW, int RY, int HX, int HY, int BPC>
 hipError_t launch_tb(hipStream_t s, Win w, const float* p, const float* div, float* p_out, float pscale, int iters, int ga, int gb)
 {
     if constexpr (NW == 8 && RY == 10 && HX == 12 && HY == 10) {  // the default shape: with small tiles for the launch's first / last rows
-        const TBTail t = tb_tail();
-        if (t.head + t.tail > 0 && gb - ga >= 3 * (t.head + t.tail)) {
+        const int rows = gb - ga;
+        TBTail t = tb_tail(rows);
+        const int full = 3 * (t.head + t.tail);
+        if (full > 0 && rows < full) {  // a shorter band: the same proportions (at most a third of the rows in small tiles)
+            t.head = (int)((long)t.head * rows / full);
+            t.tail = (int)((long)t.tail * rows / full);
+        }
+        if (t.head + t.tail > 0 && rows >= 1024) {
             if (t.ry == 5) return launch_tb_mix<NW, RY, 5, HX, HY, BPC>(s, w, p, div, p_out, pscale, iters, ga, gb, t.head, t.tail);
             if (t.ry == 6) return launch_tb_mix<NW, RY, 6, HX, HY, BPC>(s, w, p, div, p_out, pscale, iters, ga, gb, t.head, t.tail);
             return launch_tb_mix<NW, RY, 7, HX, HY, BPC>(s, w, p, div, p_out, pscale, iters, ga, gb, t.head, t.tail);
