@@ -1423,26 +1423,38 @@ const std::vector<TBRule>& tb_rules()
     return rules;
 }
 
-// FLUID_TB_TAIL="head,tail,ry": the first `head` and the last `tail` rows of a launch of the default shape take tiles of `ry` (5 / 6 / 7)
-// rows per wave (k_jacobi_tb_mix); 0,0 = one shape per launch (A/B knob).  Default: 300 / 600 rows of 8 x 5 tiles, 366 / 666 rows of 8 x 7
-// tiles for bands of more than 6144 rows.  At 4096^2 the launch goes from 46.3-47.2 to 43.0-43.6 us and the step from 0.502-0.514 to
-// 0.482-0.498 ms (four boxes, interleaved; heads of 200-400 rows and tails of 300-666 rows of 5-, 6- or 7-row tiles are within 0.5 % of
-// each other there, heads beyond ~500 rows lose); at 3072^2 the 5-row tiles are 3.6 % ahead of the 7-row ones, at 8192^2 the 7-row tiles
-// 1-3 %: profiles/r03/jacobi_small_tile_head_tail.txt
-struct TBTail { int head, tail, ry; };
-inline TBTail tb_tail(int rows)
+// How many of a launch's first / last rows take the small tiles (k_jacobi_tb_mix).  What fills the 512 workgroup slots does not depend on the
+// grid's width, rows do: the cut is expressed in small TILES — default 192 at the head, 384 at the tail, of 8 x 7 tiles for bands of at
+// least 4000 rows and 8 x 5 tiles below — and converted to whole tile rows at the launch's width.  At 4096^2 the launch goes from 46.3-47.2
+// to 43.0-44.5 us and the step down 2.3 ... 3.2 % (five boxes, interleaved; everything from 180 to 540 tiles of 5-, 6- or 7-row tiles is
+// within 0.5 % there); at 3072^2 the 5-row tiles are 3.5 % ahead of the 7-row ones, at 8192^2 the 7-row tiles 1 %; at 16384^2 a cut in ROWS
+// (366 / 666: thousands of small tiles) is slower than no cut and the same tile counts gain 1.3 % (profiles/r03/jacobi_small_tile_head_tail.txt).
+// A/B knobs: FLUID_TB_TAIL_TILES="head_tiles,tail_tiles,ry", FLUID_TB_TAIL="head_rows,tail_rows,ry" (rows win; 0,0 = one shape per launch).
+struct TBTail { int head, tail, ry, min_rows; };   // head / tail in ROWS
+inline TBTail tb_tail(int rows, int nx)
 {
-    static const TBTail forced = [] {
-        TBTail r{ -1, -1, 7 };
+    static const TBTail forced_rows = [] {
+        TBTail r{ -1, -1, 7, 0 };
         if (const char* e = getenv("FLUID_TB_TAIL")) {
-            r = TBTail{ 0, 0, 7 };
+            r = TBTail{ 0, 0, 7, 0 };   // a forced setting applies to every band height (the knob-hash test runs it on small grids)
             sscanf(e, "%d,%d,%d", &r.head, &r.tail, &r.ry);
             if (r.ry != 5 && r.ry != 6 && r.ry != 7) r.head = r.tail = 0;
         }
         return r;
     }();
-    if (forced.head >= 0) return forced;
-    return rows > 6144 ? TBTail{ 366, 666, 7 } : TBTail{ 300, 600, 5 };
+    if (forced_rows.head >= 0) return forced_rows;
+    static const TBTail forced_tiles = [] {
+        TBTail r{ -1, -1, 5, 1024 };
+        if (const char* e = getenv("FLUID_TB_TAIL_TILES")) {
+            r = TBTail{ 0, 0, 5, 1024 };
+            sscanf(e, "%d,%d,%d", &r.head, &r.tail, &r.ry);
+            if (r.ry != 5 && r.ry != 6 && r.ry != 7) r.head = r.tail = 0;
+        }
+        return r;
+    }();
+    const TBTail tiles = forced_tiles.head >= 0 ? forced_tiles : TBTail{ 192, 384, rows >= 4000 ? 7 : 5, 1024 };
+    const int vy = 8 * tiles.ry - 20;  // rows a small tile stores (apron 10 on both sides)
+    return TBTail{ (tiles.head + nx - 1) / nx * vy, (tiles.tail + nx - 1) / nx * vy, tiles.ry, tiles.min_rows };
 }
 
 template <int NW, int RYA, int RYB, int HX, int HY, int BPC>
@@ -1482,13 +1494,13 @@ hipError_t launch_tb(hipStream_t s, Win w, const float* p, const float* div, flo
 {
     if constexpr (NW == 8 && RY == 10 && HX == 12 && HY == 10) {  // the default shape: with small tiles for the launch's first / last rows
         const int rows = gb - ga;
-        TBTail t = tb_tail(rows);
+        TBTail t = tb_tail(rows, make_axis(w.x0, w.x1, w.W, 256, HX).n);
         const int full = 3 * (t.head + t.tail);
         if (full > 0 && rows < full) {  // a shorter band: the same proportions (at most a third of the rows in small tiles)
             t.head = (int)((long)t.head * rows / full);
             t.tail = (int)((long)t.tail * rows / full);
         }
-        if (t.head + t.tail > 0 && rows >= 1024) {
+        if (t.head + t.tail > 0 && rows >= t.min_rows) {
             if (t.ry == 5) return launch_tb_mix<NW, RY, 5, HX, HY, BPC>(s, w, p, div, p_out, pscale, iters, ga, gb, t.head, t.tail);
             if (t.ry == 6) return launch_tb_mix<NW, RY, 6, HX, HY, BPC>(s, w, p, div, p_out, pscale, iters, ga, gb, t.head, t.tail);
             return launch_tb_mix<NW, RY, 7, HX, HY, BPC>(s, w, p, div, p_out, pscale, iters, ga, gb, t.head, t.tail);
@@ -1805,18 +1817,24 @@ hipError_t launch_fill(hipStream_t s, float* dst, size_t n, int nc, float v0, fl
 
 bool fused_supported(Win w) { return w.W >= 1 && w.P % 4 == 0 && w.c0 % 4 == 0; }  // any width: the pitch keeps every row float4-aligned
 
-// FLUID_CVD_TAIL="head,tail": rows at the start / end of a launch that take 8 x 3-row tiles (k_curl_vort_div_mix); 0,0 = one shape (A/B knob).
-// Default 378 / 378: the pass goes from 83-84 to 75 us at 4096^2 (it is the HEAD that pays: the first tiles no longer finish loading together),
-// the step -1.1 % (profiles/r03/cvd_small_tile_head_tail.txt)
-struct CvdTail { int head, tail; };
-static CvdTail cvd_tail()
+// The first / last rows of a launch that take 8 x 3-row tiles (k_curl_vort_div_mix), in small TILES (converted to whole tile rows at the
+// launch's width, like tb_tail): default 360 / 360 — at 4096^2 378 rows each: the pass goes from 83-84 to 75 us (it is the HEAD that pays:
+// the first tiles no longer finish loading together), the step -1.1 % (profiles/r03/cvd_small_tile_head_tail.txt).
+// A/B knob: FLUID_CVD_TAIL="head_rows,tail_rows" (0,0 = one shape per launch)
+struct CvdTail { int head, tail; };   // rows
+static CvdTail cvd_tail(int nx)
 {
-    static const CvdTail t = [] {
-        CvdTail r{ 378, 378 };
-        if (const char* e = getenv("FLUID_CVD_TAIL")) sscanf(e, "%d,%d", &r.head, &r.tail);
+    static const CvdTail forced = [] {
+        CvdTail r{ -1, -1 };
+        if (const char* e = getenv("FLUID_CVD_TAIL")) {
+            r = CvdTail{ 0, 0 };
+            sscanf(e, "%d,%d", &r.head, &r.tail);
+        }
         return r;
     }();
-    return t;
+    if (forced.head >= 0) return forced;
+    const int rows = (360 + nx - 1) / nx * 18;
+    return CvdTail{ rows, rows };
 }
 
 hipError_t launch_curl_vort_div(hipStream_t s, Win w, const float2* vel, float* curl, float2* vel_out, float* div,
@@ -1824,7 +1842,7 @@ hipError_t launch_curl_vort_div(hipStream_t s, Win w, const float2* vel, float* 
 {
     ROWS_OR_RETURN();
     if (!fused_supported(w)) return hipErrorInvalidValue;
-    const CvdTail t = cvd_tail();
+    const CvdTail t = cvd_tail(make_axis(w.x0, w.x1, w.W, 256, 4).n);
     if (VD_NW == 8 && VD_RY == 5 && t.head + t.tail > 0 && gb - ga >= 3 * (t.head + t.tail)) {
         using GA = VortDiv<8, 5>;
         using GB = VortDiv<8, 3>;
