@@ -73,7 +73,9 @@ def cpu_baseline_reference(size: int, iters: int, timeout_s: float):
     if p.returncode != 0 or not lines:
         return None, "the live reference failed here: " + (se.decode(errors="replace").strip().splitlines() or ["no output"])[-1][:200]
     r = json.loads(lines[-1])
-    return {"value": r["GLUPS"], "unit": "GLUPS", "steps_per_sec": r["steps_per_sec"], "ms_per_step": r["ms_per_step"],
+    timed = [float(x) for x in r.get("ms", [])][r.get("warmup_steps", 0):]
+    spread = {"ms_per_step_min": round(min(timed), 1), "ms_per_step_max": round(max(timed), 1)} if timed else {}
+    return {"value": r["GLUPS"], "unit": "GLUPS", "steps_per_sec": r["steps_per_sec"], "ms_per_step": r["ms_per_step"], **spread,
             "cores": r["nproc"], "kind": "reference", "cpu_model": r["cpu_model"],
             "renderer": "%s / %s" % (r["gl"].get("renderer"), r["gl"].get("version")), "user_agent": r["gl"].get("userAgent"),
             "swiftshader_threads": r["gl"].get("cores"),

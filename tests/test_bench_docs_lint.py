@@ -51,3 +51,30 @@ def test_headline_line_measures_its_traffic_and_times_the_reference_in_the_same_
     assert c["kind"] == "reference" and c["cores"] >= 1 and c["unit"] == "GLUPS" and "SwiftShader" in c["renderer"] and c["sample"]
     assert 0.5 < c["steps_per_sec"] < 10 and d["steps_per_sec"] / c["steps_per_sec"] > 100
     assert d["speedup_vs_pass_structure"]["x_hbm_peak"] > 1.0      # the algorithmic-bytes figure lives under its own key, not in `roofline`
+
+
+def test_the_headline_line_reproduces_from_the_committed_counter_files():
+    """`roofline.traffic`, `roofline.valu` and the launch time of the committed headline line follow from the raw files committed beside it:
+    the FETCH_SIZE / WRITE_SIZE passes (x 2 KiB and x 1 KiB per count), the SQ counter pass, and the kernel-trace statistics of the same command"""
+    import csv
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_traffic
+    d = load("bench_4096_50.json")
+    r = d["roofline"]
+    k = r["kernel"]
+    P = os.path.join(ROOT, "profiles", "r03")
+    fetch, write = pmc_traffic.per_kernel(os.path.join(P, "pmc_fetch_fused.csv")), pmc_traffic.per_kernel(os.path.join(P, "pmc_write_fused.csv"))
+    assert abs(fetch[k][0] * 2048 + write[k][0] * 1024 - r["traffic"]) <= 1.0
+    step = sum((fetch[n][0] * 2048 + write[n][0] * 1024) * fetch[n][1] / 4.0 for n in fetch if n in write and n.startswith("k_") and not n.startswith(("k_fill", "k_splat")))
+    assert abs(step - d["step_hbm"]["bytes_per_step"]) <= 8.0          # four steps under the profiler
+    sq = pmc_traffic.per_kernel_counters(os.path.join(P, "pmc_sq_valu_fused.csv"))[k]
+    v = r["valu"]
+    assert int(sq["SQ_INSTS_VALU"][0]) == v["insts_per_launch"] and int(sq["SQ_ACTIVE_INST_VALU"][0]) == v["active_quad_cycles_per_launch"]
+    simd_cycles = 4.0 * sq["SQ_ACTIVE_INST_VALU"][0] / 1024
+    assert abs(simd_cycles / (sq["GRBM_GUI_ACTIVE"][0] / 8) - v["busy_frac"]) <= 2e-4
+    assert r["bound"] == ("valu" if v["busy_frac"] > r["frac_of_attainable"] else "hbm")
+    # rocprofv3 --kernel-trace --stats of the same command: the kernel's average launch agrees with the HIP-event figure of the line (within 5 %)
+    with open(os.path.join(P, "kernel_stats_fused_4096_50.csv")) as f:
+        rows = [row for row in csv.DictReader(f) if k.split("<")[0] + "<" in row["Name"]]
+    assert rows and abs(float(rows[0]["AverageNs"]) * 1e-6 - r["avg_launch_ms"]) <= 0.05 * r["avg_launch_ms"]
