@@ -892,6 +892,24 @@ __device__ __forceinline__ void jacobi_tb_body(const Win& w, const T* __restrict
     }
 }
 
+// Tile `b` of an nx x ny tile set over rows [ga, gb): its place in the XCD-aware order, then the body with the CLAMP_TO_EDGE selects its
+// position needs (interior / left-right border / everything).  HYT = the tile's row apron (HY, or HY + 1 with the gradient subtract folded in).
+template <int NW, int RY, int HX, int HYT, bool GS = false, class T, class V2 = float2>
+__device__ __forceinline__ void jacobi_tb_tile(const Win& w, const T* __restrict__ p, const T* __restrict__ div, T* __restrict__ p_out, float pscale,
+                                               int iters, int ga, int gb, int xs, int ys, int nx, int ny, int b, int remap,
+                                               float4 (*mail)[NW][2][64], const V2* __restrict__ vel = nullptr, V2* __restrict__ vel_out = nullptr)
+{
+    using G = JacobiTB<NW, RY, HX, HYT>;
+    int bx, by;
+    tile_of_block(b, nx, ny, remap, bx, by);
+    const int x0 = xs + bx * G::VX, y0 = ys + by * G::VY;
+    const bool xedge = (x0 <= 0) || (x0 + G::TX >= w.W), yedge = (y0 <= 0) || (y0 + G::TY >= w.H);
+    const bool ragged = (w.W & 3) != 0 && x0 + G::TX >= w.W;  // the tile holds the partly padded last quad
+    if (yedge || ragged) jacobi_tb_body<NW, RY, HX, HYT, 2, T, GS, V2>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail, vel, vel_out);
+    else if (xedge) jacobi_tb_body<NW, RY, HX, HYT, 1, T, GS, V2>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail, vel, vel_out);
+    else jacobi_tb_body<NW, RY, HX, HYT, 0, T, GS, V2>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail, vel, vel_out);
+}
+
 // BPC = workgroups that must fit on a CU together (their load / compute / store phases overlap each other):
 // the second __launch_bounds__ argument is waves per SIMD, i.e. the VGPR budget the compiler has to meet.
 template <int NW, int RY, int HX, int HY, int BPC>
@@ -899,16 +917,8 @@ __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb(Win w
                                                         float* __restrict__ p_out, float pscale, int iters, int ga, int gb,
                                                         int xs, int ys, int nx, int ny, int remap)
 {
-    using G = JacobiTB<NW, RY, HX, HY>;
     __shared__ float4 mail[2][NW][2][64];
-    int bx, by;
-    tile_of_block((int)blockIdx.x, nx, ny, remap, bx, by);
-    const int x0 = xs + bx * G::VX, y0 = ys + by * G::VY;
-    const bool xedge = (x0 <= 0) || (x0 + G::TX >= w.W), yedge = (y0 <= 0) || (y0 + G::TY >= w.H);
-    const bool ragged = (w.W & 3) != 0 && x0 + G::TX >= w.W;  // the tile holds the partly padded last quad
-    if (yedge || ragged) jacobi_tb_body<NW, RY, HX, HY, 2>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
-    else if (xedge) jacobi_tb_body<NW, RY, HX, HY, 1>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
-    else jacobi_tb_body<NW, RY, HX, HY, 0>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
+    jacobi_tb_tile<NW, RY, HX, HY>(w, p, div, p_out, pscale, iters, ga, gb, xs, ys, nx, ny, (int)blockIdx.x, remap, mail);
 }
 
 // A launch whose FIRST and / or LAST tiles are smaller (round 3).  The time of a launch is its bytes over the bandwidth plus the latency of
@@ -922,22 +932,6 @@ struct MixSegs {
     int small[3];  // tiled with RYB (1) or RYA (0) rows per wave
     int ys[3], ny[3], blk0[4];
 };
-
-template <int NW, int RY, int HX, int HY, class T>
-__device__ __forceinline__ void jacobi_tb_tile(const Win& w, const T* __restrict__ p, const T* __restrict__ div, T* __restrict__ p_out, float pscale,
-                                               int iters, int ga, int gb, int xs, int ys, int nx, int ny, int b, int remap,
-                                               float4 (*mail)[NW][2][64])
-{
-    using G = JacobiTB<NW, RY, HX, HY>;
-    int bx, by;
-    tile_of_block(b, nx, ny, remap, bx, by);
-    const int x0 = xs + bx * G::VX, y0 = ys + by * G::VY;
-    const bool xedge = (x0 <= 0) || (x0 + G::TX >= w.W), yedge = (y0 <= 0) || (y0 + G::TY >= w.H);
-    const bool ragged = (w.W & 3) != 0 && x0 + G::TX >= w.W;
-    if (yedge || ragged) jacobi_tb_body<NW, RY, HX, HY, 2>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
-    else if (xedge) jacobi_tb_body<NW, RY, HX, HY, 1>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
-    else jacobi_tb_body<NW, RY, HX, HY, 0>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
-}
 
 template <int NW, int RYA, int RYB, int HX, int HY, int BPC>
 __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_mix(Win w, const float* __restrict__ p, const float* __restrict__ div,
@@ -960,16 +954,8 @@ __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_gs(Wi
                                                            float2* __restrict__ vel_out, float pscale, int iters, int ga, int gb, int xs,
                                                            int ys, int nx, int ny, int remap)
 {
-    using G = JacobiTB<NW, RY, HX, HY + 1>;
     __shared__ float4 mail[2][NW][2][64];
-    int bx, by;
-    tile_of_block((int)blockIdx.x, nx, ny, remap, bx, by);
-    const int x0 = xs + bx * G::VX, y0 = ys + by * G::VY;
-    const bool xedge = (x0 <= 0) || (x0 + G::TX >= w.W), yedge = (y0 <= 0) || (y0 + G::TY >= w.H);
-    const bool ragged = (w.W & 3) != 0 && x0 + G::TX >= w.W;
-    if (yedge || ragged) jacobi_tb_body<NW, RY, HX, HY + 1, 2, float, true>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail, vel, vel_out);
-    else if (xedge) jacobi_tb_body<NW, RY, HX, HY + 1, 1, float, true>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail, vel, vel_out);
-    else jacobi_tb_body<NW, RY, HX, HY + 1, 0, float, true>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail, vel, vel_out);
+    jacobi_tb_tile<NW, RY, HX, HY + 1, true>(w, p, div, p_out, pscale, iters, ga, gb, xs, ys, nx, ny, (int)blockIdx.x, remap, mail, vel, vel_out);
 }
 
 template <int NW, int RY, int HX, int HY, int BPC>
@@ -978,16 +964,8 @@ __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_gs_h(
                                                              __half2* __restrict__ vel_out, float pscale, int iters, int ga, int gb, int xs,
                                                              int ys, int nx, int ny, int remap)
 {
-    using G = JacobiTB<NW, RY, HX, HY + 1>;
     __shared__ float4 mail[2][NW][2][64];
-    int bx, by;
-    tile_of_block((int)blockIdx.x, nx, ny, remap, bx, by);
-    const int x0 = xs + bx * G::VX, y0 = ys + by * G::VY;
-    const bool xedge = (x0 <= 0) || (x0 + G::TX >= w.W), yedge = (y0 <= 0) || (y0 + G::TY >= w.H);
-    const bool ragged = (w.W & 3) != 0 && x0 + G::TX >= w.W;
-    if (yedge || ragged) jacobi_tb_body<NW, RY, HX, HY + 1, 2, __half, true>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail, vel, vel_out);
-    else if (xedge) jacobi_tb_body<NW, RY, HX, HY + 1, 1, __half, true>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail, vel, vel_out);
-    else jacobi_tb_body<NW, RY, HX, HY + 1, 0, __half, true>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail, vel, vel_out);
+    jacobi_tb_tile<NW, RY, HX, HY + 1, true>(w, p, div, p_out, pscale, iters, ga, gb, xs, ys, nx, ny, (int)blockIdx.x, remap, mail, vel, vel_out);
 }
 
 // the same tile on fp16-storage fields (FLUID_STORE_F16): half the bytes per launch; every iteration's output is rounded to
@@ -997,16 +975,8 @@ __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_h(Win
                                                           __half* __restrict__ p_out, float pscale, int iters, int ga, int gb,
                                                           int xs, int ys, int nx, int ny, int remap)
 {
-    using G = JacobiTB<NW, RY, HX, HY>;
     __shared__ float4 mail[2][NW][2][64];
-    int bx, by;
-    tile_of_block((int)blockIdx.x, nx, ny, remap, bx, by);
-    const int x0 = xs + bx * G::VX, y0 = ys + by * G::VY;
-    const bool xedge = (x0 <= 0) || (x0 + G::TX >= w.W), yedge = (y0 <= 0) || (y0 + G::TY >= w.H);
-    const bool ragged = (w.W & 3) != 0 && x0 + G::TX >= w.W;  // the tile holds the partly padded last quad
-    if (yedge || ragged) jacobi_tb_body<NW, RY, HX, HY, 2>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
-    else if (xedge) jacobi_tb_body<NW, RY, HX, HY, 1>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
-    else jacobi_tb_body<NW, RY, HX, HY, 0>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail);
+    jacobi_tb_tile<NW, RY, HX, HY>(w, p, div, p_out, pscale, iters, ga, gb, xs, ys, nx, ny, (int)blockIdx.x, remap, mail);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1240,16 +1210,15 @@ __device__ __forceinline__ void vort_div_body(const Win& w, const V2* __restrict
     }
 }
 
-template <int NW, int RY>
-__global__ void __launch_bounds__(64 * NW, VD_WAVES_PER_EU) k_curl_vort_div(Win w, const float2* __restrict__ vel, float* __restrict__ curl_out,
-                                                            float2* __restrict__ vel_out, float* __restrict__ div_out,
-                                                            float curl_strength, float dt, int ga, int gb, int xs, int ys, int nx, int ny,
-                                                            int remap)
+// tile `b` of an nx x ny tile set over rows [ga, gb): its place in the XCD-aware order, then the body with the border selects it needs
+template <int NW, int RY, class V2, class S1>
+__device__ __forceinline__ void vort_div_tile(const Win& w, const V2* __restrict__ vel, S1* __restrict__ curl_out, V2* __restrict__ vel_out,
+                                              S1* __restrict__ div_out, float curl_strength, float dt, int ga, int gb, int xs, int ys, int nx,
+                                              int ny, int b, int remap, float4 (*mail)[2][2][64])
 {
     using G = VortDiv<NW, RY>;
-    __shared__ float4 mail[NW][2][2][64];
     int bx, by;
-    tile_of_block((int)blockIdx.x, nx, ny, remap, bx, by);
+    tile_of_block(b, nx, ny, remap, bx, by);
     const int x0 = xs + bx * G::VX, y0 = ys + by * G::VY;
     const bool xedge = (x0 <= 0) || (x0 + G::TX >= w.W), yedge = (y0 <= 0) || (y0 + G::TY >= w.H);
     const bool ragged = (w.W & 3) != 0 && x0 + G::TX >= w.W;  // the tile holds the partly padded last quad
@@ -1259,21 +1228,23 @@ __global__ void __launch_bounds__(64 * NW, VD_WAVES_PER_EU) k_curl_vort_div(Win 
 }
 
 template <int NW, int RY>
+__global__ void __launch_bounds__(64 * NW, VD_WAVES_PER_EU) k_curl_vort_div(Win w, const float2* __restrict__ vel, float* __restrict__ curl_out,
+                                                            float2* __restrict__ vel_out, float* __restrict__ div_out,
+                                                            float curl_strength, float dt, int ga, int gb, int xs, int ys, int nx, int ny,
+                                                            int remap)
+{
+    __shared__ float4 mail[NW][2][2][64];
+    vort_div_tile<NW, RY>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, xs, ys, nx, ny, (int)blockIdx.x, remap, mail);
+}
+
+template <int NW, int RY>
 __global__ void __launch_bounds__(64 * NW, VD_WAVES_PER_EU) k_curl_vort_div_h(Win w, const __half2* __restrict__ vel, __half* __restrict__ curl_out,
                                                               __half2* __restrict__ vel_out, __half* __restrict__ div_out,
                                                               float curl_strength, float dt, int ga, int gb, int xs, int ys, int nx, int ny,
                                                               int remap)
 {
-    using G = VortDiv<NW, RY>;
     __shared__ float4 mail[NW][2][2][64];
-    int bx, by;
-    tile_of_block((int)blockIdx.x, nx, ny, remap, bx, by);
-    const int x0 = xs + bx * G::VX, y0 = ys + by * G::VY;
-    const bool xedge = (x0 <= 0) || (x0 + G::TX >= w.W), yedge = (y0 <= 0) || (y0 + G::TY >= w.H);
-    const bool ragged = (w.W & 3) != 0 && x0 + G::TX >= w.W;  // the tile holds the partly padded last quad
-    if (yedge || ragged) vort_div_body<NW, RY, 2>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
-    else if (xedge) vort_div_body<NW, RY, 1>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
-    else vort_div_body<NW, RY, 0>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
+    vort_div_tile<NW, RY>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, xs, ys, nx, ny, (int)blockIdx.x, remap, mail);
 }
 
 struct TileRects {
@@ -1287,22 +1258,13 @@ __global__ void __launch_bounds__(64 * NW, VD_WAVES_PER_EU) k_curl_vort_div_rect
                                                                   V2* __restrict__ vel_out, S1* __restrict__ div_out, float curl_strength,
                                                                   float dt, int remap)
 {
-    using G = VortDiv<NW, RY>;
     __shared__ float4 mail[NW][2][2][64];
     const int b = (int)blockIdx.x;
     int k = 0;
     while (k + 1 < R.n && b >= R.blk0[k + 1]) k++;
-    int bx, by;
-    tile_of_block(b - R.blk0[k], R.nx[k], R.ny[k], remap, bx, by);
     w.x0 = R.x0[k];
     w.x1 = R.x1[k];
-    const int ga = R.ga[k], gb = R.gb[k];
-    const int x0 = R.xs[k] + bx * G::VX, y0 = R.ys[k] + by * G::VY;
-    const bool xedge = (x0 <= 0) || (x0 + G::TX >= w.W), yedge = (y0 <= 0) || (y0 + G::TY >= w.H);
-    const bool ragged = (w.W & 3) != 0 && x0 + G::TX >= w.W;
-    if (yedge || ragged) vort_div_body<NW, RY, 2>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
-    else if (xedge) vort_div_body<NW, RY, 1>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
-    else vort_div_body<NW, RY, 0>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
+    vort_div_tile<NW, RY>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, R.ga[k], R.gb[k], R.xs[k], R.ys[k], R.nx[k], R.ny[k], b - R.blk0[k], remap, mail);
 }
 
 // the same kernel with smaller tiles for a launch's first and last rows (see k_jacobi_tb_mix: a launch is its bytes over the bandwidth
@@ -1316,26 +1278,8 @@ __global__ void __launch_bounds__(64 * NW, VD_WAVES_PER_EU) k_curl_vort_div_mix(
     const int b = (int)blockIdx.x;
     int k = 0;
     while (k + 1 < S.n && b >= S.blk0[k + 1]) k++;
-    int bx, by;
-    tile_of_block(b - S.blk0[k], nx, S.ny[k], remap, bx, by);
-    const int ga = S.g[k], gb = S.g[k + 1];
-    if (S.small[k]) {
-        using G = VortDiv<NW, RYB>;
-        const int x0 = xs + bx * G::VX, y0 = S.ys[k] + by * G::VY;
-        const bool xedge = (x0 <= 0) || (x0 + G::TX >= w.W), yedge = (y0 <= 0) || (y0 + G::TY >= w.H);
-        const bool ragged = (w.W & 3) != 0 && x0 + G::TX >= w.W;
-        if (yedge || ragged) vort_div_body<NW, RYB, 2>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
-        else if (xedge) vort_div_body<NW, RYB, 1>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
-        else vort_div_body<NW, RYB, 0>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
-    } else {
-        using G = VortDiv<NW, RYA>;
-        const int x0 = xs + bx * G::VX, y0 = S.ys[k] + by * G::VY;
-        const bool xedge = (x0 <= 0) || (x0 + G::TX >= w.W), yedge = (y0 <= 0) || (y0 + G::TY >= w.H);
-        const bool ragged = (w.W & 3) != 0 && x0 + G::TX >= w.W;
-        if (yedge || ragged) vort_div_body<NW, RYA, 2>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
-        else if (xedge) vort_div_body<NW, RYA, 1>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
-        else vort_div_body<NW, RYA, 0>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, ga, gb, x0, y0, mail);
-    }
+    if (S.small[k]) vort_div_tile<NW, RYB>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, S.g[k], S.g[k + 1], xs, S.ys[k], nx, S.ny[k], b - S.blk0[k], remap, mail);
+    else vort_div_tile<NW, RYA>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, S.g[k], S.g[k + 1], xs, S.ys[k], nx, S.ny[k], b - S.blk0[k], remap, mail);
 }
 
 #ifndef VD_NW_
