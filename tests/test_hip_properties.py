@@ -210,6 +210,38 @@ print(json.dumps(out))
 """
 
 
+@pytest.mark.parametrize("N,iters", [(1024, 20), (4096, 10), (4096, 3)])
+def test_jacobi_tiny_values_fused_equals_passes(N, iters):
+    """The temporally blocked Jacobi kernel against the per-pass one on fields whose left part is ordinary and whose right part lives around
+    1e-36 .. 1e-45: results that are subnormal AND inexact are where (s - div) * 0.25 and a fused multiply-add part ways, so this is the
+    case any rewrite of the update has to get through (profiles/r03/jacobi_fma_probe.txt: the fused form is 2 % faster and was not
+    shipped, because nothing on gfx950 tells a tile for free that it is safe — TRAPSTS.EXCP stays 0, tools/micro/trapsts_probe.hip)."""
+    import fluid_hip
+    cfg = {"SIM_RESOLUTION": N, "DYE_RESOLUTION": N, "PRESSURE_ITERATIONS": iters, "CURL": 0}
+    sims = [fluid_hip.FluidSim(canvas=(N, N), config=cfg, schedule=s, random=fluid_hip.mulberry32(5)) for s in ("passes", "fused")]
+    try:
+        rng = np.random.default_rng(N + iters)
+        H, W = sims[0].velocity.height, sims[0].velocity.width
+        scale = np.ones((H, W, 1), np.float32)
+        scale[:, W // 3:] = rng.choice(np.array([1e-36, 1e-37, 3e-38, 1e-38, 1e-39, 1e-41, 1e-44], np.float32), (H, W - W // 3, 1))
+        scale[H // 2:H // 2 + 37, :W // 3] = 1e-38                            # and a thin tiny band inside the ordinary part
+        vel = (rng.normal(0, 1, (H, W, 2)).astype(np.float32) * scale).astype(np.float32)
+        prs = (rng.normal(0, 1, (H, W)).astype(np.float32) * scale[..., 0]).astype(np.float32)
+        for s in sims:
+            s.write("velocity", vel)
+            s.write("pressure", prs)
+            s.step(0.016666, 1)
+        a, b = sims[0].read("pressure"), sims[1].read("pressure")
+        assert np.array_equal(a, b)
+        for k in ("velocity", "divergence"):
+            assert np.array_equal(sims[0].read(k), sims[1].read(k)), k
+        tiny = (b != 0) & (np.abs(b) < 1.1754944e-38)
+        assert tiny.any() and (np.abs(b) > 1e-3).any()                         # subnormal pressures and ordinary ones came out of the same launch
+    finally:
+        for s in sims:
+            s.close()
+
+
 @pytest.mark.gpu
 def test_every_knob_of_the_fused_schedule_yields_the_same_bits():
     """Jacobi tile shapes (incl. the deep small-grid ones and their gradient-subtract instantiations), K6 folded or not, the fast or
