@@ -153,10 +153,40 @@ def test_step_n_equals_n_steps():
         a.step(0.016666, 4)
         for _ in range(4):
             b.step(0.016666)
-        for k in ("velocity", "pressure", "dye"):
-            assert np.array_equal(a.read(k), b.read(k))
+        for k in ("velocity", "pressure", "divergence", "curl", "dye"):
+            assert np.array_equal(a.read(k), b.read(k)), k
     finally:
         a.close(); b.close()
+
+
+@pytest.mark.parametrize("canvas,res,n", [((5, 3), 3, 3), ((63, 64), 64, 2), ((64, 58), 58, 3), ((65, 59), 59, 4), ((130, 7), 7, 5), ((57, 300), 57, 3),
+                                          ((1001, 700), 700, 3), ((2048, 2048), 2048, 2), ((4096, 4096), 4096, 3)])
+def test_a_call_for_n_steps_leaves_what_n_calls_leave(canvas, res, n):
+    """fluid_step_n(n > 1) hands each step's advected velocity to the next step's curl / vorticity / divergence inside one launch
+    (k_advect_cvd: 64-column tiles of one texel per lane); every field afterwards — the curl and divergence of the LAST step included —
+    must be what n separate calls leave, and what the per-pass schedule leaves.  Shapes: narrower / lower than a tile, one texel past a tile,
+    widths that are no multiple of 4, the bench grid."""
+    import fluid_hip
+    cfg = {"SIM_RESOLUTION": res, "DYE_RESOLUTION": res, "PRESSURE_ITERATIONS": 12}
+    sims = [fluid_hip.FluidSim(canvas=canvas, config=cfg, schedule=s, random=fluid_hip.mulberry32(31)) for s in ("fused", "fused", "passes")]
+    try:
+        for s in sims:
+            s.multipleSplats(6)
+        sims[0].step(0.016666, n)
+        sims[2].step(0.016666, n)
+        for _ in range(n):
+            sims[1].step(0.016666)
+        for k in ("velocity", "pressure", "divergence", "curl", "dye"):
+            ref = sims[1].read(k)
+            assert np.array_equal(sims[0].read(k), ref), k
+            assert np.array_equal(sims[2].read(k), ref), k
+        sims[0].step(0.016666, 2)        # and the chain starts from whatever the last call left
+        sims[1].step(0.016666); sims[1].step(0.016666)
+        for k in ("velocity", "pressure", "divergence", "curl", "dye"):
+            assert np.array_equal(sims[0].read(k), sims[1].read(k)), k
+    finally:
+        for s in sims:
+            s.close()
 
 
 def _random_cases(n, seed):
@@ -254,6 +284,7 @@ def test_every_knob_of_the_fused_schedule_yields_the_same_bits():
     settings = [{}] + [{"FLUID_TB_VARIANT": str(v), "FLUID_FOLD_GRADSUB": f} for v in (0, 8, 9, 10, 11, 12, 13, 14, 15) for f in ("0", "1")]
     settings += [{"FLUID_TB_VARIANT": "0", "FLUID_FOLD_GRADSUB": "0", "FLUID_TB_TAIL": t} for t in ("0,130,5", "60,100,6", "100,0,7", "0,0,7")]   # small tiles for a launch's first / last rows
     settings += [{"FLUID_CVD_TAIL": t} for t in ("0,100", "60,90", "120,0")]   # the same for the curl / vorticity / divergence kernel
+    settings += [{"FLUID_CHAIN": "0"}] + [{"FLUID_CHAIN_TILE": t} for t in ("8,8,4", "4,8,4", "4,8,3", "16,8,4")]   # advection + the next step's curl / vorticity / divergence in one launch, or not
     settings += [{"FLUID_ADVECT_FAST": "0"}, {"FLUID_ADVECT_SPLIT_ROWS": "4"}, {"FLUID_ADVECT_SPLIT_ROWS": "1"}, {"FLUID_ADVECT_ROWS": "2"},
                  {"FLUID_TB_VARIANT": "1", "FLUID_FOLD_GRADSUB": "1"}, {"FLUID_TB_VARIANT": "5"}]
     ref = None
@@ -264,3 +295,31 @@ def test_every_knob_of_the_fused_schedule_yields_the_same_bits():
         if ref is None:
             ref = got
         assert got == ref, (env, got, ref)
+
+
+_CHAIN_CHILD = r"""
+import hashlib, json, sys
+sys.path.insert(0, %r)
+import fluid_hip
+cfg = {"SIM_RESOLUTION": 4096, "DYE_RESOLUTION": 4096, "PRESSURE_ITERATIONS": 20}
+with fluid_hip.FluidSim(canvas=(4096, 4096), config=cfg, schedule="fused", random=fluid_hip.mulberry32(1234)) as sim:
+    sim.multipleSplats(20)
+    sim.step(0.016666, 4)
+    print(json.dumps({k: hashlib.sha256(sim.read(k).tobytes()).hexdigest() for k in ("velocity", "pressure", "divergence", "curl", "dye")}))
+"""
+
+
+@pytest.mark.gpu
+def test_the_chained_launch_at_the_bench_size_yields_the_same_bits():
+    """above 3072^2 texels fluid_step_n keeps the separate advection and curl / vorticity / divergence launches by default
+    (fluid_solver.cpp chain_enabled); FLUID_CHAIN=1 is the A/B knob bench visits use, so its bits are pinned at 4096^2 too"""
+    import json
+    import subprocess
+    import sys
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "webgl-fluid-simulation_amd")
+    got = []
+    for v in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", _CHAIN_CHILD % pkg], env=dict(os.environ, FLUID_CHAIN=v), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-500:]
+        got.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert got[0] == got[1]

@@ -111,6 +111,12 @@ hipError_t launch_curl_vort_div_rects(hipStream_t s, Win w, const __half2* vel, 
 // the confined velocity and its divergence for rows [ga, gb).  Any width (the pitch keeps rows float4-aligned).  Bitwise equal to the three
 // single-pass kernels run in turn.
 bool fused_supported(Win w);
+// K7a + K7b of one step and K1 + K2 + K3 of the next in one launch (fluid_step_n, n > 1): `vel` is the projected velocity, `vel_out` receives
+// the next step's velocity after vorticity confinement; `curl` may be null (the field is then left as it is: only a chain's last launch
+// writes it).  fp32, dye grid = sim grid, whole domain.
+bool advect_cvd_supported(Win w, float dt, float vel_dissipation, float dye_dissipation);
+hipError_t launch_advect_cvd(hipStream_t s, Win w, const float2* vel, float2* vel_out, const float4* dye, float4* dye_out, float* curl,
+                             float* div, float dt, float vel_dissipation, float dye_dissipation, float curl_strength, int ga, int gb);
 hipError_t launch_curl_vort_div(hipStream_t s, Win w, const float2* vel, float* curl, float2* vel_out, float* div,
                                 float curl_strength, float dt, int ga, int gb);
 

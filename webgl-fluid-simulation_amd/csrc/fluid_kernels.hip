@@ -1282,6 +1282,234 @@ __global__ void __launch_bounds__(64 * NW, VD_WAVES_PER_EU) k_curl_vort_div_mix(
     else vort_div_tile<NW, RYA>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, S.g[k], S.g[k + 1], xs, S.ys[k], nx, S.ny[k], b - S.blk0[k], remap, mail);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// K7a + K7b of one step and K1 + K2 + K3 of the NEXT in one trip through HBM (fluid_step_n with n > 1, fluid_solver.cpp step_chain).
+// Between the advection of step k and the curl pass of step k + 1 nothing happens to the velocity (splats arrive between CALLS, and a
+// call that asks for n steps cannot be observed in between), so the advected velocity never has to reach memory: the tile advects it into
+// registers — for its texels and a 3-ring apron, by the arithmetic of k_advect_both_fast — advects the dye of its own texels with it, and
+// runs the three stencil stages of k_curl_vort_div on the registers.  Per texel: velocity 8 B in (+ taps, which hit the caches), dye
+// 16 + 16, velocity after vorticity 8, divergence 4 (+ curl 4 only in the launch whose curl field a caller can read: the last of the
+// chain) = 52 B against 49 + 25 for the two launches it replaces.
+// Layout: ONE texel per lane and row (what the gathers want: a wave's tap addresses span 64 texels, not 256), a wave = 64 columns x RY
+// rows, NW waves stacked in y with the three LDS mailbox exchanges of the stencil stages; x neighbours by DPP lane shifts, the x apron
+// (4 columns a side: 3 needed, 4 keeps the stored runs 32-byte aligned) by redundancy inside the wave.
+// Same fp32 operations in the same order on the same values as the two kernels: the same bits (tests: step(dt, n) against n x step(dt, 1)
+// and against the per-pass schedule).
+#ifndef FLUID_CHAIN_CH
+#define FLUID_CHAIN_CH 4
+#endif
+#ifndef FLUID_CHAIN_CHA
+#define FLUID_CHAIN_CHA 8   // rows of the velocity advection in flight together
+#endif
+template <int NW, int RY, int AX_>
+struct AdvectCvd {
+    static constexpr int TX = 64, TY = NW * RY, AX = AX_, AY = 3;
+    static constexpr int VX = TX - 2 * AX, VY = TY - 2 * AY;
+};
+
+// The kernel is bound by its arithmetic (70 M VALU wave-instructions per launch at 4096^2 in the first version, VALU-busy 0.53 of 214 us),
+// so everything that acts on an (x, y) pair is ONE packed instruction (v_pk_mul_f32 / v_pk_add_f32: two IEEE results, the same bits as two
+// scalar operations): the back-trace, the texel coordinates and weights of a fetch, the velocity filter.
+__device__ __forceinline__ v2f mix2(v2f a, v2f b, float t) { return a + (b - a) * v2f{ t, t }; }
+
+// taps32 on a packed coordinate: the same operations (x = u W - 1/2, floor, fraction, range test, 24-bit row multiply)
+template <unsigned SZ>
+__device__ __forceinline__ Tap4 taps32p(const Win& w, const TapBox& B, v2f uv)
+{
+    const v2f xy = uv * v2f{ (float)w.W, (float)w.H } - v2f{ 0.5f, 0.5f };
+    const v2f fl = v2f{ floorf(xy.x), floorf(xy.y) };
+    const v2f fr = xy - fl;
+    Tap4 t;
+    t.fx = fr.x;
+    t.fy = fr.y;
+    const int i0 = (int)fl.x, j0 = (int)fl.y;
+    if ((unsigned)(i0 - B.xlo) < B.nx && (unsigned)(j0 - B.ylo) < B.ny) {
+        const unsigned row_bytes = (unsigned)w.P * SZ;
+        const unsigned k = 0u - (unsigned)(w.g0 * w.P + w.c0) * SZ;
+        t.a = __umul24((unsigned)j0, row_bytes) + k + (unsigned)i0 * SZ;
+        t.b = t.a + SZ;
+        t.c = t.a + row_bytes;
+        t.d = t.c + SZ;
+        t.miss = 0;
+    } else {  // bil_taps, fluid_math.h
+        const int ia = clampi(i0, 0, w.W - 1), ib = clampi(i0 + 1, 0, w.W - 1);
+        const int ja = clampi(j0, 0, w.H - 1), jb = clampi(j0 + 1, 0, w.H - 1);
+        t.miss = 0;
+        const int la = clampi(ja - w.g0, 0, w.rows - 1), lb = clampi(jb - w.g0, 0, w.rows - 1);
+        const int ka = clampi(ia - w.c0, 0, w.P - 1), kb = clampi(ib - w.c0, 0, w.P - 1);
+        t.a = (unsigned)(la * w.P + ka) * SZ;
+        t.b = (unsigned)(la * w.P + kb) * SZ;
+        t.c = (unsigned)(lb * w.P + ka) * SZ;
+        t.d = (unsigned)(lb * w.P + kb) * SZ;
+    }
+    return t;
+}
+
+// BORDER: the tile touches the domain's edge (CLAMP_TO_EDGE selects, reflecting walls, lanes / rows past the last column / row);
+// an interior tile (88 % of a 4096^2 grid) runs without any of it
+template <int NW, int RY, int AX_, bool CURL_OUT, bool BORDER>
+__device__ __forceinline__ void advect_cvd_body(const Win& w, const float2* __restrict__ vel, float2* __restrict__ vel_out,
+                                                const float4* __restrict__ dye, float4* __restrict__ dye_out, float* __restrict__ curl_out,
+                                                float* __restrict__ div_out, float dt, double rW, double rH, double rvd, double rdd, float tsx,
+                                                float tsy, float curl_strength, int ga, int gb, int x0, int y0, float (*mail)[2][3][64])
+{
+    using G = AdvectCvd<NW, RY, AX_>;
+    constexpr int CH = FLUID_CHAIN_CH;  // rows whose gathers are in flight together (k_advect_both_fast: four texels per thread)
+    static_assert(RY % CH == 0, "rows per wave in whole chunks");
+    const int lane = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int cx = x0 + lane, gy = y0 + wv * RY;
+    const int i = BORDER ? min(cx, w.W - 1) : cx;  // a lane past the last column repeats it (never stored; column W - 1 overrides what it would lend)
+    const bool at_left = BORDER && cx == 0, at_right = BORDER && cx == w.W - 1;
+    const int wb = wv > 0 ? wv - 1 : 0, wa = wv < NW - 1 ? wv + 1 : NW - 1;
+    const TapBox B = tap_box(w);
+    const float u = div_uniform((float)i + 0.5f, rW);
+    const v2f dt2 = v2f{ dt, dt }, ts2 = v2f{ tsx, tsy };
+    const unsigned col = (unsigned)(i - w.c0);
+    auto row_of = [&](int r) { return BORDER ? min(gy + r, w.H - 1) : gy + r; };  // a row past the domain repeats the last one (wave-uniform)
+
+    // ---- K7a for the wave's RY rows: V = advected velocity.  CHA rows' loads in flight together: the launch is bound by how many dependent
+    // round trips through memory a tile makes (own velocity -> its taps -> the dye taps), not by bytes or arithmetic ----
+    constexpr int CHA = FLUID_CHAIN_CHA < RY ? FLUID_CHAIN_CHA : RY;
+    static_assert(RY % CHA == 0, "rows per wave in whole chunks");
+    v2f V[RY];
+    auto vc_of = [&](int r) { return div_uniform((float)row_of(r) + 0.5f, rH); };  // the row's v coordinate (recomputed where needed: three instructions against a register per row)
+#pragma unroll
+    for (int r0 = 0; r0 < RY; r0 += CHA) {
+        v2f vv[CHA];
+#pragma unroll
+        for (int k = 0; k < CHA; k++) {
+            const float2 q = ld(at_byte(vel, ((unsigned)((row_of(r0 + k) - w.g0) * w.P) + col) * 8u), 0);
+            vv[k] = v2f{ q.x, q.y };
+        }
+        Tap4 t[CHA];
+        Fetch2 f2[CHA];
+#pragma unroll
+        for (int k = 0; k < CHA; k++) t[k] = taps32p<8>(w, B, v2f{ u, vc_of(r0 + k) } - dt2 * vv[k] * ts2);
+        gather_taps<CHA>(vel, t, f2);
+#pragma unroll
+        for (int k = 0; k < CHA; k++) {
+            const Fetch2& f = f2[k];
+            const v2f m = mix2(mix2(v2f{ f.a.x, f.a.y }, v2f{ f.b.x, f.b.y }, f.fx), mix2(v2f{ f.c.x, f.c.y }, v2f{ f.d.x, f.d.y }, f.fx), f.fy);
+            V[r0 + k] = v2f{ div_uniform(m.x, rvd), div_uniform(m.y, rvd) };
+        }
+    }
+
+    int xa, xb, out_lo, out_hi;
+    tile_exact(x0, G::TX, G::AX, w.W, w.x0, w.x1, xa, xb);
+    tile_exact(y0, G::TY, G::AY, w.H, ga, gb, out_lo, out_hi);
+    const bool col_store = (cx >= xa) && (cx < xb);
+
+    // ---- K7b for the texels this tile stores, CH rows at a time (the apron columns sit it out; an apron row costs its gathers: 6 of
+    // NW * RY) ----
+    if (col_store) {
+#pragma unroll
+        for (int r0 = 0; r0 < RY; r0 += CH) {
+            if (gy + r0 + CH <= out_lo || gy + r0 >= out_hi) continue;  // wave-uniform
+            Tap4 t[CH];
+            Fetch4 f4[CH];
+#pragma unroll
+            for (int k = 0; k < CH; k++) t[k] = taps32p<16>(w, B, v2f{ u, vc_of(r0 + k) } - dt2 * V[r0 + k] * ts2);
+            gather_taps<CH>(dye, t, f4);
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                const Fetch4& f = f4[k];
+                const v2f lo = mix2(mix2(v2f{ f.a.x, f.a.y }, v2f{ f.b.x, f.b.y }, f.fx), mix2(v2f{ f.c.x, f.c.y }, v2f{ f.d.x, f.d.y }, f.fx), f.fy);
+                const v2f hi = mix2(mix2(v2f{ f.a.z, f.a.w }, v2f{ f.b.z, f.b.w }, f.fx), mix2(v2f{ f.c.z, f.c.w }, v2f{ f.d.z, f.d.w }, f.fx), f.fy);
+                const int gj = gy + r0 + k;
+                if (gj >= out_lo && gj < out_hi)
+                    *at_byte(dye_out, ((unsigned)((gj - w.g0) * w.P) + col) * 16u) =
+                        make_float4(div_uniform(lo.x, rdd), div_uniform(lo.y, rdd), div_uniform(hi.x, rdd), div_uniform(hi.y, rdd));
+            }
+        }
+    }
+
+    // ---- K1 of the next step: curl of the advected velocity (vx of the rows below / above, vy of the columns left / right) ----
+    mail[wv][0][0][lane] = V[0].x;
+    mail[wv][1][0][lane] = V[RY - 1].x;
+    __syncthreads();
+    const float vxb = mail[wb][1][0][lane], vxa = mail[wa][0][0][lane];
+    float C[RY];
+#pragma unroll
+    for (int r = 0; r < RY; r++) {
+        const int gj = gy + r;
+        float L = from_left_lane(V[r].y), R = from_right_lane(V[r].y);
+        float Bq = r > 0 ? V[r > 0 ? r - 1 : 0].x : vxb, T = r < RY - 1 ? V[r < RY - 1 ? r + 1 : r].x : vxa;
+        if (BORDER) {  // CLAMP_TO_EDGE: an off-domain neighbour is the texel itself
+            if (at_left) L = V[r].y;
+            if (at_right) R = V[r].y;
+            if (gj == 0) Bq = V[r].x;
+            if (gj == w.H - 1) T = V[r].x;
+        }
+        const float vort = R - L - T + Bq;
+        C[r] = 0.5f * vort;
+    }
+
+    // ---- K2: vorticity confinement (curl of the four neighbours) ----
+    mail[wv][0][1][lane] = C[0];
+    mail[wv][1][1][lane] = C[RY - 1];
+    __syncthreads();
+    const float cb = mail[wb][1][1][lane], ca = mail[wa][0][1][lane];
+    float2 N[RY];
+#pragma unroll
+    for (int r = 0; r < RY; r++) {
+        const int gj = gy + r;
+        float L = from_left_lane(C[r]), R = from_right_lane(C[r]);
+        float Bq = r > 0 ? C[r > 0 ? r - 1 : 0] : cb, T = r < RY - 1 ? C[r < RY - 1 ? r + 1 : r] : ca;
+        if (BORDER) {
+            if (at_left) L = C[r];
+            if (at_right) R = C[r];
+            if (gj == 0) Bq = C[r];
+            if (gj == w.H - 1) T = C[r];
+        }
+        N[r] = vorticity_cell(L, R, T, Bq, C[r], make_float2(V[r].x, V[r].y), curl_strength, dt);
+    }
+
+    // ---- K3: divergence of the new velocity, reflecting walls (script.js:804-807) ----
+    mail[wv][0][2][lane] = N[0].y;
+    mail[wv][1][2][lane] = N[RY - 1].y;
+    __syncthreads();
+    const float nyb = mail[wb][1][2][lane], nya = mail[wa][0][2][lane];
+#pragma unroll
+    for (int r = 0; r < RY; r++) {
+        const int gj = gy + r;
+        float L = from_left_lane(N[r].x), R = from_right_lane(N[r].x);
+        float Bq = r > 0 ? N[r > 0 ? r - 1 : 0].y : nyb, T = r < RY - 1 ? N[r < RY - 1 ? r + 1 : r].y : nya;
+        if (BORDER) {
+            if (at_left) L = -N[r].x;
+            if (at_right) R = -N[r].x;
+            if (gj == w.H - 1) T = -N[r].y;
+            if (gj == 0) Bq = -N[r].y;
+        }
+        const float dv = 0.5f * (R - L + T - Bq);
+        if (col_store && gj >= out_lo && gj < out_hi) {
+            const unsigned c = (unsigned)((gj - w.g0) * w.P) + col;
+            if (CURL_OUT) *at_byte(curl_out, c * 4u) = C[r];
+            *at_byte(div_out, c * 4u) = dv;
+            *at_byte(vel_out, c * 8u) = N[r];
+        }
+    }
+}
+
+template <int NW, int RY, int AX_, bool CURL_OUT>
+__global__ void __launch_bounds__(64 * NW, 4) k_advect_cvd(Win w, const float2* __restrict__ vel, float2* __restrict__ vel_out,
+                                                                         const float4* __restrict__ dye, float4* __restrict__ dye_out,
+                                                                         float* __restrict__ curl_out, float* __restrict__ div_out, float dt,
+                                                                         double rW, double rH, double rvd, double rdd, float tsx, float tsy,
+                                                                         float curl_strength, int ga, int gb, int xs, int ys, int nx, int ny,
+                                                                         int remap)
+{
+    using G = AdvectCvd<NW, RY, AX_>;
+    __shared__ float mail[NW][2][3][64];  // [wave][first / last row][stage][lane]
+    int bx, by;
+    tile_of_block((int)blockIdx.x, nx, ny, remap, bx, by);
+    const int x0 = xs + bx * G::VX, y0 = ys + by * G::VY;
+    if (x0 <= 0 || x0 + G::TX >= w.W || y0 <= 0 || y0 + G::TY >= w.H)
+        advect_cvd_body<NW, RY, AX_, CURL_OUT, true>(w, vel, vel_out, dye, dye_out, curl_out, div_out, dt, rW, rH, rvd, rdd, tsx, tsy, curl_strength, ga, gb, x0, y0, mail);
+    else
+        advect_cvd_body<NW, RY, AX_, CURL_OUT, false>(w, vel, vel_out, dye, dye_out, curl_out, div_out, dt, rW, rH, rvd, rdd, tsx, tsy, curl_strength, ga, gb, x0, y0, mail);
+}
+
 #ifndef VD_NW_
 #define VD_NW_ 8
 #endif
@@ -1831,6 +2059,58 @@ hipError_t launch_curl_vort_div(hipStream_t s, Win w, const __half2* vel, __half
     k_curl_vort_div_h<VD_NW, VD_RY><<<dim3(ax.n * ay.n, 1, 1), dim3(64, VD_NW, 1), 0, s>>>(w, vel, curl, vel_out, div, curl_strength, dt, ga,
                                                                                       gb, ax.S, ay.S, ax.n, ay.n, cvd_remap());
     return hipGetLastError();
+}
+
+// K7a + K7b + the next step's K1 + K2 + K3 (k_advect_cvd) apply to: fp32 fields on one grid held by one domain, wherever the fast advection
+// and the fused curl / vorticity / divergence kernels both do.  (Whether fluid_step_n uses it: fluid_solver.cpp chain_enabled.)
+bool advect_cvd_supported(Win w, float dt, float vel_dissipation, float dye_dissipation)
+{
+    const float vdecay = 1.0f + vel_dissipation * dt, ddecay = 1.0f + dye_dissipation * dt;
+    return fused_supported(w) && advect_fast_ok(w, sizeof(float4), vdecay, ddecay) && w.g0 == 0 && w.c0 == 0 && w.rows == w.H && w.x0 == 0 &&
+           w.x1 == w.W;
+}
+
+static void advect_cvd_shape(int& nw, int& ry, int& ax)  // FLUID_CHAIN_TILE="waves,rows,apron columns" (A/B knob): 8,8,3 (default) | 8,8,4 | 4,8,4 | 4,8,3 | 16,8,4
+{
+    static const int forced = [] {
+        int a = 8, b = 8, c = 3;
+        if (const char* e = getenv("FLUID_CHAIN_TILE")) sscanf(e, "%d,%d,%d", &a, &b, &c);
+        return a * 10000 + b * 100 + c;
+    }();
+    nw = forced / 10000;
+    ry = forced / 100 % 100;
+    ax = forced % 100;
+}
+
+hipError_t launch_advect_cvd(hipStream_t s, Win w, const float2* vel, float2* vel_out, const float4* dye, float4* dye_out, float* curl,
+                             float* div, float dt, float vel_dissipation, float dye_dissipation, float curl_strength, int ga, int gb)
+{
+    ROWS_OR_RETURN();
+    if (!advect_cvd_supported(w, dt, vel_dissipation, dye_dissipation)) return hipErrorInvalidValue;
+    const float tsx = (float)(1.0 / w.W), tsy = (float)(1.0 / w.H);
+    const float vdecay = 1.0f + vel_dissipation * dt, ddecay = 1.0f + dye_dissipation * dt;
+    const double rW = udiv_recip((float)w.W), rH = udiv_recip((float)w.H), rvd = udiv_recip(vdecay), rdd = udiv_recip(ddecay);
+    int nw, ry, apron;
+    advect_cvd_shape(nw, ry, apron);
+#define ADVECT_CVD_CASE(NW_, RY_, AX_)                                                                                                  \
+    if (nw == NW_ && ry == RY_ && apron == AX_) {                                                                                       \
+        using G = AdvectCvd<NW_, RY_, AX_>;                                                                                             \
+        const Axis ax = make_axis(w.x0, w.x1, w.W, G::TX, G::AX), ay = make_axis(ga, gb, w.H, G::TY, G::AY);                            \
+        if (curl)                                                                                                                       \
+            k_advect_cvd<NW_, RY_, AX_, true><<<dim3(ax.n * ay.n, 1, 1), dim3(64, NW_, 1), 0, s>>>(                                     \
+                w, vel, vel_out, dye, dye_out, curl, div, dt, rW, rH, rvd, rdd, tsx, tsy, curl_strength, ga, gb, ax.S, ay.S, ax.n, ay.n, cvd_remap()); \
+        else                                                                                                                            \
+            k_advect_cvd<NW_, RY_, AX_, false><<<dim3(ax.n * ay.n, 1, 1), dim3(64, NW_, 1), 0, s>>>(                                    \
+                w, vel, vel_out, dye, dye_out, curl, div, dt, rW, rH, rvd, rdd, tsx, tsy, curl_strength, ga, gb, ax.S, ay.S, ax.n, ay.n, cvd_remap()); \
+        return hipGetLastError();                                                                                                       \
+    }
+    ADVECT_CVD_CASE(8, 8, 4)
+    ADVECT_CVD_CASE(8, 8, 3)
+    ADVECT_CVD_CASE(4, 8, 4)
+    ADVECT_CVD_CASE(4, 8, 3)
+    ADVECT_CVD_CASE(16, 8, 4)
+#undef ADVECT_CVD_CASE
+    return hipErrorInvalidValue;
 }
 
 // the tile shape for a pass over `texels` owned texels: the forced one (FLUID_TB_VARIANT), or by grid size

@@ -398,11 +398,14 @@ void advect_both_swap(fluid_ctx* c)
 namespace {
 
 // step(dt), script.js:1231-1294 — whole-domain contexts (a stripe runs the plan of fluid_stripes.cpp, with
-// ghost-row exchanges between the pass groups)
-int step_once(fluid_ctx* c, float dt, const fluid_params* P)
+// ghost-row exchanges between the pass groups).
+// `lead`: the step starts with its own curl / vorticity / divergence launch (false: the previous step's advection launch already ran them,
+// k_advect_cvd).  `chain`: 0 = the step ends with the advection launch; 1 / 2 = it ends with the launch that advects AND runs the next
+// step's curl / vorticity / divergence (2: and writes the curl field — the chain's last such launch, whose curl a caller can read).
+int step_once(fluid_ctx* c, float dt, const fluid_params* P, bool lead = true, int chain = 0)
 {
     Timer t(c);
-    CK(pass_curl_vort_div(c, P->curl, dt, 0, &t));
+    if (lead) CK(pass_curl_vort_div(c, P->curl, dt, 0, &t));
     int launches = 0;
     const bool fold_clear = jacobi_tb_applies(c) && P->iterations > 0;
     if (!fold_clear) {
@@ -416,13 +419,48 @@ int step_once(fluid_ctx* c, float dt, const fluid_params* P)
         CK(pass_gradsub(c, 0));
     }
     t.mark(P_GRADSUB);
-    CK(pass_advect(c, dt, P->velocity_dissipation, P->density_dissipation, &t));
+    if (chain) {
+        int ga, gb;
+        sim_band(c, 0, ga, gb);
+        CK(c->hip(fluid::launch_advect_cvd(c->stream, sim_cols(c, 0), (const float2*)c->vel[0], (float2*)c->vel[1], (const float4*)c->dyeb[0],
+                                           (float4*)c->dyeb[1], chain == 2 ? (float*)c->curl : nullptr, (float*)c->div, dt,
+                                           P->velocity_dissipation, P->density_dissipation, P->curl, ga, gb),
+                  "advect + curl_vort_div"));
+        std::swap(c->vel[0], c->vel[1]);
+        std::swap(c->dyeb[0], c->dyeb[1]);
+        t.mark(P_ADVD);  // charged to the advection: the next step's vorticity column then reads 0
+    } else {
+        CK(pass_advect(c, dt, P->velocity_dissipation, P->density_dissipation, &t));
+    }
     if (c->timing) {
         c->acc_steps++;
         c->acc_jacobi_launches += launches;
         c->acc_folded_launches += gradsub_done ? 1 : 0;
     }
     return FLUID_OK;
+}
+
+// n steps in one call: nobody sees the fields between them, so each step but the last hands its advected velocity to the next step's
+// curl / vorticity / divergence inside one launch (k_advect_cvd) instead of through memory.  After the call every field holds what n
+// separate calls leave (tests/test_hip_properties.py::test_step_n_equals_n_steps, bitwise).
+// FLUID_CHAIN=0 / 1 forces it off / on (A/B knob; same bits either way).  Default: below 3072^2 texels, like the folded gradient subtract
+// and for the same reason: there a step is a chain of latency-bound launches and one launch fewer is worth 4-7 % (1024^2: 13.3 k -> 13.9 k
+// steps/s, 2048^2: 6.3 k -> 6.75 k).  At 4096^2 the combined launch has the bytes of 0.70 of the two it replaces and takes their time
+// (200-222 us against 142 + 73): one texel per lane is what the gathers want and costs the stencil stages a 22 % apron, and at 62-70 M
+// VALU wave-instructions the launch is bound by issue slots, not by bytes (profiles/r03/advect_cvd_chain.txt).
+bool chain_enabled(long owned_texels)
+{
+    static const int mode = [] {
+        const char* e = getenv("FLUID_CHAIN");
+        return e ? (atoi(e) != 0 ? 1 : 0) : -1;
+    }();
+    return mode >= 0 ? mode == 1 : owned_texels < 3072l * 3072l;
+}
+
+bool chain_applies(const fluid_ctx* c, float dt, const fluid_params* P)
+{
+    return c->storage == FLUID_STORE_F32 && fused_cvd_applies(c) && fused_advect_applies(c) && chain_enabled((long)c->sim_ncols * c->sim_rows) &&
+           fluid::advect_cvd_supported(sim_cols(c, 0), dt, P->velocity_dissipation, P->density_dissipation);
 }
 
 }  // namespace
@@ -662,6 +700,10 @@ int fluid_step_n(fluid_ctx* c, int n, float dt, const fluid_params* P)
     if (P->iterations < 0) return c->fail(FLUID_ERR_INVALID, "negative PRESSURE_ITERATIONS");
     HIPCK(c, hipSetDevice(c->device));
     if (c->desc.parts != 1 || c->desc.parts_x != 1) return stripe_step_n(c, n, dt, P);  // ghost-row exchanges over RCCL (fluid_stripes.cpp)
+    if (n > 1 && chain_applies(c, dt, P)) {
+        for (int k = 0; k < n; k++) CK(step_once(c, dt, P, k == 0, k == n - 1 ? 0 : (k == n - 2 ? 2 : 1)));
+        return FLUID_OK;
+    }
     for (int k = 0; k < n; k++) CK(step_once(c, dt, P));
     return FLUID_OK;
 }
