@@ -2070,10 +2070,12 @@ bool advect_cvd_supported(Win w, float dt, float vel_dissipation, float dye_diss
            w.x1 == w.W;
 }
 
-static void advect_cvd_shape(int& nw, int& ry, int& ax)  // FLUID_CHAIN_TILE="waves,rows,apron columns" (A/B knob): 8,8,3 (default) | 8,8,4 | 4,8,4 | 4,8,3 | 16,8,4
+static void advect_cvd_shape(int& nw, int& ry, int& ax)  // FLUID_CHAIN_TILE="waves,rows,apron columns" (A/B knob): 4,8,3 (default) | 4,8,4 | 8,8,3 | 8,8,4 | 16,8,4.  Four waves of eight rows: 64 x 32
+// texels, of which 58 x 26 are stored — on the small grids that chain by default the smaller workgroup wins (1024^2: 14.6 k steps/s against
+// 13.9 k with eight waves, 2048^2: 6.9 k against 6.7 k); at 4096^2 the two are level (profiles/r03/advect_cvd_chain.txt)
 {
     static const int forced = [] {
-        int a = 8, b = 8, c = 3;
+        int a = 4, b = 8, c = 3;
         if (const char* e = getenv("FLUID_CHAIN_TILE")) sscanf(e, "%d,%d,%d", &a, &b, &c);
         return a * 10000 + b * 100 + c;
     }();
