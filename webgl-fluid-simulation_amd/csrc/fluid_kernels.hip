@@ -1052,6 +1052,9 @@ __global__ void __launch_bounds__(256) k_gradsub4_h(Win w, const __half* __restr
 #ifndef VD_WAVES_PER_EU
 #define VD_WAVES_PER_EU 4
 #endif
+#ifndef FLUID_CVD_PIN
+#define FLUID_CVD_PIN 1   // 0: A/B builds without the scheduling pin of stage 2 (tools/build_variant.sh)
+#endif
 template <int NW, int RY>
 struct VortDiv {
     static constexpr int TX = 256, TY = NW * RY, AX = 4, AY = 3;
@@ -1160,7 +1163,10 @@ __device__ __forceinline__ void vort_div_body(const Win& w, const V2* __restrict
                 if (gj == 0) B = C[r][k];
                 if (gj == w.H - 1) T = C[r][k];
             }
-            const float2 conf = vorticity_cell(L, R, T, B, C[r][k], make_float2(V[r].x[k], V[r].y[k]), curl_strength, dt);
+            float2 conf = vorticity_cell(L, R, T, B, C[r][k], make_float2(V[r].x[k], V[r].y[k]), curl_strength, dt);
+#if FLUID_CVD_PIN
+            asm volatile("" : "+v"(conf.x), "+v"(conf.y));  // finished HERE: left alone, the tail of a divide is sunk into the store branch of stage 3 and its operand spilled on the way
+#endif
             N[r].x[k] = kept(vel_out, conf.x);  // likewise the divergence pass reads the stored velocity
             N[r].y[k] = kept(vel_out, conf.y);
         }
