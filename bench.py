@@ -198,6 +198,7 @@ def collect_traffic(args, deadline, steps_under_profiler: int = 4):
 
 
 N_SIMD = 256 * 4   # MI355X: 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
+JACOBI_ISSUE_COST = round((9 * 1.67 + 2 * 1.55) / 11, 2)   # issue slots per instruction of the Jacobi sweep, relative to v_fma_f32 (see roofline.valu)
 
 
 def collect_valu(args, deadline, kernel_prefixes):
@@ -601,7 +602,8 @@ def main(argv=None, engine_factory=None, backend="nccl"):
                     "algorithmic_* = the reference's 12 B/cell/iteration for the iterations this launch performs (a speed-up over the "
                     "pass structure, may exceed the peak); bound = the larger of the memory term (frac_of_attainable: achieved / the "
                     "guide's measured 6.29 TB/s streaming ceiling) and the arithmetic term (valu.busy_frac: the average SIMD's "
-                    "VALU-issuing cycles / the launch's cycles, SQ counters of this run)",
+                    "VALU-issuing cycles / the launch's cycles, SQ counters of this run, x the issue cost of the sweep's instruction mix: "
+                    "valu.busy_frac_issue_cost)",
         }
         # the two phases of a temporally blocked launch, timed in this run: ONE iteration (the tile's loads and stores: the memory
         # phase) against the full depth (each further iteration is arithmetic on registers)
@@ -624,8 +626,14 @@ def main(argv=None, engine_factory=None, backend="nccl"):
                     valu["effective_clock_GHz"] = round(gui / inst / (avg_ms * 1e6), 3)
                 else:
                     valu["busy_frac"] = round(valu["busy_ms_at_max_clock"] / avg_ms, 4)
+                # busy_frac prices every instruction at one 4-cycle issue (the counter ticks once per instruction: cycles_per_inst reads 4.0).
+                # On gfx950 only v_fma_f32 costs that; the sweep's own mix — nine v_pk_add/mul_f32 and two v_add_f32_dpp per four texels —
+                # costs 1.65 x (tools/micro/valu_rate2.hip: v_pk_* 1.67, *_dpp 1.55 of a v_fma_f32 slot; profiles/r02/advect_experiments.txt).
+                # A MODEL on top of the measured count, hence its own field; the bound is decided with it.
+                valu["issue_cost_factor_model"] = JACOBI_ISSUE_COST
+                valu["busy_frac_issue_cost"] = round(min(valu["busy_frac"] * JACOBI_ISSUE_COST, 1.0), 4)
                 roof["valu"] = valu
-                if valu["busy_frac"] > roof["frac_of_attainable"]:
+                if valu["busy_frac_issue_cost"] > roof["frac_of_attainable"]:
                     roof["bound"] = "valu"
             else:
                 roof["valu"] = {"busy_frac": None, "why": vwhy}

@@ -47,7 +47,8 @@ def test_bench_line_is_live_and_consistent():
     assert v is not None and ("why" in v or 0 < v["busy_frac"] <= 1.0)
     assert r["bound"] in ("hbm", "valu")
     if v.get("busy_frac"):
-        assert r["bound"] == ("valu" if v["busy_frac"] > r["frac_of_attainable"] else "hbm")
+        assert abs(min(v["busy_frac"] * v["issue_cost_factor_model"], 1.0) - v["busy_frac_issue_cost"]) <= 1e-4
+        assert r["bound"] == ("valu" if v["busy_frac_issue_cost"] > r["frac_of_attainable"] else "hbm")
     assert r["mem_phase_ms"] > 0 and r["valu_phase_ms"] >= 0
     assert d["steady_ms_per_step"] > 0 and d["speedup_vs_pass_structure"]["x_hbm_peak"] > 0
 
