@@ -1290,7 +1290,7 @@ __global__ void __launch_bounds__(64 * NW, VD_WAVES_PER_EU) k_curl_vort_div_mix(
 
 
 // ------------------------------------------------------------------------------------------------
-// K7a + K7b of one step and K1 + K2 + K3 of the NEXT in one trip through HBM (fluid_step_n with n > 1, fluid_solver.cpp step_chain).
+// K7a + K7b of one step and K1 + K2 + K3 of the NEXT in one trip through HBM (fluid_step_n with n > 1, fluid_solver.cpp step_once(lead, chain)).
 // Between the advection of step k and the curl pass of step k + 1 nothing happens to the velocity (splats arrive between CALLS, and a
 // call that asks for n steps cannot be observed in between), so the advected velocity never has to reach memory: the tile advects it into
 // registers — for its texels and a 3-ring apron, by the arithmetic of k_advect_both_fast — advects the dye of its own texels with it, and
@@ -1299,11 +1299,12 @@ __global__ void __launch_bounds__(64 * NW, VD_WAVES_PER_EU) k_curl_vort_div_mix(
 // chain) = 52 B against 49 + 25 for the two launches it replaces.
 // Layout: ONE texel per lane and row (what the gathers want: a wave's tap addresses span 64 texels, not 256), a wave = 64 columns x RY
 // rows, NW waves stacked in y with the three LDS mailbox exchanges of the stencil stages; x neighbours by DPP lane shifts, the x apron
-// (4 columns a side: 3 needed, 4 keeps the stored runs 32-byte aligned) by redundancy inside the wave.
+// (AX columns a side: the three stencil stages need 3; 4 would keep the stored runs 32-byte aligned and measures the same) by redundancy
+// inside the wave.
 // Same fp32 operations in the same order on the same values as the two kernels: the same bits (tests: step(dt, n) against n x step(dt, 1)
 // and against the per-pass schedule).
 #ifndef FLUID_CHAIN_CH
-#define FLUID_CHAIN_CH 4
+#define FLUID_CHAIN_CH 4    // rows of the dye advection in flight together
 #endif
 #ifndef FLUID_CHAIN_CHA
 #define FLUID_CHAIN_CHA 8   // rows of the velocity advection in flight together
