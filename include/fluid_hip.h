@@ -146,7 +146,11 @@ int fluid_splat(fluid_ctx *ctx, float x, float y, float dx, float dy, float r, f
 
 /* step(dt), script.js:1231-1294.  On a stripe context (parts > 1): this rank's share, see the multi-GPU block below */
 int fluid_step(fluid_ctx *ctx, float dt, const fluid_params *params);
-/* n consecutive step(dt) without returning to the host (the benchmark loop) */
+/* n consecutive step(dt) without returning to the host (replays, offline runs, the benchmark loop).  Afterwards every field holds exactly
+ * what n calls of fluid_step leave — velocity, pressure, dye, and the divergence and curl of the LAST step; what lies between two of the n
+ * steps is nobody's to read, and on one grid held by one domain (fp32, below 3072^2 texels by default) the library uses that: each step's
+ * advection launch also runs the next step's curl / vorticity / divergence on the velocity it has just advected, which then never goes
+ * through memory (k_advect_cvd). */
 int fluid_step_n(fluid_ctx *ctx, int n, float dt, const fluid_params *params);
 
 int fluid_sync(fluid_ctx *ctx);
