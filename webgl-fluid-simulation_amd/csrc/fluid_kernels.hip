@@ -1499,7 +1499,7 @@ __device__ __forceinline__ void advect_cvd_body(const Win& w, const float2* __re
 }
 
 template <int NW, int RY, int AX_, bool CURL_OUT>
-__global__ void __launch_bounds__(64 * NW, 4) k_advect_cvd(Win w, const float2* __restrict__ vel, float2* __restrict__ vel_out,
+__global__ void __launch_bounds__(64 * NW, RY <= 4 ? 5 : 4) k_advect_cvd(Win w, const float2* __restrict__ vel, float2* __restrict__ vel_out,
                                                                          const float4* __restrict__ dye, float4* __restrict__ dye_out,
                                                                          float* __restrict__ curl_out, float* __restrict__ div_out, float dt,
                                                                          double rW, double rH, double rvd, double rdd, float tsx, float tsy,
@@ -2077,18 +2077,21 @@ bool advect_cvd_supported(Win w, float dt, float vel_dissipation, float dye_diss
            w.x1 == w.W;
 }
 
-static void advect_cvd_shape(int& nw, int& ry, int& ax)  // FLUID_CHAIN_TILE="waves,rows,apron columns" (A/B knob): 4,8,3 (default) | 4,8,4 | 8,8,3 | 8,8,4 | 16,8,4.  Four waves of eight rows: 64 x 32
-// texels, of which 58 x 26 are stored — on the small grids that chain by default the smaller workgroup wins (1024^2: 14.6 k steps/s against
-// 13.9 k with eight waves, 2048^2: 6.9 k against 6.7 k); at 4096^2 the two are level (profiles/r03/advect_cvd_chain.txt)
+// FLUID_CHAIN_TILE="waves,rows,apron columns" (A/B knob): 4,8,3 | 8,4,3 | 4,4,3 | 4,8,4 | 8,8,3 | 8,8,4 | 16,8,4 | 16,4,3.  Default: four waves of
+// eight rows — 64 x 32 texels, of which 58 x 26 are stored: on the small grids that chain by default the smaller workgroup wins (1024^2:
+// 14.6 k steps/s against 13.9 k with eight waves, 2048^2: 6.9 k against 6.7 k) and at 4096^2 the two are level; below 768^2 texels the same
+// tile as eight waves of four rows (512^2: 18.3 k against 17.6 k; level at 1024^2, behind at 2048^2) (profiles/r03/advect_cvd_chain.txt)
+static void advect_cvd_shape(long texels, int& nw, int& ry, int& ax)
 {
     static const int forced = [] {
-        int a = 4, b = 8, c = 3;
+        int a = 0, b = 0, c = 0;
         if (const char* e = getenv("FLUID_CHAIN_TILE")) sscanf(e, "%d,%d,%d", &a, &b, &c);
         return a * 10000 + b * 100 + c;
     }();
-    nw = forced / 10000;
-    ry = forced / 100 % 100;
-    ax = forced % 100;
+    const int pick = forced ? forced : (texels < 768l * 768l ? 80403 : 40803);
+    nw = pick / 10000;
+    ry = pick / 100 % 100;
+    ax = pick % 100;
 }
 
 hipError_t launch_advect_cvd(hipStream_t s, Win w, const float2* vel, float2* vel_out, const float4* dye, float4* dye_out, float* curl,
@@ -2100,7 +2103,7 @@ hipError_t launch_advect_cvd(hipStream_t s, Win w, const float2* vel, float2* ve
     const float vdecay = 1.0f + vel_dissipation * dt, ddecay = 1.0f + dye_dissipation * dt;
     const double rW = udiv_recip((float)w.W), rH = udiv_recip((float)w.H), rvd = udiv_recip(vdecay), rdd = udiv_recip(ddecay);
     int nw, ry, apron;
-    advect_cvd_shape(nw, ry, apron);
+    advect_cvd_shape((long)(w.x1 - w.x0) * (gb - ga), nw, ry, apron);
 #define ADVECT_CVD_CASE(NW_, RY_, AX_)                                                                                                  \
     if (nw == NW_ && ry == RY_ && apron == AX_) {                                                                                       \
         using G = AdvectCvd<NW_, RY_, AX_>;                                                                                             \
@@ -2117,6 +2120,9 @@ hipError_t launch_advect_cvd(hipStream_t s, Win w, const float2* vel, float2* ve
     ADVECT_CVD_CASE(8, 8, 3)
     ADVECT_CVD_CASE(4, 8, 4)
     ADVECT_CVD_CASE(4, 8, 3)
+    ADVECT_CVD_CASE(8, 4, 3)
+    ADVECT_CVD_CASE(4, 4, 3)
+    ADVECT_CVD_CASE(16, 4, 3)
     ADVECT_CVD_CASE(16, 8, 4)
 #undef ADVECT_CVD_CASE
     return hipErrorInvalidValue;
