@@ -338,6 +338,7 @@ __device__ __forceinline__ void advect_both_fast_body(const Win& w, const V2* __
     if (miss) atomicAdd(miss_out, (unsigned)miss);
 }
 
+// (98 VGPRs at four rows per thread = 4 waves per SIMD; held to 96 for 5 waves it is 1-4 % SLOWER: profiles/r03/advect_occupancy_ab.txt)
 template <int ROWS>
 __global__ void __launch_bounds__(BX) k_advect_both_fast(Win w, const float2* __restrict__ vel, float2* __restrict__ vel_out,
                                                           const float4* __restrict__ dye, float4* __restrict__ dye_out, float dt, double rW,
