@@ -157,7 +157,7 @@ def pmc_pass(args, counters, deadline, steps_under_profiler=4):
     import pmc_traffic
     with tempfile.TemporaryDirectory(prefix="fluid_pmc_", dir="/tmp") as d:
         cmd = [exe, "--kernel-trace", "--pmc"] + list(counters) + ["--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
-               os.path.abspath(__file__), "--steps", str(steps_under_profiler - 1), "--warmup", "1", "--cpu-budget", "0", "--no-profile-pass",
+               os.path.abspath(__file__), "--steps", str(steps_under_profiler), "--warmup", "0", "--cpu-budget", "0", "--no-profile-pass",
                "--no-traffic", "--no-steady", "--no-parity", "--size", str(args.size), "--iters", str(args.iters), "--schedule", args.schedule,
                "--storage", args.storage]
         try:
@@ -174,11 +174,15 @@ def pmc_pass(args, counters, deadline, steps_under_profiler=4):
         return out, None
 
 
-def collect_traffic(args, deadline, steps_under_profiler: int = 4):
+def collect_traffic(args, deadline, steps_under_profiler: int = 0):
     """HBM bytes per launch of every step kernel, measured IN THIS RUN: two short child runs under `rocprofv3 --kernel-trace --pmc`
     (FETCH_SIZE and WRITE_SIZE in separate passes, as the guide's HBM section prescribes), corrected as tools/pmc_traffic.py documents
     (KiB units, x2 on FETCH_SIZE for gfx950, WRITE_SIZE calibrated to 1.0 on k_clear in profiles/r01).
     Returns ({kernels, bytes_per_step}, None) or (None, reason)."""
+    if not steps_under_profiler:
+        # ONE call of this many steps.  Below 3072^2 texels a call for n steps chains n - 1 of them (k_advect_cvd): sixteen steps put the
+        # launch mix within 6 % of the timed call's (the bytes per launch are what they are either way)
+        steps_under_profiler = 4 if args.size * args.size >= 3072 * 3072 else 16
     per = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         got, why = pmc_pass(args, [ctr], deadline, steps_under_profiler)
