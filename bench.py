@@ -650,8 +650,14 @@ def main(argv=None, engine_factory=None, backend="nccl"):
                                            for k, v in traffic["kernels"].items()}}
         per_step = {k: round(v / max(tm["steps"], 1), 4) for k, v in tm.items() if k.endswith("_ms")}
         out["pass_ms_per_step"] = per_step
+        notes = []
         if tm.get("folded_launches", 0):
-            out["pass_ms_note"] = "gradsub_ms = the last Jacobi launch of the step with the gradient subtract folded in (k_jacobi_tb_gs); jacobi_ms = the other launches"
+            notes.append("gradsub_ms = the last Jacobi launch of the step with the gradient subtract folded in (k_jacobi_tb_gs); jacobi_ms = the other launches")
+        if traffic and any(k.startswith("k_advect_cvd") for k in traffic["kernels"]):
+            notes.append("advect_dye_ms = the launch that advects AND runs the next step's curl / vorticity / divergence (k_advect_cvd, fluid_step_n below "
+                         "3072^2 texels); vorticity_ms = the first step's own launch only")
+        if notes:
+            out["pass_ms_note"] = "; ".join(notes)
 
     # ---- the same loop well inside steady clocks: the contract's K steps may be as few as 20 (11 ms), inside the clock ramp ----
     if rank == 0 and N == 1 and not args.no_steady:
