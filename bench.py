@@ -575,7 +575,7 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         # the kernel that runs the loop: the temporally blocked register tile, or one launch per iteration under --schedule passes
         if args.schedule == "fused":
             # (k_jacobi_tb_mix: the same tile kernel with smaller tiles for the launch's first and last rows — what large grids run)
-            cands = ["k_jacobi_tb_h<", "k_jacobi_tb<"] if args.storage == "f16" else ["k_jacobi_tb_mix<", "k_jacobi_tb<"]
+            cands = ["k_jacobi_tb_h<", "k_jacobi_tb<"] if args.storage == "f16" else ["k_jacobi_tb_mix<", "k_jacobi_tb<", "k_jacobi_tb2<"]
         else:
             cands = ["k_h_jacobi", "k_jacobi"] if args.storage == "f16" else ["k_jacobi"]
         kname = cands[0]

@@ -281,7 +281,7 @@ def test_every_knob_of_the_fused_schedule_yields_the_same_bits():
     import subprocess
     import sys
     pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "webgl-fluid-simulation_amd")
-    settings = [{}] + [{"FLUID_TB_VARIANT": str(v), "FLUID_FOLD_GRADSUB": f} for v in (0, 8, 9, 10, 11, 12, 13, 14, 15) for f in ("0", "1")]
+    settings = [{}] + [{"FLUID_TB_VARIANT": str(v), "FLUID_FOLD_GRADSUB": f} for v in (0, 8, 9, 10, 11, 12, 13, 14, 15, 20) for f in ("0", "1")]
     settings += [{"FLUID_TB_VARIANT": "0", "FLUID_FOLD_GRADSUB": "0", "FLUID_TB_TAIL": t} for t in ("0,130,5", "60,100,6", "100,0,7", "0,0,7")]   # small tiles for a launch's first / last rows
     settings += [{"FLUID_CVD_TAIL": t} for t in ("0,100", "60,90", "120,0")]   # the same for the curl / vorticity / divergence kernel
     settings += [{"FLUID_CHAIN": "0"}] + [{"FLUID_CHAIN_TILE": t} for t in ("8,8,4", "4,8,4", "8,8,3", "16,8,4", "8,4,3", "4,4,3", "16,4,3")]   # advection + the next step's curl / vorticity / divergence in one launch, or not

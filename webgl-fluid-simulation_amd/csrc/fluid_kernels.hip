@@ -981,6 +981,187 @@ __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_h(Win
 }
 
 // ------------------------------------------------------------------------------------------------
+// The temporally blocked Jacobi tile with TWO texels per lane: 128 columns x NW * RY rows (round 3, small grids).  At 1024^2 the four-texel
+// tile makes 260 workgroups — one per CU, two waves per SIMD — and each of them runs its ten iterations as a latency chain (0.59 us an
+// iteration: profiles/r03/jacobi_iter_cost.txt); half the columns per workgroup are twice the workgroups with half the arithmetic per row
+// (6 instructions for two texels: two v_add_f32_dpp + four packed), three of them per CU.  The price is the column apron (12 of 128
+// columns a side instead of 12 of 256) — arithmetic a latency-bound launch has to spare, which is why only grids below 1280^2 texels take
+// this shape (jacobi_tb_pick).  Same operand order per texel as jacobi_row, hence the same bits.  fp32 fields only (fp16 storage keeps the
+// four-texel tile).
+template <int NW, int RY, int HX, int HY>
+struct JacobiTB2 {
+    static constexpr int TX = 128, TY = NW * RY;
+    static constexpr int VX = TX - 2 * HX, VY = TY - 2 * HY;
+    static_assert(HX % 2 == 0 && HX >= HY && VX > 0 && VY > 0, "pair tile geometry");
+};
+
+// EDGE as in jacobi_row; nv = texels of the lane's pair inside the domain (1 in the lane that holds column W - 1 of an odd width)
+template <int EDGE>
+__device__ __forceinline__ v2f jacobi_row2(v2f C, v2f T, v2f B, const v2f D, int gj, int H, bool at_left, int nv)
+{
+    if (EDGE == 2 && nv < 2) C.y = C.x;  // CLAMP_TO_EDGE inside the partly padded last pair
+    float L = from_left_lane(C.y);   // column 2*lane - 1
+    float R = from_right_lane(C.x);  // column 2*lane + 2
+    if (EDGE) {
+        if (at_left) L = C.x;
+        if (nv <= 2) R = C.y;  // the lane that holds column W - 1 (lanes beyond it only feed texels outside the domain)
+    }
+    if (EDGE == 2) {
+        if (gj == 0) B = C;
+        if (gj == H - 1) T = C;
+    }
+    float h0 = L + C.y;  // texel 0: left + right
+    float h1 = C.x + R;  // texel 1
+    if (!EDGE) {  // scalar, so that the lane shift folds into the add (v_add_f32_dpp), as in jacobi_row
+        asm("" : "+v"(h0));
+        asm("" : "+v"(h1));
+    }
+    const v2f quarter = v2f{ 0.25f, 0.25f };
+    return (v2f{ h0, h1 } + B + T - D) * quarter;
+}
+
+template <int NW, int RY, int EDGE>
+__device__ __forceinline__ void jacobi_sweep2(v2f (&P)[RY], const v2f (&D)[RY], v2f (*box)[2][64], int wv, int lane, int gy, int H, bool at_left,
+                                              int nv)
+{
+    static_assert(RY >= 3, "a wave needs an inner row");
+    box[wv][0][lane] = P[0];
+    box[wv][1][lane] = P[RY - 1];
+    const v2f old0 = P[0], old1 = P[1];
+    v2f below = old0;
+#pragma unroll
+    for (int r = 1; r < RY - 1; r++) {
+        const v2f C = P[r];
+        P[r] = jacobi_row2<EDGE>(C, P[r + 1], below, D[r], gy + r, H, at_left, nv);
+        below = C;
+    }
+    __syncthreads();
+    const v2f lo = box[wv > 0 ? wv - 1 : 0][1][lane];
+    const v2f hi = box[wv < NW - 1 ? wv + 1 : NW - 1][0][lane];
+    P[RY - 1] = jacobi_row2<EDGE>(P[RY - 1], hi, below, D[RY - 1], gy + RY - 1, H, at_left, nv);
+    P[0] = jacobi_row2<EDGE>(old0, old1, lo, D[0], gy, H, at_left, nv);
+}
+
+typedef float pair_f __attribute__((ext_vector_type(2), aligned(8)));
+template <int NW, int RY, int HX, int HY, int EDGE, bool GS>
+__device__ __forceinline__ void jacobi_tb2_body(const Win& w, const float* __restrict__ p, const float* __restrict__ div, float* __restrict__ p_out,
+                                                float pscale, int iters, int ga, int gb, int x0, int y0, v2f (*mail)[NW][2][64],
+                                                const float2* __restrict__ vel, float2* __restrict__ vel_out)
+{
+    using G = JacobiTB2<NW, RY, HX, HY>;
+    const int lane = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int cx = x0 + 2 * lane, gy = y0 + wv * RY;
+    v2f P[RY], D[RY];
+    const unsigned cxs = (unsigned)(min(max(cx, w.c0), w.c0 + w.P - 2) - w.c0);  // array column of the lane's pair, kept inside the array
+    const v2f ps = v2f{ pscale, pscale };
+#pragma unroll
+    for (int r = 0; r < RY; r++) {  // unconditional loads from clamped addresses, as in jacobi_tb_body
+        const int lr = min(max(gy + r - w.g0, 0), w.rows - 1);
+        const size_t row = (size_t)lr * (size_t)w.P;
+        P[r] = *reinterpret_cast<const pair_f*>(p + row + cxs);
+        D[r] = *reinterpret_cast<const pair_f*>(div + row + cxs);
+    }
+#pragma unroll
+    for (int r = 0; r < RY; r++) P[r] = ps * P[r];  // clearShader folded in
+
+    const bool at_left = (cx == 0);
+    const int nv = w.W - cx;
+    int it = 0;
+    for (; it + 2 <= iters; it += 2) {
+        jacobi_sweep2<NW, RY, EDGE>(P, D, mail[0], wv, lane, gy, w.H, at_left, nv);
+        jacobi_sweep2<NW, RY, EDGE>(P, D, mail[1], wv, lane, gy, w.H, at_left, nv);
+    }
+    if (it < iters) jacobi_sweep2<NW, RY, EDGE>(P, D, mail[0], wv, lane, gy, w.H, at_left, nv);
+
+    int xa, xb, out_lo, out_hi;
+    tile_exact(x0, G::TX, HX, w.W, w.x0, w.x1, xa, xb);
+    tile_exact(y0, G::TY, HY, w.H, ga, gb, out_lo, out_hi);
+    const bool col_store = (cx >= xa) && (cx < xb);
+#pragma unroll
+    for (int r = 0; r < RY; r++) {
+        const int gj = gy + r;
+        if (col_store && gj >= out_lo && gj < out_hi) *reinterpret_cast<pair_f*>(p_out + (size_t)at(w, gj, cx)) = P[r];
+    }
+
+    if constexpr (GS) {  // K6 on the final pressure, as in jacobi_tb_body
+        v2f (*box)[2][64] = mail[iters & 1];
+        box[wv][0][lane] = P[0];
+        box[wv][1][lane] = P[RY - 1];
+        __syncthreads();
+        const v2f lo = box[wv > 0 ? wv - 1 : 0][1][lane];
+        const v2f hi = box[wv < NW - 1 ? wv + 1 : NW - 1][0][lane];
+        float4 va[RY];
+#pragma unroll
+        for (int r = 0; r < RY; r++) {
+            const int gj = gy + r;
+            if (gj >= out_lo && gj < out_hi && col_store) va[r] = *reinterpret_cast<const float4*>(vel + (size_t)at(w, gj, cx));
+        }
+#pragma unroll
+        for (int r = 0; r < RY; r++) {
+            const int gj = gy + r;
+            if (gj >= out_lo && gj < out_hi) {  // wave-uniform
+                v2f C = P[r];
+                v2f Tq = r < RY - 1 ? P[r < RY - 1 ? r + 1 : r] : hi;
+                v2f Bq = r > 0 ? P[r > 0 ? r - 1 : 0] : lo;
+                if (EDGE == 2 && nv < 2) C.y = C.x;
+                float L = from_left_lane(C.y), R = from_right_lane(C.x);  // all lanes active here
+                if (EDGE) {
+                    if (at_left) L = C.x;
+                    if (nv <= 2) R = C.y;
+                }
+                if (EDGE == 2) {
+                    if (gj == 0) Bq = C;
+                    if (gj == w.H - 1) Tq = C;
+                }
+                if (col_store) {
+                    float4 o;
+                    o.x = va[r].x - (C.y - L);
+                    o.y = va[r].y - (Tq.x - Bq.x);
+                    o.z = va[r].z - (R - C.x);
+                    o.w = va[r].w - (Tq.y - Bq.y);
+                    *reinterpret_cast<float4*>(vel_out + (size_t)at(w, gj, cx)) = o;
+                }
+            }
+        }
+    }
+}
+
+template <int NW, int RY, int HX, int HYT, bool GS>
+__device__ __forceinline__ void jacobi_tb2_tile(const Win& w, const float* __restrict__ p, const float* __restrict__ div, float* __restrict__ p_out,
+                                                float pscale, int iters, int ga, int gb, int xs, int ys, int nx, int ny, int b, int remap,
+                                                v2f (*mail)[NW][2][64], const float2* __restrict__ vel = nullptr, float2* __restrict__ vel_out = nullptr)
+{
+    using G = JacobiTB2<NW, RY, HX, HYT>;
+    int bx, by;
+    tile_of_block(b, nx, ny, remap, bx, by);
+    const int x0 = xs + bx * G::VX, y0 = ys + by * G::VY;
+    const bool xedge = (x0 <= 0) || (x0 + G::TX >= w.W), yedge = (y0 <= 0) || (y0 + G::TY >= w.H);
+    const bool ragged = (w.W & 1) != 0 && x0 + G::TX >= w.W;  // the tile holds the partly padded last pair
+    if (yedge || ragged) jacobi_tb2_body<NW, RY, HX, HYT, 2, GS>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail, vel, vel_out);
+    else if (xedge) jacobi_tb2_body<NW, RY, HX, HYT, 1, GS>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail, vel, vel_out);
+    else jacobi_tb2_body<NW, RY, HX, HYT, 0, GS>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail, vel, vel_out);
+}
+
+template <int NW, int RY, int HX, int HY, int BPC>
+__global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb2(Win w, const float* __restrict__ p, const float* __restrict__ div,
+                                                         float* __restrict__ p_out, float pscale, int iters, int ga, int gb, int xs, int ys,
+                                                         int nx, int ny, int remap)
+{
+    __shared__ v2f mail[2][NW][2][64];
+    jacobi_tb2_tile<NW, RY, HX, HY, false>(w, p, div, p_out, pscale, iters, ga, gb, xs, ys, nx, ny, (int)blockIdx.x, remap, mail);
+}
+
+template <int NW, int RY, int HX, int HY, int BPC>
+__global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb2_gs(Win w, const float* __restrict__ p, const float* __restrict__ div,
+                                                            float* __restrict__ p_out, const float2* __restrict__ vel,
+                                                            float2* __restrict__ vel_out, float pscale, int iters, int ga, int gb, int xs,
+                                                            int ys, int nx, int ny, int remap)
+{
+    __shared__ v2f mail[2][NW][2][64];
+    jacobi_tb2_tile<NW, RY, HX, HY + 1, true>(w, p, div, p_out, pscale, iters, ga, gb, xs, ys, nx, ny, (int)blockIdx.x, remap, mail, vel, vel_out);
+}
+
+// ------------------------------------------------------------------------------------------------
 // K6 gradient subtract, four texels per lane (fused schedule): the per-texel kernel issues six memory instructions for
 // 20 bytes; here a wave moves one 256-texel row segment with five 16-byte loads and two 16-byte stores per lane, the
 // horizontal pressure neighbours come from the lane's own float4 and the adjacent lanes (DPP), and only the two
@@ -1553,7 +1734,9 @@ constexpr TBVariant kTB[] = {
     {4, 16, 12, 10, 2, false},  // 17: 4 waves x 16 rows
     {2, 20, 12, 10, 4, false},  // 18: the 40-row tile as TWO waves x 20 rows
     {16, 3, 12, 10, 1, false},  // 19: 16 waves x 3 rows (48-row tile)      (16-19: profiles/r03/jacobi_iter_cost.txt)
+    {8, 5, 12, 10, 3, true},    // 20: the 40-row tile with TWO texels per lane (128 columns, k_jacobi_tb2): grids below 1280^2
 };
+constexpr int kPairTB = 20;     // not in TB_VARIANTS: its own kernels, fp32 fields only (fp16 storage runs shape 8 in its place)
 constexpr int kNumTB = sizeof(kTB) / sizeof(kTB[0]);
 constexpr int kDefaultTB = 0;  // measured best of the table at 4096^2 (profiles/r01/jacobi_variants.txt, there listed as "8x10 h12/10")
 
@@ -1577,7 +1760,8 @@ int tb_variant_env()  // FLUID_TB_VARIANT, or -1
 }
 
 // FLUID_TB_SMALL="texels:shape,texels:shape,...": grids below `texels` owned texels take `shape` (first match; A/B knob for the
-// grid-driven choice).  Default: below 3072^2 the 40-row tile (profiles/r03/jacobi_shapes_small_grids.txt).
+// grid-driven choice).  Default: below 2000^2 the 40-row tile with two texels per lane (shape 20), below 3072^2 the 40-row tile
+// (profiles/r03/jacobi_shapes_small_grids.txt, jacobi_pair_tile_ab.txt).
 struct TBRule { long below; int shape; };
 const std::vector<TBRule>& tb_rules()
 {
@@ -1596,6 +1780,7 @@ const std::vector<TBRule>& tb_rules()
                 p = *q == ',' ? q + 1 : q;
             }
         } else {
+            r.push_back({ 2000l * 2000l, kPairTB });  // two texels per lane: 512^2 +35 %, 1024^2 +14 %, 1536^2 +5 %, level at 2048^2 (profiles/r03/jacobi_pair_tile_ab.txt)
             r.push_back({ 3072l * 3072l, 8 });
         }
         return r;
@@ -1723,6 +1908,26 @@ hipError_t launch_tb_gs(hipStream_t s, Win w, const __half* p, const __half* div
     const Axis ax = make_axis(w.x0, w.x1, w.W, G::TX, HX), ay = make_axis(ga, gb, w.H, G::TY, HY + 1);
     k_jacobi_tb_gs_h<NW, RY, HX, HY, BPC><<<dim3(ax.n * ay.n, 1, 1), dim3(64, NW, 1), 0, s>>>(w, p, div, p_out, vel, vel_out, pscale, iters, ga,
                                                                                       gb, ax.S, ay.S, ax.n, ay.n, xcd_remap());
+    return hipGetLastError();
+}
+
+template <int NW, int RY, int HX, int HY, int BPC>
+hipError_t launch_tb2(hipStream_t s, Win w, const float* p, const float* div, float* p_out, float pscale, int iters, int ga, int gb)
+{
+    using G = JacobiTB2<NW, RY, HX, HY>;
+    const Axis ax = make_axis(w.x0, w.x1, w.W, G::TX, HX), ay = make_axis(ga, gb, w.H, G::TY, HY);
+    k_jacobi_tb2<NW, RY, HX, HY, BPC><<<dim3(ax.n * ay.n, 1, 1), dim3(64, NW, 1), 0, s>>>(w, p, div, p_out, pscale, iters, ga, gb, ax.S, ay.S, ax.n,
+                                                                                  ay.n, xcd_remap());
+    return hipGetLastError();
+}
+template <int NW, int RY, int HX, int HY, int BPC>
+hipError_t launch_tb2_gs(hipStream_t s, Win w, const float* p, const float* div, float* p_out, const float2* vel, float2* vel_out, float pscale,
+                         int iters, int ga, int gb)
+{
+    using G = JacobiTB2<NW, RY, HX, HY + 1>;
+    const Axis ax = make_axis(w.x0, w.x1, w.W, G::TX, HX), ay = make_axis(ga, gb, w.H, G::TY, HY + 1);
+    k_jacobi_tb2_gs<NW, RY, HX, HY, BPC><<<dim3(ax.n * ay.n, 1, 1), dim3(64, NW, 1), 0, s>>>(w, p, div, p_out, vel, vel_out, pscale, iters, ga, gb,
+                                                                                     ax.S, ay.S, ax.n, ay.n, xcd_remap());
     return hipGetLastError();
 }
 
@@ -2187,6 +2392,10 @@ hipError_t launch_jacobi_tb_any(hipStream_t s, Win w, const T* p, const T* div, 
     ROWS_OR_RETURN();
     if (!jacobi_tb_supported(w) || v < 0 || v >= kNumTB) return hipErrorInvalidValue;
     if (iters < 1 || iters > kTB[v].hy) return hipErrorInvalidValue;
+    if (v == kPairTB) {
+        if constexpr (sizeof(T) == 4) return launch_tb2<8, 5, 12, 10, 3>(s, w, p, div, p_out, pscale, iters, ga, gb);
+        v = 8;  // fp16 storage: the same 40-row tile with four texels per lane
+    }
     switch (v) {
 #define TB_CASE(k, NW, RY, HX, HY, BPC) \
     case k: return launch_tb<NW, RY, HX, HY, BPC>(s, w, p, div, p_out, pscale, iters, ga, gb);
@@ -2206,6 +2415,10 @@ hipError_t launch_jacobi_tb_gradsub_any(hipStream_t s, Win w, const T* p, const 
     w.x0 &= ~3;  // whole float4 groups, as launch_gradsub4
     w.x1 = (w.x1 + 3) & ~3;
     if (w.x1 > w.W) w.x1 = w.W;
+    if (v == kPairTB) {
+        if constexpr (sizeof(T) == 4) return launch_tb2_gs<8, 5, 12, 10, 3>(s, w, p, div, p_out, vel, vel_out, pscale, iters, ga, gb);
+        v = 8;
+    }
     switch (v) {
 #define TB_CASE(k, NW, RY, HX, HY, BPC) \
     case k: return launch_tb_gs<NW, RY, HX, HY, BPC>(s, w, p, div, p_out, vel, vel_out, pscale, iters, ga, gb);
