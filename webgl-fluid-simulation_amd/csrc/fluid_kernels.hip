@@ -2386,6 +2386,20 @@ TB_VARIANTS(TB_CHECK)
 #define TB_GS_CHECK(k, NW, RY, HX, HY, BPC) TB_CHECK(k, NW, RY, HX, HY, BPC) static_assert(kTB[k].gs && HX >= HY + 1, "gs variant");
 TB_GS_VARIANTS(TB_GS_CHECK)
 
+// rows per wave of the two-texel tile by grid size: 8 waves x 4 rows below 768^2 texels (512^2: 26.5 k steps/s against 24.7 k with 5 rows),
+// x 5 below 1280^2 (1024^2: 16.7 k against 15.8 k / 15.6 k with 4 / 6), x 6 above (1536^2: 11.1 k against 10.6 k)
+// (profiles/r03/jacobi_pair_tile_ab.txt).  FLUID_TB2="waves,rows" forces one (A/B knob): 8,5 | 8,4 | 8,6 | 4,10 | 16,3
+static int tb2_shape(long texels)
+{
+    static const int forced = [] {
+        int a = 0, b = 0;
+        if (const char* e = getenv("FLUID_TB2")) sscanf(e, "%d,%d", &a, &b);
+        return a * 100 + b;
+    }();
+    if (forced) return forced;
+    return texels < 768l * 768l ? 804 : (texels < 1280l * 1280l ? 805 : 806);
+}
+
 template <class T>
 hipError_t launch_jacobi_tb_any(hipStream_t s, Win w, const T* p, const T* div, T* p_out, float pscale, int iters, int ga, int gb, int v)
 {
@@ -2393,7 +2407,15 @@ hipError_t launch_jacobi_tb_any(hipStream_t s, Win w, const T* p, const T* div, 
     if (!jacobi_tb_supported(w) || v < 0 || v >= kNumTB) return hipErrorInvalidValue;
     if (iters < 1 || iters > kTB[v].hy) return hipErrorInvalidValue;
     if (v == kPairTB) {
-        if constexpr (sizeof(T) == 4) return launch_tb2<8, 5, 12, 10, 3>(s, w, p, div, p_out, pscale, iters, ga, gb);
+        if constexpr (sizeof(T) == 4) {
+            switch (tb2_shape((long)(w.x1 - w.x0) * (gb - ga))) {
+            case 804: return launch_tb2<8, 4, 12, 10, 4>(s, w, p, div, p_out, pscale, iters, ga, gb);
+            case 806: return launch_tb2<8, 6, 12, 10, 3>(s, w, p, div, p_out, pscale, iters, ga, gb);
+            case 410: return launch_tb2<4, 10, 12, 10, 4>(s, w, p, div, p_out, pscale, iters, ga, gb);
+            case 1603: return launch_tb2<16, 3, 12, 10, 2>(s, w, p, div, p_out, pscale, iters, ga, gb);
+            default: return launch_tb2<8, 5, 12, 10, 3>(s, w, p, div, p_out, pscale, iters, ga, gb);
+            }
+        }
         v = 8;  // fp16 storage: the same 40-row tile with four texels per lane
     }
     switch (v) {
@@ -2416,7 +2438,15 @@ hipError_t launch_jacobi_tb_gradsub_any(hipStream_t s, Win w, const T* p, const 
     w.x1 = (w.x1 + 3) & ~3;
     if (w.x1 > w.W) w.x1 = w.W;
     if (v == kPairTB) {
-        if constexpr (sizeof(T) == 4) return launch_tb2_gs<8, 5, 12, 10, 3>(s, w, p, div, p_out, vel, vel_out, pscale, iters, ga, gb);
+        if constexpr (sizeof(T) == 4) {
+            switch (tb2_shape((long)(w.x1 - w.x0) * (gb - ga))) {
+            case 804: return launch_tb2_gs<8, 4, 12, 10, 4>(s, w, p, div, p_out, vel, vel_out, pscale, iters, ga, gb);
+            case 806: return launch_tb2_gs<8, 6, 12, 10, 3>(s, w, p, div, p_out, vel, vel_out, pscale, iters, ga, gb);
+            case 410: return launch_tb2_gs<4, 10, 12, 10, 4>(s, w, p, div, p_out, vel, vel_out, pscale, iters, ga, gb);
+            case 1603: return launch_tb2_gs<16, 3, 12, 10, 2>(s, w, p, div, p_out, vel, vel_out, pscale, iters, ga, gb);
+            default: return launch_tb2_gs<8, 5, 12, 10, 3>(s, w, p, div, p_out, vel, vel_out, pscale, iters, ga, gb);
+            }
+        }
         v = 8;
     }
     switch (v) {
