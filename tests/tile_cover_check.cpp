@@ -1,0 +1,93 @@
+// Host check of the tiling arithmetic the register-tile kernels share (csrc/fluid_tiles.h: make_axis, tile_exact, tile_of_block), on the real
+// header: for every (domain, output range, tile span, apron) a kernel uses — and a few thousand random ones — the tiles' exact ranges must
+// cover the output range once and only once, each exact range must keep its apron from the tile's rim (except where the rim is the domain's),
+// and the XCD-aware block order must be a bijection.  Built and run by tests/test_tile_cover.py (hipcc, no GPU involved).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "fluid_tiles.h"
+
+using namespace fluid;
+
+static long fails = 0, cases = 0;
+
+static void check_axis(int dom, int lo, int hi, int T, int A)
+{
+    cases++;
+    const Axis ax = make_axis(lo, hi, dom, T, A);
+    std::vector<int> cover(hi - lo, 0);
+    if (ax.V != T - 2 * A || ax.S < 0 || ax.n < 1) {
+        printf("axis dom %d [%d, %d) T %d A %d: S %d V %d n %d\n", dom, lo, hi, T, A, ax.S, ax.V, ax.n);
+        fails++;
+        return;
+    }
+    for (int b = 0; b < ax.n; b++) {
+        const int t0 = ax.S + b * ax.V;
+        int a, e;
+        tile_exact(t0, T, A, dom, lo, hi, a, e);
+        for (int i = a; i < e; i++) {
+            const bool apron_ok = (i - t0 >= A || t0 <= 0) && (t0 + T - 1 - i >= A || t0 + T >= dom) && i >= t0 && i < t0 + T;
+            if (!apron_ok || i < lo || i >= hi) {
+                printf("axis dom %d [%d, %d) T %d A %d: tile %d at %d claims %d\n", dom, lo, hi, T, A, b, t0, i);
+                fails++;
+                return;
+            }
+            cover[i - lo]++;
+        }
+    }
+    for (int i = lo; i < hi; i++)
+        if (cover[i - lo] != 1) {
+            printf("axis dom %d [%d, %d) T %d A %d (S %d V %d n %d): position %d stored %d times\n", dom, lo, hi, T, A, ax.S, ax.V, ax.n, i, cover[i - lo]);
+            fails++;
+            return;
+        }
+}
+
+static void check_order(int nx, int ny, int remap)
+{
+    cases++;
+    std::vector<int> seen(nx * ny, 0);
+    for (int b = 0; b < nx * ny; b++) {
+        int bx = -1, by = -1;
+        tile_of_block(b, nx, ny, remap, bx, by);
+        if (bx < 0 || bx >= nx || by < 0 || by >= ny || seen[by * nx + bx]++) {
+            printf("order %d x %d remap %d: block %d -> (%d, %d)\n", nx, ny, remap, b, bx, by);
+            fails++;
+            return;
+        }
+    }
+}
+
+int main()
+{
+    // (tile span, apron) of every kernel: Jacobi columns 256 / 12 and 128 / 12 (two texels per lane), rows NW * RY with apron 10 / 11 (K6 folded) and
+    // the deep shapes; curl-vorticity-divergence 256 / 4 columns, 40 / 24 rows apron 3; k_advect_cvd 64 / 3, 64 / 4 columns, 32 / 64 / 128 rows apron 3
+    const int shapes[][2] = { { 256, 12 }, { 128, 12 }, { 80, 10 }, { 80, 11 }, { 56, 10 }, { 48, 10 }, { 48, 11 }, { 40, 10 }, { 40, 11 }, { 32, 10 }, { 32, 11 },
+                              { 64, 8 }, { 96, 10 }, { 96, 13 }, { 56, 17 }, { 64, 25 }, { 256, 20 }, { 256, 28 }, { 256, 4 }, { 40, 3 }, { 24, 3 },
+                              { 64, 3 }, { 64, 4 }, { 32, 3 }, { 128, 3 } };
+    const int doms[] = { 1, 2, 3, 5, 31, 40, 57, 58, 63, 64, 65, 100, 127, 128, 129, 250, 256, 257, 300, 455, 512, 700, 1001, 1024, 2048, 4096, 8192, 16384 };
+    for (const auto& sh : shapes)
+        for (int dom : doms) {
+            check_axis(dom, 0, dom, sh[0], sh[1]);                                  // the whole domain
+            if (dom >= 8) {
+                check_axis(dom, dom / 3, dom - dom / 5, sh[0], sh[1]);              // a stripe's band
+                check_axis(dom, 0, dom / 2 + 1, sh[0], sh[1]);
+                check_axis(dom, dom / 2 - 1, dom, sh[0], sh[1]);
+                check_axis(dom, dom / 2, dom / 2 + 1, sh[0], sh[1]);                // one row / column
+            }
+        }
+    srand(20260923);
+    for (int k = 0; k < 20000; k++) {
+        const auto& sh = shapes[rand() % (sizeof shapes / sizeof shapes[0])];
+        const int dom = 1 + rand() % 5000, lo = rand() % dom, hi = lo + 1 + rand() % (dom - lo);
+        check_axis(dom, lo, hi, sh[0], sh[1]);
+    }
+    for (int remap = 0; remap < 4; remap++)
+        for (int nx = 1; nx <= 40; nx++)
+            for (int ny = 1; ny <= 40; ny += (ny < 12 ? 1 : 7)) check_order(nx, ny, remap);
+    printf("%s: %ld cases, %ld failed\n", fails ? "FAILED" : "ok", cases, fails);
+    return fails ? 1 : 0;
+}

@@ -38,7 +38,7 @@ __host__ inline Axis make_axis(int lo, int hi, int dom, int T, int A)
 // whole rows of the field, i.e. long contiguous address runs — measured 7 % faster for the Jacobi kernel at 4096^2,
 // profiles/r01/jacobi_tile_order.txt) or column-major.  Bijective for any tile count; placement only affects
 // speed, never results.
-__device__ __forceinline__ void tile_of_block(int b, int nx, int ny, int remap, int& bx, int& by)
+__host__ __device__ __forceinline__ void tile_of_block(int b, int nx, int ny, int remap, int& bx, int& by)  // (host: tests/tile_cover_check.cpp)
 {
     const int n = nx * ny;
     int t = b;
@@ -59,7 +59,7 @@ __device__ __forceinline__ void tile_of_block(int b, int nx, int ny, int remap, 
 }
 
 // exact (storable) global range [a, b) of the tile starting at t0, intersected with [lo, hi)
-__device__ __forceinline__ void tile_exact(int t0, int T, int A, int dom, int lo, int hi, int& a, int& b)
+__host__ __device__ __forceinline__ void tile_exact(int t0, int T, int A, int dom, int lo, int hi, int& a, int& b)
 {
     a = t0 <= 0 ? 0 : t0 + A;
     b = t0 + T >= dom ? dom : t0 + T - A;
