@@ -282,7 +282,8 @@ def test_every_knob_of_the_fused_schedule_yields_the_same_bits():
     import sys
     pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "webgl-fluid-simulation_amd")
     settings = [{}] + [{"FLUID_TB_VARIANT": str(v), "FLUID_FOLD_GRADSUB": f} for v in (0, 8, 9, 10, 11, 12, 13, 14, 15, 20) for f in ("0", "1")]
-    settings += [{"FLUID_TB_VARIANT": "0", "FLUID_FOLD_GRADSUB": "0", "FLUID_TB_TAIL": t} for t in ("0,130,5", "60,100,6", "100,0,7", "0,0,7")]   # small tiles for a launch's first / last rows
+    settings += [{"FLUID_TB_VARIANT": "0", "FLUID_FOLD_GRADSUB": "0", "FLUID_TB_TAIL": t} for t in ("0,130,5", "60,100,6", "100,0,7", "0,0,7", "60,100,2", "0,120,2")]   # small tiles for a launch's first / last rows (2 = the two-texel tile)
+    settings += [{"FLUID_SKIP_CURL": "0"}]   # every step of a call for n steps stores its curl field, or only the last one
     settings += [{"FLUID_CVD_TAIL": t} for t in ("0,100", "60,90", "120,0")]   # the same for the curl / vorticity / divergence kernel
     settings += [{"FLUID_TB2": t, "FLUID_FOLD_GRADSUB": f} for t in ("8,4", "8,5", "8,6", "4,10", "16,3") for f in ("0", "1")]   # rows / waves of the two-texel Jacobi tile
     settings += [{"FLUID_CHAIN": "0"}] + [{"FLUID_CHAIN_TILE": t} for t in ("8,8,4", "4,8,4", "8,8,3", "16,8,4", "8,4,3", "4,4,3", "16,4,3")]   # advection + the next step's curl / vorticity / divergence in one launch, or not
@@ -319,8 +320,12 @@ def test_the_chained_launch_at_the_bench_size_yields_the_same_bits():
     import sys
     pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "webgl-fluid-simulation_amd")
     got = []
-    for v in ("0", "1"):
-        r = subprocess.run([sys.executable, "-c", _CHAIN_CHILD % pkg], env=dict(os.environ, FLUID_CHAIN=v), capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, r.stderr[-500:]
+    # ... and the other settings that only a big grid exercises: the two-texel tile as head / tail of the mixed Jacobi launch, the curl
+    # field stored by every step of the call
+    envs = [{"FLUID_CHAIN": "0"}, {"FLUID_CHAIN": "1"}, {"FLUID_TB_TAIL_TILES": "384,768,2"}, {"FLUID_SKIP_CURL": "0"}, {"FLUID_TB_TAIL_TILES": "0,0,7"}]
+    for env in envs:
+        r = subprocess.run([sys.executable, "-c", _CHAIN_CHILD % pkg], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (env, r.stderr[-500:])
         got.append(json.loads(r.stdout.strip().splitlines()[-1]))
-    assert got[0] == got[1]
+    for env, g in zip(envs, got):
+        assert g == got[0], env

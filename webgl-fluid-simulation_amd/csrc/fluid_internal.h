@@ -31,6 +31,9 @@ struct fluid_ctx {
     void* div = nullptr;
     void* curl = nullptr;
     unsigned int* miss = nullptr;  // advection taps that fell outside the window
+    // false while fluid_step_n runs a step that is not the call's last: that step's curl field is overwritten before the call returns, so
+    // the fused curl / vorticity / divergence kernel does not store it (4 of its 24 B/texel).  The per-pass kernels always need the field.
+    bool keep_curl = true;
 
     bool timing = false;
     hipEvent_t ev[P_COUNT + 1] = {};
@@ -83,6 +86,7 @@ struct fluid_ctx {
 #define DYE(c, k) ((S::T4*)(c)->dyeb[k])
 #define DIVG(c) ((S::T1*)(c)->div)
 #define CURL(c) ((S::T1*)(c)->curl)
+#define CURL_FUSED(c) ((c)->keep_curl ? CURL(c) : (S::T1*)nullptr)   // output of the fused kernel: null = not stored
 
 namespace fluid_impl {
 
@@ -146,6 +150,7 @@ int advect_both_rects(fluid_ctx* c, float dt, float vel_diss, float dye_diss, co
 void advect_both_swap(fluid_ctx* c);
 
 // fluid_stripes.cpp
+bool skip_hidden_curl();                                                 // FLUID_SKIP_CURL=0: every step stores its curl field (A/B knob)
 int stripe_step_n(fluid_ctx* c, int n, float dt, const fluid_params* P);  // this rank's stripe, exchanges over RCCL
 void stripes_release(fluid_ctx* c);                                       // frees the communicator (fluid_destroy)
 // fluid_display.cpp

@@ -1391,7 +1391,7 @@ __device__ __forceinline__ void vort_div_body(const Win& w, const V2* __restrict
         }
         if (col_store && gj >= out_lo && gj < out_hi) {
             const size_t c = (size_t)at(w, gj, cx);
-            store_s4(curl_out, c, make_float4(C[r][0], C[r][1], C[r][2], C[r][3]));
+            if (curl_out) store_s4(curl_out, c, make_float4(C[r][0], C[r][1], C[r][2], C[r][3]));  // null: a step of fluid_step_n whose curl field nobody can read (wave-uniform)
             store_s4(div_out, c, make_float4(dv[0], dv[1], dv[2], dv[3]));
             store_v4(vel_out, c, make_float4(N[r].x[0], N[r].y[0], N[r].x[1], N[r].y[1]), make_float4(N[r].x[2], N[r].y[2], N[r].x[3], N[r].y[3]));
         }
@@ -1803,7 +1803,7 @@ inline TBTail tb_tail(int rows, int nx)
         if (const char* e = getenv("FLUID_TB_TAIL")) {
             r = TBTail{ 0, 0, 7, 0 };   // a forced setting applies to every band height (the knob-hash test runs it on small grids)
             sscanf(e, "%d,%d,%d", &r.head, &r.tail, &r.ry);
-            if (r.ry != 5 && r.ry != 6 && r.ry != 7) r.head = r.tail = 0;
+            if (r.ry != 2 && r.ry != 5 && r.ry != 6 && r.ry != 7) r.head = r.tail = 0;   // 2 = the two-texel tile (8 x 5 rows, 128 columns)
         }
         return r;
     }();
@@ -1813,12 +1813,13 @@ inline TBTail tb_tail(int rows, int nx)
         if (const char* e = getenv("FLUID_TB_TAIL_TILES")) {
             r = TBTail{ 0, 0, 5, 1024 };
             sscanf(e, "%d,%d,%d", &r.head, &r.tail, &r.ry);
-            if (r.ry != 5 && r.ry != 6 && r.ry != 7) r.head = r.tail = 0;
+            if (r.ry != 2 && r.ry != 5 && r.ry != 6 && r.ry != 7) r.head = r.tail = 0;   // 2 = the two-texel tile (8 x 5 rows, 128 columns)
         }
         return r;
     }();
     const TBTail tiles = forced_tiles.head >= 0 ? forced_tiles : TBTail{ 192, 384, rows >= 4000 ? 7 : 5, 1024 };
-    const int vy = 8 * tiles.ry - 20;  // rows a small tile stores (apron 10 on both sides)
+    if (tiles.ry == 2) nx = (nx * 232 + 103) / 104;   // tiles per row of the two-texel shape: 104 stored columns each instead of 232
+    const int vy = 8 * (tiles.ry == 2 ? 5 : tiles.ry) - 20;  // rows a small tile stores (apron 10 on both sides)
     return TBTail{ (tiles.head + nx - 1) / nx * vy, (tiles.tail + nx - 1) / nx * vy, tiles.ry, tiles.min_rows };
 }
 
@@ -1854,6 +1855,10 @@ hipError_t launch_tb_mix(hipStream_t s, Win w, const float* p, const float* div,
     return hipGetLastError();
 }
 
+template <int NW, int RYA, int RYP, int HX, int HY, int BPC>
+hipError_t launch_tb_mix2(hipStream_t s, Win w, const float* p, const float* div, float* p_out, float pscale, int iters, int ga, int gb, int head,
+                          int tail);   // defined behind the two-texel tile's launchers
+
 template <int NW, int RY, int HX, int HY, int BPC>
 hipError_t launch_tb(hipStream_t s, Win w, const float* p, const float* div, float* p_out, float pscale, int iters, int ga, int gb)
 {
@@ -1866,6 +1871,7 @@ hipError_t launch_tb(hipStream_t s, Win w, const float* p, const float* div, flo
             t.tail = (int)((long)t.tail * rows / full);
         }
         if (t.head + t.tail > 0 && rows >= t.min_rows) {
+            if (t.ry == 2) return launch_tb_mix2<NW, RY, 5, HX, HY, BPC>(s, w, p, div, p_out, pscale, iters, ga, gb, t.head, t.tail);
             if (t.ry == 5) return launch_tb_mix<NW, RY, 5, HX, HY, BPC>(s, w, p, div, p_out, pscale, iters, ga, gb, t.head, t.tail);
             if (t.ry == 6) return launch_tb_mix<NW, RY, 6, HX, HY, BPC>(s, w, p, div, p_out, pscale, iters, ga, gb, t.head, t.tail);
             return launch_tb_mix<NW, RY, 7, HX, HY, BPC>(s, w, p, div, p_out, pscale, iters, ga, gb, t.head, t.tail);
@@ -1928,6 +1934,57 @@ hipError_t launch_tb2_gs(hipStream_t s, Win w, const float* p, const float* div,
     const Axis ax = make_axis(w.x0, w.x1, w.W, G::TX, HX), ay = make_axis(ga, gb, w.H, G::TY, HY + 1);
     k_jacobi_tb2_gs<NW, RY, HX, HY, BPC><<<dim3(ax.n * ay.n, 1, 1), dim3(64, NW, 1), 0, s>>>(w, p, div, p_out, vel, vel_out, pscale, iters, ga, gb,
                                                                                      ax.S, ay.S, ax.n, ay.n, xcd_remap());
+    return hipGetLastError();
+}
+
+// The mixed launch with the TWO-texel tile (k_jacobi_tb2's 128-column tile) as the shape of its first / last rows: the shortest latency
+// chain of all the tiles (6 instructions a row) for the part of a launch whose iterations nothing overlaps.  Same bits by construction
+// (jacobi_row2).  FLUID_TB_TAIL_TILES / FLUID_TB_TAIL with 2 as the third field (A/B: profiles/r04/jacobi_pair_head_tail_ab.txt).
+template <int NW, int RYA, int RYP, int HX, int HY, int BPC>
+__global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_mix2(Win w, const float* __restrict__ p, const float* __restrict__ div,
+                                                             float* __restrict__ p_out, float pscale, int iters, MixSegs S, int xs, int nx,
+                                                             int xs2, int nx2, int remap)
+{
+    __shared__ float4 mail[2][NW][2][64];
+    const int b = (int)blockIdx.x;
+    int k = 0;
+    while (k + 1 < S.n && b >= S.blk0[k + 1]) k++;
+    if (S.small[k])  // a head / tail segment: 128-column tiles of two texels per lane (their mailboxes fit in half of the same LDS)
+        jacobi_tb2_tile<NW, RYP, HX, HY, false>(w, p, div, p_out, pscale, iters, S.g[k], S.g[k + 1], xs2, S.ys[k], nx2, S.ny[k], b - S.blk0[k], remap,
+                                                reinterpret_cast<v2f(*)[NW][2][64]>(mail));
+    else
+        jacobi_tb_tile<NW, RYA, HX, HY>(w, p, div, p_out, pscale, iters, S.g[k], S.g[k + 1], xs, S.ys[k], nx, S.ny[k], b - S.blk0[k], remap, mail);
+}
+
+template <int NW, int RYA, int RYP, int HX, int HY, int BPC>
+hipError_t launch_tb_mix2(hipStream_t s, Win w, const float* p, const float* div, float* p_out, float pscale, int iters, int ga, int gb, int head,
+                          int tail)
+{
+    using GA = JacobiTB<NW, RYA, HX, HY>;
+    using GP = JacobiTB2<NW, RYP, HX, HY>;
+    const Axis ax = make_axis(w.x0, w.x1, w.W, GA::TX, HX), ax2 = make_axis(w.x0, w.x1, w.W, GP::TX, HX);
+    MixSegs S{};
+    int total = 0;
+    auto seg = [&](int a, int b, int small) {
+        if (b <= a) return;
+        const Axis ay = small ? make_axis(a, b, w.H, GP::TY, HY) : make_axis(a, b, w.H, GA::TY, HY);
+        const int k = S.n++;
+        S.g[k] = a; S.g[k + 1] = b; S.small[k] = small; S.ys[k] = ay.S; S.ny[k] = ay.n; S.blk0[k] = total;
+        total += (small ? ax2.n : ax.n) * ay.n;
+    };
+    const int lo = ga + head;
+    int gmid = gb - tail;
+    if (tail > 0) {  // the cut in front of the tail snaps down to a boundary of the big tiles (launch_tb_mix)
+        const int base = (lo - HY > 0 ? lo - HY : 0) + GA::TY - HY;
+        if (gmid > base) gmid = base + (gmid - base) / GA::VY * GA::VY;
+    }
+    if (gmid < lo) gmid = lo;
+    seg(ga, lo, 1);
+    seg(lo, gmid, 0);
+    seg(gmid, gb, 1);
+    S.blk0[S.n] = total;
+    k_jacobi_tb_mix2<NW, RYA, RYP, HX, HY, BPC><<<dim3(total, 1, 1), dim3(64, NW, 1), 0, s>>>(w, p, div, p_out, pscale, iters, S, ax.S, ax.n, ax2.S, ax2.n,
+                                                                                      xcd_remap());
     return hipGetLastError();
 }
 

@@ -178,7 +178,7 @@ int pass_curl_vort_div(fluid_ctx* c, float curl, float dt, int ext, Timer* t)
         CK(check_ext(c, ext, 3));
         int ga, gb;
         row_range(c->sim, c->sim_row0, c->sim_rows, ext, ga, gb);
-        CK(c->hip(STORE_CALL(c, launch_curl_vort_div(c->stream, sim_cols(c, ext), VEL(c, 0), CURL(c), VEL(c, 1), DIVG(c), curl, dt, ga, gb)),
+        CK(c->hip(STORE_CALL(c, launch_curl_vort_div(c->stream, sim_cols(c, ext), VEL(c, 0), CURL_FUSED(c), VEL(c, 1), DIVG(c), curl, dt, ga, gb)),
                   "curl_vort_div"));
         std::swap(c->vel[0], c->vel[1]);
         if (t) t->mark(P_VORT);
@@ -340,6 +340,16 @@ bool gradsub_fold_enabled(long owned_texels)
     return mode >= 0 ? mode == 1 : owned_texels < 3072l * 3072l;
 }
 
+// FLUID_SKIP_CURL=0: every step of fluid_step_n stores its curl field (A/B knob; what a caller can read is the same either way)
+bool skip_hidden_curl()
+{
+    static const bool on = [] {
+        const char* e = getenv("FLUID_SKIP_CURL");
+        return !(e && atoi(e) == 0);
+    }();
+    return on;
+}
+
 bool jacobi_tb_applies(const fluid_ctx* c) { return c->desc.schedule == FLUID_SCHED_FUSED && jacobi_tb_supported(c->sim); }
 
 bool fused_cvd_applies(const fluid_ctx* c) { return c->desc.schedule == FLUID_SCHED_FUSED && fused_supported(c->sim); }
@@ -353,12 +363,12 @@ int cvd_band(fluid_ctx* c, float curl, float dt, int ga, int gb, int xa, int xb)
     Win w = c->sim;
     w.x0 = xa;
     w.x1 = xb;
-    return c->hip(STORE_CALL(c, launch_curl_vort_div(c->stream, w, VEL(c, 0), CURL(c), VEL(c, 1), DIVG(c), curl, dt, ga, gb)), "curl_vort_div");
+    return c->hip(STORE_CALL(c, launch_curl_vort_div(c->stream, w, VEL(c, 0), CURL_FUSED(c), VEL(c, 1), DIVG(c), curl, dt, ga, gb)), "curl_vort_div");
 }
 
 int cvd_rects(fluid_ctx* c, float curl, float dt, const BandRects& B)
 {
-    return c->hip(STORE_CALL(c, launch_curl_vort_div_rects(c->stream, c->sim, VEL(c, 0), CURL(c), VEL(c, 1), DIVG(c), curl, dt, B)), "curl_vort_div");
+    return c->hip(STORE_CALL(c, launch_curl_vort_div_rects(c->stream, c->sim, VEL(c, 0), CURL_FUSED(c), VEL(c, 1), DIVG(c), curl, dt, B)), "curl_vort_div");
 }
 
 void cvd_swap(fluid_ctx* c) { std::swap(c->vel[0], c->vel[1]); }
@@ -700,11 +710,23 @@ int fluid_step_n(fluid_ctx* c, int n, float dt, const fluid_params* P)
     if (P->iterations < 0) return c->fail(FLUID_ERR_INVALID, "negative PRESSURE_ITERATIONS");
     HIPCK(c, hipSetDevice(c->device));
     if (c->desc.parts != 1 || c->desc.parts_x != 1) return stripe_step_n(c, n, dt, P);  // ghost-row exchanges over RCCL (fluid_stripes.cpp)
+    // the curl field is a by-product that only a caller reads: of a call for n steps, the LAST step's (the header's contract)
+    struct CurlGuard {   // whatever way the loop ends, the next call stores its curl again
+        fluid_ctx* c;
+        ~CurlGuard() { c->keep_curl = true; }
+    } guard{ c };
+    const bool skip = fluid_impl::skip_hidden_curl();
     if (n > 1 && chain_applies(c, dt, P)) {
-        for (int k = 0; k < n; k++) CK(step_once(c, dt, P, k == 0, k == n - 1 ? 0 : (k == n - 2 ? 2 : 1)));
+        for (int k = 0; k < n; k++) {
+            c->keep_curl = !skip;   // the lead step's own launch: the chain's last k_advect_cvd writes the field a caller reads
+            CK(step_once(c, dt, P, k == 0, k == n - 1 ? 0 : (k == n - 2 ? 2 : 1)));
+        }
         return FLUID_OK;
     }
-    for (int k = 0; k < n; k++) CK(step_once(c, dt, P));
+    for (int k = 0; k < n; k++) {
+        c->keep_curl = k == n - 1 || !skip;
+        CK(step_once(c, dt, P));
+    }
     return FLUID_OK;
 }
 

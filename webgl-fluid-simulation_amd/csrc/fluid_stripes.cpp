@@ -707,8 +707,14 @@ int stripe_step_n(fluid_ctx* c, int n, float dt, const fluid_params* P)
     CK(ensure_comm_stream(c));
     std::vector<fluid_stripe_op> ops;
     CK(plan_for(c, P, ops));
+    struct CurlGuard {
+        fluid_ctx* c;
+        ~CurlGuard() { c->keep_curl = true; }
+    } guard{ c };
+    const bool skip = skip_hidden_curl();
     for (int k = 0; k < n; k++)
         for (size_t i = 0; i < ops.size(); i++) {
+            c->keep_curl = k == n - 1 || !skip;   // only the call's last step leaves a curl field a caller can read (fluid_step_n)
             const fluid_stripe_op& op = ops[i];
             if (op.kind != FLUID_OP_EXCHANGE) {
                 if (folds_gradsub(ops, i)) {
@@ -908,8 +914,15 @@ int fluid_group_step_n(fluid_ctx** cs, int n_ctx, int steps, float dt, const flu
         }
         return (int)FLUID_OK;
     };
+    struct CurlGuard {
+        fluid_ctx** cs;
+        int n;
+        ~CurlGuard() { for (int r = 0; r < n; r++) cs[r]->keep_curl = true; }
+    } guard{ cs, n_ctx };
+    const bool skip = skip_hidden_curl();
     for (int k = 0; k < steps; k++)
         for (size_t i = 0; i < ops.size(); i++) {
+            for (int r = 0; r < n_ctx; r++) cs[r]->keep_curl = k == steps - 1 || !skip;   // as in stripe_step_n
             const fluid_stripe_op& op = ops[i];
             if (op.kind != FLUID_OP_EXCHANGE) {
                 if (folds_gradsub(ops, i)) {
