@@ -130,6 +130,46 @@ def cpu_baseline(size: int, iters: int, budget_s: float, kind: str = "auto", max
     return out
 
 
+def fluid_knobs():
+    """every FLUID_* variable in the environment: the library's A/B knobs (tile shapes, folds, chains, another build of the library, an
+    RCCL stand-in) change what is timed, so the line lists them (`config.knobs`; empty = the shipped defaults)"""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("FLUID_") and k not in ("FLUID_BENCH_KEEP_PMC",)}
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv, script=None, timeout=None):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks ourselves — the driver's own command line,
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <the same arguments>` —
+    and pass rank 0's one JSON line through.  `script` is what the ranks run (this file; tests/test_bench_multi.py passes the entry that
+    injects CPU ranks).  Returns the exit code; if the ranks die without a line, prints an error line that says how many GPUs were asked for."""
+    import subprocess
+    script = script or os.path.abspath(__file__)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), script] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, timeout=timeout)
+        rc, so = r.returncode, r.stdout.decode(errors="replace")
+    except subprocess.TimeoutExpired as ex:
+        rc, so = 124, (ex.stdout or b"").decode(errors="replace")
+    lines = [l for l in so.splitlines() if l.startswith("{")]
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+    else:
+        sys.stdout.write(json.dumps({"metric": "cell-updates/sec (GLUPS)", "value": None, "unit": "GLUPS", "n_gpus": n, "higher_is_better": True,
+                                     "error": "the %d ranks started by bench.py itself (torch.distributed.run) ended with exit code %d and no JSON line" % (n, rc)}) + "\n")
+    sys.stdout.flush()
+    return rc if (rc or lines) else 1
+
+
 class Deadline:
     """The extras behind the timed section (PMC child runs, steady timing, the CPU baseline) share one budget (--extras-budget): the
     headline line must not wait for a slow rocprofv3 or SwiftShader; an extra that no longer fits is skipped and says so."""
@@ -351,6 +391,9 @@ def main(argv=None, engine_factory=None, backend="nccl"):
                                                                      "before the watchdog reports which stage hung")
     args = ap.parse_args(argv)
     on_cpu = engine_factory is not None   # only tests/test_bench_multi.py: the launcher path on CPU ranks
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # no launcher around us: be the launcher (the ranks re-enter here with WORLD_SIZE set)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:] if argv is None else argv, script=os.path.abspath(sys.argv[0]) if on_cpu else None))
 
     # stdout must carry exactly ONE JSON line: RCCL / HIP libraries print banners to fd 1 from C, so everything
     # else is routed to stderr and the JSON is written to the saved descriptor at the end
@@ -367,7 +410,8 @@ def main(argv=None, engine_factory=None, backend="nccl"):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     N, size, iters = world, args.size, args.iters
     base = {"metric": "cell-updates/sec (GLUPS) at %d^2 per GPU, %d Jacobi iters/step" % (size, iters), "value": None, "unit": "GLUPS",
-            "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True}
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True}
+    knobs = fluid_knobs()
 
     def fail(msg, code=2):
         print("bench.py: " + msg, file=sys.stderr)
@@ -376,7 +420,10 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         sys.exit(code)
 
     if world != args.gpus:
-        fail("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE is %d)" % (args.gpus, args.gpus, world))
+        fail("--gpus %d but the launcher started %d ranks (WORLD_SIZE)" % (args.gpus, world))
+    if N > 1 and not on_cpu and "FLUID_RCCL_LIB" in knobs:
+        # tests/fake_rccl is an in-process stand-in for single-GPU tests: a number measured over it is not a multi-GPU number
+        fail("FLUID_RCCL_LIB=%s is set: bench.py measures over the RCCL that torch ships, not over a stand-in — unset it" % knobs["FLUID_RCCL_LIB"])
     if not on_cpu:
         if not torch.cuda.is_available():
             fail("no GPU visible; the HIP path has no CPU fallback")
@@ -435,6 +482,15 @@ def main(argv=None, engine_factory=None, backend="nccl"):
             return "another rank failed (see its message on stderr)"
         return err
 
+    def marks_of(sm):
+        """the object that owns the native context of this rank (step marks live in libfluid_hip.so), or None (CPU ranks, hosted driver)"""
+        if on_cpu:
+            return None
+        if hasattr(sm, "set_step_marks"):
+            return sm
+        eng = getattr(sm, "engine", None)
+        return eng if (eng is not None and hasattr(eng, "set_step_marks") and getattr(sm, "native", False)) else None
+
     def measure(sm, warmup, steps, label):
         """`warmup` untimed steps, then EXACTLY `steps` steps bracketed by sync + barrier + sync; MAX over ranks"""
         def sync():
@@ -444,6 +500,8 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         if dog:
             dog.at("%s: warm-up, %d steps (the first ghost-row exchanges over RCCL / xGMI)" % (label, warmup))
         try:
+            if marks_of(sm) is not None and steps <= 512:
+                marks_of(sm).set_step_marks(steps)   # events between the steps, nobody waits for them: `timed_window_regime`
             sm.step(DT, warmup)   # N > 1, native driver: the plan and its RCCL exchanges run inside libfluid_hip.so
             sync(); barrier(); sync()
             if dog:
@@ -475,6 +533,17 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         dev_sync()
 
     elapsed = measure(sim, args.warmup, args.steps, "headline")
+    regime = None
+    if rank == 0 and marks_of(sim) is not None and args.steps <= 512:
+        per = marks_of(sim).step_marks()
+        marks_of(sim).set_step_marks(0)
+        if per:
+            # device time of each of the K timed steps, in order: the first steps after the (short) warm-up run slower than the steady state
+            # (profiles/r04/first_steps.txt names the mechanism); `head_over_tail` = mean of the first quarter / mean of the last quarter
+            q = max(1, len(per) // 4)
+            regime = {"ms_per_timed_step": [round(x, 4) for x in per], "sum_ms": round(sum(per), 4),
+                      "head_over_tail": round((sum(per[:q]) / q) / max(sum(per[-q:]) / q, 1e-9), 4),
+                      "source": "events recorded between the steps inside the timed fluid_step_n call (fluid_set_step_marks; nothing waits for them)"}
 
     steps_per_s = args.steps / elapsed
     glups = grid_w * grid_h * steps_per_s / 1e9
@@ -503,6 +572,16 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         "speedup_vs_pass_structure": {"algorithmic_GBps": round(alg_step_bytes * steps_per_s / 1e9, 1),
                                       "x_hbm_peak": round(alg_step_bytes * steps_per_s / 1e9 / (HBM_PEAK_GBPS * N), 4)},
     })
+    out["config"]["knobs"] = knobs   # FLUID_* variables in the environment (A/B knobs of the library); {} = shipped defaults
+    if regime:
+        out["timed_window_regime"] = regime
+    if N == 1 and not on_cpu:
+        si = sim.schedule_info(args.steps, DT)
+        # which kernels the timed call launched (the library picks by grid size): chained = steps whose advection launch also ran the next
+        # step's curl / vorticity / divergence (fluid_step_n below 3072^2 texels); a per-frame fluid_step never chains
+        out["config"]["kernels"] = {"jacobi_shape": si["jacobi_shape"], "jacobi_launches_per_step": si["jacobi_launches"],
+                                    "gradsub_folded": bool(si["gradsub_folded"]), "chained_steps": si["chained"],
+                                    "curl_field_stored_by_steps": si["curl_stores"], "launches_in_timed_call": si["launches"]}
     if on_cpu:
         out["config"]["engine"] = "injected stripe engine on CPU ranks over %s (launcher-path test, not a measurement)" % backend
     if N > 1:
@@ -569,8 +648,14 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         sim.set_timing(False)
         # launches of the loop that are ONLY Jacobi (the last launch of a step also carries the gradient subtract under the fused
         # schedule: k_jacobi_tb_gs, timed under gradsub_ms)
-        launches = max(tm["jacobi_launches"] - tm.get("folded_launches", 0), 1)
-        avg_ms = tm["jacobi_ms"] / launches
+        plain = tm["jacobi_launches"] - tm.get("folded_launches", 0)
+        only_folded = plain <= 0 and tm.get("folded_launches", 0) > 0
+        if only_folded:   # iterations <= the tile depth on a small grid: the step's ONE Jacobi launch also carries the gradient subtract
+            launches, avg_ms = tm["folded_launches"], tm["gradsub_ms"] / tm["folded_launches"]
+        else:
+            launches = max(plain, 1)
+            avg_ms = tm["jacobi_ms"] / launches
+        avg_ms = max(avg_ms, 1e-6)
         alg_launch = 12.0 * iters * size * size * tm["steps"] / max(tm["jacobi_launches"], 1) * half  # 12 B/cell/iteration, SURVEY.md 8(d)
         # the kernel that runs the loop: the temporally blocked register tile, or one launch per iteration under --schedule passes
         if args.schedule == "fused":
@@ -578,6 +663,8 @@ def main(argv=None, engine_factory=None, backend="nccl"):
             cands = ["k_jacobi_tb_h<", "k_jacobi_tb<"] if args.storage == "f16" else ["k_jacobi_tb_mix<", "k_jacobi_tb<", "k_jacobi_tb2<"]
         else:
             cands = ["k_h_jacobi", "k_jacobi"] if args.storage == "f16" else ["k_jacobi"]
+        if only_folded and args.schedule == "fused":
+            cands = ["k_jacobi_tb_gs_h<"] if args.storage == "f16" else ["k_jacobi_tb2_gs<", "k_jacobi_tb_gs<"]
         kname = cands[0]
         traffic, why = (None, "--no-traffic") if args.no_traffic else collect_traffic(args, deadline)
         entry = None
@@ -598,6 +685,10 @@ def main(argv=None, engine_factory=None, backend="nccl"):
             "kernel": kname, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": bytes_launch, "traffic_source": source,
             "attainable": HBM_ATTAINABLE_GBPS, "frac_of_attainable": round(achieved / HBM_ATTAINABLE_GBPS, 4),
+            # the same with the bytes a launch MUST move (pressure in, divergence in, pressure out: 12 B/texel; + 16 velocity in / out when the
+            # launch carries the gradient subtract) instead of the bytes it did move: apron re-reads do not count as achievement here
+            "compulsory_bytes_per_launch": int((28.0 if only_folded else 12.0) * size * size * half),
+            "frac_compulsory": round((28.0 if only_folded else 12.0) * size * size * half / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
             "avg_launch_ms": round(avg_ms, 5), "launches_per_step": launches / max(tm["steps"], 1),
             "iterations_per_launch": iters * tm["steps"] / max(tm["jacobi_launches"], 1),
             "algorithmic_bytes_per_launch": int(alg_launch),
@@ -646,6 +737,10 @@ def main(argv=None, engine_factory=None, backend="nccl"):
             out["step_hbm"] = {"bytes_per_step": traffic["bytes_per_step"], "GBps": round(traffic["bytes_per_step"] * steps_per_s / 1e9, 1),
                                "frac": round(traffic["bytes_per_step"] * steps_per_s / 1e9 / HBM_PEAK_GBPS, 4),
                                "frac_of_attainable": round(traffic["bytes_per_step"] * steps_per_s / 1e9 / HBM_ATTAINABLE_GBPS, 4),
+                               # the bytes the fused schedule MUST move per step (no apron re-reads): curl/vorticity/divergence 20 (+ 4 for a
+                               # step that stores its curl field), Jacobi 12 per launch, gradient subtract 20, advection 48
+                               "compulsory_bytes_per_step": int(compulsory_step_bytes(size, iters, tm, args.steps) * half),
+                               "frac_compulsory": round(compulsory_step_bytes(size, iters, tm, args.steps) * half * steps_per_s / 1e9 / HBM_PEAK_GBPS, 4),
                                "kernels": {k: {"bytes_per_launch": v["bytes_per_launch"], "launches_per_step": v["launches_per_step"]}
                                            for k, v in traffic["kernels"].items()}}
         per_step = {k: round(v / max(tm["steps"], 1), 4) for k, v in tm.items() if k.endswith("_ms")}
@@ -710,6 +805,15 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         dist.barrier()
         dist.destroy_process_group()
     return out
+
+
+def compulsory_step_bytes(size, iters, tm, steps_in_call):
+    """HBM bytes one fused step cannot avoid at `size`^2 (fp32, dye grid = sim grid), from the launches the timing pass counted"""
+    per_step_launches = tm["jacobi_launches"] / max(tm["steps"], 1)
+    folded = tm.get("folded_launches", 0) / max(tm["steps"], 1)
+    curl = 4.0 / max(steps_in_call, 1)   # only the call's last step stores the curl field
+    b = 20.0 + curl + 12.0 * per_step_launches + (16.0 if folded else 20.0) + 48.0
+    return b * size * size
 
 
 def time_jacobi_launch(sim, k, reps=20):

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define FLUID_ABI_VERSION 7
+#define FLUID_ABI_VERSION 8
 
 typedef enum fluid_status {
     FLUID_OK = 0,
@@ -290,6 +290,27 @@ int fluid_read_display_buffer(fluid_ctx *ctx, int which, float *host, size_t byt
 
 int fluid_set_timing(fluid_ctx *ctx, int enabled);
 int fluid_get_timings(fluid_ctx *ctx, fluid_timings *out);
+
+/* What fluid_step_n(ctx, n_steps, dt, params) would launch on this context right now (since ABI 8) — the library picks kernels by grid
+ * size (and by its FLUID_* A/B knobs), and a measurement has to be able to say which ones it timed (bench.py `config`). */
+typedef struct fluid_schedule_info {
+    int fused;             /* the context runs FLUID_SCHED_FUSED kernels                                                         */
+    int jacobi_shape;      /* tile-shape table index of the temporally blocked Jacobi launches; -1: one launch per iteration     */
+    int jacobi_launches;   /* Jacobi launches per step                                                                           */
+    int gradsub_folded;    /* the gradient subtract rides in a step's last Jacobi launch                                         */
+    int chained;           /* steps of the call whose advection launch also runs the next step's curl / vorticity / divergence  */
+    int curl_stores;       /* steps of the call that store their curl field (the last one always does)                           */
+    int launches;          /* kernel launches of the whole call (whole-domain contexts; 0 for stripes: see fluid_stripe_plan)    */
+} fluid_schedule_info;
+int fluid_schedule_info_get(fluid_ctx *ctx, int n_steps, float dt, const fluid_params *params, fluid_schedule_info *out);
+
+/* Step marks (since ABI 8): one event on the context's stream in front of the first and behind every step of the NEXT fluid_step_n /
+ * fluid_group_step_n calls (the first `capacity` steps of each call; 0 switches the marks off).  Unlike fluid_set_timing nothing waits:
+ * the stream runs exactly as it does unmarked, so the marks show how a step's time develops INSIDE a timed window (bench.py
+ * `timed_window_regime`: the first steps after an idle run slower than the steady state).  fluid_get_step_marks waits for the last
+ * mark of the last call and returns the device time of each of its marked steps in milliseconds. */
+int fluid_set_step_marks(fluid_ctx *ctx, int capacity);
+int fluid_get_step_marks(fluid_ctx *ctx, float *ms, int capacity, int *n_steps);
 
 #ifdef __cplusplus
 }

@@ -329,3 +329,33 @@ def test_the_chained_launch_at_the_bench_size_yields_the_same_bits():
         got.append(json.loads(r.stdout.strip().splitlines()[-1]))
     for env, g in zip(envs, got):
         assert g == got[0], env
+
+
+@pytest.mark.gpu
+def test_step_marks_and_schedule_info():
+    """ABI 8: events between the steps of a call (nothing waits for them) and the description of what a call launches"""
+    import fluid_hip
+    DT = 0.016666
+    cfg = {"SIM_RESOLUTION": 512, "DYE_RESOLUTION": 512, "PRESSURE_ITERATIONS": 50}
+    with fluid_hip.FluidSim(canvas=(512, 512), config=cfg, random=fluid_hip.mulberry32(5)) as sim:
+        sim.multipleSplats(4)
+        si = sim.schedule_info(6)
+        assert si["fused"] == 1 and si["jacobi_launches"] == 5 and si["gradsub_folded"] == 1 and si["chained"] == 5 and si["curl_stores"] == 1
+        assert si["launches"] == 6 * 6 + 1   # five Jacobi launches (the last with K6) + advection (+ next curl) per step, one leading curl launch
+        assert sim.schedule_info(1)["chained"] == 0 and sim.schedule_info(1)["launches"] == 7
+        sim.set_step_marks(4)
+        sim.step(DT, 6)                      # the first four steps are marked
+        ms = sim.step_marks()
+        assert len(ms) == 4 and all(0.0 < x < 50.0 for x in ms)
+        sim.step(DT, 2)
+        assert len(sim.step_marks()) == 2
+        sim.set_step_marks(0)
+        sim.step(DT, 2)
+        assert sim.step_marks() == []
+        want = sim.fields()
+    with fluid_hip.FluidSim(canvas=(512, 512), config=cfg, random=fluid_hip.mulberry32(5)) as sim:   # marks change nothing
+        sim.multipleSplats(4)
+        sim.step(DT, 6); sim.step(DT, 2); sim.step(DT, 2)
+        got = sim.fields()
+    for k in want:
+        assert np.array_equal(want[k], got[k]), k

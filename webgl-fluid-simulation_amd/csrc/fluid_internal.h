@@ -5,6 +5,7 @@
 #include "fluid_kernels.h"
 
 #include <string>
+#include <vector>
 
 struct fluid_display_state;  // fluid_display.cpp
 
@@ -40,6 +41,10 @@ struct fluid_ctx {
     double acc_ms[P_COUNT] = {};
     double acc_total = 0;
     int acc_steps = 0, acc_jacobi_launches = 0, acc_folded_launches = 0;
+
+    // step marks (fluid_set_step_marks): events between the steps of a call, nobody waits for them until they are read
+    std::vector<hipEvent_t> marks;
+    int marks_used = 0;   // events recorded by the last call (marked steps + 1)
 
     // stripe driver (fluid_stripes.cpp): RCCL communicator of the stripe set, exchange bookkeeping
     void* comm = nullptr;                // ncclComm_t, rank == desc.part, nranks == desc.parts
@@ -150,6 +155,7 @@ int advect_both_rects(fluid_ctx* c, float dt, float vel_diss, float dye_diss, co
 void advect_both_swap(fluid_ctx* c);
 
 // fluid_stripes.cpp
+void mark_step(fluid_ctx* c, int k);                                     // step marks: k = 0 in front of a call's first step, k behind its k-th
 bool skip_hidden_curl();                                                 // FLUID_SKIP_CURL=0: every step stores its curl field (A/B knob)
 int stripe_step_n(fluid_ctx* c, int n, float dt, const fluid_params* P);  // this rank's stripe, exchanges over RCCL
 void stripes_release(fluid_ctx* c);                                       // frees the communicator (fluid_destroy)

@@ -340,6 +340,16 @@ bool gradsub_fold_enabled(long owned_texels)
     return mode >= 0 ? mode == 1 : owned_texels < 3072l * 3072l;
 }
 
+void mark_step(fluid_ctx* c, int k)
+{
+    if (c->marks.empty()) return;
+    if (k == 0) c->marks_used = 0;
+    if (k < (int)c->marks.size() && k == c->marks_used) {
+        (void)hipEventRecord(c->marks[k], c->stream);
+        c->marks_used = k + 1;
+    }
+}
+
 // FLUID_SKIP_CURL=0: every step of fluid_step_n stores its curl field (A/B knob; what a caller can read is the same either way)
 bool skip_hidden_curl()
 {
@@ -589,6 +599,7 @@ int fluid_destroy(fluid_ctx* c)
     if (c->miss) (void)hipFree(c->miss);
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->marks) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return FLUID_OK;
@@ -716,16 +727,19 @@ int fluid_step_n(fluid_ctx* c, int n, float dt, const fluid_params* P)
         ~CurlGuard() { c->keep_curl = true; }
     } guard{ c };
     const bool skip = fluid_impl::skip_hidden_curl();
+    fluid_impl::mark_step(c, 0);
     if (n > 1 && chain_applies(c, dt, P)) {
         for (int k = 0; k < n; k++) {
             c->keep_curl = !skip;   // the lead step's own launch: the chain's last k_advect_cvd writes the field a caller reads
             CK(step_once(c, dt, P, k == 0, k == n - 1 ? 0 : (k == n - 2 ? 2 : 1)));
+            fluid_impl::mark_step(c, k + 1);
         }
         return FLUID_OK;
     }
     for (int k = 0; k < n; k++) {
         c->keep_curl = k == n - 1 || !skip;
         CK(step_once(c, dt, P));
+        fluid_impl::mark_step(c, k + 1);
     }
     return FLUID_OK;
 }
@@ -937,6 +951,56 @@ int fluid_set_timing(fluid_ctx* c, int enabled)
     std::fill(std::begin(c->acc_ms), std::end(c->acc_ms), 0.0);
     c->acc_total = 0;
     c->acc_steps = c->acc_jacobi_launches = c->acc_folded_launches = 0;
+    return FLUID_OK;
+}
+
+int fluid_schedule_info_get(fluid_ctx* c, int n_steps, float dt, const fluid_params* P, fluid_schedule_info* out)
+{
+    if (!c || !P || !out || n_steps < 0) return FLUID_ERR_INVALID;
+    *out = fluid_schedule_info{};
+    const bool whole = c->desc.parts == 1 && c->desc.parts_x == 1;
+    const long owned = (long)c->sim_ncols * c->sim_rows;
+    out->fused = c->desc.schedule == FLUID_SCHED_FUSED;
+    const bool tb = fluid_impl::jacobi_tb_applies(c) && P->iterations > 0;
+    out->jacobi_shape = tb ? fluid::jacobi_tb_pick(owned) : -1;
+    const int depth = tb ? fluid::jacobi_tb_depth(out->jacobi_shape) : 1;
+    out->jacobi_launches = tb ? (P->iterations + depth - 1) / depth : P->iterations;
+    out->gradsub_folded = tb && fluid::jacobi_tb_has_gradsub(out->jacobi_shape) && fluid_impl::gradsub_fold_enabled(owned);
+    const bool chain = whole && n_steps > 1 && chain_applies(c, dt, P);
+    out->chained = chain ? n_steps - 1 : 0;
+    const bool fused_cvd = fluid_impl::fused_cvd_applies(c);
+    out->curl_stores = (fused_cvd && fluid_impl::skip_hidden_curl() && n_steps > 0) ? 1 : n_steps;
+    if (whole) {
+        const int cvd = fused_cvd ? 1 : 3, clear = tb ? 0 : 1, gs = out->gradsub_folded ? 0 : 1;
+        const int adv = fluid_impl::fused_advect_applies(c) ? 1 : 2;
+        const int per_step = cvd + clear + out->jacobi_launches + gs + adv;
+        out->launches = chain ? n_steps * (per_step - 1) + 1 : n_steps * per_step;   // a chained step has no curl launch of its own: the first one does
+    }
+    return FLUID_OK;
+}
+
+int fluid_set_step_marks(fluid_ctx* c, int capacity)
+{
+    if (!c || capacity < 0 || capacity > 4096) return c ? c->fail(FLUID_ERR_INVALID, "step marks: capacity 0 .. 4096") : FLUID_ERR_INVALID;
+    HIPCK(c, hipSetDevice(c->device));
+    for (auto& e : c->marks) (void)hipEventDestroy(e);
+    c->marks.clear();
+    c->marks_used = 0;
+    if (capacity > 0) {
+        c->marks.resize((size_t)capacity + 1, nullptr);
+        for (auto& e : c->marks) HIPCK(c, hipEventCreate(&e));
+    }
+    return FLUID_OK;
+}
+
+int fluid_get_step_marks(fluid_ctx* c, float* ms, int capacity, int* n_steps)
+{
+    if (!c || !n_steps || capacity < 0 || (capacity > 0 && !ms)) return FLUID_ERR_INVALID;
+    const int n = c->marks_used > 0 ? c->marks_used - 1 : 0;
+    *n_steps = n;
+    if (n == 0) return FLUID_OK;
+    HIPCK(c, hipEventSynchronize(c->marks[n]));
+    for (int k = 0; k < n && k < capacity; k++) HIPCK(c, hipEventElapsedTime(&ms[k], c->marks[k], c->marks[k + 1]));
     return FLUID_OK;
 }
 

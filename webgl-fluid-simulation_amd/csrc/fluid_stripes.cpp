@@ -712,7 +712,8 @@ int stripe_step_n(fluid_ctx* c, int n, float dt, const fluid_params* P)
         ~CurlGuard() { c->keep_curl = true; }
     } guard{ c };
     const bool skip = skip_hidden_curl();
-    for (int k = 0; k < n; k++)
+    mark_step(c, 0);
+    for (int k = 0; k < n; mark_step(c, ++k))
         for (size_t i = 0; i < ops.size(); i++) {
             c->keep_curl = k == n - 1 || !skip;   // only the call's last step leaves a curl field a caller can read (fluid_step_n)
             const fluid_stripe_op& op = ops[i];
@@ -920,7 +921,9 @@ int fluid_group_step_n(fluid_ctx** cs, int n_ctx, int steps, float dt, const flu
         ~CurlGuard() { for (int r = 0; r < n; r++) cs[r]->keep_curl = true; }
     } guard{ cs, n_ctx };
     const bool skip = skip_hidden_curl();
-    for (int k = 0; k < steps; k++)
+    auto mark_all = [&](int k) { for (int r = 0; r < n_ctx; r++) mark_step(cs[r], k); };
+    mark_all(0);
+    for (int k = 0; k < steps; mark_all(++k))
         for (size_t i = 0; i < ops.size(); i++) {
             for (int r = 0; r < n_ctx; r++) cs[r]->keep_curl = k == steps - 1 || !skip;   // as in stripe_step_n
             const fluid_stripe_op& op = ops[i];

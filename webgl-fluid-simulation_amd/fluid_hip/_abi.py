@@ -60,6 +60,10 @@ class DisplayParams(C.Structure):
 DISPLAY_BLOOM, DISPLAY_SUNRAYS = 0, 1
 
 
+class ScheduleInfo(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("fused", "jacobi_shape", "jacobi_launches", "gradsub_folded", "chained", "curl_stores", "launches")]
+
+
 class StripeOp(C.Structure):
     _fields_ = [("kind", C.c_int), ("iters", C.c_int), ("ext", C.c_int), ("n_items", C.c_int), ("field", C.c_int * 2), ("rows", C.c_int * 2)]
 
@@ -124,6 +128,9 @@ SYMBOLS = {
     "fluid_read_display_buffer": (_I, [_CTX, _I, C.c_void_p, C.c_size_t, C.POINTER(_I), C.POINTER(_I)]),
     "fluid_set_timing": (_I, [_CTX, _I]),
     "fluid_get_timings": (_I, [_CTX, C.POINTER(Timings)]),
+    "fluid_schedule_info_get": (_I, [_CTX, _I, _F, C.POINTER(Params), C.POINTER(ScheduleInfo)]),
+    "fluid_set_step_marks": (_I, [_CTX, _I]),
+    "fluid_get_step_marks": (_I, [_CTX, C.POINTER(_F), _I, C.POINTER(_I)]),
 }
 
 _lib = None
@@ -164,7 +171,7 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the header and the library disagree
             fn.restype = res
             fn.argtypes = args
-        if L.fluid_abi_version() != 7:
+        if L.fluid_abi_version() != 8:
             raise FluidError(ERR_UNSUPPORTED, "ABI version mismatch")
         _lib = L
         _point_at_torch_rccl(L)

@@ -501,3 +501,22 @@ class FluidSim:
         t = _abi.Timings()
         self._check(self._lib.fluid_get_timings(self._ctx, C.byref(t)))
         return {k: getattr(t, k) for k, _ in _abi.Timings._fields_}
+
+    def set_step_marks(self, capacity: int):
+        """events between the first `capacity` steps of every following step(dt, n) call; nothing waits for them (0 = off)"""
+        self._check(self._lib.fluid_set_step_marks(self._ctx, int(capacity)))
+
+    def step_marks(self) -> list:
+        """device milliseconds of each marked step of the last step(dt, n) call (waits for that call's last mark)"""
+        n = C.c_int(0)
+        self._check(self._lib.fluid_get_step_marks(self._ctx, None, 0, C.byref(n)))
+        buf = (C.c_float * max(n.value, 1))()
+        self._check(self._lib.fluid_get_step_marks(self._ctx, buf, n.value, C.byref(n)))
+        return [float(buf[k]) for k in range(n.value)]
+
+    def schedule_info(self, n_steps: int = 1, dt: float = 0.016666) -> Dict[str, int]:
+        """which kernels step(dt, n_steps) would launch on this context right now (fluid_schedule_info_get)"""
+        P = self.params()
+        info = _abi.ScheduleInfo()
+        self._check(self._lib.fluid_schedule_info_get(self._ctx, int(n_steps), dt, C.byref(P), C.byref(info)))
+        return {k: getattr(info, k) for k, _ in _abi.ScheduleInfo._fields_}

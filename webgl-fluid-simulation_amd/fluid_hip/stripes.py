@@ -145,6 +145,16 @@ class HipStripeEngine:
     def check_halo(self): self._ck(self.lib.fluid_halo_check(self.ctx))
 
     # -- native driver: the library runs the plan and the RCCL exchanges itself ---------------------------------
+    def set_step_marks(self, capacity):
+        self._ck(self.lib.fluid_set_step_marks(self.ctx, int(capacity)))
+
+    def step_marks(self):
+        n = C.c_int(0)
+        self._ck(self.lib.fluid_get_step_marks(self.ctx, None, 0, C.byref(n)))
+        buf = (C.c_float * max(n.value, 1))()
+        self._ck(self.lib.fluid_get_step_marks(self.ctx, buf, n.value, C.byref(n)))
+        return [float(buf[k]) for k in range(n.value)]
+
     def use_own_stream(self):
         """back to the context's own HIP stream (the native driver does not involve torch streams)"""
         self._ck(self.lib.fluid_set_stream(self.ctx, None, 0))
