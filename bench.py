@@ -198,7 +198,7 @@ def pmc_pass(args, counters, deadline, steps_under_profiler=4):
     with tempfile.TemporaryDirectory(prefix="fluid_pmc_", dir="/tmp") as d:
         cmd = [exe, "--kernel-trace", "--pmc"] + list(counters) + ["--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
                os.path.abspath(__file__), "--steps", str(steps_under_profiler), "--warmup", "0", "--cpu-budget", "0", "--no-profile-pass",
-               "--no-traffic", "--no-steady", "--no-parity", "--size", str(args.size), "--iters", str(args.iters), "--schedule", args.schedule,
+               "--no-traffic", "--no-steady", "--no-parity", "--settle-ms", "0", "--size", str(args.size), "--iters", str(args.iters), "--schedule", args.schedule,
                "--storage", args.storage]
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=limit)
@@ -387,6 +387,11 @@ def main(argv=None, engine_factory=None, backend="nccl"):
                          "configurations when N matches — N = 4: 8192,50,2 (configs[3]); N = 8: 16384,200,1 (configs[4]); 'none' disables")
     ap.add_argument("--hosted", action="store_true", help="N > 1: drive the passes from Python with torch.distributed send/recv "
                                                           "instead of the native plan + RCCL inside libfluid_hip.so")
+    ap.add_argument("--settle-ms", type=float, default=40.0,
+                    help="milliseconds of the same workload on a scratch context enqueued directly in front of the warm-up (0 = none).  After an idle "
+                         "of >= 1 ms the MI355X answers a load step by dropping its shader clock from 2.4 to ~1.8 GHz for a few milliseconds and "
+                         "ramping back over ~15 ms (profiles/r04/first_steps.txt: measured from inside the stream, touched or untouched buffers "
+                         "alike); `--steps 20 --warmup 5` is 13 ms of work, all of it inside that dip.  The line reports the window without it as well (`cold_start`)")
     ap.add_argument("--comm-timeout", type=float, default=120.0, help="N > 1: seconds the communicator set-up and the warm-up steps may take "
                                                                      "before the watchdog reports which stage hung")
     args = ap.parse_args(argv)
@@ -471,6 +476,28 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         barrier = dist.barrier
         grid_w, grid_h = gw, gh
 
+    # ---- the chip's power state in front of the timed window (see --settle-ms) ----
+    scratch, settle = None, None
+    if args.settle_ms > 0 and not on_cpu:
+        scratch = fluid_hip.FluidSim(canvas=(size, size), config=cfg, device=local_rank, schedule=args.schedule,
+                                     random=fluid_hip.mulberry32(4321), storage=args.storage)
+        scratch.multipleSplats(20)
+        scratch.step(DT, 2)
+        scratch.sync()
+        t0 = time.perf_counter()
+        scratch.step(DT, 4)
+        scratch.sync()
+        est = max((time.perf_counter() - t0) / 4, 1e-6)
+        n_settle = max(1, int(args.settle_ms / 1e3 / est + 0.999))
+        settle = {"steps": n_settle, "est_ms": round(1e3 * est * n_settle, 1),
+                  "what": "%d steps of the same %dx%d workload on a scratch context, enqueued directly in front of the warm-up and not waited for: "
+                          "the warm-up and the timed steps start on a chip that is already under load (no DVFS dip; profiles/r04/first_steps.txt)"
+                          % (n_settle, size, size)}
+
+    def preload():
+        if scratch is not None:
+            scratch.step(DT, settle["steps"])   # asynchronous: the sync in front of the timed steps waits for it together with the warm-up
+
     def agree(err):
         """N > 1: a failure on ONE rank (a reach violation is counted per rank) must end EVERY rank — the others would sit in the next
         exchange or collective until the RCCL timeout.  Every rank contributes its flag; all of them fail together."""
@@ -502,6 +529,7 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         try:
             if marks_of(sm) is not None and steps <= 512:
                 marks_of(sm).set_step_marks(steps)   # events between the steps, nobody waits for them: `timed_window_regime`
+            preload()
             sm.step(DT, warmup)   # N > 1, native driver: the plan and its RCCL exchanges run inside libfluid_hip.so
             sync(); barrier(); sync()
             if dog:
@@ -572,6 +600,8 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         "speedup_vs_pass_structure": {"algorithmic_GBps": round(alg_step_bytes * steps_per_s / 1e9, 1),
                                       "x_hbm_peak": round(alg_step_bytes * steps_per_s / 1e9 / (HBM_PEAK_GBPS * N), 4)},
     })
+    if settle:
+        out["config"]["settle"] = settle
     out["config"]["knobs"] = knobs   # FLUID_* variables in the environment (A/B knobs of the library); {} = shipped defaults
     if regime:
         out["timed_window_regime"] = regime
@@ -635,6 +665,11 @@ def main(argv=None, engine_factory=None, backend="nccl"):
             out["extra_configs"] = extra
     if dog:
         dog.stop()
+
+    if scratch is not None:
+        scratch.sync()
+        scratch.close()
+        scratch = None
 
     deadline = Deadline(args.extras_budget)
     skipped = {}
@@ -766,6 +801,26 @@ def main(argv=None, engine_factory=None, backend="nccl"):
             out["steady_steps"] = n_long
         else:
             skipped["steady_ms_per_step"] = "extras budget spent"
+
+    # ---- the same W + K from a cold chip: what `ms_per_step` would read without the load in front of the warm-up ----
+    if rank == 0 and N == 1 and settle and not args.no_steady and deadline.left() > 20:
+        sync()
+        time.sleep(0.3)
+        with fluid_hip.FluidSim(canvas=(size, size), config=cfg, device=local_rank, schedule=args.schedule, random=fluid_hip.mulberry32(1234),
+                                storage=args.storage) as cold:
+            cold.multipleSplats(20)
+            if args.steps <= 512:
+                cold.set_step_marks(args.steps)
+            cold.step(DT, args.warmup)
+            cold.sync(); dev_sync()
+            t0 = time.perf_counter()
+            cold.step(DT, args.steps)
+            cold.sync(); dev_sync()
+            el = time.perf_counter() - t0
+            per = cold.step_marks() if args.steps <= 512 else []
+        out["cold_start"] = {"ms_per_step": round(1e3 * el / args.steps, 4), "ms_per_timed_step": [round(x, 4) for x in per],
+                             "what": "the same %d warm-up + %d timed steps on a fresh context after 300 ms of idle, nothing in front of the splats: "
+                                     "inside the shader-clock dip that follows a load step (config.settle)" % (args.warmup, args.steps)}
 
     # the in-run parity check, on every rank's own GPU, BEHIND every timed section of this run (see parity_in_run): a mismatch replaces
     # the line by an error

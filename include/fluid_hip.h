@@ -121,6 +121,9 @@ typedef struct fluid_timings {
 typedef struct fluid_ctx fluid_ctx;
 
 int fluid_abi_version(void);
+/* "product" (make: the kernels the grid-driven schedule can pick, no tuning knobs read) or "probes" (make PROBES=1: libfluid_hip_probes.so, every
+ * lab shape of profiles/ and the FLUID_* A/B knobs that select them).  Since ABI 8. */
+const char *fluid_build_flavor(void);
 const char *fluid_error_string(int status);
 const char *fluid_last_error(const fluid_ctx *ctx); /* ctx may be NULL: last create() failure */
 int fluid_device_count(int *count);

@@ -290,7 +290,11 @@ def test_every_knob_of_the_fused_schedule_yields_the_same_bits():
     settings += [{"FLUID_ADVECT_FAST": "0"}, {"FLUID_ADVECT_SPLIT_ROWS": "4"}, {"FLUID_ADVECT_SPLIT_ROWS": "1"}, {"FLUID_ADVECT_ROWS": "2"},
                  {"FLUID_TB_VARIANT": "1", "FLUID_FOLD_GRADSUB": "1"}, {"FLUID_TB_VARIANT": "5"}]
     ref = None
+    probes = os.path.join(pkg, "libfluid_hip_probes.so")   # make PROBES=1: the lab build, where the knobs are read at all
+    assert os.path.exists(probes), "build the lab library first: make -C webgl-fluid-simulation_amd PROBES=1"
     for env in settings:
+        if env:   # the first setting, {}, is the PRODUCT library: every lab shape has to reproduce ITS bits
+            env = dict(env, FLUID_HIP_LIB=probes)
         r = subprocess.run([sys.executable, "-c", _KNOB_CHILD % pkg], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, (env, r.stderr[-500:])
         got = json.loads(r.stdout.strip().splitlines()[-1])
@@ -323,6 +327,8 @@ def test_the_chained_launch_at_the_bench_size_yields_the_same_bits():
     # ... and the other settings that only a big grid exercises: the two-texel tile as head / tail of the mixed Jacobi launch, the curl
     # field stored by every step of the call
     envs = [{"FLUID_CHAIN": "0"}, {"FLUID_CHAIN": "1"}, {"FLUID_TB_TAIL_TILES": "384,768,2"}, {"FLUID_SKIP_CURL": "0"}, {"FLUID_TB_TAIL_TILES": "0,0,7"}]
+    probes = os.path.join(pkg, "libfluid_hip_probes.so")
+    envs = [{}] + [dict(e, FLUID_HIP_LIB=probes) for e in envs]   # the product library's own bits first
     for env in envs:
         r = subprocess.run([sys.executable, "-c", _CHAIN_CHILD % pkg], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, (env, r.stderr[-500:])

@@ -23,6 +23,8 @@ def main():
             for kv in st.split():
                 k, _, v = kv.partition("=")
                 env[k] = v
+            if st.split() and "FLUID_HIP_LIB" not in env:   # knobs are read by the lab build only (make PROBES=1); "" = the product library
+                env["FLUID_HIP_LIB"] = os.path.join(ROOT, "webgl-fluid-simulation_amd", "libfluid_hip_probes.so")
             cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-budget", "0", "--no-traffic", "--no-steady"] + a.args.split()
             p = subprocess.run(cmd, env=env, capture_output=True, text=True)
             try:

@@ -52,7 +52,7 @@ def main():
     for v, name in enumerate(names):
         if v not in only:
             continue
-        env = dict(os.environ, FLUID_TB_VARIANT=str(v), _TB_CHILD="1")
+        env = dict(os.environ, FLUID_TB_VARIANT=str(v), FLUID_HIP_LIB=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'webgl-fluid-simulation_amd', 'libfluid_hip_probes.so'), _TB_CHILD="1")
         r = subprocess.run([sys.executable, os.path.abspath(__file__), str(N), str(iters)], env=env, capture_output=True, text=True)
         line = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:]
         print("variant %d (%s) N=%d iters=%d: %s" % (v, name, N, iters, line), flush=True)

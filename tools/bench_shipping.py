@@ -59,7 +59,7 @@ def main():
     if os.environ.get("_SHIP_CHILD"):
         return child()
     res = {}
-    for label, env in (("fast", {}), ("general", {"FLUID_ADVECT_FAST": "0"})):
+    for label, env in (("fast", {}), ("general", {"FLUID_ADVECT_FAST": "0", "FLUID_HIP_LIB": os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "webgl-fluid-simulation_amd", "libfluid_hip_probes.so")})):   # knobs: the lab build
         p = subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, _SHIP_CHILD="1", **env), capture_output=True, text=True)
         lines = [l for l in p.stdout.splitlines() if l.startswith("[")]
         res[label] = json.loads(lines[-1]) if lines else {"error": p.stderr[-400:]}

@@ -42,7 +42,7 @@ def main():
     shapes = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "0 8 16 18 19").split()]
     for N in sizes:
         for v in shapes:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), str(N)], env=dict(os.environ, _JIC_CHILD="1", FLUID_TB_VARIANT=str(v)),
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), str(N)], env=dict(os.environ, _JIC_CHILD="1", FLUID_TB_VARIANT=str(v), FLUID_HIP_LIB=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'webgl-fluid-simulation_amd', 'libfluid_hip_probes.so')),
                                capture_output=True, text=True)
             try:
                 d = {int(k): x for k, x in json.loads(r.stdout.strip().splitlines()[-1]).items()}

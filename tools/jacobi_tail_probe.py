@@ -41,7 +41,7 @@ def main():
         return child(int(sys.argv[1]), int(sys.argv[2]))
     cases = [(H, 0) for H in (1690, 1750, 3370, 3430, 3490, 3730, 4096, 5050, 5110)] + [(726, v) for v in (0, 8, 9, 10)] + [(1446, v) for v in (0, 9, 10)]
     for H, v in cases:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "4096", str(H)], env=dict(os.environ, _JTP_CHILD="1", FLUID_TB_VARIANT=str(v)),
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "4096", str(H)], env=dict(os.environ, _JTP_CHILD="1", FLUID_TB_VARIANT=str(v), FLUID_HIP_LIB=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'webgl-fluid-simulation_amd', 'libfluid_hip_probes.so')),
                            capture_output=True, text=True)
         try:
             d = json.loads(r.stdout.strip().splitlines()[-1])

@@ -4,7 +4,22 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 namespace fluid {
+
+// The FLUID_* tuning knobs (tile shapes, folds, chains, rows per thread: every A/B of the rounds' profiles/) exist in the lab build only —
+// `make PROBES=1` -> libfluid_hip_probes.so, -DFLUID_PROBES — together with the kernel shapes they select.  The product library reads none of
+// them: what it launches is decided by the grid alone (fluid_schedule_info_get says what).
+inline const char* lab_env(const char* name)
+{
+#ifdef FLUID_PROBES
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 // A window onto one field: the device array holds `rows` rows x P columns of a field whose global size is
 // W x H; array row r is global row g0 + r (g0 < 0 is allowed: ghost rows below the domain are

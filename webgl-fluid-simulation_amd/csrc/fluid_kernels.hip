@@ -719,14 +719,12 @@ __device__ __forceinline__ Quad jacobi_row(Quad C, Quad T, Quad B, const Quad D,
     const v2f quarter = v2f{ 0.25f, 0.25f };
     float h0 = L + C.i.x;  // texel 0: left + c1
     float h3 = C.i.y + R;  // texel 3: c2 + right
-#ifndef FLUID_NO_DPP_FOLD  // (A/B switch, tools/ab_build_bench.sh)
     if (!EDGE) {
         // keep these two adds scalar: as a packed pair (what the SLP vectoriser makes of them) they need two
         // v_mov_b32_dpp in front; scalar, the lane shift folds into the add itself (v_add_f32_dpp)
         asm("" : "+v"(h0));
         asm("" : "+v"(h3));
     }
-#endif
     const v2f h_o = v2f{ h0, h3 };
     const v2f h_i = C.o + __builtin_shufflevector(C.i, C.i, 1, 0);   // texels 1, 2: c0 + c2, c3 + c1
     Quad n;
@@ -1234,9 +1232,6 @@ __global__ void __launch_bounds__(256) k_gradsub4_h(Win w, const __half* __restr
 #ifndef VD_WAVES_PER_EU
 #define VD_WAVES_PER_EU 4
 #endif
-#ifndef FLUID_CVD_PIN
-#define FLUID_CVD_PIN 1   // 0: A/B builds without the scheduling pin of stage 2 (tools/build_variant.sh)
-#endif
 template <int NW, int RY>
 struct VortDiv {
     static constexpr int TX = 256, TY = NW * RY, AX = 4, AY = 3;
@@ -1346,9 +1341,7 @@ __device__ __forceinline__ void vort_div_body(const Win& w, const V2* __restrict
                 if (gj == w.H - 1) T = C[r][k];
             }
             float2 conf = vorticity_cell(L, R, T, B, C[r][k], make_float2(V[r].x[k], V[r].y[k]), curl_strength, dt);
-#if FLUID_CVD_PIN
-            asm volatile("" : "+v"(conf.x), "+v"(conf.y));  // finished HERE: left alone, the tail of a divide is sunk into the store branch of stage 3 and its operand spilled on the way
-#endif
+            asm volatile("" : "+v"(conf.x), "+v"(conf.y));  // finished HERE: left alone, the tail of a divide is sunk into the store branch of stage 3 and its operand spilled on the way (96 VGPRs, no scratch, against 128 + 8 B: profiles/r03/cvd_pin_ab.txt)
             N[r].x[k] = kept(vel_out, conf.x);  // likewise the divergence pass reads the stored velocity
             N[r].y[k] = kept(vel_out, conf.y);
         }
@@ -1740,10 +1733,77 @@ constexpr int kPairTB = 20;     // not in TB_VARIANTS: its own kernels, fp32 fie
 constexpr int kNumTB = sizeof(kTB) / sizeof(kTB[0]);
 constexpr int kDefaultTB = 0;  // measured best of the table at 4096^2 (profiles/r01/jacobi_variants.txt, there listed as "8x10 h12/10")
 
+// The PRODUCT library (make) holds the shapes the grid-driven choice can return (jacobi_tb_pick, tb_rules: 0 at >= 3072^2 texels, 8 and the
+// two-texel tile below); everything else in the table is a lab shape of some round's A/B and exists in libfluid_hip_probes.so only
+// (make PROBES=1: -DFLUID_PROBES, where the FLUID_* knobs that select them are read at all — fluid_kernels.h lab_env).
+#ifdef FLUID_PROBES
+#define TB_VARIANTS(X)      \
+    X(0, 8, 10, 12, 10, 2)  \
+    X(1, 8, 8, 8, 8, 2)     \
+    X(2, 8, 11, 12, 10, 2)  \
+    X(3, 8, 12, 12, 10, 2)  \
+    X(4, 8, 12, 16, 13, 2)  \
+    X(5, 8, 16, 20, 17, 1)  \
+    X(6, 16, 12, 20, 17, 1) \
+    X(7, 4, 24, 16, 13, 2)  \
+    X(8, 8, 5, 12, 10, 2)   \
+    X(9, 8, 6, 12, 10, 2)   \
+    X(10, 8, 7, 12, 10, 2)  \
+    X(11, 8, 4, 12, 10, 3)  \
+    X(12, 8, 7, 20, 17, 2)  \
+    X(13, 8, 8, 28, 25, 2)  \
+    X(14, 8, 6, 20, 17, 2)  \
+    X(15, 16, 6, 28, 25, 1) \
+    X(16, 4, 10, 12, 10, 4) \
+    X(17, 4, 16, 12, 10, 2) \
+    X(18, 2, 20, 12, 10, 4) \
+    X(19, 16, 3, 12, 10, 1)
+#define TB_GS_VARIANTS(X)  \
+    X(0, 8, 10, 12, 10, 2) \
+    X(3, 8, 12, 12, 10, 2) \
+    X(8, 8, 5, 12, 10, 2)  \
+    X(9, 8, 6, 12, 10, 2)  \
+    X(10, 8, 7, 12, 10, 2) \
+    X(11, 8, 4, 12, 10, 3) \
+    X(12, 8, 7, 20, 17, 2) \
+    X(13, 8, 8, 28, 25, 2) \
+    X(14, 8, 6, 20, 17, 2) \
+    X(15, 16, 6, 28, 25, 1)
+#else
+#define TB_VARIANTS(X)     \
+    X(0, 8, 10, 12, 10, 2) \
+    X(8, 8, 5, 12, 10, 2)
+#define TB_GS_VARIANTS(X) X(8, 8, 5, 12, 10, 2)
+#endif
+#define TB_CHECK(k, NW, RY, HX, HY, BPC) \
+    static_assert(kTB[k].nw == NW && kTB[k].ry == RY && kTB[k].hx == HX && kTB[k].hy == HY && kTB[k].bpc == BPC, "variant table");
+TB_VARIANTS(TB_CHECK)
+#define TB_GS_CHECK(k, NW, RY, HX, HY, BPC) TB_CHECK(k, NW, RY, HX, HY, BPC) static_assert(kTB[k].gs && HX >= HY + 1, "gs variant");
+TB_GS_VARIANTS(TB_GS_CHECK)
+// which shapes of the table THIS library holds kernels for
+#define TB_IS(k, NW, RY, HX, HY, BPC) case k:
+constexpr bool tb_built(int k)
+{
+    switch (k) {
+        TB_VARIANTS(TB_IS)
+    case kPairTB: return true;
+    default: return false;
+    }
+}
+constexpr bool tb_gs_built(int k)
+{
+    switch (k) {
+        TB_GS_VARIANTS(TB_IS)
+    case kPairTB: return true;
+    default: return false;
+    }
+}
+#undef TB_IS
+
 int cvd_remap()  // FLUID_CVD_REMAP: tile order of the fused curl/vorticity/divergence kernel (same encoding)
 {
     static const int v = [] {
-        const char* e = getenv("FLUID_CVD_REMAP");
+        const char* e = lab_env("FLUID_CVD_REMAP");
         return (e ? atoi(e) : 3) & 3;  // row-major XCD runs, as for the Jacobi kernel (82 us vs 85 us column-major at 4096^2)
     }();
     return v;
@@ -1752,9 +1812,9 @@ int cvd_remap()  // FLUID_CVD_REMAP: tile order of the fused curl/vorticity/dive
 int tb_variant_env()  // FLUID_TB_VARIANT, or -1
 {
     static const int v = [] {
-        const char* e = getenv("FLUID_TB_VARIANT");
+        const char* e = lab_env("FLUID_TB_VARIANT");
         const int k = e ? atoi(e) : -1;
-        return (k >= 0 && k < kNumTB) ? k : -1;
+        return (k >= 0 && k < kNumTB && tb_built(k)) ? k : -1;
     }();
     return v;
 }
@@ -1767,7 +1827,7 @@ const std::vector<TBRule>& tb_rules()
 {
     static const std::vector<TBRule> rules = [] {
         std::vector<TBRule> r;
-        if (const char* e = getenv("FLUID_TB_SMALL")) {
+        if (const char* e = lab_env("FLUID_TB_SMALL")) {
             const char* p = e;
             while (*p) {
                 char* q = nullptr;
@@ -1776,7 +1836,7 @@ const std::vector<TBRule>& tb_rules()
                 p = q + 1;
                 const long sh = strtol(p, &q, 10);
                 if (q == p) break;
-                if (sh >= 0 && sh < kNumTB) r.push_back({ t, (int)sh });
+                if (sh >= 0 && sh < kNumTB && tb_built((int)sh)) r.push_back({ t, (int)sh });
                 p = *q == ',' ? q + 1 : q;
             }
         } else {
@@ -1800,7 +1860,7 @@ inline TBTail tb_tail(int rows, int nx)
 {
     static const TBTail forced_rows = [] {
         TBTail r{ -1, -1, 7, 0 };
-        if (const char* e = getenv("FLUID_TB_TAIL")) {
+        if (const char* e = lab_env("FLUID_TB_TAIL")) {
             r = TBTail{ 0, 0, 7, 0 };   // a forced setting applies to every band height (the knob-hash test runs it on small grids)
             sscanf(e, "%d,%d,%d", &r.head, &r.tail, &r.ry);
             if (r.ry != 2 && r.ry != 5 && r.ry != 6 && r.ry != 7) r.head = r.tail = 0;   // 2 = the two-texel tile (8 x 5 rows, 128 columns)
@@ -1810,7 +1870,7 @@ inline TBTail tb_tail(int rows, int nx)
     if (forced_rows.head >= 0) return forced_rows;
     static const TBTail forced_tiles = [] {
         TBTail r{ -1, -1, 5, 1024 };
-        if (const char* e = getenv("FLUID_TB_TAIL_TILES")) {
+        if (const char* e = lab_env("FLUID_TB_TAIL_TILES")) {
             r = TBTail{ 0, 0, 5, 1024 };
             sscanf(e, "%d,%d,%d", &r.head, &r.tail, &r.ry);
             if (r.ry != 2 && r.ry != 5 && r.ry != 6 && r.ry != 7) r.head = r.tail = 0;   // 2 = the two-texel tile (8 x 5 rows, 128 columns)
@@ -1871,9 +1931,11 @@ hipError_t launch_tb(hipStream_t s, Win w, const float* p, const float* div, flo
             t.tail = (int)((long)t.tail * rows / full);
         }
         if (t.head + t.tail > 0 && rows >= t.min_rows) {
+#ifdef FLUID_PROBES
             if (t.ry == 2) return launch_tb_mix2<NW, RY, 5, HX, HY, BPC>(s, w, p, div, p_out, pscale, iters, ga, gb, t.head, t.tail);
-            if (t.ry == 5) return launch_tb_mix<NW, RY, 5, HX, HY, BPC>(s, w, p, div, p_out, pscale, iters, ga, gb, t.head, t.tail);
             if (t.ry == 6) return launch_tb_mix<NW, RY, 6, HX, HY, BPC>(s, w, p, div, p_out, pscale, iters, ga, gb, t.head, t.tail);
+#endif
+            if (t.ry == 5) return launch_tb_mix<NW, RY, 5, HX, HY, BPC>(s, w, p, div, p_out, pscale, iters, ga, gb, t.head, t.tail);
             return launch_tb_mix<NW, RY, 7, HX, HY, BPC>(s, w, p, div, p_out, pscale, iters, ga, gb, t.head, t.tail);
         }
     }
@@ -2066,7 +2128,7 @@ hipError_t launch_gradsub4(hipStream_t s, Win w, const __half* p, const __half2*
 static bool advect_fast_ok(const Win& w, size_t texel_bytes, float decay_a, float decay_b)
 {
     static const bool enabled = [] {
-        const char* e = getenv("FLUID_ADVECT_FAST");
+        const char* e = lab_env("FLUID_ADVECT_FAST");
         return !(e && atoi(e) == 0);
     }();
     return enabled && udiv_decay_ok(decay_a) && udiv_decay_ok(decay_b) && (size_t)w.rows * (size_t)w.P * texel_bytes <= (1ull << 32) &&
@@ -2078,7 +2140,7 @@ static bool advect_fast_ok(const Win& w, size_t texel_bytes, float decay_a, floa
 static int split_advect_rows(long texels)
 {
     static const int forced = [] {
-        const char* e = getenv("FLUID_ADVECT_SPLIT_ROWS");
+        const char* e = lab_env("FLUID_ADVECT_SPLIT_ROWS");
         const int k = e ? atoi(e) : 0;
         return (k == 1 || k == 2 || k == 4) ? k : 0;
     }();
@@ -2095,7 +2157,9 @@ hipError_t launch_advect_velocity_any(hipStream_t s, Win w, const V2* vel, V2* o
         const double rW = udiv_recip((float)w.W), rH = udiv_recip((float)w.H), rvd = udiv_recip(decay);
         const unsigned gx = (w.x1 - w.x0 + BX - 1) / BX;
         switch (split_advect_rows((long)(w.x1 - w.x0) * (gb - ga))) {
+#ifdef FLUID_PROBES
         case 4: k_advect_velocity_fast<4><<<dim3(gx, (gb - ga + 3) / 4, 1), BX, 0, s>>>(w, vel, out, dt, rW, rH, rvd, tsx, tsy, ga, gb, miss); break;
+#endif
         case 2: k_advect_velocity_fast<2><<<dim3(gx, (gb - ga + 1) / 2, 1), BX, 0, s>>>(w, vel, out, dt, rW, rH, rvd, tsx, tsy, ga, gb, miss); break;
         default: k_advect_velocity_fast<1><<<dim3(gx, gb - ga, 1), BX, 0, s>>>(w, vel, out, dt, rW, rH, rvd, tsx, tsy, ga, gb, miss); break;
         }
@@ -2114,7 +2178,9 @@ hipError_t launch_advect_dye_any(hipStream_t s, Win vw, const V2* vel, Win dw, c
         const double rW = udiv_recip((float)dw.W), rH = udiv_recip((float)dw.H), rdd = udiv_recip(decay);
         const unsigned gx = (dw.x1 - dw.x0 + BX - 1) / BX;
         switch (split_advect_rows((long)(dw.x1 - dw.x0) * (gb - ga))) {
+#ifdef FLUID_PROBES
         case 4: k_advect_dye_fast<4><<<dim3(gx, (gb - ga + 3) / 4, 1), BX, 0, s>>>(vw, vel, dw, dye, out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss); break;
+#endif
         case 2: k_advect_dye_fast<2><<<dim3(gx, (gb - ga + 1) / 2, 1), BX, 0, s>>>(vw, vel, dw, dye, out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss); break;
         default: k_advect_dye_fast<1><<<dim3(gx, gb - ga, 1), BX, 0, s>>>(vw, vel, dw, dye, out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss); break;
         }
@@ -2151,7 +2217,7 @@ hipError_t launch_advect_dye(hipStream_t s, Win vw, const float2* vel, Win dw, c
 // texels per thread of the fast kernel (FLUID_ADVECT_ROWS / FLUID_ADVECT_ROWS_F16: A/B knobs); the general kernel runs with two
 static int advect_rows(const char* env, int dflt)
 {
-    const char* e = getenv(env);
+    const char* e = lab_env(env);
     const int k = e ? atoi(e) : dflt;
     return (k == 1 || k == 2 || k == 3 || k == 4 || k == 6 || k == 8) ? k : dflt;
 }
@@ -2171,12 +2237,14 @@ hipError_t launch_advect_both(hipStream_t s, Win w, const float2* vel, float2* v
     if (advect_fast_ok(w, sizeof(float4), vdecay, ddecay)) {
         const double rW = udiv_recip((float)w.W), rH = udiv_recip((float)w.H), rvd = udiv_recip(vdecay), rdd = udiv_recip(ddecay);
         switch (rows) {
+#ifdef FLUID_PROBES
             ADVECT_FAST_CASE(k_advect_both_fast, 1)
             ADVECT_FAST_CASE(k_advect_both_fast, 2)
             ADVECT_FAST_CASE(k_advect_both_fast, 3)
-            ADVECT_FAST_CASE(k_advect_both_fast, 4)
             ADVECT_FAST_CASE(k_advect_both_fast, 6)
             ADVECT_FAST_CASE(k_advect_both_fast, 8)
+#endif
+            ADVECT_FAST_CASE(k_advect_both_fast, 4)
         }
         return hipGetLastError();
     }
@@ -2195,12 +2263,14 @@ hipError_t launch_advect_both(hipStream_t s, Win w, const __half2* vel, __half2*
     if (advect_fast_ok(w, sizeof(half4), vdecay, ddecay)) {
         const double rW = udiv_recip((float)w.W), rH = udiv_recip((float)w.H), rvd = udiv_recip(vdecay), rdd = udiv_recip(ddecay);
         switch (rows) {
+#ifdef FLUID_PROBES
             ADVECT_FAST_CASE(k_advect_both_fast_h, 1)
             ADVECT_FAST_CASE(k_advect_both_fast_h, 2)
             ADVECT_FAST_CASE(k_advect_both_fast_h, 3)
-            ADVECT_FAST_CASE(k_advect_both_fast_h, 4)
             ADVECT_FAST_CASE(k_advect_both_fast_h, 6)
             ADVECT_FAST_CASE(k_advect_both_fast_h, 8)
+#endif
+            ADVECT_FAST_CASE(k_advect_both_fast_h, 4)
         }
         return hipGetLastError();
     }
@@ -2268,7 +2338,7 @@ static CvdTail cvd_tail(int nx)
 {
     static const CvdTail forced = [] {
         CvdTail r{ -1, -1 };
-        if (const char* e = getenv("FLUID_CVD_TAIL")) {
+        if (const char* e = lab_env("FLUID_CVD_TAIL")) {
             r = CvdTail{ 0, 0 };
             sscanf(e, "%d,%d", &r.head, &r.tail);
         }
@@ -2348,7 +2418,7 @@ static void advect_cvd_shape(long texels, int& nw, int& ry, int& ax)
 {
     static const int forced = [] {
         int a = 0, b = 0, c = 0;
-        if (const char* e = getenv("FLUID_CHAIN_TILE")) sscanf(e, "%d,%d,%d", &a, &b, &c);
+        if (const char* e = lab_env("FLUID_CHAIN_TILE")) sscanf(e, "%d,%d,%d", &a, &b, &c);
         return a * 10000 + b * 100 + c;
     }();
     const int pick = forced ? forced : (texels < 768l * 768l ? 80403 : 40803);
@@ -2379,14 +2449,16 @@ hipError_t launch_advect_cvd(hipStream_t s, Win w, const float2* vel, float2* ve
                 w, vel, vel_out, dye, dye_out, curl, div, dt, rW, rH, rvd, rdd, tsx, tsy, curl_strength, ga, gb, ax.S, ay.S, ax.n, ay.n, cvd_remap()); \
         return hipGetLastError();                                                                                                       \
     }
+    ADVECT_CVD_CASE(4, 8, 3)
+    ADVECT_CVD_CASE(8, 4, 3)
+#ifdef FLUID_PROBES
     ADVECT_CVD_CASE(8, 8, 4)
     ADVECT_CVD_CASE(8, 8, 3)
     ADVECT_CVD_CASE(4, 8, 4)
-    ADVECT_CVD_CASE(4, 8, 3)
-    ADVECT_CVD_CASE(8, 4, 3)
     ADVECT_CVD_CASE(4, 4, 3)
     ADVECT_CVD_CASE(16, 4, 3)
     ADVECT_CVD_CASE(16, 8, 4)
+#endif
 #undef ADVECT_CVD_CASE
     return hipErrorInvalidValue;
 }
@@ -2401,47 +2473,10 @@ int jacobi_tb_pick(long texels)
     return kDefaultTB;
 }
 int jacobi_tb_depth(int shape) { return kTB[shape].hy; }
-bool jacobi_tb_has_gradsub(int shape) { return kTB[shape].gs; }
+bool jacobi_tb_has_gradsub(int shape) { return tb_gs_built(shape); }
 
 bool jacobi_tb_supported(Win w) { return fused_supported(w); }
 
-#define TB_VARIANTS(X)      \
-    X(0, 8, 10, 12, 10, 2)  \
-    X(1, 8, 8, 8, 8, 2)     \
-    X(2, 8, 11, 12, 10, 2)  \
-    X(3, 8, 12, 12, 10, 2)  \
-    X(4, 8, 12, 16, 13, 2)  \
-    X(5, 8, 16, 20, 17, 1)  \
-    X(6, 16, 12, 20, 17, 1) \
-    X(7, 4, 24, 16, 13, 2)  \
-    X(8, 8, 5, 12, 10, 2)   \
-    X(9, 8, 6, 12, 10, 2)   \
-    X(10, 8, 7, 12, 10, 2)  \
-    X(11, 8, 4, 12, 10, 3)  \
-    X(12, 8, 7, 20, 17, 2)  \
-    X(13, 8, 8, 28, 25, 2)  \
-    X(14, 8, 6, 20, 17, 2)  \
-    X(15, 16, 6, 28, 25, 1) \
-    X(16, 4, 10, 12, 10, 4) \
-    X(17, 4, 16, 12, 10, 2) \
-    X(18, 2, 20, 12, 10, 4) \
-    X(19, 16, 3, 12, 10, 1)
-#define TB_GS_VARIANTS(X)  \
-    X(0, 8, 10, 12, 10, 2) \
-    X(3, 8, 12, 12, 10, 2) \
-    X(8, 8, 5, 12, 10, 2)  \
-    X(9, 8, 6, 12, 10, 2)  \
-    X(10, 8, 7, 12, 10, 2) \
-    X(11, 8, 4, 12, 10, 3) \
-    X(12, 8, 7, 20, 17, 2) \
-    X(13, 8, 8, 28, 25, 2) \
-    X(14, 8, 6, 20, 17, 2) \
-    X(15, 16, 6, 28, 25, 1)
-#define TB_CHECK(k, NW, RY, HX, HY, BPC) \
-    static_assert(kTB[k].nw == NW && kTB[k].ry == RY && kTB[k].hx == HX && kTB[k].hy == HY && kTB[k].bpc == BPC, "variant table");
-TB_VARIANTS(TB_CHECK)
-#define TB_GS_CHECK(k, NW, RY, HX, HY, BPC) TB_CHECK(k, NW, RY, HX, HY, BPC) static_assert(kTB[k].gs && HX >= HY + 1, "gs variant");
-TB_GS_VARIANTS(TB_GS_CHECK)
 
 // rows per wave of the two-texel tile by grid size: 8 waves x 4 rows below 768^2 texels (512^2: 26.5 k steps/s against 24.7 k with 5 rows),
 // x 5 below 1280^2 (1024^2: 16.7 k against 15.8 k / 15.6 k with 4 / 6), x 6 above (1536^2: 11.1 k against 10.6 k)
@@ -2450,7 +2485,7 @@ static int tb2_shape(long texels)
 {
     static const int forced = [] {
         int a = 0, b = 0;
-        if (const char* e = getenv("FLUID_TB2")) sscanf(e, "%d,%d", &a, &b);
+        if (const char* e = lab_env("FLUID_TB2")) sscanf(e, "%d,%d", &a, &b);
         return a * 100 + b;
     }();
     if (forced) return forced;
@@ -2461,15 +2496,17 @@ template <class T>
 hipError_t launch_jacobi_tb_any(hipStream_t s, Win w, const T* p, const T* div, T* p_out, float pscale, int iters, int ga, int gb, int v)
 {
     ROWS_OR_RETURN();
-    if (!jacobi_tb_supported(w) || v < 0 || v >= kNumTB) return hipErrorInvalidValue;
+    if (!jacobi_tb_supported(w) || v < 0 || v >= kNumTB || !tb_built(v)) return hipErrorInvalidValue;
     if (iters < 1 || iters > kTB[v].hy) return hipErrorInvalidValue;
     if (v == kPairTB) {
         if constexpr (sizeof(T) == 4) {
             switch (tb2_shape((long)(w.x1 - w.x0) * (gb - ga))) {
             case 804: return launch_tb2<8, 4, 12, 10, 4>(s, w, p, div, p_out, pscale, iters, ga, gb);
             case 806: return launch_tb2<8, 6, 12, 10, 3>(s, w, p, div, p_out, pscale, iters, ga, gb);
+#ifdef FLUID_PROBES
             case 410: return launch_tb2<4, 10, 12, 10, 4>(s, w, p, div, p_out, pscale, iters, ga, gb);
             case 1603: return launch_tb2<16, 3, 12, 10, 2>(s, w, p, div, p_out, pscale, iters, ga, gb);
+#endif
             default: return launch_tb2<8, 5, 12, 10, 3>(s, w, p, div, p_out, pscale, iters, ga, gb);
             }
         }
@@ -2489,7 +2526,7 @@ hipError_t launch_jacobi_tb_gradsub_any(hipStream_t s, Win w, const T* p, const 
                                         int iters, int ga, int gb, int v)
 {
     ROWS_OR_RETURN();
-    if (!jacobi_tb_supported(w) || v < 0 || v >= kNumTB || !kTB[v].gs) return hipErrorInvalidValue;
+    if (!jacobi_tb_supported(w) || v < 0 || v >= kNumTB || !tb_gs_built(v)) return hipErrorInvalidValue;
     if (iters < 1 || iters > kTB[v].hy) return hipErrorInvalidValue;
     w.x0 &= ~3;  // whole float4 groups, as launch_gradsub4
     w.x1 = (w.x1 + 3) & ~3;
@@ -2499,8 +2536,10 @@ hipError_t launch_jacobi_tb_gradsub_any(hipStream_t s, Win w, const T* p, const 
             switch (tb2_shape((long)(w.x1 - w.x0) * (gb - ga))) {
             case 804: return launch_tb2_gs<8, 4, 12, 10, 4>(s, w, p, div, p_out, vel, vel_out, pscale, iters, ga, gb);
             case 806: return launch_tb2_gs<8, 6, 12, 10, 3>(s, w, p, div, p_out, vel, vel_out, pscale, iters, ga, gb);
+#ifdef FLUID_PROBES
             case 410: return launch_tb2_gs<4, 10, 12, 10, 4>(s, w, p, div, p_out, vel, vel_out, pscale, iters, ga, gb);
             case 1603: return launch_tb2_gs<16, 3, 12, 10, 2>(s, w, p, div, p_out, vel, vel_out, pscale, iters, ga, gb);
+#endif
             default: return launch_tb2_gs<8, 5, 12, 10, 3>(s, w, p, div, p_out, vel, vel_out, pscale, iters, ga, gb);
             }
         }

@@ -334,7 +334,7 @@ int pass_advect(fluid_ctx* c, float dt, float vel_diss, float dye_diss, Timer* t
 bool gradsub_fold_enabled(long owned_texels)
 {
     static const int mode = [] {
-        const char* e = getenv("FLUID_FOLD_GRADSUB");
+        const char* e = fluid::lab_env("FLUID_FOLD_GRADSUB");
         return e ? (atoi(e) != 0 ? 1 : 0) : -1;
     }();
     return mode >= 0 ? mode == 1 : owned_texels < 3072l * 3072l;
@@ -354,7 +354,7 @@ void mark_step(fluid_ctx* c, int k)
 bool skip_hidden_curl()
 {
     static const bool on = [] {
-        const char* e = getenv("FLUID_SKIP_CURL");
+        const char* e = fluid::lab_env("FLUID_SKIP_CURL");
         return !(e && atoi(e) == 0);
     }();
     return on;
@@ -471,7 +471,7 @@ int step_once(fluid_ctx* c, float dt, const fluid_params* P, bool lead = true, i
 bool chain_enabled(long owned_texels)
 {
     static const int mode = [] {
-        const char* e = getenv("FLUID_CHAIN");
+        const char* e = fluid::lab_env("FLUID_CHAIN");
         return e ? (atoi(e) != 0 ? 1 : 0) : -1;
     }();
     return mode >= 0 ? mode == 1 : owned_texels < 3072l * 3072l;
@@ -507,6 +507,15 @@ int field_ref(fluid_ctx* c, int field, FieldRef* f)
 extern "C" {
 
 int fluid_abi_version(void) { return FLUID_ABI_VERSION; }
+
+const char* fluid_build_flavor(void)
+{
+#ifdef FLUID_PROBES
+    return "probes";
+#else
+    return "product";
+#endif
+}
 
 const char* fluid_error_string(int status)
 {

@@ -259,7 +259,7 @@ int ensure_comm_stream(fluid_ctx* c)
     HIPCK(c, hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
     HIPCK(c, hipEventCreateWithFlags(&c->ev_landed, hipEventDisableTiming));
     HIPCK(c, hipEventCreateWithFlags(&c->ev_mid, hipEventDisableTiming));
-    if (const char* e = getenv("FLUID_STRIPE_OVERLAP")) c->overlap = atoi(e) != 0;
+    if (const char* e = fluid::lab_env("FLUID_STRIPE_OVERLAP")) c->overlap = atoi(e) != 0;
     return FLUID_OK;
 }
 
@@ -618,7 +618,7 @@ int pass_interior(fluid_ctx* c, const fluid_stripe_op& op, float dt, const fluid
 bool strip_rects_enabled()
 {
     static const bool on = [] {
-        const char* e = getenv("FLUID_STRIP_RECTS");
+        const char* e = fluid::lab_env("FLUID_STRIP_RECTS");
         return !(e && atoi(e) == 0);
     }();
     return on;

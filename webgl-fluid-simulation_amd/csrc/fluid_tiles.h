@@ -94,7 +94,7 @@ __device__ __forceinline__ float from_right_lane(float v)  // value held by lane
 inline int xcd_remap()  // FLUID_XCD_REMAP: tile order of the Jacobi kernel (A/B knob); bit 0 = XCD-contiguous runs, bit 1 = row-major
 {
     static const int v = [] {
-        const char* e = getenv("FLUID_XCD_REMAP");
+        const char* e = lab_env("FLUID_XCD_REMAP");
         return (e ? atoi(e) : 3) & 3;
     }();
     return v;

@@ -11,6 +11,8 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # FLUID_HIP_LIB: load another build of the same library (kernel A/B experiments); the default is the in-tree build
 LIB_PATH = os.environ.get("FLUID_HIP_LIB") or os.path.join(PKG_DIR, "libfluid_hip.so")
+# the lab build (make PROBES=1): every tile shape / variant of profiles/ and the FLUID_* knobs that select them; the product reads no knob
+PROBES_LIB_PATH = os.path.join(PKG_DIR, "libfluid_hip_probes.so")
 
 FLUID_OK = 0
 ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_OOM, ERR_HALO, ERR_UNSUPPORTED, ERR_COMM = -1, -2, -3, -4, -5, -6, -7
@@ -80,6 +82,7 @@ _F = C.c_float
 _I = C.c_int
 SYMBOLS = {
     "fluid_abi_version": (_I, []),
+    "fluid_build_flavor": (C.c_char_p, []),
     "fluid_error_string": (C.c_char_p, [_I]),
     "fluid_last_error": (C.c_char_p, [_CTX]),
     "fluid_device_count": (_I, [C.POINTER(_I)]),
