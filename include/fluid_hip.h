@@ -304,6 +304,9 @@ typedef struct fluid_schedule_info {
     int chained;           /* steps of the call whose advection launch also runs the next step's curl / vorticity / divergence  */
     int curl_stores;       /* steps of the call that store their curl field (the last one always does)                           */
     int launches;          /* kernel launches of the whole call (whole-domain contexts; 0 for stripes: see fluid_stripe_plan)    */
+    int runs_ahead;        /* the call's LAST advection launch also runs the next call's curl / vorticity / divergence into       */
+                           /* pending buffers (what makes one fluid_step per frame cost six launches instead of seven)            */
+    int pending_adopted;   /* this call's first curl / vorticity / divergence was already run ahead by the previous call         */
 } fluid_schedule_info;
 int fluid_schedule_info_get(fluid_ctx *ctx, int n_steps, float dt, const fluid_params *params, fluid_schedule_info *out);
 

@@ -7,7 +7,13 @@
 // pair of ranks match in issue order; a group issues all its operations together; a send is complete on the sender's
 // stream only after the receiver has copied the data; everything is ordered on the streams the caller passes.
 // Never shipped, never on a product path.
+//
+// A link that takes time (the interior-first overlap had only ever met instantaneous copies): FAKE_RCCL_DELAY_US=<us> and /
+// or FAKE_RCCL_GBPS=<GB/s> make every receive wait that long (latency + bytes / bandwidth) ON THE RECEIVER'S STREAM, behind the sender's
+// "data exists" event and in front of the copy — a one-thread kernel spinning on the 100 MHz s_memrealtime counter, so the host never sleeps
+// and the other streams of the device keep running, as they do while a real xGMI transfer is in flight (tools/overlap_vs_link.py).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include <condition_variable>
 #include <cstdio>
@@ -64,6 +70,19 @@ struct Op {
     FakeComm* comm;
     hipStream_t stream;
 };
+__global__ void k_link_delay(unsigned long long ticks)   // 10 ns per tick
+{
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+double link_us(size_t bytes)
+{
+    static const double lat = [] { const char* e = getenv("FAKE_RCCL_DELAY_US"); return e ? atof(e) : 0.0; }();
+    static const double gbps = [] { const char* e = getenv("FAKE_RCCL_GBPS"); return e ? atof(e) : 0.0; }();
+    return lat + (gbps > 0 ? (double)bytes / (gbps * 1e3) : 0.0);
+}
+
 thread_local int t_depth = 0;
 thread_local std::vector<Op> t_ops;
 
@@ -97,6 +116,7 @@ ncclResult_t run(std::vector<Op>& ops)
             }
             if (p->bytes != o.bytes) return ncclInvalidArgument;  // count mismatch between the two sides
             if (hipStreamWaitEvent(o.stream, p->ready, 0) != hipSuccess) return ncclUnhandledCudaError;
+            if (const double us = link_us(o.bytes); us > 0) k_link_delay<<<1, 1, 0, o.stream>>>((unsigned long long)(us * 100.0));
             if (hipMemcpyAsync(o.ptr, p->src, o.bytes, hipMemcpyDeviceToDevice, o.stream) != hipSuccess) return ncclUnhandledCudaError;
             if (hipEventRecord(p->copied, o.stream) != hipSuccess) return ncclUnhandledCudaError;
             {

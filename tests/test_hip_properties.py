@@ -346,9 +346,10 @@ def test_step_marks_and_schedule_info():
     with fluid_hip.FluidSim(canvas=(512, 512), config=cfg, random=fluid_hip.mulberry32(5)) as sim:
         sim.multipleSplats(4)
         si = sim.schedule_info(6)
-        assert si["fused"] == 1 and si["jacobi_launches"] == 5 and si["gradsub_folded"] == 1 and si["chained"] == 5 and si["curl_stores"] == 1
+        assert si["fused"] == 1 and si["jacobi_launches"] == 5 and si["gradsub_folded"] == 1 and si["runs_ahead"] == 1 and si["pending_adopted"] == 0
+        assert si["chained"] == 6   # every advection launch of the call also runs a curl / vorticity / divergence: five for the call's own steps, the last one ahead
         assert si["launches"] == 6 * 6 + 1   # five Jacobi launches (the last with K6) + advection (+ next curl) per step, one leading curl launch
-        assert sim.schedule_info(1)["chained"] == 0 and sim.schedule_info(1)["launches"] == 7
+        assert sim.schedule_info(1)["chained"] == 1 and sim.schedule_info(1)["launches"] == 7
         sim.set_step_marks(4)
         sim.step(DT, 6)                      # the first four steps are marked
         ms = sim.step_marks()
@@ -365,3 +366,41 @@ def test_step_marks_and_schedule_info():
         got = sim.fields()
     for k in want:
         assert np.array_equal(want[k], got[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [1024, 250])
+def test_one_step_per_call_works_ahead_and_leaves_what_the_passes_leave(N):
+    """The per-frame path (update() -> step(dt) once per call, script.js:1176-1186): on grids where fluid_step_n chains, the launch that ends a
+    call also runs the NEXT call's curl / vorticity / divergence into pending buffers; the next call adopts them unless something touched the
+    fields or dt / CURL changed.  After EVERY call all five fields are what the per-pass schedule leaves — the advected velocity, this
+    step's divergence and curl — with a splat, a dt change, a CURL change, a field write and a multi-step call in between."""
+    import fluid_hip
+    DT = 0.016666
+    a, b = sim_of(N, "passes"), sim_of(N, "fused")
+    adopted = []
+    try:
+        a.multipleSplats(5); b.multipleSplats(5)
+        assert b.schedule_info(1)["runs_ahead"] == 1
+        for k in range(12):
+            dt, n = DT, 1
+            if k == 3:
+                for s_ in (a, b):
+                    s_.splat(0.4, 0.6, 300.0, -200.0, {"r": 0.3, "g": 0.1, "b": 0.2})
+            if k == 5:
+                dt = 0.01
+            if k == 7:
+                a.config["CURL"] = b.config["CURL"] = 10
+            if k == 9:
+                v = b.read("velocity")
+                a.write("velocity", v * 0.5); b.write("velocity", v * 0.5)
+            if k == 10:
+                n = 3
+            adopted.append(b.schedule_info(n, dt)["pending_adopted"])
+            a.step(dt, n); b.step(dt, n)
+            for f in ("velocity", "pressure", "divergence", "curl", "dye"):
+                assert np.array_equal(a.read(f), b.read(f)), (k, f)
+        #          k: 0  1  2  3(splat) 4  5(dt) 6(dt back) 7(CURL) 8  9(write) 10 11
+        assert adopted == [0, 1, 1, 0, 1, 0, 0, 0, 1, 0, 1, 1], adopted
+    finally:
+        a.close(); b.close()

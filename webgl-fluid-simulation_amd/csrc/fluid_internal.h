@@ -35,6 +35,16 @@ struct fluid_ctx {
     // false while fluid_step_n runs a step that is not the call's last: that step's curl field is overwritten before the call returns, so
     // the fused curl / vorticity / divergence kernel does not store it (4 of its 24 B/texel).  The per-pass kernels always need the field.
     bool keep_curl = true;
+    // The NEXT step's curl / vorticity / divergence, computed ahead by the launch that ended the last call (k_advect_cvd MODE 2; whole-domain
+    // fp32 contexts where fluid_step_n chains): velocity after vorticity confinement, divergence, curl.  A page calls step() once per frame
+    // (script.js:1176-1186): with this a frame is the six launches of a chained step instead of seven.  Valid until anything else touches the
+    // fields (splat, write, resize, a per-pass call, a raw device pointer handed out) or the next step comes with another dt / CURL.
+    void* pend_vel = nullptr;
+    void* pend_div = nullptr;
+    void* pend_curl = nullptr;
+    bool pend_valid = false;
+    float pend_dt = 0.0f, pend_curl_strength = 0.0f;
+    void touched() { pend_valid = false; }   // call from every entry point that changes a field or hands out its memory
 
     bool timing = false;
     hipEvent_t ev[P_COUNT + 1] = {};

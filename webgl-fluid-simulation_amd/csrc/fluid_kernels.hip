@@ -1530,10 +1530,14 @@ __device__ __forceinline__ Tap4 taps32p(const Win& w, const TapBox& B, v2f uv)
 
 // BORDER: the tile touches the domain's edge (CLAMP_TO_EDGE selects, reflecting walls, lanes / rows past the last column / row);
 // an interior tile (88 % of a 4096^2 grid) runs without any of it
-template <int NW, int RY, int AX_, bool CURL_OUT, bool BORDER>
+// MODE: 0 = a step in the middle of a fluid_step_n chain (the curl field is nobody's to read: not stored); 1 = the chain's last such launch
+// (curl stored); 2 = the launch that ends a CALL (fluid_step, or the last step of fluid_step_n): the advected velocity is what the caller can
+// read, so it is stored too (vel_adv_out), and the next step's curl / vorticity / divergence go to the context's `pending` buffers — the
+// next call takes them over if nothing touched the fields in between (fluid_solver.cpp: pend_*), else they are simply dropped.
+template <int NW, int RY, int AX_, int MODE, bool BORDER>
 __device__ __forceinline__ void advect_cvd_body(const Win& w, const float2* __restrict__ vel, float2* __restrict__ vel_out,
                                                 const float4* __restrict__ dye, float4* __restrict__ dye_out, float* __restrict__ curl_out,
-                                                float* __restrict__ div_out, float dt, double rW, double rH, double rvd, double rdd, float tsx,
+                                                float* __restrict__ div_out, float2* __restrict__ vel_adv_out, float dt, double rW, double rH, double rvd, double rdd, float tsx,
                                                 float tsy, float curl_strength, int ga, int gb, int x0, int y0, float (*mail)[2][3][64])
 {
     using G = AdvectCvd<NW, RY, AX_>;
@@ -1581,6 +1585,16 @@ __device__ __forceinline__ void advect_cvd_body(const Win& w, const float2* __re
     tile_exact(x0, G::TX, G::AX, w.W, w.x0, w.x1, xa, xb);
     tile_exact(y0, G::TY, G::AY, w.H, ga, gb, out_lo, out_hi);
     const bool col_store = (cx >= xa) && (cx < xb);
+
+    if constexpr (MODE == 2) {  // the advected velocity itself, for whoever reads the field between two calls
+        if (col_store) {
+#pragma unroll
+            for (int r = 0; r < RY; r++) {
+                const int gj = gy + r;
+                if (gj >= out_lo && gj < out_hi) *at_byte(vel_adv_out, ((unsigned)((gj - w.g0) * w.P) + col) * 8u) = make_float2(V[r].x, V[r].y);
+            }
+        }
+    }
 
     // ---- K7b for the texels this tile stores, CH rows at a time (the apron columns sit it out; an apron row costs its gathers: 6 of
     // NW * RY) ----
@@ -1666,17 +1680,18 @@ __device__ __forceinline__ void advect_cvd_body(const Win& w, const float2* __re
         const float dv = 0.5f * (R - L + T - Bq);
         if (col_store && gj >= out_lo && gj < out_hi) {
             const unsigned c = (unsigned)((gj - w.g0) * w.P) + col;
-            if (CURL_OUT) *at_byte(curl_out, c * 4u) = C[r];
+            if (MODE >= 1) *at_byte(curl_out, c * 4u) = C[r];
             *at_byte(div_out, c * 4u) = dv;
             *at_byte(vel_out, c * 8u) = N[r];
         }
     }
 }
 
-template <int NW, int RY, int AX_, bool CURL_OUT>
+template <int NW, int RY, int AX_, int MODE>
 __global__ void __launch_bounds__(64 * NW, RY <= 4 ? 5 : 4) k_advect_cvd(Win w, const float2* __restrict__ vel, float2* __restrict__ vel_out,
                                                                          const float4* __restrict__ dye, float4* __restrict__ dye_out,
-                                                                         float* __restrict__ curl_out, float* __restrict__ div_out, float dt,
+                                                                         float* __restrict__ curl_out, float* __restrict__ div_out,
+                                                                         float2* __restrict__ vel_adv_out, float dt,
                                                                          double rW, double rH, double rvd, double rdd, float tsx, float tsy,
                                                                          float curl_strength, int ga, int gb, int xs, int ys, int nx, int ny,
                                                                          int remap)
@@ -1687,9 +1702,9 @@ __global__ void __launch_bounds__(64 * NW, RY <= 4 ? 5 : 4) k_advect_cvd(Win w, 
     tile_of_block((int)blockIdx.x, nx, ny, remap, bx, by);
     const int x0 = xs + bx * G::VX, y0 = ys + by * G::VY;
     if (x0 <= 0 || x0 + G::TX >= w.W || y0 <= 0 || y0 + G::TY >= w.H)
-        advect_cvd_body<NW, RY, AX_, CURL_OUT, true>(w, vel, vel_out, dye, dye_out, curl_out, div_out, dt, rW, rH, rvd, rdd, tsx, tsy, curl_strength, ga, gb, x0, y0, mail);
+        advect_cvd_body<NW, RY, AX_, MODE, true>(w, vel, vel_out, dye, dye_out, curl_out, div_out, vel_adv_out, dt, rW, rH, rvd, rdd, tsx, tsy, curl_strength, ga, gb, x0, y0, mail);
     else
-        advect_cvd_body<NW, RY, AX_, CURL_OUT, false>(w, vel, vel_out, dye, dye_out, curl_out, div_out, dt, rW, rH, rvd, rdd, tsx, tsy, curl_strength, ga, gb, x0, y0, mail);
+        advect_cvd_body<NW, RY, AX_, MODE, false>(w, vel, vel_out, dye, dye_out, curl_out, div_out, vel_adv_out, dt, rW, rH, rvd, rdd, tsx, tsy, curl_strength, ga, gb, x0, y0, mail);
 }
 
 #ifndef VD_NW_
@@ -2428,8 +2443,9 @@ static void advect_cvd_shape(long texels, int& nw, int& ry, int& ax)
 }
 
 hipError_t launch_advect_cvd(hipStream_t s, Win w, const float2* vel, float2* vel_out, const float4* dye, float4* dye_out, float* curl,
-                             float* div, float dt, float vel_dissipation, float dye_dissipation, float curl_strength, int ga, int gb)
+                             float* div, float2* vel_adv, float dt, float vel_dissipation, float dye_dissipation, float curl_strength, int ga, int gb)
 {
+    if (vel_adv && !curl) return hipErrorInvalidValue;   // the launch that ends a call stores the curl field as well
     ROWS_OR_RETURN();
     if (!advect_cvd_supported(w, dt, vel_dissipation, dye_dissipation)) return hipErrorInvalidValue;
     const float tsx = (float)(1.0 / w.W), tsy = (float)(1.0 / w.H);
@@ -2441,12 +2457,15 @@ hipError_t launch_advect_cvd(hipStream_t s, Win w, const float2* vel, float2* ve
     if (nw == NW_ && ry == RY_ && apron == AX_) {                                                                                       \
         using G = AdvectCvd<NW_, RY_, AX_>;                                                                                             \
         const Axis ax = make_axis(w.x0, w.x1, w.W, G::TX, G::AX), ay = make_axis(ga, gb, w.H, G::TY, G::AY);                            \
-        if (curl)                                                                                                                       \
-            k_advect_cvd<NW_, RY_, AX_, true><<<dim3(ax.n * ay.n, 1, 1), dim3(64, NW_, 1), 0, s>>>(                                     \
-                w, vel, vel_out, dye, dye_out, curl, div, dt, rW, rH, rvd, rdd, tsx, tsy, curl_strength, ga, gb, ax.S, ay.S, ax.n, ay.n, cvd_remap()); \
+        if (vel_adv)                                                                                                                    \
+            k_advect_cvd<NW_, RY_, AX_, 2><<<dim3(ax.n * ay.n, 1, 1), dim3(64, NW_, 1), 0, s>>>(                                        \
+                w, vel, vel_out, dye, dye_out, curl, div, vel_adv, dt, rW, rH, rvd, rdd, tsx, tsy, curl_strength, ga, gb, ax.S, ay.S, ax.n, ay.n, cvd_remap()); \
+        else if (curl)                                                                                                                  \
+            k_advect_cvd<NW_, RY_, AX_, 1><<<dim3(ax.n * ay.n, 1, 1), dim3(64, NW_, 1), 0, s>>>(                                        \
+                w, vel, vel_out, dye, dye_out, curl, div, vel_adv, dt, rW, rH, rvd, rdd, tsx, tsy, curl_strength, ga, gb, ax.S, ay.S, ax.n, ay.n, cvd_remap()); \
         else                                                                                                                            \
-            k_advect_cvd<NW_, RY_, AX_, false><<<dim3(ax.n * ay.n, 1, 1), dim3(64, NW_, 1), 0, s>>>(                                    \
-                w, vel, vel_out, dye, dye_out, curl, div, dt, rW, rH, rvd, rdd, tsx, tsy, curl_strength, ga, gb, ax.S, ay.S, ax.n, ay.n, cvd_remap()); \
+            k_advect_cvd<NW_, RY_, AX_, 0><<<dim3(ax.n * ay.n, 1, 1), dim3(64, NW_, 1), 0, s>>>(                                        \
+                w, vel, vel_out, dye, dye_out, curl, div, vel_adv, dt, rW, rH, rvd, rdd, tsx, tsy, curl_strength, ga, gb, ax.S, ay.S, ax.n, ay.n, cvd_remap()); \
         return hipGetLastError();                                                                                                       \
     }
     ADVECT_CVD_CASE(4, 8, 3)

@@ -40,6 +40,11 @@ void free_fields(fluid_ctx* c)
     if (c->div) (void)hipFree(c->div);
     if (c->curl) (void)hipFree(c->curl);
     c->div = c->curl = nullptr;
+    for (void** p : { &c->pend_vel, &c->pend_div, &c->pend_curl }) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    c->pend_valid = false;
 }
 
 // window geometry of this context's stripe for a (sim_w, sim_h, dye_w, dye_h) grid
@@ -421,7 +426,8 @@ namespace {
 // ghost-row exchanges between the pass groups).
 // `lead`: the step starts with its own curl / vorticity / divergence launch (false: the previous step's advection launch already ran them,
 // k_advect_cvd).  `chain`: 0 = the step ends with the advection launch; 1 / 2 = it ends with the launch that advects AND runs the next
-// step's curl / vorticity / divergence (2: and writes the curl field — the chain's last such launch, whose curl a caller can read).
+// step's curl / vorticity / divergence (2: and writes the curl field — the chain's last such launch, whose curl a caller can read);
+// 3 = the same at the END of a call: the advected velocity is stored for the caller and the next step's results go to the pending buffers.
 int step_once(fluid_ctx* c, float dt, const fluid_params* P, bool lead = true, int chain = 0)
 {
     Timer t(c);
@@ -439,11 +445,24 @@ int step_once(fluid_ctx* c, float dt, const fluid_params* P, bool lead = true, i
         CK(pass_gradsub(c, 0));
     }
     t.mark(P_GRADSUB);
-    if (chain) {
+    if (chain == 3) {  // the call's last step: advect, and run the NEXT call's curl / vorticity / divergence into the pending buffers
+        int ga, gb;
+        sim_band(c, 0, ga, gb);
+        CK(c->hip(fluid::launch_advect_cvd(c->stream, sim_cols(c, 0), (const float2*)c->vel[0], (float2*)c->pend_vel, (const float4*)c->dyeb[0],
+                                           (float4*)c->dyeb[1], (float*)c->pend_curl, (float*)c->pend_div, (float2*)c->vel[1], dt,
+                                           P->velocity_dissipation, P->density_dissipation, P->curl, ga, gb),
+                  "advect + the next call's curl_vort_div"));
+        std::swap(c->vel[0], c->vel[1]);   // the advected velocity: what the caller reads
+        std::swap(c->dyeb[0], c->dyeb[1]);
+        c->pend_valid = true;
+        c->pend_dt = dt;
+        c->pend_curl_strength = P->curl;
+        t.mark(P_ADVD);
+    } else if (chain) {
         int ga, gb;
         sim_band(c, 0, ga, gb);
         CK(c->hip(fluid::launch_advect_cvd(c->stream, sim_cols(c, 0), (const float2*)c->vel[0], (float2*)c->vel[1], (const float4*)c->dyeb[0],
-                                           (float4*)c->dyeb[1], chain == 2 ? (float*)c->curl : nullptr, (float*)c->div, dt,
+                                           (float4*)c->dyeb[1], chain == 2 ? (float*)c->curl : nullptr, (float*)c->div, nullptr, dt,
                                            P->velocity_dissipation, P->density_dissipation, P->curl, ga, gb),
                   "advect + curl_vort_div"));
         std::swap(c->vel[0], c->vel[1]);
@@ -475,6 +494,30 @@ bool chain_enabled(long owned_texels)
         return e ? (atoi(e) != 0 ? 1 : 0) : -1;
     }();
     return mode >= 0 ? mode == 1 : owned_texels < 3072l * 3072l;
+}
+
+// FLUID_RUN_AHEAD=0 (lab build): a call never ends with the launch that computes the next call's curl / vorticity / divergence ahead
+bool run_ahead_enabled()
+{
+    static const bool on = [] {
+        const char* e = fluid::lab_env("FLUID_RUN_AHEAD");
+        return !(e && atoi(e) == 0);
+    }();
+    return on;
+}
+
+int pending_buffers(fluid_ctx* c)   // allocated on first use: whole-domain fp32 contexts below 3072^2 texels only (<= 150 MB)
+{
+    if (c->pend_vel) return FLUID_OK;
+    const size_t n = cells(c->sim);
+    HIPCK(c, hipMalloc(&c->pend_vel, n * 2 * sizeof(float)));
+    HIPCK(c, hipMalloc(&c->pend_div, n * sizeof(float)));
+    HIPCK(c, hipMalloc(&c->pend_curl, n * sizeof(float)));
+    // the padding columns are never meaningful but are copied around: give them defined content once
+    HIPCK(c, hipMemsetAsync(c->pend_vel, 0, n * 2 * sizeof(float), c->stream));
+    HIPCK(c, hipMemsetAsync(c->pend_div, 0, n * sizeof(float), c->stream));
+    HIPCK(c, hipMemsetAsync(c->pend_curl, 0, n * sizeof(float), c->stream));
+    return FLUID_OK;
 }
 
 bool chain_applies(const fluid_ctx* c, float dt, const fluid_params* P)
@@ -617,6 +660,7 @@ int fluid_destroy(fluid_ctx* c)
 int fluid_resize(fluid_ctx* c, int sw, int sh, int dw, int dh)
 {
     if (!c) return FLUID_ERR_INVALID;
+    c->touched();
     if (c->desc.parts != 1 || c->desc.parts_x != 1) return c->fail(FLUID_ERR_UNSUPPORTED, "resize of a stripe / tile context");
     if (sw < 1 || sh < 1 || dw < 1 || dh < 1) return c->fail(FLUID_ERR_INVALID, "field sizes must be >= 1");
     HIPCK(c, hipSetDevice(c->device));
@@ -668,6 +712,10 @@ int fluid_resize(fluid_ctx* c, int sw, int sh, int dw, int dh)
         (void)hipFree(c->curl);
         c->div = nscal[2];
         c->curl = nscal[3];
+        for (void** p : { &c->pend_vel, &c->pend_div, &c->pend_curl }) {   // of the old size: reallocated when a call next works ahead
+            if (*p) (void)hipFree(*p);
+            *p = nullptr;
+        }
     }
     c->desc.sim_w = sw;
     c->desc.sim_h = sh;
@@ -682,6 +730,7 @@ int fluid_resize(fluid_ctx* c, int sw, int sh, int dw, int dh)
 int fluid_set_schedule(fluid_ctx* c, int schedule)
 {
     if (!c) return FLUID_ERR_INVALID;
+    c->touched();
     if (schedule != FLUID_SCHED_PASSES && schedule != FLUID_SCHED_FUSED) return c->fail(FLUID_ERR_INVALID, "unknown schedule");
     c->desc.schedule = schedule;
     return FLUID_OK;
@@ -699,6 +748,7 @@ int fluid_set_stream(fluid_ctx* c, void* hip_stream, int external)
 int fluid_pass_splat(fluid_ctx* c, int field, float x, float y, float aspect, float radius, float c0, float c1, float c2)
 {
     if (!c) return FLUID_ERR_INVALID;
+    c->touched();
     HIPCK(c, hipSetDevice(c->device));
     int ga, gb;
     if (field == FLUID_VELOCITY) {
@@ -737,10 +787,25 @@ int fluid_step_n(fluid_ctx* c, int n, float dt, const fluid_params* P)
     } guard{ c };
     const bool skip = fluid_impl::skip_hidden_curl();
     fluid_impl::mark_step(c, 0);
-    if (n > 1 && chain_applies(c, dt, P)) {
+    if (n == 0) return FLUID_OK;
+    const bool chains = chain_applies(c, dt, P);
+    // did the launch that ended the previous call already run this call's first curl / vorticity / divergence?  Then adopt its buffers.
+    bool lead = true;
+    if (c->pend_valid) {
+        if (chains && dt == c->pend_dt && P->curl == c->pend_curl_strength) {
+            std::swap(c->vel[0], c->pend_vel);   // the velocity after vorticity confinement (the advected one moves to the spare buffer)
+            std::swap(c->div, c->pend_div);
+            std::swap(c->curl, c->pend_curl);
+            lead = false;
+        }
+        c->pend_valid = false;
+    }
+    const bool ahead = chains && run_ahead_enabled() && pending_buffers(c) == FLUID_OK;   // end the call with the launch that works ahead
+    if (chains && (n > 1 || ahead || !lead)) {
         for (int k = 0; k < n; k++) {
-            c->keep_curl = !skip;   // the lead step's own launch: the chain's last k_advect_cvd writes the field a caller reads
-            CK(step_once(c, dt, P, k == 0, k == n - 1 ? 0 : (k == n - 2 ? 2 : 1)));
+            c->keep_curl = !skip || n == 1;   // a lead launch of a call for ONE step writes the curl a caller reads; else the chain's last launch does
+            const int chain = k < n - 2 ? 1 : (k == n - 2 ? 2 : (ahead ? 3 : 0));
+            CK(step_once(c, dt, P, k == 0 && lead, chain));
             fluid_impl::mark_step(c, k + 1);
         }
         return FLUID_OK;
@@ -820,6 +885,7 @@ int fluid_read_field(fluid_ctx* c, int field, float* host, size_t bytes)
 int fluid_write_field(fluid_ctx* c, int field, const float* host, size_t bytes)
 {
     if (!c || !host) return FLUID_ERR_INVALID;
+    c->touched();
     HostBlock b;
     CK(host_block(c, field, bytes, "write_field", &b));
     HIPCK(c, hipSetDevice(c->device));
@@ -848,57 +914,68 @@ int fluid_write_field(fluid_ctx* c, int field, const float* host, size_t bytes)
 
 int fluid_pass_curl(fluid_ctx* c, int ext)
 {
+    if (c) c->touched();
     PASS_PROLOGUE();
     return pass_curl(c, ext);
 }
 int fluid_pass_vorticity(fluid_ctx* c, float curl, float dt, int ext)
 {
+    if (c) c->touched();
     PASS_PROLOGUE();
     return pass_vorticity(c, curl, dt, ext);
 }
 int fluid_pass_divergence(fluid_ctx* c, int ext)
 {
+    if (c) c->touched();
     PASS_PROLOGUE();
     return pass_divergence(c, ext);
 }
 int fluid_pass_curl_vorticity_divergence(fluid_ctx* c, float curl, float dt, int ext)
 {
+    if (c) c->touched();
     PASS_PROLOGUE();
     return pass_curl_vort_div(c, curl, dt, ext, nullptr);
 }
 int fluid_pass_clear(fluid_ctx* c, float value, int ext)
 {
+    if (c) c->touched();
     PASS_PROLOGUE();
     return pass_clear(c, value, ext);
 }
 int fluid_pass_jacobi(fluid_ctx* c, int iters, int ext_out)
 {
+    if (c) c->touched();
     PASS_PROLOGUE();
     return pass_jacobi(c, iters, ext_out, 1.0f, nullptr, nullptr, nullptr);
 }
 int fluid_pass_clear_jacobi(fluid_ctx* c, float value, int iters, int ext_out)
 {
+    if (c) c->touched();
     PASS_PROLOGUE();
     return pass_clear_jacobi(c, value, iters, ext_out, nullptr, nullptr);
 }
 int fluid_pass_gradsub(fluid_ctx* c, int ext)
 {
+    if (c) c->touched();
     PASS_PROLOGUE();
     return pass_gradsub(c, ext);
 }
 int fluid_pass_advect_velocity(fluid_ctx* c, float dt, float dissipation, int ext)
 {
+    if (c) c->touched();
     PASS_PROLOGUE();
     return pass_advect_velocity(c, dt, dissipation, ext);
 }
 int fluid_pass_advect_dye(fluid_ctx* c, float dt, float dissipation)
 {
+    if (c) c->touched();
     PASS_PROLOGUE();
     return pass_advect_dye(c, dt, dissipation);
 }
 
 int fluid_pass_advect(fluid_ctx* c, float dt, float velocity_dissipation, float density_dissipation)
 {
+    if (c) c->touched();
     PASS_PROLOGUE();
     return pass_advect(c, dt, velocity_dissipation, density_dissipation, nullptr);
 }
@@ -925,12 +1002,14 @@ int fluid_halo_pack(fluid_ctx* c, int field, int side, int nrows, void* dev_buf)
 
 int fluid_halo_unpack(fluid_ctx* c, int field, int side, int nrows, const void* dev_buf)
 {
+    if (c) c->touched();
     return halo_copy(c, field, side, nrows, const_cast<void*>(dev_buf), false);
 }
 
 int fluid_field_device_ptr(fluid_ctx* c, int field, void** dev_ptr)
 {
     if (!c || !dev_ptr) return FLUID_ERR_INVALID;
+    c->touched();
     FieldRef f;
     CK(field_ref(c, field, &f));
     *dev_ptr = f.ptr;
@@ -975,15 +1054,19 @@ int fluid_schedule_info_get(fluid_ctx* c, int n_steps, float dt, const fluid_par
     const int depth = tb ? fluid::jacobi_tb_depth(out->jacobi_shape) : 1;
     out->jacobi_launches = tb ? (P->iterations + depth - 1) / depth : P->iterations;
     out->gradsub_folded = tb && fluid::jacobi_tb_has_gradsub(out->jacobi_shape) && fluid_impl::gradsub_fold_enabled(owned);
-    const bool chain = whole && n_steps > 1 && chain_applies(c, dt, P);
-    out->chained = chain ? n_steps - 1 : 0;
+    const bool chains = whole && n_steps > 0 && chain_applies(c, dt, P);
+    out->pending_adopted = chains && c->pend_valid && dt == c->pend_dt && P->curl == c->pend_curl_strength;
+    out->runs_ahead = chains && run_ahead_enabled();
+    const bool chain = chains && (n_steps > 1 || out->runs_ahead || out->pending_adopted);
+    out->chained = chain ? n_steps - 1 + out->runs_ahead : 0;
     const bool fused_cvd = fluid_impl::fused_cvd_applies(c);
-    out->curl_stores = (fused_cvd && fluid_impl::skip_hidden_curl() && n_steps > 0) ? 1 : n_steps;
+    out->curl_stores = (fused_cvd && fluid_impl::skip_hidden_curl() && n_steps > 0) ? 1 + (out->runs_ahead ? 1 : 0) : n_steps + (out->runs_ahead ? 1 : 0);
     if (whole) {
         const int cvd = fused_cvd ? 1 : 3, clear = tb ? 0 : 1, gs = out->gradsub_folded ? 0 : 1;
         const int adv = fluid_impl::fused_advect_applies(c) ? 1 : 2;
         const int per_step = cvd + clear + out->jacobi_launches + gs + adv;
-        out->launches = chain ? n_steps * (per_step - 1) + 1 : n_steps * per_step;   // a chained step has no curl launch of its own: the first one does
+        // a chained step has no curl launch of its own: only the call's first step does, unless the previous call already ran it ahead
+        out->launches = chain ? n_steps * (per_step - 1) + (out->pending_adopted ? 0 : 1) : n_steps * per_step;
     }
     return FLUID_OK;
 }
