@@ -214,15 +214,15 @@ def pmc_pass(args, counters, deadline, steps_under_profiler=4):
         return out, None
 
 
-def collect_traffic(args, deadline, steps_under_profiler: int = 0):
+def collect_traffic(args, deadline, steps_under_profiler: int = 0, chained: bool = False):
     """HBM bytes per launch of every step kernel, measured IN THIS RUN: two short child runs under `rocprofv3 --kernel-trace --pmc`
     (FETCH_SIZE and WRITE_SIZE in separate passes, as the guide's HBM section prescribes), corrected as tools/pmc_traffic.py documents
     (KiB units, x2 on FETCH_SIZE for gfx950, WRITE_SIZE calibrated to 1.0 on k_clear in profiles/r01).
     Returns ({kernels, bytes_per_step}, None) or (None, reason)."""
     if not steps_under_profiler:
-        # ONE call of this many steps.  Below 3072^2 texels a call for n steps chains n - 1 of them (k_advect_cvd): sixteen steps put the
+        # ONE call of this many steps.  Where a call for n steps chains them (k_advect_cvd; fluid_schedule_info says so), sixteen steps put the
         # launch mix within 6 % of the timed call's (the bytes per launch are what they are either way)
-        steps_under_profiler = 4 if args.size * args.size >= 3072 * 3072 else 16
+        steps_under_profiler = 16 if chained else 4
     per = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         got, why = pmc_pass(args, [ctr], deadline, steps_under_profiler)
@@ -701,7 +701,7 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         if only_folded and args.schedule == "fused":
             cands = ["k_jacobi_tb_gs_h<"] if args.storage == "f16" else ["k_jacobi_tb2_gs<", "k_jacobi_tb_gs<"]
         kname = cands[0]
-        traffic, why = (None, "--no-traffic") if args.no_traffic else collect_traffic(args, deadline)
+        traffic, why = (None, "--no-traffic") if args.no_traffic else collect_traffic(args, deadline, chained=sim.schedule_info(args.steps, DT)["chained"] > 0)
         entry = None
         if traffic:
             for c in cands:

@@ -217,7 +217,12 @@ typedef enum fluid_stripe_op_kind {
     FLUID_OP_CLEAR = 2,          /* 1253-1257                                                                  */
     FLUID_OP_CLEAR_JACOBI = 3,   /* 1253-1266: clear, then `iters` Jacobi iterations leaving `ext` ghost rows  */
     FLUID_OP_JACOBI = 4,         /* `iters` more iterations                                                    */
-    FLUID_OP_GRADSUB = 5,        /* 1268-1273                                                                  */
+    FLUID_OP_GRADSUB = 5,        /* 1268-1273.  The NATIVE driver (fluid_step_n / fluid_group_step_n) runs this op INSIDE the launch of the */
+                                 /* JACOBI / CLEAR_JACOBI block in front of it where the library folds the gradient subtract (grids below   */
+                                 /* 3072^2 owned texels: fluid_schedule_info.gradsub_folded).  That block then stores the pressure for the */
+                                 /* OWNED rows / columns only (ext 0) — after the step the pressure ghost ring is stale, where the plan's  */
+                                 /* JACOBI(ext 1) and a driver that runs the ops one by one (fluid_pass_*) leave it valid.  Nothing reads  */
+                                 /* it: the next step's first exchange refreshes the pressure ghosts before its CLEAR_JACOBI.              */
     FLUID_OP_ADVECT = 6          /* 1275-1293                                                                  */
 } fluid_stripe_op_kind;
 

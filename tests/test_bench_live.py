@@ -56,7 +56,7 @@ def test_bench_line_is_live_and_consistent():
     assert len(t["ms_per_timed_step"]) == 5 and abs(sum(t["ms_per_timed_step"]) - t["sum_ms"]) < 1e-2 and t["sum_ms"] <= 5 * d["ms_per_step"] * 1.05
     assert d["config"]["knobs"] == {} and d["config"]["settle"]["steps"] >= 1
     k = d["config"]["kernels"]
-    assert k["chained_steps"] == 5 and k["gradsub_folded"] is True and k["curl_field_stored_by_steps"] == 1 and k["jacobi_launches_per_step"] == 5
+    assert k["chained_steps"] == 5 and k["gradsub_folded"] is True and k["curl_field_stored_by_steps"] == 2 and k["jacobi_launches_per_step"] == 5
     assert d["cold_start"]["ms_per_step"] > 0 and len(d["cold_start"]["ms_per_timed_step"]) == 5
     assert 0 < r["frac_compulsory"] <= r["frac"] * 1.02 and r["compulsory_bytes_per_launch"] == 12 * 1024 * 1024
     if "step_hbm" in d:

@@ -92,18 +92,25 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", action="append", default=None)
     ap.add_argument("--rounds", type=int, default=2)
+    ap.add_argument("--hw-queues", type=int, default=16,
+                    help="GPU_MAX_HW_QUEUES for the children.  The HIP runtime maps a process's streams onto 4 hardware queues by default; the "
+                         "rank THREADS of this probe own 2-3 streams each, so with the default two ranks' compute and comm streams share queues "
+                         "and wait for each other — an artefact of running several ranks in one process, which a one-rank-per-process run does "
+                         "not have (own stream + comm stream + torch's: within 4).  0 = leave the default")
     args = ap.parse_args()
     lib = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
     for name in (args.config or list(CONFIGS)):
         canvas, res, iters, world, tx, halo, steps = CONFIGS[name]
-        print("## %s: %dx%d global, %d ranks (%s) on ONE GPU, %d Jacobi iterations, halo %d, %d timed steps; link = latency per receive (+ bytes / bandwidth)"
-              % (name, canvas[0], canvas[1], world, "%dx%d tiles" % (world // tx, tx) if tx > 1 else "stripes", iters, halo, steps), flush=True)
+        print("## %s [GPU_MAX_HW_QUEUES=%s]: %dx%d global, %d ranks (%s) on ONE GPU, %d Jacobi iterations, halo %d, %d timed steps; link = latency per receive (+ bytes / bandwidth)"
+              % (name, args.hw_queues or "default", canvas[0], canvas[1], world, "%dx%d tiles" % (world // tx, tx) if tx > 1 else "stripes", iters, halo, steps), flush=True)
         base = {}
         for rnd in range(args.rounds):
             for overlap in (1, 0):
                 for delay, gbps in ((0, 0), (60, 0), (200, 0), (20, 100)):
                     env = dict(os.environ, FLUID_RCCL_LIB=lib, _OVL_CHILD=json.dumps({"config": name, "overlap": overlap}))
                     env.pop("FAKE_RCCL_DELAY_US", None); env.pop("FAKE_RCCL_GBPS", None)
+                    if args.hw_queues:
+                        env["GPU_MAX_HW_QUEUES"] = str(args.hw_queues)
                     if delay:
                         env["FAKE_RCCL_DELAY_US"] = str(delay)
                     if gbps:

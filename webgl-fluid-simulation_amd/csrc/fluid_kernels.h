@@ -11,6 +11,18 @@ namespace fluid {
 // The FLUID_* tuning knobs (tile shapes, folds, chains, rows per thread: every A/B of the rounds' profiles/) exist in the lab build only —
 // `make PROBES=1` -> libfluid_hip_probes.so, -DFLUID_PROBES — together with the kernel shapes they select.  The product library reads none of
 // them: what it launches is decided by the grid alone (fluid_schedule_info_get says what).
+// ONE threshold for everything the library does differently on small grids (owned texels of a context below it): the 40-row Jacobi tile
+// instead of the 80-row one, the gradient subtract folded into the last Jacobi launch, fluid_step_n / fluid_step chaining the advection with
+// the next step's curl / vorticity / divergence.  Below it a step is a chain of latency-bound launches; above it, of bandwidth-bound ones
+// (profiles/r03/jacobi_shapes_small_grids.txt, gradsub_fold_ab.txt, advect_cvd_chain.txt).
+constexpr long kSmallGridTexels = 3072l * 3072l;
+
+// Working ahead (the launch that ends a call also runs the next call's curl / vorticity / divergence into pending buffers) keeps a third
+// velocity buffer and second divergence / curl buffers alive: 80 B per texel instead of 64.  Up to 1536^2 that stays inside the 256 MB
+// Infinity Cache (512^2: 0.98 of fluid_step_n per frame instead of 0.82, 1024^2: 0.99 instead of 0.90); at 2048^2 it falls out of it and the
+// per-frame path gets SLOWER (0.83 against 0.92: profiles/r04/single_step_path.txt).
+constexpr long kRunAheadTexels = 1536l * 1536l + 1;
+
 inline const char* lab_env(const char* name)
 {
 #ifdef FLUID_PROBES

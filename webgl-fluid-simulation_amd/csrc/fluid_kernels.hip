@@ -1856,7 +1856,7 @@ const std::vector<TBRule>& tb_rules()
             }
         } else {
             r.push_back({ 2000l * 2000l, kPairTB });  // two texels per lane: 512^2 +35 %, 1024^2 +14 %, 1536^2 +5 %, level at 2048^2 (profiles/r03/jacobi_pair_tile_ab.txt)
-            r.push_back({ 3072l * 3072l, 8 });
+            r.push_back({ kSmallGridTexels, 8 });
         }
         return r;
     }();
@@ -2547,9 +2547,10 @@ hipError_t launch_jacobi_tb_gradsub_any(hipStream_t s, Win w, const T* p, const 
     ROWS_OR_RETURN();
     if (!jacobi_tb_supported(w) || v < 0 || v >= kNumTB || !tb_gs_built(v)) return hipErrorInvalidValue;
     if (iters < 1 || iters > kTB[v].hy) return hipErrorInvalidValue;
-    w.x0 &= ~3;  // whole float4 groups, as launch_gradsub4
-    w.x1 = (w.x1 + 3) & ~3;
-    if (w.x1 > w.W) w.x1 = w.W;
+    // This launch stores the pressure AND the velocity over [x0, x1) x [ga, gb): a column range that is not made of whole float4 groups
+    // would have to be widened for the velocity (as launch_gradsub4 does) and would then write pressure into columns whose apron inputs
+    // are not exact.  The stripe / tile driver only hands whole groups (cols_of); anything else is a caller's error, not something to widen.
+    if ((w.x0 & 3) != 0 || ((w.x1 & 3) != 0 && w.x1 != w.W)) return hipErrorInvalidValue;
     if (v == kPairTB) {
         if constexpr (sizeof(T) == 4) {
             switch (tb2_shape((long)(w.x1 - w.x0) * (gb - ga))) {

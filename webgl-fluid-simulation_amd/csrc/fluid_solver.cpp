@@ -342,7 +342,7 @@ bool gradsub_fold_enabled(long owned_texels)
         const char* e = fluid::lab_env("FLUID_FOLD_GRADSUB");
         return e ? (atoi(e) != 0 ? 1 : 0) : -1;
     }();
-    return mode >= 0 ? mode == 1 : owned_texels < 3072l * 3072l;
+    return mode >= 0 ? mode == 1 : owned_texels < fluid::kSmallGridTexels;
 }
 
 void mark_step(fluid_ctx* c, int k)
@@ -493,17 +493,17 @@ bool chain_enabled(long owned_texels)
         const char* e = fluid::lab_env("FLUID_CHAIN");
         return e ? (atoi(e) != 0 ? 1 : 0) : -1;
     }();
-    return mode >= 0 ? mode == 1 : owned_texels < 3072l * 3072l;
+    return mode >= 0 ? mode == 1 : owned_texels < fluid::kSmallGridTexels;
 }
 
 // FLUID_RUN_AHEAD=0 (lab build): a call never ends with the launch that computes the next call's curl / vorticity / divergence ahead
-bool run_ahead_enabled()
+bool run_ahead_enabled(long owned_texels)
 {
-    static const bool on = [] {
-        const char* e = fluid::lab_env("FLUID_RUN_AHEAD");
-        return !(e && atoi(e) == 0);
+    static const int mode = [] {
+        const char* e = fluid::lab_env("FLUID_RUN_AHEAD");   // 0 / 1 force it off / on (lab build)
+        return e ? (atoi(e) != 0 ? 1 : 0) : -1;
     }();
-    return on;
+    return mode >= 0 ? mode == 1 : owned_texels < fluid::kRunAheadTexels;
 }
 
 int pending_buffers(fluid_ctx* c)   // allocated on first use: whole-domain fp32 contexts below 3072^2 texels only (<= 150 MB)
@@ -800,7 +800,7 @@ int fluid_step_n(fluid_ctx* c, int n, float dt, const fluid_params* P)
         }
         c->pend_valid = false;
     }
-    const bool ahead = chains && run_ahead_enabled() && pending_buffers(c) == FLUID_OK;   // end the call with the launch that works ahead
+    const bool ahead = chains && run_ahead_enabled((long)c->sim_ncols * c->sim_rows) && pending_buffers(c) == FLUID_OK;   // end the call with the launch that works ahead
     if (chains && (n > 1 || ahead || !lead)) {
         for (int k = 0; k < n; k++) {
             c->keep_curl = !skip || n == 1;   // a lead launch of a call for ONE step writes the curl a caller reads; else the chain's last launch does
@@ -1056,7 +1056,7 @@ int fluid_schedule_info_get(fluid_ctx* c, int n_steps, float dt, const fluid_par
     out->gradsub_folded = tb && fluid::jacobi_tb_has_gradsub(out->jacobi_shape) && fluid_impl::gradsub_fold_enabled(owned);
     const bool chains = whole && n_steps > 0 && chain_applies(c, dt, P);
     out->pending_adopted = chains && c->pend_valid && dt == c->pend_dt && P->curl == c->pend_curl_strength;
-    out->runs_ahead = chains && run_ahead_enabled();
+    out->runs_ahead = chains && run_ahead_enabled((long)c->sim_ncols * c->sim_rows);
     const bool chain = chains && (n_steps > 1 || out->runs_ahead || out->pending_adopted);
     out->chained = chain ? n_steps - 1 + out->runs_ahead : 0;
     const bool fused_cvd = fluid_impl::fused_cvd_applies(c);

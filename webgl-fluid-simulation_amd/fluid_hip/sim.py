@@ -451,12 +451,17 @@ class FluidSim:
 
     def device_view(self, name: str):
         """torch tensor [rows, width, channels] aliasing the field's CURRENT read buffer on the device (zero copy through
-        __cuda_array_interface__; the padding columns of the pitch are sliced off).  Valid until the next call that swaps the
-        field's ping-pong buffers; the caller orders its torch work against the solver stream (sim.sync())."""
+        __cuda_array_interface__; the padding columns of the pitch are sliced off).  READ-ONLY and short-lived: the pointer is the buffer
+        that is current NOW — any step, splat, pass or write swaps the field's ping-pong buffers (and may free them: resize), after which
+        the view shows the spare buffer or dangles.  The caller orders its torch work against the solver stream (sim.sync())."""
         import torch
         ptr = C.c_void_p()
         self._check(self._lib.fluid_field_device_ptr(self._ctx, FIELD_IDS[name], C.byref(ptr)))
         fi = self._info(name)
+        # a FluidSim is a whole-domain context: no ghost rows / columns, array column 0 = global column 0 (a stripe or tile context has its
+        # own view with the ghost geometry: fluid_hip.stripes.HipStripeEngine.view)
+        if fi.halo or fi.halo_x or fi.array_col0 or fi.cols != fi.width or fi.rows != fi.height:
+            raise FluidError(_abi.ERR_UNSUPPORTED, "device_view is for whole-domain contexts")
         shape = (fi.rows + 2 * fi.halo, fi.pitch, fi.channels)
 
         class _DeviceArray:  # minimal CUDA-array-interface carrier
