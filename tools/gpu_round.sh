@@ -43,7 +43,7 @@ cat "$OUT/bench_f16.json" | tee -a "$OUT/log.txt"
 
 echo "== rocprofv3 kernel trace ==" | tee -a "$OUT/log.txt"
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o ks -- \
-    python "$GRAFT_REPO_ROOT/bench.py" --cpu-budget 0 --no-traffic --no-steady --no-parity --no-profile-pass >"$OUT/bench_under_rocprof.json" 2>"$OUT/rocprof.err" )
+    python "$GRAFT_REPO_ROOT/bench.py" --cpu-budget 0 --no-traffic --no-steady --no-parity --no-profile-pass --settle-ms 0 >"$OUT/bench_under_rocprof.json" 2>"$OUT/rocprof.err" )
 echo "rocprof exit $?" | tee -a "$OUT/log.txt"
 KS=$(find "$OUT/prof" -name '*kernel_stats.csv' | head -1)
 [ -n "$KS" ] && cp "$KS" "$OUT/kernel_stats.csv" && head -12 "$OUT/kernel_stats.csv" | cut -c1-200 | tee -a "$OUT/log.txt"

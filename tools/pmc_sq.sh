@@ -9,7 +9,7 @@ i=0
 for P in "$P1" "$P2"; do
   i=$((i+1))
   ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/p$i -o pmc -- \
-      python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 0 --cpu-budget 0 --no-profile-pass --no-traffic --no-steady --no-parity >/dev/null 2>>$OUT/err.txt )
+      python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 0 --cpu-budget 0 --no-profile-pass --no-traffic --no-steady --no-parity --settle-ms 0 >/dev/null 2>>$OUT/err.txt )
   F=$(find $OUT/p$i -name '*counter_collection.csv' | head -1)
   [ -n "$F" ] && cp $F $OUT/pmc$i.csv
   rm -rf $OUT/p$i
