@@ -58,9 +58,11 @@ def test_bench_line_is_live_and_consistent():
     k = d["config"]["kernels"]
     assert k["chained_steps"] == 5 and k["gradsub_folded"] is True and k["curl_field_stored_by_steps"] == 2 and k["jacobi_launches_per_step"] == 5
     assert d["cold_start"]["ms_per_step"] > 0 and len(d["cold_start"]["ms_per_timed_step"]) == 5
-    assert 0 < r["frac_compulsory"] <= r["frac"] * 1.02 and r["compulsory_bytes_per_launch"] == 12 * 1024 * 1024
+    # (at 1024^2 the fields sit in the caches: the counters may see FEWER bytes than a launch must move, so no order between the two fractions)
+    assert 0 < r["frac_compulsory"] <= 1.0 and r["compulsory_bytes_per_launch"] == 12 * 1024 * 1024
+    assert abs(r["frac_compulsory"] - r["compulsory_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9 / 8000.0) <= 2e-3
     if "step_hbm" in d:
-        assert 0 < d["step_hbm"]["frac_compulsory"] <= d["step_hbm"]["frac"] * 1.02
+        assert 0 < d["step_hbm"]["frac_compulsory"] <= 1.0
 
 
 @pytest.mark.gpu

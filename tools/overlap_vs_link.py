@@ -2,15 +2,20 @@
 """GPU box (ONE GPU): does the interior-first overlap of the stripe / tile driver hide a link that TAKES TIME?  (VERDICT r03 item 4:
 tests/fake_rccl copies instantly and in-process copies are intra-device, so the overlap had never met a slow link.)
 
-`world` rank threads step their stripe (or 2-D tile) contexts through fluid_step_n — the native plan with grouped ncclSend / ncclRecv on the
-comm stream, csrc/fluid_stripes.cpp — against tests/fake_rccl with FAKE_RCCL_DELAY_US / FAKE_RCCL_GBPS: every receive then waits
-latency + bytes / bandwidth on the receiver's comm stream (a spinning one-thread kernel; the host never sleeps).  All ranks share the one
-GPU, so a step costs the SUM of the ranks' compute; what the link adds on top is what the overlap does not hide.  The ranks exchange at the
-same points of their steps, so an exposed wait idles the whole device and shows in the wall time; with overlap switched off
-(fluid_set_overlap 0) it must show in full — that row is the probe's own check.
+ONE rank of a larger world runs alone (FAKE_RCCL_LOOPBACK=1: tests/fake_rccl serves every receive from this rank's own send to that
+neighbour, so nothing waits for another rank and nothing else runs on the device): a MIDDLE stripe of three, or the centre tile of 3 x 3,
+stepping through fluid_step_n — the native plan with grouped ncclSend / ncclRecv on the comm stream, csrc/fluid_stripes.cpp.
+FAKE_RCCL_DELAY_US / FAKE_RCCL_GBPS make every exchange take latency + bytes / bandwidth on the comm stream (one spinning single-thread
+kernel per group; the host never sleeps).  The rank then sees exactly a middle rank's timing: its own compute plus exchanges that take time.
+What the link adds to the step is what the overlap does not hide; with overlap switched off (fluid_set_overlap 0) it must show in full —
+that row is the probe's own check.
+
+(The first form of this probe — several rank THREADS sharing the GPU, profiles/r04/overlap_vs_link_latency_visit2_raw.txt — measured
+the device's arbitration between the ranks' queues instead: with 4 hardware queues two ranks' streams share queues, with 16 the ranks'
+kernels thrash each other, 1.0 -> 1.5 ms per step with an instantaneous link.)
 
 One child process per setting (the stand-in reads its environment once).
-Usage: python tools/overlap_vs_link.py [--config stripes2|tiles2x2|deep] > profiles/r04/overlap_vs_link_latency.txt"""
+Usage: python tools/overlap_vs_link.py [--config stripe|tile|deep] > profiles/r04/overlap_vs_link_latency.txt"""
 import argparse
 import json
 import os
@@ -24,10 +29,10 @@ sys.path.insert(0, os.path.join(ROOT, "webgl-fluid-simulation_amd"))
 DT = 0.016666
 
 CONFIGS = {
-    # name: (canvas, SIM = DYE resolution, iterations, world, tiles_x, halo, steps)
-    "stripes2": ((4096, 8192), 4096, 50, 2, 1, 56, 40),       # weak scaling of configs[2]: two stripes of 4096^2, 2 exchanges per step
-    "tiles2x2": ((4096, 4096), 4096, 50, 4, 2, 56, 40),       # configs[3]'s shape at half the edge: 2 x 2 tiles of 2048^2, two-phase exchange
-    "deep": ((8192, 4096), 4096, 200, 2, 1, 56, 12),          # configs[4]'s regime: 200 iterations -> 5 exchanges per step, two stripes of 8192 x 2048
+    # name: (canvas, SIM = DYE resolution, iterations, world, tiles_x, rank, halo, steps)
+    "stripe": ((4096, 12288), 4096, 50, 3, 1, 1, 56, 60),       # weak scaling of configs[2]: the middle one of three 4096^2 stripes, 2 exchanges / step
+    "tile": ((12288, 12288), 12288, 50, 9, 3, 4, 56, 60),       # configs[3]'s per-rank shape: the centre 4096^2 tile of 3 x 3, two-phase exchange
+    "deep": ((8192, 6144), 6144, 200, 3, 1, 1, 56, 16),         # configs[4]'s regime: 8192 x 2048 per rank, 200 iterations -> 5 exchanges / step
 }
 
 
@@ -36,11 +41,10 @@ def child(a):
     from fluid_hip import _abi
     from fluid_hip.sim import getResolution
     from fluid_hip.stripes import HipStripeEngine, new_comm_id
-    canvas, res, iters, world, tx, halo, steps = CONFIGS[a["config"]]
+    canvas, res, iters, world, tx, r, halo, steps = CONFIGS[a["config"]]
     ty = world // tx
     cfg = dict(fluid_hip.DEFAULT_CONFIG, SIM_RESOLUTION=res, DYE_RESOLUTION=res, PRESSURE_ITERATIONS=iters)
     sim = getResolution(res, *canvas)
-    cid = new_comm_id()
     rnd = fluid_hip.mulberry32(1234)
     splats = []
     for _ in range(20):
@@ -48,42 +52,23 @@ def child(a):
         splats.append((rnd(), rnd(), 1000.0 * (rnd() - 0.5), 1000.0 * (rnd() - 0.5), c["r"] * 10.0, c["g"] * 10.0, c["b"] * 10.0))
     aspect = canvas[0] / canvas[1]
     radius = cfg["SPLAT_RADIUS"] / 100.0 * (aspect if aspect > 1 else 1.0)
-    bar = threading.Barrier(world)
-    times, errs, exch = [0.0] * world, [], [0] * world
-
-    def rank(r):
-        try:
-            e = HipStripeEngine((sim["width"], sim["height"]), (sim["width"], sim["height"]), r // tx, ty, halo, _abi.SCHED_FUSED, 0, part_x=r % tx, parts_x=tx)
-            e.use_own_stream()
-            e.set_overlap(a["overlap"])
-            e.comm_init(cid)
-            for s in splats:
-                e.splat(*s, aspect, radius)
-            e.step_n(5, DT, cfg)
-            e.sync()
-            n0 = e.exchange_count()
-            bar.wait()
-            t0 = time.perf_counter()
-            e.step_n(steps, DT, cfg)
-            e.sync()
-            bar.wait()
-            times[r] = time.perf_counter() - t0
-            exch[r] = (e.exchange_count() - n0) / steps
-            e.check_halo()
-            e.close()
-        except BaseException as ex:  # noqa: BLE001
-            errs.append(repr(ex))
-            try:
-                bar.abort()
-            except Exception:
-                pass
-
-    ts = [threading.Thread(target=rank, args=(r,)) for r in range(world)]
-    for t in ts:
-        t.start()
-    for t in ts:
-        t.join(timeout=600)
-    print(json.dumps({"ok": not errs, "errors": errs, "ms_per_step": round(1e3 * max(times) / steps, 4), "exchanges_per_step": exch[0]}))
+    e = HipStripeEngine((sim["width"], sim["height"]), (sim["width"], sim["height"]), r // tx, ty, halo, _abi.SCHED_FUSED, 0, part_x=r % tx, parts_x=tx)
+    e.use_own_stream()
+    e.set_overlap(a["overlap"])
+    e.comm_init(new_comm_id())      # loopback: returns at once
+    for s in splats:
+        e.splat(*s, aspect, radius)
+    e.step_n(40, DT, cfg)            # past the shader-clock dip of a load step (profiles/r04/first_steps.txt)
+    e.sync()
+    n0 = e.exchange_count()
+    t0 = time.perf_counter()
+    e.step_n(steps, DT, cfg)
+    e.sync()
+    el = time.perf_counter() - t0
+    ex = (e.exchange_count() - n0) / steps
+    fi = e.info("velocity")
+    e.close()
+    print(json.dumps({"ok": True, "ms_per_step": round(1e3 * el / steps, 4), "exchanges_per_step": ex, "owned": [fi.cols, fi.rows]}))
 
 
 def main():
@@ -92,25 +77,18 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", action="append", default=None)
     ap.add_argument("--rounds", type=int, default=2)
-    ap.add_argument("--hw-queues", type=int, default=16,
-                    help="GPU_MAX_HW_QUEUES for the children.  The HIP runtime maps a process's streams onto 4 hardware queues by default; the "
-                         "rank THREADS of this probe own 2-3 streams each, so with the default two ranks' compute and comm streams share queues "
-                         "and wait for each other — an artefact of running several ranks in one process, which a one-rank-per-process run does "
-                         "not have (own stream + comm stream + torch's: within 4).  0 = leave the default")
     args = ap.parse_args()
     lib = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
     for name in (args.config or list(CONFIGS)):
-        canvas, res, iters, world, tx, halo, steps = CONFIGS[name]
-        print("## %s [GPU_MAX_HW_QUEUES=%s]: %dx%d global, %d ranks (%s) on ONE GPU, %d Jacobi iterations, halo %d, %d timed steps; link = latency per receive (+ bytes / bandwidth)"
-              % (name, args.hw_queues or "default", canvas[0], canvas[1], world, "%dx%d tiles" % (world // tx, tx) if tx > 1 else "stripes", iters, halo, steps), flush=True)
+        canvas, res, iters, world, tx, rk, halo, steps = CONFIGS[name]
+        print("## %s: rank %d of %d (%s) of a %dx%d grid, alone on the GPU (loopback), %d Jacobi iterations, halo %d, %d timed steps; link = latency per exchange (+ bytes / bandwidth)"
+              % (name, rk, world, "%dx%d tiles" % (world // tx, tx) if tx > 1 else "stripes", canvas[0], canvas[1], iters, halo, steps), flush=True)
         base = {}
         for rnd in range(args.rounds):
             for overlap in (1, 0):
-                for delay, gbps in ((0, 0), (60, 0), (200, 0), (20, 100)):
-                    env = dict(os.environ, FLUID_RCCL_LIB=lib, _OVL_CHILD=json.dumps({"config": name, "overlap": overlap}))
+                for delay, gbps in ((0, 0), (60, 0), (200, 0), (20, 100), (20, 40)):
+                    env = dict(os.environ, FLUID_RCCL_LIB=lib, FAKE_RCCL_LOOPBACK="1", _OVL_CHILD=json.dumps({"config": name, "overlap": overlap}))
                     env.pop("FAKE_RCCL_DELAY_US", None); env.pop("FAKE_RCCL_GBPS", None)
-                    if args.hw_queues:
-                        env["GPU_MAX_HW_QUEUES"] = str(args.hw_queues)
                     if delay:
                         env["FAKE_RCCL_DELAY_US"] = str(delay)
                     if gbps:

@@ -275,7 +275,9 @@ __device__ __forceinline__ void gather_taps(const T* __restrict__ F, const Tap4 
     }
 }
 
-template <int ROWS, class V2, class D4>
+// WY: waves of a block stacked in y (1 = the four waves side by side: 256 columns x ROWS rows per block; 4 = one wave wide: 64 columns x
+// 4 ROWS rows — the block's waves then share the rows between them in the CU's L1, at the price of more column seams between XCDs)
+template <int ROWS, class V2, class D4, int WY = 1>
 __device__ __forceinline__ void advect_both_fast_body(const Win& w, const V2* __restrict__ vel, V2* __restrict__ vel_out,
                                                       const D4* __restrict__ dye, D4* __restrict__ dye_out, float dt, double rW, double rH,
                                                       double rvd, double rdd, float tsx, float tsy, int ga, int gb,
@@ -283,10 +285,12 @@ __device__ __forceinline__ void advect_both_fast_body(const Win& w, const V2* __
 {
     // (bx, by): the block's position in its band — blockIdx for a one-band launch, or its place in one of the launch's rectangles
     // a lane past the last column repeats it (loads stay in bounds, nothing stored, nothing counted), like a row past the band
-    const int lane_i = w.x0 + bx * BX + threadIdx.x;
+    constexpr int CW = BX / WY;  // columns per block
+    const int tx = WY == 1 ? (int)threadIdx.x : (int)threadIdx.x % CW, ty = WY == 1 ? 0 : (int)threadIdx.x / CW;
+    const int lane_i = w.x0 + bx * CW + tx;
     const bool live = lane_i < w.x1;
     const int i = live ? lane_i : w.x1 - 1;
-    const int gj0 = ga + by * ROWS;
+    const int gj0 = ga + (by * WY + ty) * ROWS;
     const TapBox B = tap_box(w);
     const float u = div_uniform((float)i + 0.5f, rW);
     int miss = 0;
@@ -347,6 +351,17 @@ __global__ void __launch_bounds__(BX) k_advect_both_fast(Win w, const float2* __
 {
     advect_both_fast_body<ROWS>(w, vel, vel_out, dye, dye_out, dt, rW, rH, rvd, rdd, tsx, tsy, ga, gb, miss_out, (int)blockIdx.x, (int)blockIdx.y);
 }
+
+#ifdef FLUID_PROBES
+template <int ROWS, int WY>
+__global__ void __launch_bounds__(BX) k_advect_both_fast_wy(Win w, const float2* __restrict__ vel, float2* __restrict__ vel_out,
+                                                             const float4* __restrict__ dye, float4* __restrict__ dye_out, float dt, double rW,
+                                                             double rH, double rvd, double rdd, float tsx, float tsy, int ga, int gb,
+                                                             unsigned int* __restrict__ miss_out)
+{
+    advect_both_fast_body<ROWS, float2, float4, WY>(w, vel, vel_out, dye, dye_out, dt, rW, rH, rvd, rdd, tsx, tsy, ga, gb, miss_out, (int)blockIdx.x, (int)blockIdx.y);
+}
+#endif
 
 template <int ROWS>
 __global__ void __launch_bounds__(BX) k_advect_both_fast_h(Win w, const __half2* __restrict__ vel, __half2* __restrict__ vel_out,
@@ -429,15 +444,17 @@ __device__ __forceinline__ void advect_velocity_fast_body(const Win& w, const V2
     if (miss) atomicAdd(miss_out, (unsigned)miss);
 }
 
-template <int ROWS, class V2, class D4>
+template <int ROWS, class V2, class D4, int WY = 1>
 __device__ __forceinline__ void advect_dye_fast_body(const Win& vw, const V2* __restrict__ vel, const Win& dw, const D4* __restrict__ dye,
                                                      D4* __restrict__ dye_out, float dt, double rW, double rH, double rdd, float tsx, float tsy,
                                                      int ga, int gb, unsigned int* __restrict__ miss_out)
 {
-    const int lane_i = dw.x0 + blockIdx.x * BX + threadIdx.x;
+    constexpr int CW = BX / WY;  // columns per block (advect_both_fast_body)
+    const int tx = WY == 1 ? (int)threadIdx.x : (int)threadIdx.x % CW, ty = WY == 1 ? 0 : (int)threadIdx.x / CW;
+    const int lane_i = dw.x0 + (int)blockIdx.x * CW + tx;
     const bool live = lane_i < dw.x1;
     const int i = live ? lane_i : dw.x1 - 1;
-    const int gj0 = ga + blockIdx.y * ROWS;
+    const int gj0 = ga + ((int)blockIdx.y * WY + ty) * ROWS;
     const TapBox Bv = tap_box(vw), Bd = tap_box(dw);
     const float u = div_uniform((float)i + 0.5f, rW);
     int miss = 0;
@@ -496,6 +513,16 @@ __global__ void __launch_bounds__(BX) k_advect_dye_fast(Win vw, const V2* __rest
 {
     advect_dye_fast_body<ROWS>(vw, vel, dw, dye, dye_out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss_out);
 }
+
+#ifdef FLUID_PROBES
+template <int ROWS, int WY>
+__global__ void __launch_bounds__(BX) k_advect_dye_fast_wy(Win vw, const float2* __restrict__ vel, Win dw, const float4* __restrict__ dye,
+                                                            float4* __restrict__ dye_out, float dt, double rW, double rH, double rdd, float tsx,
+                                                            float tsy, int ga, int gb, unsigned int* __restrict__ miss_out)
+{
+    advect_dye_fast_body<ROWS, float2, float4, WY>(vw, vel, dw, dye, dye_out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss_out);
+}
+#endif
 
 template <int ROWS>
 __global__ void __launch_bounds__(BX) k_advect_both(Win w, const float2* __restrict__ vel, float2* __restrict__ vel_out,
@@ -2150,6 +2177,18 @@ static bool advect_fast_ok(const Win& w, size_t texel_bytes, float decay_a, floa
            (size_t)w.P * texel_bytes < (1u << 24) && w.H < (1 << 24);
 }
 
+#ifdef FLUID_PROBES
+static int advect_wy()   // FLUID_ADVECT_WY (lab): 1 (default), 2 or 4 waves of an advection block stacked in y
+{
+    static const int v = [] {
+        const char* e = lab_env("FLUID_ADVECT_WY");
+        const int k = e ? atoi(e) : 1;
+        return (k == 2 || k == 4) ? k : 1;
+    }();
+    return v;
+}
+#endif
+
 // texels per thread of the separate fast kernels: four, or fewer on small grids so that the launch still spreads over the chip
 // (FLUID_ADVECT_SPLIT_ROWS=1 / 2 / 4 forces one: A/B knob)
 static int split_advect_rows(long texels)
@@ -2192,6 +2231,18 @@ hipError_t launch_advect_dye_any(hipStream_t s, Win vw, const V2* vel, Win dw, c
     if (!(vw.W == dw.W && vw.H == dw.H) && advect_fast_ok(dw, sizeof(D4), decay, decay) && advect_fast_ok(vw, sizeof(V2), decay, decay)) {
         const double rW = udiv_recip((float)dw.W), rH = udiv_recip((float)dw.H), rdd = udiv_recip(decay);
         const unsigned gx = (dw.x1 - dw.x0 + BX - 1) / BX;
+#ifdef FLUID_PROBES
+        if constexpr (sizeof(V2) == sizeof(float2)) {
+            const int rows_ = split_advect_rows((long)(dw.x1 - dw.x0) * (gb - ga));
+            if (const int wy = advect_wy(); wy > 1 && (rows_ == 2 || rows_ == 4)) {
+                const unsigned cw = BX / wy, gxx = (dw.x1 - dw.x0 + cw - 1) / cw, gyy = (gb - ga + rows_ * wy - 1) / (rows_ * wy);
+#define WY_CASE(R, Y) if (rows_ == R && wy == Y) k_advect_dye_fast_wy<R, Y><<<dim3(gxx, gyy, 1), BX, 0, s>>>(vw, vel, dw, dye, out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss);
+                WY_CASE(2, 2) WY_CASE(2, 4) WY_CASE(4, 2) WY_CASE(4, 4)
+#undef WY_CASE
+                return hipGetLastError();
+            }
+        }
+#endif
         switch (split_advect_rows((long)(dw.x1 - dw.x0) * (gb - ga))) {
 #ifdef FLUID_PROBES
         case 4: k_advect_dye_fast<4><<<dim3(gx, (gb - ga + 3) / 4, 1), BX, 0, s>>>(vw, vel, dw, dye, out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss); break;
@@ -2251,6 +2302,16 @@ hipError_t launch_advect_both(hipStream_t s, Win w, const float2* vel, float2* v
     const float vdecay = 1.0f + vel_dissipation * dt, ddecay = 1.0f + dye_dissipation * dt;
     if (advect_fast_ok(w, sizeof(float4), vdecay, ddecay)) {
         const double rW = udiv_recip((float)w.W), rH = udiv_recip((float)w.H), rvd = udiv_recip(vdecay), rdd = udiv_recip(ddecay);
+#ifdef FLUID_PROBES
+        // FLUID_ADVECT_WY=2 / 4 (lab): the block's four waves stacked 2 x 2 / 1 x 4 instead of side by side, with FLUID_ADVECT_ROWS 4 or 2
+        if (const int wy = advect_wy(); wy > 1 && (rows == 4 || rows == 2)) {
+            const unsigned cw = BX / wy, gxx = (w.x1 - w.x0 + cw - 1) / cw, gyy = (gb - ga + rows * wy - 1) / (rows * wy);
+#define WY_CASE(R, Y) if (rows == R && wy == Y) k_advect_both_fast_wy<R, Y><<<dim3(gxx, gyy, 1), BX, 0, s>>>(w, vel, vel_out, dye, dye_out, dt, rW, rH, rvd, rdd, tsx, tsy, ga, gb, miss);
+            WY_CASE(4, 2) WY_CASE(4, 4) WY_CASE(2, 2) WY_CASE(2, 4)
+#undef WY_CASE
+            return hipGetLastError();
+        }
+#endif
         switch (rows) {
 #ifdef FLUID_PROBES
             ADVECT_FAST_CASE(k_advect_both_fast, 1)
