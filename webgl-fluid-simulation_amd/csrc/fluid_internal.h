@@ -142,7 +142,8 @@ int pass_divergence(fluid_ctx* c, int ext);
 int pass_curl_vort_div(fluid_ctx* c, float curl, float dt, int ext, Timer* t);
 int pass_clear(fluid_ctx* c, float value, int ext);
 struct Timer;
-int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launches, bool* gradsub, Timer* t);
+int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launches, bool* gradsub, Timer* t, int split = 0);
+bool jacobi_split_ok(const fluid_ctx* c, int iters, bool wants_gradsub);
 bool gradsub_fold_enabled(long owned_texels);
 int pass_clear_jacobi(fluid_ctx* c, float value, int iters, int ext_out, int* launches, bool* gradsub);
 int pass_gradsub(fluid_ctx* c, int ext);

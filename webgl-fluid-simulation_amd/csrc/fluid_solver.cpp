@@ -212,7 +212,21 @@ int pass_clear(fluid_ctx* c, float value, int ext)
 // `gradsub` (in: fold K6 into the last launch if that launch has the instantiation; out: whether it was): the last block then writes
 // the pressure AND velocity - grad(pressure) for the owned rows / columns (ext 0), and the caller skips pass_gradsub.  The blocks in
 // front of it leave the pressure valid one ring further out (ext_out >= 1), which is what the separate pass needs as well.
-int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launches, bool* gradsub, Timer* t)
+// `split` (stripe driver, a pressure-only exchange in front of this block — fluid_stripes.cpp): 1 = ONLY the rows of the block's first
+// launch whose inputs are all owned (they compute while the ghost rows travel; no ping-pong swap yet), 2 = the rest of the block: the
+// first launch's strips next to the ghost rows, then every further launch.  1 then 2 leave exactly what 0 leaves (same launches over
+// the same rows, cut differently).  jacobi_split_ok() says whether a block can be cut this way.
+bool jacobi_split_ok(const fluid_ctx* c, int iters, bool wants_gradsub)
+{
+    if (!jacobi_tb_applies(c) || c->desc.parts_x != 1 || iters < 1) return false;
+    const long owned = (long)c->sim_ncols * c->sim_rows;
+    const int shape = jacobi_tb_pick(owned), depth = jacobi_tb_depth(shape);
+    const bool fold = wants_gradsub && jacobi_tb_has_gradsub(shape) && gradsub_fold_enabled(owned);
+    if (fold && iters <= depth) return false;            // the block's only launch carries the gradient subtract: not cut
+    return c->sim_rows > 4 * depth;                      // an interior worth a launch of its own
+}
+
+int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launches, bool* gradsub, Timer* t, int split)
 {
     if (iters < 0) return c->fail(FLUID_ERR_INVALID, "negative iteration count");
     const bool tb = jacobi_tb_applies(c);
@@ -246,6 +260,25 @@ int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launche
                 return FLUID_OK;
             }
             row_range(c->sim, c->sim_row0, c->sim_rows, ext_out + (iters - done - k), ga, gb);
+            if (split && done == 0) {
+                // rows of this launch that read nothing of the ghost rows: a tile loads its apron (tb_max rows) whatever k is
+                const int r0 = c->sim_row0, r1 = r0 + c->sim_rows;
+                const int ia = c->desc.part > 0 ? std::min(std::max(r0 + tb_max, ga), gb) : ga;
+                const int ib = c->desc.part < c->desc.parts - 1 ? std::max(std::min(r1 - tb_max, gb), ia) : gb;
+                auto band = [&](int a, int b) {
+                    return b > a ? c->hip(STORE_CALL(c, launch_jacobi_tb(c->stream, sim_cols(c, ext_out + (iters - k)), (const S::T1*)c->prs[0],
+                                                                         (const S::T1*)c->div, (S::T1*)c->prs[1], pscale, k, a, b, shape)),
+                                          "jacobi_tb")
+                                 : (int)FLUID_OK;
+                };
+                if (split == 1) return band(ia, ib);      // interior only; the caller comes back with split == 2 once the ghost rows are in
+                CK(band(ga, ia));
+                CK(band(ib, gb));
+                if (launches) (*launches)++;
+                std::swap(c->prs[0], c->prs[1]);
+                done += k;
+                continue;
+            }
             CK(c->hip(STORE_CALL(c, launch_jacobi_tb(c->stream, sim_cols(c, ext_out + (iters - done - k)), (const S::T1*)c->prs[0], (const S::T1*)c->div,
                                                      (S::T1*)c->prs[1], done == 0 ? pscale : 1.0f, k, ga, gb, shape)),
                       "jacobi_tb"));

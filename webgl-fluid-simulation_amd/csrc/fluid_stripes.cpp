@@ -362,6 +362,11 @@ enum Dir { LEFT = 0, RIGHT = 1, DOWN = 2, UP = 3 };
 
 struct Blocks {
     Rect send[4], recv[4];
+    // the same DOWN / UP rows cut for the RCCL driver, whose phases run side by side: `core` = over the owned columns only (needs nothing
+    // of phase A), `corner[dir][side]` = the part over the left (0) / right (1) ghost columns, forwarded once phase A has filled them
+    Rect send_core[4], recv_core[4];
+    Rect send_corner[4][2], recv_corner[4][2];
+    bool corner_side[2];   // the tile has ghost columns on that side
 };
 
 int col_depth(const fluid_ctx* c, const FieldRef& f, int n)  // ghost columns that go with n ghost rows of this field
@@ -396,6 +401,19 @@ int blocks_of(fluid_ctx* c, int field, int n, Blocks* b)
     b->recv[DOWN] = rect(h - n, n, cs, ce - cs);
     b->send[UP] = rect(h + R - n, n, cs, ce - cs);
     b->recv[UP] = rect(h + R, n, cs, ce - cs);
+    b->send_core[DOWN] = rect(h, n, c0, c1 - c0);
+    b->recv_core[DOWN] = rect(h - n, n, c0, c1 - c0);
+    b->send_core[UP] = rect(h + R - n, n, c0, c1 - c0);
+    b->recv_core[UP] = rect(h + R, n, c0, c1 - c0);
+    b->corner_side[0] = c->desc.part_x > 0;
+    b->corner_side[1] = c->desc.part_x < c->desc.parts_x - 1;
+    const int side_col[2] = { c0 - nx, c1 };
+    for (int sd = 0; sd < 2; sd++) {
+        b->send_corner[DOWN][sd] = rect(h, n, side_col[sd], nx);
+        b->recv_corner[DOWN][sd] = rect(h - n, n, side_col[sd], nx);
+        b->send_corner[UP][sd] = rect(h + R - n, n, side_col[sd], nx);
+        b->recv_corner[UP][sd] = rect(h + R, n, side_col[sd], nx);
+    }
     return FLUID_OK;
 }
 
@@ -440,7 +458,14 @@ int ensure_stage(fluid_ctx* c, int slot, size_t bytes)
     return FLUID_OK;
 }
 
-// the whole exchange over RCCL on the comm stream (begun here, ended by rccl_exchange_end)
+// The whole exchange over RCCL on the comm stream (begun here, ended by rccl_exchange_end).  Two message rounds, but only the first
+// carries weight (round 4: the two-phase form — columns, THEN rows over owned + fresh ghost columns — put two full link times on
+// every exchange; against a link of 60 us the centre tile of 3 x 3 paid +25 % per step, profiles/r04/overlap_vs_link_latency.txt):
+//   round 1: ghost columns from LEFT / RIGHT (owned rows) and ghost rows from DOWN / UP over the OWNED columns — four neighbours, four
+//            links, side by side in one ncclGroup;
+//   round 2: the corner blocks (nx x n texels per field: a few tens of KB): what round 1 put into this tile's ghost columns next to its
+//            bottom / top rows is forwarded DOWN / UP — the diagonal neighbours' data arrives in two hops without diagonal messages.
+// Same bytes into the same ghost texels as the two-phase form (which the in-process group driver keeps).
 int rccl_exchange_2d_begin(fluid_ctx* c, const fluid_stripe_op& op)
 {
     const Rccl* R = rccl(nullptr);
@@ -451,32 +476,53 @@ int rccl_exchange_2d_begin(fluid_ctx* c, const fluid_stripe_op& op)
     HIPCK(c, hipEventRecord(c->ev_ready, c->stream));
     HIPCK(c, hipStreamWaitEvent(c->comm_stream, c->ev_ready, 0));
     const int unit = (int)c->esz;  // every line, pitch and staging offset is a multiple of the channel size
-    for (int phase = 0; phase < 2; phase++) {
-        const int dirs[2] = { phase == 0 ? LEFT : DOWN, phase == 0 ? RIGHT : UP };
-        size_t total[2] = { 0, 0 };
+    for (int round = 0; round < 2; round++) {
+        size_t total[4] = { 0, 0, 0, 0 };
         fluid::CopyRects pack{}, unpack{};
         pack.unit = unpack.unit = unit;
-        for (int k = 0; k < 2; k++) {
-            if (!has_neighbour(c, dirs[k])) continue;
-            for (int i = 0; i < op.n_items; i++) total[k] += blk[i].send[dirs[k]].bytes();
-            CK(ensure_stage(c, 2 * dirs[k], total[k]));      // send staging of this direction
-            CK(ensure_stage(c, 2 * dirs[k] + 1, total[k]));  // receive staging (the neighbour's block has the same shape)
+        // the rectangles one direction carries in this round, in the order both ends agree on (items, then sides)
+        auto rects_of = [&](int dir, int i, const Rect** sr, const Rect** rr) -> int {
+            int n = 0;
+            if (round == 0) {
+                sr[n] = dir >= DOWN ? &blk[i].send_core[dir] : &blk[i].send[dir];
+                rr[n++] = dir >= DOWN ? &blk[i].recv_core[dir] : &blk[i].recv[dir];
+            } else if (dir >= DOWN) {
+                for (int sd = 0; sd < 2; sd++)
+                    if (blk[i].corner_side[sd]) {
+                        sr[n] = &blk[i].send_corner[dir][sd];
+                        rr[n++] = &blk[i].recv_corner[dir][sd];
+                    }
+            }
+            return n;
+        };
+        for (int dir = 0; dir < 4; dir++) {
+            if (!has_neighbour(c, dir)) continue;
+            const Rect *sr[2], *rr[2];
+            for (int i = 0; i < op.n_items; i++) {
+                const int n = rects_of(dir, i, sr, rr);
+                for (int k = 0; k < n; k++) total[dir] += sr[k]->bytes();
+            }
+            if (!total[dir]) continue;
+            CK(ensure_stage(c, 2 * dir, total[dir]));      // send staging of this direction (round 2 reuses it: stream order)
+            CK(ensure_stage(c, 2 * dir + 1, total[dir]));  // receive staging (the neighbour's blocks have the same shapes)
             size_t off = 0;
             for (int i = 0; i < op.n_items; i++) {
-                const Rect& sr = blk[i].send[dirs[k]];
-                const Rect& rr = blk[i].recv[dirs[k]];
-                pack.r[pack.n++] = { sr.p, (char*)c->stage[2 * dirs[k]] + off, sr.pitch, sr.line, (unsigned)(sr.line / unit), (unsigned)sr.nrows };
-                unpack.r[unpack.n++] = { (char*)c->stage[2 * dirs[k] + 1] + off, rr.p, rr.line, rr.pitch, (unsigned)(rr.line / unit), (unsigned)rr.nrows };
-                off += sr.bytes();
+                const int n = rects_of(dir, i, sr, rr);
+                for (int k = 0; k < n; k++) {
+                    if (pack.n >= 8) return c->fail(FLUID_ERR_INVALID, "tile exchange: more blocks than one copy launch takes");
+                    pack.r[pack.n++] = { sr[k]->p, (char*)c->stage[2 * dir] + off, sr[k]->pitch, sr[k]->line, (unsigned)(sr[k]->line / unit), (unsigned)sr[k]->nrows };
+                    unpack.r[unpack.n++] = { (char*)c->stage[2 * dir + 1] + off, rr[k]->p, rr[k]->line, rr[k]->pitch, (unsigned)(rr[k]->line / unit), (unsigned)rr[k]->nrows };
+                    off += sr[k]->bytes();
+                }
             }
         }
-        if (!total[0] && !total[1]) continue;
-        HIPCK(c, fluid::launch_copy_rects(c->comm_stream, pack));      // every field and direction of the phase: one launch
+        if (!(total[0] | total[1] | total[2] | total[3])) continue;
+        HIPCK(c, fluid::launch_copy_rects(c->comm_stream, pack));      // every field and direction of the round: one launch
         NCCLCK(c, R, R->GroupStart());
-        for (int k = 0; k < 2; k++)
-            if (total[k]) {
-                NCCLCK(c, R, R->Send(c->stage[2 * dirs[k]], total[k], ncclChar, neighbour_rank(c, dirs[k]), comm, c->comm_stream));
-                NCCLCK(c, R, R->Recv(c->stage[2 * dirs[k] + 1], total[k], ncclChar, neighbour_rank(c, dirs[k]), comm, c->comm_stream));
+        for (int dir = 0; dir < 4; dir++)
+            if (total[dir]) {
+                NCCLCK(c, R, R->Send(c->stage[2 * dir], total[dir], ncclChar, neighbour_rank(c, dir), comm, c->comm_stream));
+                NCCLCK(c, R, R->Recv(c->stage[2 * dir + 1], total[dir], ncclChar, neighbour_rank(c, dir), comm, c->comm_stream));
             }
         NCCLCK(c, R, R->GroupEnd());
         HIPCK(c, fluid::launch_copy_rects(c->comm_stream, unpack));
@@ -687,6 +733,27 @@ int pass_whole(fluid_ctx* c, const fluid_stripe_op& op, float dt, const fluid_pa
     return rc;
 }
 
+// A pressure-only exchange in front of a further Jacobi block (more iterations than the ghost rows carry: BASELINE configs[4] runs 200):
+// nothing but that block follows, so the block's FIRST launch is cut — the rows whose inputs are all owned compute while the ghost rows
+// travel, the strips next to them and every further launch follow (pass_jacobi split 1 / 2).  Round 4: against a link of 60 us per
+// exchange the three such exchanges of a 200-iteration step were fully exposed (profiles/r04/overlap_vs_link_latency.txt).
+bool jacobi_overlap_ok(const fluid_ctx* c, const std::vector<fluid_stripe_op>& ops, size_t i)
+{
+    if (!c->overlap || i + 1 >= ops.size() || ops[i].kind != FLUID_OP_EXCHANGE || ops[i].n_items != 1 || ops[i].field[0] != FLUID_PRESSURE) return false;
+    return ops[i + 1].kind == FLUID_OP_JACOBI && jacobi_split_ok(c, ops[i + 1].iters, folds_gradsub(ops, i + 1));
+}
+
+int jacobi_block_interior(fluid_ctx* c, const fluid_stripe_op& blk) { return pass_jacobi(c, blk.iters, blk.ext, 1.0f, nullptr, nullptr, nullptr, 1); }
+
+// the rest of the block; `gs` = the gradient-subtract op behind it, or null
+int jacobi_block_rest(fluid_ctx* c, const fluid_stripe_op& blk, const fluid_stripe_op* gs)
+{
+    if (!gs) return pass_jacobi(c, blk.iters, blk.ext, 1.0f, nullptr, nullptr, nullptr, 2);
+    bool folded = true;
+    CK(pass_jacobi(c, blk.iters, blk.ext, 1.0f, nullptr, &folded, nullptr, 2));
+    return folded ? (int)FLUID_OK : pass_gradsub(c, gs->ext);
+}
+
 int plan_for(fluid_ctx* c, const fluid_params* P, std::vector<fluid_stripe_op>& ops)
 {
     int va, vd;
@@ -733,6 +800,12 @@ int stripe_step_n(fluid_ctx* c, int n, float dt, const fluid_params* P)
                 CK(rccl_exchange_end(c));
                 CK(pass_strips(c, ops[i + 1], dt, P));
                 i++;
+            } else if (jacobi_overlap_ok(c, ops, i)) {
+                const bool gs = folds_gradsub(ops, i + 1);
+                CK(jacobi_block_interior(c, ops[i + 1]));
+                CK(rccl_exchange_end(c));
+                CK(jacobi_block_rest(c, ops[i + 1], gs ? &ops[i + 2] : nullptr));
+                i += gs ? 2 : 1;
             } else {
                 CK(rccl_exchange_end(c));
             }
@@ -946,6 +1019,13 @@ int fluid_group_step_n(fluid_ctx** cs, int n_ctx, int steps, float dt, const flu
                 CK(tiles ? group_exchange_2d_end(cs, n_ctx) : group_exchange_end(cs, n_ctx));
                 CK(each([&](fluid_ctx* c) { return pass_strips(c, next, dt, P); }));
                 i++;
+            } else if (jacobi_overlap_ok(cs[0], ops, i)) {   // every stripe of a group has the same rows: the same answer
+                const bool gs = folds_gradsub(ops, i + 1);
+                const fluid_stripe_op& blk = ops[i + 1];
+                CK(each([&](fluid_ctx* c) { return jacobi_block_interior(c, blk); }));
+                CK(group_exchange_end(cs, n_ctx));
+                CK(each([&](fluid_ctx* c) { return jacobi_block_rest(c, blk, gs ? &ops[i + 2] : nullptr); }));
+                i += gs ? 2 : 1;
             } else {
                 CK(tiles ? group_exchange_2d_end(cs, n_ctx) : group_exchange_end(cs, n_ctx));
             }
