@@ -255,7 +255,14 @@ int ensure_comm_stream(fluid_ctx* c)
 {
     if (c->comm_stream) return FLUID_OK;
     HIPCK(c, hipSetDevice(c->device));
-    HIPCK(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    // The HIGHEST stream priority: what runs here — the pack / unpack launches of a tile exchange, RCCL's own send / receive kernels — is
+    // small and sits on the step's critical path, while the context stream floods the chip with the interior rows of the next pass.  At
+    // equal priority those few workgroups wait for the big launch's workgroups to retire one by one (every register of a CU is taken), and a
+    // 60 us link costs the centre tile of 3 x 3 +29 % per step instead of the +10 % its interior compute leaves exposed
+    // (profiles/r04/overlap_vs_link_latency.txt).
+    int prio_least = 0, prio_greatest = 0;
+    HIPCK(c, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    HIPCK(c, hipStreamCreateWithPriority(&c->comm_stream, hipStreamNonBlocking, prio_greatest));
     HIPCK(c, hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
     HIPCK(c, hipEventCreateWithFlags(&c->ev_landed, hipEventDisableTiming));
     HIPCK(c, hipEventCreateWithFlags(&c->ev_mid, hipEventDisableTiming));
