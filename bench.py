@@ -611,7 +611,8 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         # step's curl / vorticity / divergence (fluid_step_n below 3072^2 texels); a per-frame fluid_step never chains
         out["config"]["kernels"] = {"jacobi_shape": si["jacobi_shape"], "jacobi_launches_per_step": si["jacobi_launches"],
                                     "gradsub_folded": bool(si["gradsub_folded"]), "chained_steps": si["chained"],
-                                    "curl_field_stored_by_steps": si["curl_stores"], "launches_in_timed_call": si["launches"]}
+                                    "curl_field_stored_by_steps": si["curl_stores"], "launches_in_timed_call": si["launches"],
+                                    "dye_packed_rgb": bool(si["dye_packed"])}
     if on_cpu:
         out["config"]["engine"] = "injected stripe engine on CPU ranks over %s (launcher-path test, not a measurement)" % backend
     if N > 1:
@@ -774,8 +775,8 @@ def main(argv=None, engine_factory=None, backend="nccl"):
                                "frac_of_attainable": round(traffic["bytes_per_step"] * steps_per_s / 1e9 / HBM_ATTAINABLE_GBPS, 4),
                                # the bytes the fused schedule MUST move per step (no apron re-reads): curl/vorticity/divergence 20 (+ 4 for a
                                # step that stores its curl field), Jacobi 12 per launch, gradient subtract 20, advection 48
-                               "compulsory_bytes_per_step": int(compulsory_step_bytes(size, iters, tm, args.steps) * half),
-                               "frac_compulsory": round(compulsory_step_bytes(size, iters, tm, args.steps) * half * steps_per_s / 1e9 / HBM_PEAK_GBPS, 4),
+                               "compulsory_bytes_per_step": int(compulsory_step_bytes(size, iters, tm, args.steps, out["config"].get("kernels", {}).get("dye_packed_rgb", False)) * half),
+                               "frac_compulsory": round(compulsory_step_bytes(size, iters, tm, args.steps, out["config"].get("kernels", {}).get("dye_packed_rgb", False)) * half * steps_per_s / 1e9 / HBM_PEAK_GBPS, 4),
                                "kernels": {k: {"bytes_per_launch": v["bytes_per_launch"], "launches_per_step": v["launches_per_step"]}
                                            for k, v in traffic["kernels"].items()}}
         per_step = {k: round(v / max(tm["steps"], 1), 4) for k, v in tm.items() if k.endswith("_ms")}
@@ -862,12 +863,12 @@ def main(argv=None, engine_factory=None, backend="nccl"):
     return out
 
 
-def compulsory_step_bytes(size, iters, tm, steps_in_call):
+def compulsory_step_bytes(size, iters, tm, steps_in_call, dye_packed=False):
     """HBM bytes one fused step cannot avoid at `size`^2 (fp32, dye grid = sim grid), from the launches the timing pass counted"""
     per_step_launches = tm["jacobi_launches"] / max(tm["steps"], 1)
     folded = tm.get("folded_launches", 0) / max(tm["steps"], 1)
     curl = 4.0 / max(steps_in_call, 1)   # only the call's last step stores the curl field
-    b = 20.0 + curl + 12.0 * per_step_launches + (16.0 if folded else 20.0) + 48.0
+    b = 20.0 + curl + 12.0 * per_step_launches + (16.0 if folded else 20.0) + (40.0 if dye_packed else 48.0)   # advection: velocity 8 + 8, dye 16 + 16 (12 + 12 packed)
     return b * size * size
 
 

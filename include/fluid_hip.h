@@ -312,6 +312,9 @@ typedef struct fluid_schedule_info {
     int runs_ahead;        /* the call's LAST advection launch also runs the next call's curl / vorticity / divergence into       */
                            /* pending buffers (what makes one fluid_step per frame cost six launches instead of seven)            */
     int pending_adopted;   /* this call's first curl / vorticity / divergence was already run ahead by the previous call         */
+    int dye_packed;        /* the fused advection runs on the dye PACKED to three floats per texel (its alpha is one known value:  */
+                           /* 40 instead of 48 B/texel; whole-domain fp32 contexts at >= 3072^2 texels); anything that reads or     */
+                           /* writes dye texels sees RGBA — the library converts on demand                                          */
 } fluid_schedule_info;
 int fluid_schedule_info_get(fluid_ctx *ctx, int n_steps, float dt, const fluid_params *params, fluid_schedule_info *out);
 

@@ -327,7 +327,8 @@ def test_the_chained_launch_at_the_bench_size_yields_the_same_bits():
     got = []
     # ... and the other settings that only a big grid exercises: the two-texel tile as head / tail of the mixed Jacobi launch, the curl
     # field stored by every step of the call
-    envs = [{"FLUID_CHAIN": "0"}, {"FLUID_CHAIN": "1"}, {"FLUID_TB_TAIL_TILES": "384,768,2"}, {"FLUID_SKIP_CURL": "0"}, {"FLUID_TB_TAIL_TILES": "0,0,7"}]
+    envs = [{"FLUID_CHAIN": "0"}, {"FLUID_CHAIN": "1"}, {"FLUID_TB_TAIL_TILES": "384,768,2"}, {"FLUID_SKIP_CURL": "0"}, {"FLUID_TB_TAIL_TILES": "0,0,7"},
+            {"FLUID_DYE_PACK": "0"}]   # the dye kept RGBA through the fused advection (the product packs it to three floats at this size)
     probes = os.path.join(pkg, "libfluid_hip_probes.so")
     envs = [{}] + [dict(e, FLUID_HIP_LIB=probes) for e in envs]   # the product library's own bits first
     for env in envs:
@@ -403,5 +404,41 @@ def test_one_step_per_call_works_ahead_and_leaves_what_the_passes_leave(N):
                 assert np.array_equal(a.read(f), b.read(f)), (k, f)
         #          k: 0  1  2  3(splat) 4  5(dt) 6(dt back) 7(CURL) 8  9(write) 10 11
         assert adopted == [0, 1, 1, 0, 1, 0, 0, 0, 1, 0, 1, 1], adopted
+    finally:
+        a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_packed_dye_leaves_the_same_bits():
+    """At and above 3072^2 texels the fused advection runs on the dye packed to three floats per texel while the context knows its alpha
+    to be one value (1 after a splat, divided by the decay at every advection); everything that reads or writes dye texels sees RGBA.
+    Against the per-pass schedule, bit for bit, through: a long call (packed), reads (unpack), a splat on the packed field, a short
+    read-every-few-steps pattern (the hold-off: packing stops paying), and a dye written with NON-uniform alpha (must never be packed)."""
+    import fluid_hip
+    DT, N = 0.016666, 3072
+    a, b = sim_of(N, "passes", iters=20), sim_of(N, "fused", iters=20)
+    def same(tag):
+        for f in ("velocity", "pressure", "divergence", "curl", "dye"):
+            assert np.array_equal(a.read(f), b.read(f)), (tag, f)
+    try:
+        a.multipleSplats(6); b.multipleSplats(6)
+        assert b.schedule_info(20)["dye_packed"] == 1 and a.schedule_info(20)["dye_packed"] == 0
+        a.step(DT, 20); b.step(DT, 20)
+        same("20 steps packed")                      # alpha = 1 / decay^20 comes back from the scalar
+        assert b.schedule_info(1)["dye_packed"] == 1  # 20 advections between two readers: packing keeps paying
+        b.step(DT, 1); a.step(DT, 1)                  # packs again ...
+        for s_ in (a, b):
+            s_.splat(0.3, 0.7, -400.0, 250.0, {"r": 0.2, "g": 0.5, "b": 0.1})   # ... and the splat lands on the PACKED field (alpha -> 1)
+        a.step(DT, 2); b.step(DT, 2)
+        same("splat on the packed field")             # a reader after 3 advections: hold-off
+        assert b.schedule_info(1)["dye_packed"] == 0
+        a.step(DT, 2); b.step(DT, 2)
+        same("held off: RGBA")
+        d = b.read("dye")
+        d[..., 3] = np.linspace(0.25, 2.0, d.shape[0] * d.shape[1], dtype=np.float32).reshape(d.shape[:2])   # alpha is data now
+        a.write("dye", d); b.write("dye", d)
+        a.step(DT, 3); b.step(DT, 3)
+        same("non-uniform alpha is advected, not replaced by a scalar")
+        assert b.schedule_info(400)["dye_packed"] == 0
     finally:
         a.close(); b.close()

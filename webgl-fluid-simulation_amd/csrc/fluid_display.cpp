@@ -62,6 +62,7 @@ int default_dither(fluid_ctx* c, fluid_display_state* d)
 // fp32 in both modes.
 int dye_texels(fluid_ctx* c, fluid_display_state* d, const float4** read, float4** write)
 {
+    CK(fluid_impl::ensure_rgba(c));            // the compositor reads RGBA texels (a packed dye field is unpacked here)
     const bool dense = c->dye.P == c->dye.W;   // the compositor's kernels take dense W x H images
     if (c->storage == FLUID_STORE_F32 && dense) {
         *read = (const float4*)c->dyeb[0];

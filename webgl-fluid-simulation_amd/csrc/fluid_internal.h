@@ -46,6 +46,19 @@ struct fluid_ctx {
     float pend_dt = 0.0f, pend_curl_strength = 0.0f;
     void touched() { pend_valid = false; }   // call from every entry point that changes a field or hands out its memory
 
+    // The dye's alpha channel, when the context KNOWS it to be one value everywhere (fluid_kernels.h rgb3): 1 after creation and after
+    // every splat, divided by the dye's decay at every advection (the same fp32 division every texel sees); unknown after anything that can
+    // write other values (a field write with non-uniform alpha, a raw pointer, a ghost-row unpack) until the next splat.  While it is known,
+    // a whole-domain fp32 context at >= kSmallGridTexels keeps the dye PACKED (dye_packed: the two dye buffers then hold 12-byte texels)
+    // between the fused advections; every other consumer of the dye goes through ensure_rgba() first.
+    bool alpha_known = false;
+    float dye_alpha = 1.0f;
+    bool dye_packed = false;
+    // Packing costs a conversion each way (28 B/texel) and saves 8 B/texel per advection: it pays from ~8 steps between two consumers of
+    // the RGBA texels.  A host that renders or reads the dye every frame would lose: when a packed field is unpacked after fewer than 16
+    // advections, the next 256 advections stay RGBA (pack_holdoff counts them down) before packing is tried again.
+    int packed_advects = 0, pack_holdoff = 0;
+
     bool timing = false;
     hipEvent_t ev[P_COUNT + 1] = {};
     double acc_ms[P_COUNT] = {};
@@ -114,6 +127,7 @@ struct FieldRef {
     size_t texel() const { return (size_t)nc * esz; }
 };
 int field_ref(fluid_ctx* c, int field, FieldRef* f);
+int ensure_rgba(fluid_ctx* c);   // the dye buffers hold RGBA texels from here on (unpacks a packed dye field: fluid_ctx::dye_packed)
 
 // per-pass device time (fluid_set_timing): events on the context stream around each pass group
 struct Timer {

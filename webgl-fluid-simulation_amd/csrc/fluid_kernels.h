@@ -70,6 +70,14 @@ inline Win make_win_cols(int W, int H, int g0, int rows, int ca, int cb)
 struct alignas(8) half4 {
     __half2 lo, hi;
 };
+// The dye field PACKED: three floats per texel.  The dye's alpha channel is spatially uniform by construction — splats write 1
+// (script.js:544: vec4(base + splat, 1.0)), the advection's bilinear mix of four equal values is that value, and the decay divides every
+// texel by the same number — so a context that knows the value (fluid_ctx::alpha_known) keeps it as ONE scalar and the big fused
+// advection moves 40 instead of 48 B/texel.  Everything else sees RGBA: fluid_solver.cpp unpacks on demand (ensure_rgba).
+struct rgb3 {
+    float r, g, b;
+};
+
 struct StoreF32 {
     using T1 = float;
     using T2 = float2;
@@ -98,6 +106,14 @@ hipError_t launch_advect_dye(hipStream_t s, Win vw, const float2* vel, Win dw, c
 // K7a + K7b in one kernel; only when the dye grid equals the sim grid (same window)
 hipError_t launch_advect_both(hipStream_t s, Win w, const float2* vel, float2* vel_out, const float4* dye, float4* dye_out,
                               float dt, float vel_dissipation, float dye_dissipation, int ga, int gb, unsigned int* miss);
+// packed dye (rgb3): the fused advection where k_advect_both_fast applies (hipErrorNotReady otherwise: the caller unpacks and takes the
+// RGBA path), the dye splat, and the two conversions over a whole array of n texels
+hipError_t launch_advect_both_rgb(hipStream_t s, Win w, const float2* vel, float2* vel_out, const rgb3* dye, rgb3* dye_out, float dt,
+                                  float vel_dissipation, float dye_dissipation, int ga, int gb, unsigned int* miss);
+hipError_t launch_splat_dye_rgb(hipStream_t s, Win w, const rgb3* base, rgb3* out, float x, float y, float aspect, float radius, float c0,
+                                float c1, float c2, int ga, int gb);
+hipError_t launch_dye_pack(hipStream_t s, const float4* rgba, rgb3* rgb, size_t n);
+hipError_t launch_dye_unpack(hipStream_t s, const rgb3* rgb, float4* rgba, size_t n, float alpha);
 hipError_t launch_splat_velocity(hipStream_t s, Win w, const float2* base, float2* out, float x, float y, float aspect,
                                  float radius, float c0, float c1, int ga, int gb);
 hipError_t launch_splat_dye(hipStream_t s, Win w, const float4* base, float4* out, float x, float y, float aspect,

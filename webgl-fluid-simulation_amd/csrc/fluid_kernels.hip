@@ -352,6 +352,40 @@ __global__ void __launch_bounds__(BX) k_advect_both_fast(Win w, const float2* __
     advect_both_fast_body<ROWS>(w, vel, vel_out, dye, dye_out, dt, rW, rH, rvd, rdd, tsx, tsy, ga, gb, miss_out, (int)blockIdx.x, (int)blockIdx.y);
 }
 
+// the same kernel on the PACKED dye field (fluid_kernels.h rgb3: 12-byte texels, the uniform alpha kept as a scalar by the context):
+// 40 B/texel instead of 48.  Same body, same arithmetic on the three colour channels, hence the same bits.
+template <int ROWS>
+__global__ void __launch_bounds__(BX) k_advect_both_fast_rgb(Win w, const float2* __restrict__ vel, float2* __restrict__ vel_out,
+                                                              const rgb3* __restrict__ dye, rgb3* __restrict__ dye_out, float dt, double rW,
+                                                              double rH, double rvd, double rdd, float tsx, float tsy, int ga, int gb,
+                                                              unsigned int* __restrict__ miss_out)
+{
+    advect_both_fast_body<ROWS>(w, vel, vel_out, dye, dye_out, dt, rW, rH, rvd, rdd, tsx, tsy, ga, gb, miss_out, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+__global__ void __launch_bounds__(BX) k_splat_dye_rgb(Win w, const rgb3* __restrict__ base, rgb3* __restrict__ out, float x, float y, float aspect,
+                                                       float radius, float c0, float c1, float c2, int ga)
+{
+    TEXEL_OR_RETURN(w);
+    splat_dye_texel(w, base, out, x, y, aspect, radius, c0, c1, c2, i, gj);
+}
+
+__global__ void __launch_bounds__(BX) k_dye_pack(const float4* __restrict__ rgba, rgb3* __restrict__ rgb, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * BX + threadIdx.x; i < n; i += (size_t)gridDim.x * BX) {
+        const float4 v = rgba[i];
+        rgb[i] = rgb3{ v.x, v.y, v.z };
+    }
+}
+
+__global__ void __launch_bounds__(BX) k_dye_unpack(const rgb3* __restrict__ rgb, float4* __restrict__ rgba, size_t n, float alpha)
+{
+    for (size_t i = (size_t)blockIdx.x * BX + threadIdx.x; i < n; i += (size_t)gridDim.x * BX) {
+        const rgb3 v = rgb[i];
+        rgba[i] = make_float4(v.r, v.g, v.b, alpha);
+    }
+}
+
 #ifdef FLUID_PROBES
 template <int ROWS, int WY>
 __global__ void __launch_bounds__(BX) k_advect_both_fast_wy(Win w, const float2* __restrict__ vel, float2* __restrict__ vel_out,
@@ -2354,6 +2388,41 @@ hipError_t launch_advect_both(hipStream_t s, Win w, const __half2* vel, __half2*
     return hipGetLastError();
 }
 #undef ADVECT_FAST_CASE
+
+hipError_t launch_advect_both_rgb(hipStream_t s, Win w, const float2* vel, float2* vel_out, const rgb3* dye, rgb3* dye_out, float dt,
+                                  float vel_dissipation, float dye_dissipation, int ga, int gb, unsigned int* miss)
+{
+    ROWS_OR_RETURN();
+    const float vdecay = 1.0f + vel_dissipation * dt, ddecay = 1.0f + dye_dissipation * dt;
+    if (!advect_fast_ok(w, sizeof(float4), vdecay, ddecay)) return hipErrorNotReady;   // the RGBA array's bound: what the buffer was sized for
+    const float tsx = (float)(1.0 / w.W), tsy = (float)(1.0 / w.H);
+    const unsigned gx = (w.x1 - w.x0 + BX - 1) / BX;
+    const double rW = udiv_recip((float)w.W), rH = udiv_recip((float)w.H), rvd = udiv_recip(vdecay), rdd = udiv_recip(ddecay);
+    k_advect_both_fast_rgb<4><<<dim3(gx, (gb - ga + 3) / 4, 1), BX, 0, s>>>(w, vel, vel_out, dye, dye_out, dt, rW, rH, rvd, rdd, tsx, tsy, ga, gb, miss);
+    return hipGetLastError();
+}
+
+hipError_t launch_splat_dye_rgb(hipStream_t s, Win w, const rgb3* base, rgb3* out, float x, float y, float aspect, float radius, float c0,
+                                float c1, float c2, int ga, int gb)
+{
+    ROWS_OR_RETURN();
+    k_splat_dye_rgb<<<row_grid(w, ga, gb), BX, 0, s>>>(w, base, out, x, y, aspect, radius, c0, c1, c2, ga);
+    return hipGetLastError();
+}
+
+hipError_t launch_dye_pack(hipStream_t s, const float4* rgba, rgb3* rgb, size_t n)
+{
+    if (n == 0) return hipSuccess;
+    k_dye_pack<<<(unsigned)std::min<size_t>((n + BX - 1) / BX, 8192), BX, 0, s>>>(rgba, rgb, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_dye_unpack(hipStream_t s, const rgb3* rgb, float4* rgba, size_t n, float alpha)
+{
+    if (n == 0) return hipSuccess;
+    k_dye_unpack<<<(unsigned)std::min<size_t>((n + BX - 1) / BX, 8192), BX, 0, s>>>(rgb, rgba, n, alpha);
+    return hipGetLastError();
+}
 
 hipError_t launch_splat_velocity(hipStream_t s, Win w, const float2* base, float2* out, float x, float y, float aspect,
                                  float radius, float c0, float c1, int ga, int gb)

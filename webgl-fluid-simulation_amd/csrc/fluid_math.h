@@ -26,6 +26,13 @@ __device__ __forceinline__ float kept(const float*, float v) { return v; }
 __device__ __forceinline__ float kept(const float2*, float v) { return v; }
 __device__ __forceinline__ float kept(const __half*, float v) { return __half2float(__float2half_rn(v)); }
 __device__ __forceinline__ float kept(const __half2*, float v) { return __half2float(__float2half_rn(v)); }
+// packed dye texels (fluid_kernels.h rgb3): the alpha lane of what a kernel computes is dropped — the context carries it as a scalar
+__device__ __forceinline__ float4 ld(const rgb3* p, long i)
+{
+    const rgb3 v = p[i];
+    return make_float4(v.r, v.g, v.b, 0.0f);
+}
+__device__ __forceinline__ void st(rgb3* p, long i, float4 v) { p[i] = rgb3{ v.x, v.y, v.z }; }
 __device__ __forceinline__ void st(float* p, long i, float v) { p[i] = v; }
 __device__ __forceinline__ void st(float2* p, long i, float2 v) { p[i] = v; }
 __device__ __forceinline__ void st(float4* p, long i, float4 v) { p[i] = v; }

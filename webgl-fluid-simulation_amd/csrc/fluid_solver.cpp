@@ -319,6 +319,50 @@ int pass_gradsub(fluid_ctx* c, int ext)
     return FLUID_OK;
 }
 
+// ---- the dye field packed to three floats per texel while its alpha is one known value (fluid_internal.h) ----
+// FLUID_DYE_PACK=0 (lab build): never pack (A/B knob; same bits either way)
+bool dye_pack_enabled()
+{
+    static const bool on = [] {
+        const char* e = fluid::lab_env("FLUID_DYE_PACK");
+        return !(e && atoi(e) == 0);
+    }();
+    return on;
+}
+
+int ensure_rgba(fluid_ctx* c)
+{
+    if (!c->dye_packed) return FLUID_OK;
+    CK(c->hip(fluid::launch_dye_unpack(c->stream, (const fluid::rgb3*)c->dyeb[0], (float4*)c->dyeb[1], cells(c->dye), c->dye_alpha), "unpack dye"));
+    std::swap(c->dyeb[0], c->dyeb[1]);
+    c->dye_packed = false;
+    if (c->packed_advects < 16) c->pack_holdoff = 256;   // somebody needs RGBA texels every few steps: packing would cost more than it saves
+    return FLUID_OK;
+}
+
+int ensure_packed(fluid_ctx* c)
+{
+    if (c->dye_packed) return FLUID_OK;
+    CK(c->hip(fluid::launch_dye_pack(c->stream, (const float4*)c->dyeb[0], (fluid::rgb3*)c->dyeb[1], cells(c->dye)), "pack dye"));
+    std::swap(c->dyeb[0], c->dyeb[1]);
+    c->dye_packed = true;
+    c->packed_advects = 0;
+    return FLUID_OK;
+}
+
+// the advection divides every dye texel, alpha included, by 1 + dissipation dt (advectionShader script.js:780-782): the same fp32 division here
+void note_dye_advected(fluid_ctx* c, float dt, float dissipation)
+{
+    if (c->alpha_known) c->dye_alpha = c->dye_alpha / (1.0f + dissipation * dt);
+}
+
+// a whole-domain fp32 context whose step is bandwidth-bound (no chained launches) and whose alpha is known
+bool dye_pack_applies(const fluid_ctx* c)
+{
+    return dye_pack_enabled() && c->alpha_known && c->storage == FLUID_STORE_F32 && c->desc.parts == 1 && c->desc.parts_x == 1 &&
+           fused_advect_applies(c) && (long)c->sim_ncols * c->sim_rows >= fluid::kSmallGridTexels;
+}
+
 int pass_advect_velocity(fluid_ctx* c, float dt, float dissipation, int ext)
 {
     CK(check_ext(c, ext, 0));
@@ -332,6 +376,8 @@ int pass_advect_velocity(fluid_ctx* c, float dt, float dissipation, int ext)
 
 int pass_advect_dye(fluid_ctx* c, float dt, float dissipation)
 {
+    CK(ensure_rgba(c));
+    note_dye_advected(c, dt, dissipation);
     int ga, gb;
     row_range(c->dye, c->dye_row0, c->dye_rows, 0, ga, gb);
     CK(c->hip(STORE_CALL(c, launch_advect_dye(c->stream, c->sim, VEL(c, 0), dye_cols(c, 0), DYE(c, 0), DYE(c, 1), dt, dissipation, ga, gb, c->miss)),
@@ -348,6 +394,23 @@ int pass_advect(fluid_ctx* c, float dt, float vel_diss, float dye_diss, Timer* t
     if (fused_advect_applies(c)) {
         int ga, gb;
         row_range(c->sim, c->sim_row0, c->sim_rows, 0, ga, gb);
+        if (c->pack_holdoff > 0 && !c->dye_packed) c->pack_holdoff--;
+        if (dye_pack_applies(c) && (c->dye_packed || c->pack_holdoff == 0)) {   // 40 instead of 48 B/texel: the dye as three floats, its uniform alpha as a scalar
+            CK(ensure_packed(c));
+            c->packed_advects++;
+            const hipError_t e = fluid::launch_advect_both_rgb(c->stream, sim_cols(c, 0), (const float2*)c->vel[0], (float2*)c->vel[1],
+                                                               (const fluid::rgb3*)c->dyeb[0], (fluid::rgb3*)c->dyeb[1], dt, vel_diss, dye_diss, ga, gb, c->miss);
+            if (e != hipErrorNotReady) {
+                CK(c->hip(e, "advect"));
+                note_dye_advected(c, dt, dye_diss);
+                std::swap(c->vel[0], c->vel[1]);
+                std::swap(c->dyeb[0], c->dyeb[1]);
+                if (t) t->mark(P_ADVD);
+                return FLUID_OK;
+            }
+        }
+        CK(ensure_rgba(c));   // (also when the fast kernel does not apply to these decays: the general kernel reads RGBA)
+        note_dye_advected(c, dt, dye_diss);
         CK(c->hip(STORE_CALL(c, launch_advect_both(c->stream, sim_cols(c, 0), VEL(c, 0), VEL(c, 1), DYE(c, 0), DYE(c, 1), dt, vel_diss, dye_diss, ga, gb,
                                                    c->miss)),
                   "advect"));
@@ -423,6 +486,7 @@ void cvd_swap(fluid_ctx* c) { std::swap(c->vel[0], c->vel[1]); }
 
 int advect_both_band(fluid_ctx* c, float dt, float vel_diss, float dye_diss, int ga, int gb, int xa, int xb, int v0, int v1, int u0, int u1)
 {
+    CK(ensure_rgba(c));
     Win w = c->sim;  // dye grid == sim grid: one window serves both gathers
     w.x0 = xa;
     w.x1 = xb;
@@ -436,6 +500,7 @@ int advect_both_band(fluid_ctx* c, float dt, float vel_diss, float dye_diss, int
 
 int advect_both_rects(fluid_ctx* c, float dt, float vel_diss, float dye_diss, const BandRects& B, int v0, int v1, int u0, int u1)
 {
+    CK(ensure_rgba(c));
     Win w = c->sim;  // dye grid == sim grid: one window serves both gathers
     w.v0 = v0;
     w.v1 = v1;
@@ -478,6 +543,10 @@ int step_once(fluid_ctx* c, float dt, const fluid_params* P, bool lead = true, i
         CK(pass_gradsub(c, 0));
     }
     t.mark(P_GRADSUB);
+    if (chain) {
+        CK(ensure_rgba(c));   // (chained launches run below kSmallGridTexels, packing at and above it: never both)
+        note_dye_advected(c, dt, P->density_dissipation);
+    }
     if (chain == 3) {  // the call's last step: advect, and run the NEXT call's curl / vorticity / divergence into the pending buffers
         int ga, gb;
         sim_band(c, 0, ga, gb);
@@ -571,7 +640,9 @@ int field_ref(fluid_ctx* c, int field, FieldRef* f)
     case FLUID_PRESSURE: *f = { c->prs[0], &c->sim, c->sim_row0, c->sim_rows, h, 1, c->sim_col0, c->sim_ncols, hx, c->esz }; break;
     case FLUID_DIVERGENCE: *f = { c->div, &c->sim, c->sim_row0, c->sim_rows, h, 1, c->sim_col0, c->sim_ncols, hx, c->esz }; break;
     case FLUID_CURL: *f = { c->curl, &c->sim, c->sim_row0, c->sim_rows, h, 1, c->sim_col0, c->sim_ncols, hx, c->esz }; break;
-    case FLUID_DYE: *f = { c->dyeb[0], &c->dye, c->dye_row0, c->dye_rows, c->dye_halo, 4, c->dye_col0, c->dye_ncols, c->dye_halo_x, c->esz }; break;
+    case FLUID_DYE:
+        CK(ensure_rgba(c));   // whoever asks for the dye field's memory (read, write, ghost rows, a raw pointer) gets RGBA texels
+        *f = { c->dyeb[0], &c->dye, c->dye_row0, c->dye_rows, c->dye_halo, 4, c->dye_col0, c->dye_ncols, c->dye_halo_x, c->esz }; break;
     default: return c->fail(FLUID_ERR_INVALID, "unknown field id");
     }
     return FLUID_OK;
@@ -669,6 +740,8 @@ int fluid_create(const fluid_desc* desc, fluid_ctx** out)
         fluid_destroy(c);
         return rc;
     }
+    c->alpha_known = c->desc.parts == 1 && c->desc.parts_x == 1 && c->storage == FLUID_STORE_F32;   // alloc_fields filled alpha = 1
+    c->dye_alpha = 1.0f;
     *out = c;
     return FLUID_OK;
 }
@@ -697,6 +770,7 @@ int fluid_resize(fluid_ctx* c, int sw, int sh, int dw, int dh)
     if (c->desc.parts != 1 || c->desc.parts_x != 1) return c->fail(FLUID_ERR_UNSUPPORTED, "resize of a stripe / tile context");
     if (sw < 1 || sh < 1 || dw < 1 || dh < 1) return c->fail(FLUID_ERR_INVALID, "field sizes must be >= 1");
     HIPCK(c, hipSetDevice(c->device));
+    CK(ensure_rgba(c));
     const Win osim = c->sim, odye = c->dye;
     const bool sim_changed = (sw != osim.W || sh != osim.H), dye_changed = (dw != odye.W || dh != odye.H);
     const Win ns = make_win(sw, sh, 0, sh), nd = make_win(dw, dh, 0, dh);
@@ -791,9 +865,20 @@ int fluid_pass_splat(fluid_ctx* c, int field, float x, float y, float aspect, fl
         std::swap(c->vel[0], c->vel[1]);
     } else if (field == FLUID_DYE) {
         row_range(c->dye, c->dye.g0, c->dye.rows, 0, ga, gb);
-        CK(c->hip(STORE_CALL(c, launch_splat_dye(c->stream, dye_cols(c, c->dye_halo_x), DYE(c, 0), DYE(c, 1), x, y, aspect, radius, c0, c1, c2, ga, gb)),
-                  "splat dye"));
+        if (c->dye_packed)
+            CK(c->hip(fluid::launch_splat_dye_rgb(c->stream, dye_cols(c, c->dye_halo_x), (const fluid::rgb3*)c->dyeb[0], (fluid::rgb3*)c->dyeb[1], x, y,
+                                                  aspect, radius, c0, c1, c2, ga, gb),
+                      "splat dye"));
+        else
+            CK(c->hip(STORE_CALL(c, launch_splat_dye(c->stream, dye_cols(c, c->dye_halo_x), DYE(c, 0), DYE(c, 1), x, y, aspect, radius, c0, c1, c2, ga, gb)),
+                      "splat dye"));
         std::swap(c->dyeb[0], c->dyeb[1]);
+        // the splat writes alpha = 1 into every texel it covers — all of them on a whole-domain fp32 context (a stripe's ranks are splatted one
+        // by one by their host; fp16 storage rounds the decayed alpha: neither tracks it)
+        if (c->desc.parts == 1 && c->desc.parts_x == 1 && c->storage == FLUID_STORE_F32) {
+            c->alpha_known = true;
+            c->dye_alpha = 1.0f;
+        }
     } else {
         return c->fail(FLUID_ERR_INVALID, "splat target must be velocity or dye");
     }
@@ -924,6 +1009,14 @@ int fluid_write_field(fluid_ctx* c, int field, const float* host, size_t bytes)
     HIPCK(c, hipSetDevice(c->device));
     const size_t pitch32 = (size_t)b.f.win->P * b.f.nc * sizeof(float);
     const size_t col = (size_t)(b.f.col0 - b.f.win->c0);  // array column of the first owned column
+    if (field == FLUID_DYE && c->alpha_known) {   // does the caller's dye keep ONE alpha?  (whole-domain fp32 contexts only ever know theirs)
+        const size_t n = (size_t)b.f.rows * b.f.cols;
+        const float a0 = n ? host[3] : c->dye_alpha;
+        bool uniform = true;
+        for (size_t k = 0; k < n && uniform; k++) uniform = std::memcmp(&host[4 * k + 3], &a0, sizeof(float)) == 0;
+        c->alpha_known = uniform;
+        c->dye_alpha = a0;
+    }
     if (c->storage == FLUID_STORE_F32) {
         HIPCK(c, hipMemcpy2DAsync(b.first_row + col * b.f.texel(), pitch32, host, b.line, b.line, b.f.rows, hipMemcpyHostToDevice, c->stream));
         HIPCK(c, hipStreamSynchronize(c->stream));
@@ -1045,6 +1138,7 @@ int fluid_field_device_ptr(fluid_ctx* c, int field, void** dev_ptr)
     c->touched();
     FieldRef f;
     CK(field_ref(c, field, &f));
+    if (field == FLUID_DYE) c->alpha_known = false;   // a raw pointer: whatever gets written through it, the context does not see (until the next splat)
     *dev_ptr = f.ptr;
     return FLUID_OK;
 }
@@ -1093,6 +1187,7 @@ int fluid_schedule_info_get(fluid_ctx* c, int n_steps, float dt, const fluid_par
     const bool chain = chains && (n_steps > 1 || out->runs_ahead || out->pending_adopted);
     out->chained = chain ? n_steps - 1 + out->runs_ahead : 0;
     const bool fused_cvd = fluid_impl::fused_cvd_applies(c);
+    out->dye_packed = whole && dye_pack_applies(c) && (c->dye_packed || c->pack_holdoff == 0);
     out->curl_stores = (fused_cvd && fluid_impl::skip_hidden_curl() && n_steps > 0) ? 1 + (out->runs_ahead ? 1 : 0) : n_steps + (out->runs_ahead ? 1 : 0);
     if (whole) {
         const int cvd = fused_cvd ? 1 : 3, clear = tb ? 0 : 1, gs = out->gradsub_folded ? 0 : 1;
