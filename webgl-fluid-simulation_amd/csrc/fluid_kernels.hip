@@ -2387,7 +2387,6 @@ hipError_t launch_advect_both(hipStream_t s, Win w, const __half2* vel, __half2*
     k_advect_both_h<2><<<dim3(gx, (gb - ga + 1) / 2, 1), BX, 0, s>>>(w, vel, vel_out, dye, dye_out, dt, vel_dissipation, dye_dissipation, tsx, tsy, ga, gb, miss);
     return hipGetLastError();
 }
-#undef ADVECT_FAST_CASE
 
 hipError_t launch_advect_both_rgb(hipStream_t s, Win w, const float2* vel, float2* vel_out, const rgb3* dye, rgb3* dye_out, float dt,
                                   float vel_dissipation, float dye_dissipation, int ga, int gb, unsigned int* miss)
@@ -2398,9 +2397,22 @@ hipError_t launch_advect_both_rgb(hipStream_t s, Win w, const float2* vel, float
     const float tsx = (float)(1.0 / w.W), tsy = (float)(1.0 / w.H);
     const unsigned gx = (w.x1 - w.x0 + BX - 1) / BX;
     const double rW = udiv_recip((float)w.W), rH = udiv_recip((float)w.H), rvd = udiv_recip(vdecay), rdd = udiv_recip(ddecay);
+#ifdef FLUID_PROBES
+    static const int rows = advect_rows("FLUID_ADVECT_ROWS", 4);   // (lab: texels per thread, as for the RGBA kernel)
+    switch (rows) {
+        ADVECT_FAST_CASE(k_advect_both_fast_rgb, 2)
+        ADVECT_FAST_CASE(k_advect_both_fast_rgb, 3)
+        ADVECT_FAST_CASE(k_advect_both_fast_rgb, 6)
+        ADVECT_FAST_CASE(k_advect_both_fast_rgb, 8)
+    default: break;
+    }
+    if (rows == 2 || rows == 3 || rows == 6 || rows == 8) return hipGetLastError();
+#endif
     k_advect_both_fast_rgb<4><<<dim3(gx, (gb - ga + 3) / 4, 1), BX, 0, s>>>(w, vel, vel_out, dye, dye_out, dt, rW, rH, rvd, rdd, tsx, tsy, ga, gb, miss);
     return hipGetLastError();
 }
+
+#undef ADVECT_FAST_CASE
 
 hipError_t launch_splat_dye_rgb(hipStream_t s, Win w, const rgb3* base, rgb3* out, float x, float y, float aspect, float radius, float c0,
                                 float c1, float c2, int ga, int gb)
