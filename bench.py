@@ -231,8 +231,8 @@ def collect_traffic(args, deadline, steps_under_profiler: int = 0, chained: bool
         per[ctr] = {k: v[ctr] for k, v in got.items() if ctr in v}
     kernels, step_bytes = {}, 0.0
     for k in sorted(set(per["FETCH_SIZE"]) & set(per["WRITE_SIZE"])):
-        if not k.startswith("k_") or k.startswith("k_fill") or k.startswith("k_splat"):
-            continue   # start-up kernels (fills, splats) are not part of a step
+        if not k.startswith("k_") or k.startswith("k_fill") or k.startswith("k_splat") or k.startswith("k_dye_"):
+            continue   # start-up kernels (fills, splats, the one-off packing of the dye field) are not part of a step
         rd = per["FETCH_SIZE"][k][0] * 1024.0 * 2.0
         wr = per["WRITE_SIZE"][k][0] * 1024.0 * 1.0
         n = per["FETCH_SIZE"][k][1]
