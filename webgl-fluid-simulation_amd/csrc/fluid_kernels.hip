@@ -387,6 +387,24 @@ __global__ void __launch_bounds__(BX) k_dye_unpack(const rgb3* __restrict__ rgb,
 }
 
 #ifdef FLUID_PROBES
+// lab: the packed-dye advection with its block's waves stacked in y (WY) AND the blocks handed to the XCDs in contiguous column ranges
+// (block b runs on XCD b % 8: with the plain (bx, by) grid horizontally adjacent blocks never share an L2; here XCD k takes the k-th
+// eighth of every block row, so that a tap row displaced across a block seam is refetched at 8 seams per row instead of at every one)
+template <int ROWS, int WY>
+__global__ void __launch_bounds__(BX) k_advect_both_fast_rgb_wy(Win w, const float2* __restrict__ vel, float2* __restrict__ vel_out,
+                                                                 const rgb3* __restrict__ dye, rgb3* __restrict__ dye_out, float dt, double rW,
+                                                                 double rH, double rvd, double rdd, float tsx, float tsy, int ga, int gb,
+                                                                 unsigned int* __restrict__ miss_out, int gx, int xcd_cols)
+{
+    const int b = (int)blockIdx.x, by = b / gx, r = b - by * gx;
+    int bx = r;
+    if (xcd_cols && (gx & 7) == 0) {
+        const int per = gx >> 3;            // blocks of a row per XCD
+        bx = (r & 7) * per + (r >> 3);      // consecutive block ids of a row alternate XCDs: give XCD (r & 7) its (r >> 3)-th block
+    }
+    advect_both_fast_body<ROWS, float2, rgb3, WY>(w, vel, vel_out, dye, dye_out, dt, rW, rH, rvd, rdd, tsx, tsy, ga, gb, miss_out, bx, by);
+}
+
 template <int ROWS, int WY>
 __global__ void __launch_bounds__(BX) k_advect_both_fast_wy(Win w, const float2* __restrict__ vel, float2* __restrict__ vel_out,
                                                              const float4* __restrict__ dye, float4* __restrict__ dye_out, float dt, double rW,
@@ -2399,6 +2417,14 @@ hipError_t launch_advect_both_rgb(hipStream_t s, Win w, const float2* vel, float
     const double rW = udiv_recip((float)w.W), rH = udiv_recip((float)w.H), rvd = udiv_recip(vdecay), rdd = udiv_recip(ddecay);
 #ifdef FLUID_PROBES
     static const int rows = advect_rows("FLUID_ADVECT_ROWS", 4);   // (lab: texels per thread, as for the RGBA kernel)
+    static const int xcd_cols = [] { const char* e = lab_env("FLUID_ADVECT_XCD"); return e ? atoi(e) : 0; }();
+    if (const int wy = advect_wy(); (wy > 1 || xcd_cols) && (rows == 4 || rows == 2)) {   // FLUID_ADVECT_WY / FLUID_ADVECT_XCD (lab)
+        const int cw = BX / wy, gxx = (w.x1 - w.x0 + cw - 1) / cw, gyy = (gb - ga + rows * wy - 1) / (rows * wy);
+#define WY_CASE(R, Y) if (rows == R && wy == Y) k_advect_both_fast_rgb_wy<R, Y><<<dim3(gxx * gyy, 1, 1), BX, 0, s>>>(w, vel, vel_out, dye, dye_out, dt, rW, rH, rvd, rdd, tsx, tsy, ga, gb, miss, gxx, xcd_cols);
+        WY_CASE(4, 1) WY_CASE(4, 2) WY_CASE(4, 4) WY_CASE(2, 2) WY_CASE(2, 4)
+#undef WY_CASE
+        return hipGetLastError();
+    }
     switch (rows) {
         ADVECT_FAST_CASE(k_advect_both_fast_rgb, 2)
         ADVECT_FAST_CASE(k_advect_both_fast_rgb, 3)
