@@ -410,6 +410,31 @@ def test_one_step_per_call_works_ahead_and_leaves_what_the_passes_leave(N):
 
 
 @pytest.mark.gpu
+def test_packed_dye_with_a_coarser_sim_grid_leaves_the_same_bits():
+    """the same when the dye grid differs from the sim grid (the reference's default shape: dye 8 x sim): the dye pass alone runs on the
+    packed field (k_advect_dye_fast_rgb: 24 instead of 32 B/texel) once the DYE grid has 3072^2 texels"""
+    import fluid_hip
+    DT = 0.016666
+    cfg = {"SIM_RESOLUTION": 512, "DYE_RESOLUTION": 3072, "PRESSURE_ITERATIONS": 20}
+    a = fluid_hip.FluidSim(canvas=(3072, 3072), config=cfg, schedule="passes", random=fluid_hip.mulberry32(7))
+    b = fluid_hip.FluidSim(canvas=(3072, 3072), config=cfg, schedule="fused", random=fluid_hip.mulberry32(7))
+    try:
+        a.multipleSplats(5); b.multipleSplats(5)
+        assert b.schedule_info(20)["dye_packed"] == 1
+        a.step(DT, 20); b.step(DT, 20)
+        for f in ("velocity", "pressure", "divergence", "curl", "dye"):
+            assert np.array_equal(a.read(f), b.read(f)), f
+        for s_ in (a, b):
+            s_.splat(0.6, 0.2, 100.0, 300.0, {"r": 0.1, "g": 0.1, "b": 0.4})
+        a.step(DT, 17); b.step(DT, 17)
+        assert np.array_equal(a.read("dye"), b.read("dye")) and np.array_equal(a.read("velocity"), b.read("velocity"))
+        img_a, img_b = a.render(256, 256), b.render(256, 256)       # the compositor reads RGBA: unpacks
+        assert np.array_equal(img_a, img_b)
+    finally:
+        a.close(); b.close()
+
+
+@pytest.mark.gpu
 def test_packed_dye_leaves_the_same_bits():
     """At and above 3072^2 texels the fused advection runs on the dye packed to three floats per texel while the context knows its alpha
     to be one value (1 after a splat, divided by the decay at every advection); everything that reads or writes dye texels sees RGBA.

@@ -576,6 +576,15 @@ __global__ void __launch_bounds__(BX) k_advect_dye_fast_wy(Win vw, const float2*
 }
 #endif
 
+// ... on the PACKED dye field (rgb3; the dye grid differs from the sim grid): 24 instead of 32 B/texel
+template <int ROWS>
+__global__ void __launch_bounds__(BX) k_advect_dye_fast_rgb(Win vw, const float2* __restrict__ vel, Win dw, const rgb3* __restrict__ dye,
+                                                             rgb3* __restrict__ dye_out, float dt, double rW, double rH, double rdd, float tsx,
+                                                             float tsy, int ga, int gb, unsigned int* __restrict__ miss_out)
+{
+    advect_dye_fast_body<ROWS>(vw, vel, dw, dye, dye_out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss_out);
+}
+
 template <int ROWS>
 __global__ void __launch_bounds__(BX) k_advect_both(Win w, const float2* __restrict__ vel, float2* __restrict__ vel_out,
                                                      const float4* __restrict__ dye, float4* __restrict__ dye_out, float dt,
@@ -2439,6 +2448,23 @@ hipError_t launch_advect_both_rgb(hipStream_t s, Win w, const float2* vel, float
 }
 
 #undef ADVECT_FAST_CASE
+
+// the dye pass alone on the packed field (dye grid != sim grid); hipErrorNotReady where the fast kernel does not apply
+hipError_t launch_advect_dye_rgb(hipStream_t s, Win vw, const float2* vel, Win dw, const rgb3* dye, rgb3* out, float dt, float dissipation, int ga,
+                                 int gb, unsigned int* miss)
+{
+    ROWS_OR_RETURN();
+    const float tsx = (float)(1.0 / vw.W), tsy = (float)(1.0 / vw.H), decay = 1.0f + dissipation * dt;
+    if ((vw.W == dw.W && vw.H == dw.H) || !advect_fast_ok(dw, sizeof(float4), decay, decay) || !advect_fast_ok(vw, sizeof(float2), decay, decay))
+        return hipErrorNotReady;
+    const double rW = udiv_recip((float)dw.W), rH = udiv_recip((float)dw.H), rdd = udiv_recip(decay);
+    const unsigned gx = (dw.x1 - dw.x0 + BX - 1) / BX;
+    if (split_advect_rows((long)(dw.x1 - dw.x0) * (gb - ga)) == 1)
+        k_advect_dye_fast_rgb<1><<<dim3(gx, gb - ga, 1), BX, 0, s>>>(vw, vel, dw, dye, out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss);
+    else
+        k_advect_dye_fast_rgb<2><<<dim3(gx, (gb - ga + 1) / 2, 1), BX, 0, s>>>(vw, vel, dw, dye, out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss);
+    return hipGetLastError();
+}
 
 hipError_t launch_splat_dye_rgb(hipStream_t s, Win w, const rgb3* base, rgb3* out, float x, float y, float aspect, float radius, float c0,
                                 float c1, float c2, int ga, int gb)

@@ -356,11 +356,12 @@ void note_dye_advected(fluid_ctx* c, float dt, float dissipation)
     if (c->alpha_known) c->dye_alpha = c->dye_alpha / (1.0f + dissipation * dt);
 }
 
-// a whole-domain fp32 context whose step is bandwidth-bound (no chained launches) and whose alpha is known
+// a whole-domain fp32 context whose DYE passes are bandwidth-bound (a dye grid of at least kSmallGridTexels: on the sim grid that is where no
+// launches are chained either) and whose alpha is known; fused schedule (the per-pass kernels read RGBA)
 bool dye_pack_applies(const fluid_ctx* c)
 {
     return dye_pack_enabled() && c->alpha_known && c->storage == FLUID_STORE_F32 && c->desc.parts == 1 && c->desc.parts_x == 1 &&
-           fused_advect_applies(c) && (long)c->sim_ncols * c->sim_rows >= fluid::kSmallGridTexels;
+           c->desc.schedule == FLUID_SCHED_FUSED && (long)c->dye_ncols * c->dye_rows >= fluid::kSmallGridTexels;
 }
 
 int pass_advect_velocity(fluid_ctx* c, float dt, float dissipation, int ext)
@@ -376,10 +377,23 @@ int pass_advect_velocity(fluid_ctx* c, float dt, float dissipation, int ext)
 
 int pass_advect_dye(fluid_ctx* c, float dt, float dissipation)
 {
-    CK(ensure_rgba(c));
-    note_dye_advected(c, dt, dissipation);
     int ga, gb;
     row_range(c->dye, c->dye_row0, c->dye_rows, 0, ga, gb);
+    if (c->pack_holdoff > 0 && !c->dye_packed) c->pack_holdoff--;
+    if (dye_pack_applies(c) && (c->dye_packed || c->pack_holdoff == 0)) {   // the dye as three floats per texel: 24 instead of 32 B/texel
+        CK(ensure_packed(c));
+        const hipError_t e = fluid::launch_advect_dye_rgb(c->stream, c->sim, (const float2*)c->vel[0], dye_cols(c, 0), (const fluid::rgb3*)c->dyeb[0],
+                                                          (fluid::rgb3*)c->dyeb[1], dt, dissipation, ga, gb, c->miss);
+        if (e != hipErrorNotReady) {
+            CK(c->hip(e, "advect dye"));
+            c->packed_advects++;
+            note_dye_advected(c, dt, dissipation);
+            std::swap(c->dyeb[0], c->dyeb[1]);
+            return FLUID_OK;
+        }
+    }
+    CK(ensure_rgba(c));
+    note_dye_advected(c, dt, dissipation);
     CK(c->hip(STORE_CALL(c, launch_advect_dye(c->stream, c->sim, VEL(c, 0), dye_cols(c, 0), DYE(c, 0), DYE(c, 1), dt, dissipation, ga, gb, c->miss)),
               "advect dye"));
     std::swap(c->dyeb[0], c->dyeb[1]);
