@@ -989,6 +989,13 @@ __device__ __forceinline__ void jacobi_tb_tile(const Win& w, const T* __restrict
     using G = JacobiTB<NW, RY, HX, HYT>;
     int bx, by;
     tile_of_block(b, nx, ny, remap, bx, by);
+#ifdef FLUID_PROBES
+    // lab (FLUID_XCD_REMAP bit 2): every other octet of workgroups runs at a raised wave priority — when the two workgroups of a CU differ,
+    // the favoured one iterates at the rate of a workgroup alone and reaches its store / load phase while the other still computes
+    if ((remap & 4) && ((int)blockIdx.x & 8)) __builtin_amdgcn_s_setprio(2);
+    // (bit 3: the second-dispatched half of a workgroup's waves — the arbitration losers on their SIMDs, MI355X guide — at priority 1)
+    if ((remap & 8) && (int)threadIdx.y >= NW / 2) __builtin_amdgcn_s_setprio(1);
+#endif
     const int x0 = xs + bx * G::VX, y0 = ys + by * G::VY;
     const bool xedge = (x0 <= 0) || (x0 + G::TX >= w.W), yedge = (y0 <= 0) || (y0 + G::TY >= w.H);
     const bool ragged = (w.W & 3) != 0 && x0 + G::TX >= w.W;  // the tile holds the partly padded last quad

@@ -95,7 +95,7 @@ inline int xcd_remap()  // FLUID_XCD_REMAP: tile order of the Jacobi kernel (A/B
 {
     static const int v = [] {
         const char* e = lab_env("FLUID_XCD_REMAP");
-        return (e ? atoi(e) : 3) & 3;
+        return (e ? atoi(e) : 3) & 15;   // bits 2, 3 (lab): wave priorities inside the Jacobi tile kernel (jacobi_tb_tile)
     }();
     return v;
 }
