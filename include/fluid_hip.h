@@ -198,7 +198,11 @@ int fluid_pass_splat(fluid_ctx *ctx, int field, float x, float y, float aspect, 
 int fluid_halo_pack(fluid_ctx *ctx, int field, int side, int nrows, void *dev_buf);
 int fluid_halo_unpack(fluid_ctx *ctx, int field, int side, int nrows, const void *dev_buf);
 /* device address of array row 0 (ghost rows included) of the field's CURRENT read buffer, for zero-copy ghost-row
- * send/recv by the stripe driver.  Passes that swap read/write invalidate it: query after each pass. */
+ * send/recv by the stripe driver.  Passes that swap read/write invalidate it: query after each pass.
+ * The texels behind the pointer are always the layout fluid_field_info describes (dye: RGBA).  Internally the library may keep state that
+ * the pointer cannot see — the next step's curl / vorticity / divergence computed ahead, the dye packed to three floats while its alpha is
+ * one known value: asking for a pointer drops the former and converts the latter back, and — because whatever is written through the
+ * pointer is invisible to the library — the dye is not packed again until the next splat.  A cost in speed only, never in results. */
 int fluid_field_device_ptr(fluid_ctx *ctx, int field, void **dev_ptr);
 /* synchronises, then returns FLUID_ERR_HALO if any advection tap since the last check fell outside the stripe's rows.
  * fluid_step / fluid_step_n / fluid_group_step_n on stripe and tile contexts call it themselves at the end of every call

@@ -334,3 +334,28 @@ def test_native_random_decompositions_equal_single_domain_bitwise(canvas, cfg, h
             assert np.array_equal(g.read(k), want[k]), (k, canvas, cfg, halo, ty, tx)
     finally:
         g.close()
+
+
+@pytest.mark.gpu
+def test_overlap_probe_runs_one_rank_in_loopback():
+    """tools/overlap_vs_link.py (the probe behind profiles/r04/overlap_vs_link_latency.txt): one rank of three in tests/fake_rccl's loopback
+    mode, with a link that takes time — the child must step and report, and a 200 us link with the overlap off must cost at least the two
+    exchanges' 400 us per step (the probe's own check that the delay is real)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    tool = os.path.join(os.path.dirname(here), "tools", "overlap_vs_link.py")
+    lib = fake_rccl_lib()
+    out = {}
+    for delay in (0, 200):
+        env = dict(os.environ, FLUID_RCCL_LIB=lib, FAKE_RCCL_LOOPBACK="1", _OVL_CHILD=json.dumps({"config": "stripe", "overlap": 0}))
+        env.pop("FAKE_RCCL_GBPS", None)
+        env["FAKE_RCCL_DELAY_US"] = str(delay)
+        r = subprocess.run([sys.executable, tool], env=env, capture_output=True, text=True, timeout=600)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert lines, r.stderr[-500:]
+        out[delay] = json.loads(lines[-1])
+        assert out[delay]["ok"] and out[delay]["exchanges_per_step"] == 2.0
+    assert out[200]["ms_per_step"] - out[0]["ms_per_step"] > 0.35, out
