@@ -468,3 +468,20 @@ def test_packed_dye_leaves_the_same_bits():
         assert b.schedule_info(400)["dye_packed"] == 0
     finally:
         a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_packed_dye_is_not_tried_where_its_kernel_does_not_apply():
+    """a dye decay outside [1, 2) (DENSITY_DISSIPATION 100: 1 + 100 dt = 2.67) takes the general advection kernel, which reads RGBA: the field
+    must not be packed for it (and the bits must be the per-pass schedule's either way)"""
+    a, b = sim_of(3072, "passes", iters=10, DENSITY_DISSIPATION=100), sim_of(3072, "fused", iters=10, DENSITY_DISSIPATION=100)
+    try:
+        a.multipleSplats(4); b.multipleSplats(4)
+        a.step(0.016666, 3); b.step(0.016666, 3)
+        for f in ("velocity", "dye"):
+            assert np.array_equal(a.read(f), b.read(f)), f
+        b.config["DENSITY_DISSIPATION"] = a.config["DENSITY_DISSIPATION"] = 1
+        a.step(0.016666, 2); b.step(0.016666, 2)      # now it applies: packs (no hold-off: the field was never packed before)
+        assert np.array_equal(a.read("dye"), b.read("dye"))
+    finally:
+        a.close(); b.close()

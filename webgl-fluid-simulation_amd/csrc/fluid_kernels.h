@@ -110,6 +110,8 @@ hipError_t launch_advect_both(hipStream_t s, Win w, const float2* vel, float2* v
 // RGBA path), the dye splat, and the two conversions over a whole array of n texels
 hipError_t launch_advect_both_rgb(hipStream_t s, Win w, const float2* vel, float2* vel_out, const rgb3* dye, rgb3* dye_out, float dt,
                                   float vel_dissipation, float dye_dissipation, int ga, int gb, unsigned int* miss);
+// whether the packed-dye kernels apply to these windows and decays (checked BEFORE a field is packed for them)
+bool advect_rgb_supported(Win vw, Win dw, float dt, float vel_dissipation, float dye_dissipation);
 hipError_t launch_advect_dye_rgb(hipStream_t s, Win vw, const float2* vel, Win dw, const rgb3* dye, rgb3* out, float dt, float dissipation, int ga,
                                  int gb, unsigned int* miss);
 hipError_t launch_splat_dye_rgb(hipStream_t s, Win w, const rgb3* base, rgb3* out, float x, float y, float aspect, float radius, float c0,

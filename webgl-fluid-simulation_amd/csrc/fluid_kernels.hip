@@ -2456,6 +2456,13 @@ hipError_t launch_advect_both_rgb(hipStream_t s, Win w, const float2* vel, float
 
 #undef ADVECT_FAST_CASE
 
+bool advect_rgb_supported(Win vw, Win dw, float dt, float vel_dissipation, float dye_dissipation)
+{
+    const float vdecay = 1.0f + vel_dissipation * dt, ddecay = 1.0f + dye_dissipation * dt;
+    if (vw.W == dw.W && vw.H == dw.H) return advect_fast_ok(dw, sizeof(float4), vdecay, ddecay);
+    return advect_fast_ok(dw, sizeof(float4), ddecay, ddecay) && advect_fast_ok(vw, sizeof(float2), ddecay, ddecay);
+}
+
 // the dye pass alone on the packed field (dye grid != sim grid); hipErrorNotReady where the fast kernel does not apply
 hipError_t launch_advect_dye_rgb(hipStream_t s, Win vw, const float2* vel, Win dw, const rgb3* dye, rgb3* out, float dt, float dissipation, int ga,
                                  int gb, unsigned int* miss)

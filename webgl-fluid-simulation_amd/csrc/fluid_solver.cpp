@@ -380,7 +380,8 @@ int pass_advect_dye(fluid_ctx* c, float dt, float dissipation)
     int ga, gb;
     row_range(c->dye, c->dye_row0, c->dye_rows, 0, ga, gb);
     if (c->pack_holdoff > 0 && !c->dye_packed) c->pack_holdoff--;
-    if (dye_pack_applies(c) && (c->dye_packed || c->pack_holdoff == 0)) {   // the dye as three floats per texel: 24 instead of 32 B/texel
+    if (dye_pack_applies(c) && (c->dye_packed || c->pack_holdoff == 0) &&
+        fluid::advect_rgb_supported(c->sim, dye_cols(c, 0), dt, dissipation, dissipation)) {   // the dye as three floats per texel: 24 instead of 32 B/texel
         CK(ensure_packed(c));
         const hipError_t e = fluid::launch_advect_dye_rgb(c->stream, c->sim, (const float2*)c->vel[0], dye_cols(c, 0), (const fluid::rgb3*)c->dyeb[0],
                                                           (fluid::rgb3*)c->dyeb[1], dt, dissipation, ga, gb, c->miss);
@@ -409,7 +410,8 @@ int pass_advect(fluid_ctx* c, float dt, float vel_diss, float dye_diss, Timer* t
         int ga, gb;
         row_range(c->sim, c->sim_row0, c->sim_rows, 0, ga, gb);
         if (c->pack_holdoff > 0 && !c->dye_packed) c->pack_holdoff--;
-        if (dye_pack_applies(c) && (c->dye_packed || c->pack_holdoff == 0)) {   // 40 instead of 48 B/texel: the dye as three floats, its uniform alpha as a scalar
+        if (dye_pack_applies(c) && (c->dye_packed || c->pack_holdoff == 0) &&
+            fluid::advect_rgb_supported(sim_cols(c, 0), sim_cols(c, 0), dt, vel_diss, dye_diss)) {   // 40 instead of 48 B/texel: the dye as three floats, its uniform alpha as a scalar
             CK(ensure_packed(c));
             c->packed_advects++;
             const hipError_t e = fluid::launch_advect_both_rgb(c->stream, sim_cols(c, 0), (const float2*)c->vel[0], (float2*)c->vel[1],
