@@ -372,15 +372,20 @@ def test_step_marks_and_schedule_info():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N", [1024, 250])
-def test_one_step_per_call_works_ahead_and_leaves_what_the_passes_leave(N):
+@pytest.mark.parametrize("N,DYE", [(1024, 1024), (250, 250), (128, 1024), (303, 700)])
+def test_one_step_per_call_works_ahead_and_leaves_what_the_passes_leave(N, DYE):
     """The per-frame path (update() -> step(dt) once per call, script.js:1176-1186): on grids where fluid_step_n chains, the launch that ends a
     call also runs the NEXT call's curl / vorticity / divergence into pending buffers; the next call adopts them unless something touched the
     fields or dt / CURL changed.  After EVERY call all five fields are what the per-pass schedule leaves — the advected velocity, this
     step's divergence and curl — with a splat, a dt change, a CURL change, a field write and a multi-step call in between."""
     import fluid_hip
     DT = 0.016666
-    a, b = sim_of(N, "passes"), sim_of(N, "fused")
+    # (dye grid != sim grid — the reference's default shape — chains too since round 4: the velocity's advection + the next step's curl /
+    # vorticity / divergence in one launch, the dye pass behind it; every step hands over through the pending buffers)
+    side = max(N, DYE)
+    mk = lambda sched: fluid_hip.FluidSim(canvas=(side, side), config={"SIM_RESOLUTION": N, "DYE_RESOLUTION": DYE, "PRESSURE_ITERATIONS": 50},
+                                          schedule=sched, random=fluid_hip.mulberry32(1234))
+    a, b = mk("passes"), mk("fused")
     adopted = []
     try:
         a.multipleSplats(5); b.multipleSplats(5)

@@ -126,7 +126,7 @@ struct FieldRef {
     size_t esz;              // bytes per channel of the device array (4, or 2 with fp16 storage)
     size_t texel() const { return (size_t)nc * esz; }
 };
-int field_ref(fluid_ctx* c, int field, FieldRef* f);
+int field_ref(fluid_ctx* c, int field, FieldRef* f, bool geometry_only = false);
 int ensure_rgba(fluid_ctx* c);   // the dye buffers hold RGBA texels from here on (unpacks a packed dye field: fluid_ctx::dye_packed)
 
 // per-pass device time (fluid_set_timing): events on the context stream around each pass group

@@ -162,6 +162,9 @@ bool fused_supported(Win w);
 // the next step's velocity after vorticity confinement; `curl` may be null (the field is then left as it is: only a chain's last launch
 // writes it).  fp32, dye grid = sim grid, whole domain.
 bool advect_cvd_supported(Win w, float dt, float vel_dissipation, float dye_dissipation);
+// ... with `dye` == null (dye grid != sim grid): the velocity alone is advected and ALWAYS stored to `vel_adv` (the dye pass that follows
+// samples it), the next step's curl / vorticity / divergence go to vel_out / curl / div as before
+bool advect_cvd_velocity_supported(Win w, float dt, float vel_dissipation);
 // `vel_adv` non-null (then `curl` must be too): the launch that ENDS a call — it also stores the advected velocity there (what a caller reads
 // as the velocity field), and vel_out / curl / div are the context's pending buffers, which the next call adopts or drops.
 hipError_t launch_advect_cvd(hipStream_t s, Win w, const float2* vel, float2* vel_out, const float4* dye, float4* dye_out, float* curl,

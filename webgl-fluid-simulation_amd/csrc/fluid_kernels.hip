@@ -1629,7 +1629,9 @@ __device__ __forceinline__ Tap4 taps32p(const Win& w, const TapBox& B, v2f uv)
 // (curl stored); 2 = the launch that ends a CALL (fluid_step, or the last step of fluid_step_n): the advected velocity is what the caller can
 // read, so it is stored too (vel_adv_out), and the next step's curl / vorticity / divergence go to the context's `pending` buffers — the
 // next call takes them over if nothing touched the fields in between (fluid_solver.cpp: pend_*), else they are simply dropped.
-template <int NW, int RY, int AX_, int MODE, bool BORDER>
+// DYE = false: the dye grid differs from the sim grid (the reference's default shape) — the launch advects the velocity only and always
+// stores it (the separate dye pass that follows samples the ADVECTED velocity bilinearly, script.js:1287-1293); MODE is then 2.
+template <int NW, int RY, int AX_, int MODE, bool BORDER, bool DYE = true>
 __device__ __forceinline__ void advect_cvd_body(const Win& w, const float2* __restrict__ vel, float2* __restrict__ vel_out,
                                                 const float4* __restrict__ dye, float4* __restrict__ dye_out, float* __restrict__ curl_out,
                                                 float* __restrict__ div_out, float2* __restrict__ vel_adv_out, float dt, double rW, double rH, double rvd, double rdd, float tsx,
@@ -1693,7 +1695,7 @@ __device__ __forceinline__ void advect_cvd_body(const Win& w, const float2* __re
 
     // ---- K7b for the texels this tile stores, CH rows at a time (the apron columns sit it out; an apron row costs its gathers: 6 of
     // NW * RY) ----
-    if (col_store) {
+    if (DYE && col_store) {
 #pragma unroll
         for (int r0 = 0; r0 < RY; r0 += CH) {
             if (gy + r0 + CH <= out_lo || gy + r0 >= out_hi) continue;  // wave-uniform
@@ -1782,7 +1784,7 @@ __device__ __forceinline__ void advect_cvd_body(const Win& w, const float2* __re
     }
 }
 
-template <int NW, int RY, int AX_, int MODE>
+template <int NW, int RY, int AX_, int MODE, bool DYE = true>
 __global__ void __launch_bounds__(64 * NW, RY <= 4 ? 5 : 4) k_advect_cvd(Win w, const float2* __restrict__ vel, float2* __restrict__ vel_out,
                                                                          const float4* __restrict__ dye, float4* __restrict__ dye_out,
                                                                          float* __restrict__ curl_out, float* __restrict__ div_out,
@@ -1797,9 +1799,9 @@ __global__ void __launch_bounds__(64 * NW, RY <= 4 ? 5 : 4) k_advect_cvd(Win w, 
     tile_of_block((int)blockIdx.x, nx, ny, remap, bx, by);
     const int x0 = xs + bx * G::VX, y0 = ys + by * G::VY;
     if (x0 <= 0 || x0 + G::TX >= w.W || y0 <= 0 || y0 + G::TY >= w.H)
-        advect_cvd_body<NW, RY, AX_, MODE, true>(w, vel, vel_out, dye, dye_out, curl_out, div_out, vel_adv_out, dt, rW, rH, rvd, rdd, tsx, tsy, curl_strength, ga, gb, x0, y0, mail);
+        advect_cvd_body<NW, RY, AX_, MODE, true, DYE>(w, vel, vel_out, dye, dye_out, curl_out, div_out, vel_adv_out, dt, rW, rH, rvd, rdd, tsx, tsy, curl_strength, ga, gb, x0, y0, mail);
     else
-        advect_cvd_body<NW, RY, AX_, MODE, false>(w, vel, vel_out, dye, dye_out, curl_out, div_out, vel_adv_out, dt, rW, rH, rvd, rdd, tsx, tsy, curl_strength, ga, gb, x0, y0, mail);
+        advect_cvd_body<NW, RY, AX_, MODE, false, DYE>(w, vel, vel_out, dye, dye_out, curl_out, div_out, vel_adv_out, dt, rW, rH, rvd, rdd, tsx, tsy, curl_strength, ga, gb, x0, y0, mail);
 }
 
 #ifndef VD_NW_
@@ -2633,6 +2635,13 @@ bool advect_cvd_supported(Win w, float dt, float vel_dissipation, float dye_diss
            w.x1 == w.W;
 }
 
+// the same launch WITHOUT the dye (dye grid != sim grid): only the velocity's decay matters
+bool advect_cvd_velocity_supported(Win w, float dt, float vel_dissipation)
+{
+    const float vdecay = 1.0f + vel_dissipation * dt;
+    return fused_supported(w) && advect_fast_ok(w, sizeof(float2), vdecay, vdecay) && w.g0 == 0 && w.c0 == 0 && w.rows == w.H && w.x0 == 0 && w.x1 == w.W;
+}
+
 // FLUID_CHAIN_TILE="waves,rows,apron columns" (A/B knob): 4,8,3 | 8,4,3 | 4,4,3 | 4,8,4 | 8,8,3 | 8,8,4 | 16,8,4 | 16,4,3.  Default: four waves of
 // eight rows — 64 x 32 texels, of which 58 x 26 are stored: on the small grids that chain by default the smaller workgroup wins (1024^2:
 // 14.6 k steps/s against 13.9 k with eight waves, 2048^2: 6.9 k against 6.7 k) and at 4096^2 the two are level; below 768^2 texels the same
@@ -2654,8 +2663,9 @@ hipError_t launch_advect_cvd(hipStream_t s, Win w, const float2* vel, float2* ve
                              float* div, float2* vel_adv, float dt, float vel_dissipation, float dye_dissipation, float curl_strength, int ga, int gb)
 {
     if (vel_adv && !curl) return hipErrorInvalidValue;   // the launch that ends a call stores the curl field as well
+    if (!dye && !vel_adv) return hipErrorInvalidValue;   // without the dye the launch stores the advected velocity for the dye pass that follows
     ROWS_OR_RETURN();
-    if (!advect_cvd_supported(w, dt, vel_dissipation, dye_dissipation)) return hipErrorInvalidValue;
+    if (!(dye ? advect_cvd_supported(w, dt, vel_dissipation, dye_dissipation) : advect_cvd_velocity_supported(w, dt, vel_dissipation))) return hipErrorInvalidValue;
     const float tsx = (float)(1.0 / w.W), tsy = (float)(1.0 / w.H);
     const float vdecay = 1.0f + vel_dissipation * dt, ddecay = 1.0f + dye_dissipation * dt;
     const double rW = udiv_recip((float)w.W), rH = udiv_recip((float)w.H), rvd = udiv_recip(vdecay), rdd = udiv_recip(ddecay);
@@ -2665,7 +2675,10 @@ hipError_t launch_advect_cvd(hipStream_t s, Win w, const float2* vel, float2* ve
     if (nw == NW_ && ry == RY_ && apron == AX_) {                                                                                       \
         using G = AdvectCvd<NW_, RY_, AX_>;                                                                                             \
         const Axis ax = make_axis(w.x0, w.x1, w.W, G::TX, G::AX), ay = make_axis(ga, gb, w.H, G::TY, G::AY);                            \
-        if (vel_adv)                                                                                                                    \
+        if (!dye)                                                                                                                       \
+            k_advect_cvd<NW_, RY_, AX_, 2, false><<<dim3(ax.n * ay.n, 1, 1), dim3(64, NW_, 1), 0, s>>>(                                 \
+                w, vel, vel_out, dye, dye_out, curl, div, vel_adv, dt, rW, rH, rvd, rdd, tsx, tsy, curl_strength, ga, gb, ax.S, ay.S, ax.n, ay.n, cvd_remap()); \
+        else if (vel_adv)                                                                                                               \
             k_advect_cvd<NW_, RY_, AX_, 2><<<dim3(ax.n * ay.n, 1, 1), dim3(64, NW_, 1), 0, s>>>(                                        \
                 w, vel, vel_out, dye, dye_out, curl, div, vel_adv, dt, rW, rH, rvd, rdd, tsx, tsy, curl_strength, ga, gb, ax.S, ay.S, ax.n, ay.n, cvd_remap()); \
         else if (curl)                                                                                                                  \

@@ -559,23 +559,31 @@ int step_once(fluid_ctx* c, float dt, const fluid_params* P, bool lead = true, i
         CK(pass_gradsub(c, 0));
     }
     t.mark(P_GRADSUB);
-    if (chain) {
+    const bool with_dye = fused_advect_applies(c);   // the launch advects the dye too (dye grid = sim grid)
+    if (chain && with_dye) {
         CK(ensure_rgba(c));   // (chained launches run below kSmallGridTexels, packing at and above it: never both)
         note_dye_advected(c, dt, P->density_dissipation);
     }
-    if (chain == 3) {  // the call's last step: advect, and run the NEXT call's curl / vorticity / divergence into the pending buffers
+    if (chain == 3) {  // advect, and run the NEXT step's curl / vorticity / divergence into the pending buffers
         int ga, gb;
         sim_band(c, 0, ga, gb);
-        CK(c->hip(fluid::launch_advect_cvd(c->stream, sim_cols(c, 0), (const float2*)c->vel[0], (float2*)c->pend_vel, (const float4*)c->dyeb[0],
-                                           (float4*)c->dyeb[1], (float*)c->pend_curl, (float*)c->pend_div, (float2*)c->vel[1], dt,
-                                           P->velocity_dissipation, P->density_dissipation, P->curl, ga, gb),
-                  "advect + the next call's curl_vort_div"));
-        std::swap(c->vel[0], c->vel[1]);   // the advected velocity: what the caller reads
-        std::swap(c->dyeb[0], c->dyeb[1]);
+        CK(c->hip(fluid::launch_advect_cvd(c->stream, sim_cols(c, 0), (const float2*)c->vel[0], (float2*)c->pend_vel,
+                                           with_dye ? (const float4*)c->dyeb[0] : nullptr, with_dye ? (float4*)c->dyeb[1] : nullptr,
+                                           (float*)c->pend_curl, (float*)c->pend_div, (float2*)c->vel[1], dt, P->velocity_dissipation,
+                                           P->density_dissipation, P->curl, ga, gb),
+                  "advect + the next step's curl_vort_div"));
+        std::swap(c->vel[0], c->vel[1]);   // the advected velocity: what the caller reads — and what the dye pass samples
+        if (with_dye) std::swap(c->dyeb[0], c->dyeb[1]);
         c->pend_valid = true;
         c->pend_dt = dt;
         c->pend_curl_strength = P->curl;
-        t.mark(P_ADVD);
+        if (with_dye) {
+            t.mark(P_ADVD);
+        } else {   // dye grid != sim grid: the dye pass is its own launch on its own grid, behind the advected velocity
+            t.mark(P_ADVV);
+            CK(pass_advect_dye(c, dt, P->density_dissipation));
+            t.mark(P_ADVD);
+        }
     } else if (chain) {
         int ga, gb;
         sim_band(c, 0, ga, gb);
@@ -644,11 +652,21 @@ bool chain_applies(const fluid_ctx* c, float dt, const fluid_params* P)
            fluid::advect_cvd_supported(sim_cols(c, 0), dt, P->velocity_dissipation, P->density_dissipation);
 }
 
+// dye grid != sim grid (the reference's default shape, script.js:60-66): K7a and the next step's K1-K3 still go into one launch — without
+// the dye, which keeps its own pass behind it — with EVERY step handing its successor's curl / vorticity / divergence over through the
+// pending buffers (step_once chain 3).  Five launches per step become four on the tiny sim grids of that shape.
+bool split_chain_applies(const fluid_ctx* c, float dt, const fluid_params* P)
+{
+    const long owned = (long)c->sim_ncols * c->sim_rows;
+    return c->storage == FLUID_STORE_F32 && c->desc.parts == 1 && c->desc.parts_x == 1 && fused_cvd_applies(c) && !fused_advect_applies(c) &&
+           chain_enabled(owned) && run_ahead_enabled(owned) && fluid::advect_cvd_velocity_supported(sim_cols(c, 0), dt, P->velocity_dissipation);
+}
+
 }  // namespace
 
 namespace fluid_impl {
 
-int field_ref(fluid_ctx* c, int field, FieldRef* f)
+int field_ref(fluid_ctx* c, int field, FieldRef* f, bool geometry_only)
 {
     const int h = c->desc.parts > 1 ? c->desc.halo : 0, hx = c->desc.parts_x > 1 ? c->desc.halo : 0;
     switch (field) {
@@ -657,7 +675,7 @@ int field_ref(fluid_ctx* c, int field, FieldRef* f)
     case FLUID_DIVERGENCE: *f = { c->div, &c->sim, c->sim_row0, c->sim_rows, h, 1, c->sim_col0, c->sim_ncols, hx, c->esz }; break;
     case FLUID_CURL: *f = { c->curl, &c->sim, c->sim_row0, c->sim_rows, h, 1, c->sim_col0, c->sim_ncols, hx, c->esz }; break;
     case FLUID_DYE:
-        CK(ensure_rgba(c));   // whoever asks for the dye field's memory (read, write, ghost rows, a raw pointer) gets RGBA texels
+        if (!geometry_only) CK(ensure_rgba(c));   // whoever asks for the dye field's MEMORY (read, write, ghost rows, a raw pointer) gets RGBA texels
         *f = { c->dyeb[0], &c->dye, c->dye_row0, c->dye_rows, c->dye_halo, 4, c->dye_col0, c->dye_ncols, c->dye_halo_x, c->esz }; break;
     default: return c->fail(FLUID_ERR_INVALID, "unknown field id");
     }
@@ -923,17 +941,29 @@ int fluid_step_n(fluid_ctx* c, int n, float dt, const fluid_params* P)
     fluid_impl::mark_step(c, 0);
     if (n == 0) return FLUID_OK;
     const bool chains = chain_applies(c, dt, P);
-    // did the launch that ended the previous call already run this call's first curl / vorticity / divergence?  Then adopt its buffers.
-    bool lead = true;
-    if (c->pend_valid) {
-        if (chains && dt == c->pend_dt && P->curl == c->pend_curl_strength) {
+    const bool split = !chains && split_chain_applies(c, dt, P) && pending_buffers(c) == FLUID_OK;
+    // did the launch that ended the previous call (or step) already run the next curl / vorticity / divergence?  Then adopt its buffers.
+    auto adopt = [&]() {
+        bool taken = false;
+        if (c->pend_valid && (chains || split) && dt == c->pend_dt && P->curl == c->pend_curl_strength) {
             std::swap(c->vel[0], c->pend_vel);   // the velocity after vorticity confinement (the advected one moves to the spare buffer)
             std::swap(c->div, c->pend_div);
             std::swap(c->curl, c->pend_curl);
-            lead = false;
+            taken = true;
         }
         c->pend_valid = false;
+        return taken;
+    };
+    if (split) {   // dye grid != sim grid: every step works ahead for the next (split_chain_applies)
+        for (int k = 0; k < n; k++) {
+            const bool lead_k = !adopt();
+            c->keep_curl = true;   // a lead launch writes this step's own curl; otherwise it came with the pending buffers
+            CK(step_once(c, dt, P, lead_k, 3));
+            fluid_impl::mark_step(c, k + 1);
+        }
+        return FLUID_OK;
     }
+    bool lead = !adopt();
     const bool ahead = chains && run_ahead_enabled((long)c->sim_ncols * c->sim_rows) && pending_buffers(c) == FLUID_OK;   // end the call with the launch that works ahead
     if (chains && (n > 1 || ahead || !lead)) {
         for (int k = 0; k < n; k++) {
@@ -966,7 +996,7 @@ int fluid_field_info_get(const fluid_ctx* c, int field, fluid_field_info* out)
 {
     if (!c || !out) return FLUID_ERR_INVALID;
     FieldRef f;
-    CK(field_ref(const_cast<fluid_ctx*>(c), field, &f));
+    CK(field_ref(const_cast<fluid_ctx*>(c), field, &f, true));   // sizes and layout only: nothing is converted for a query
     *out = fluid_field_info{ f.win->W, f.win->H, f.nc, f.row0, f.rows, f.halo, f.col0, f.cols, f.halo_x, (int)f.esz, f.win->P, f.win->c0 };
     return FLUID_OK;
 }
@@ -1197,9 +1227,10 @@ int fluid_schedule_info_get(fluid_ctx* c, int n_steps, float dt, const fluid_par
     const int depth = tb ? fluid::jacobi_tb_depth(out->jacobi_shape) : 1;
     out->jacobi_launches = tb ? (P->iterations + depth - 1) / depth : P->iterations;
     out->gradsub_folded = tb && fluid::jacobi_tb_has_gradsub(out->jacobi_shape) && fluid_impl::gradsub_fold_enabled(owned);
-    const bool chains = whole && n_steps > 0 && chain_applies(c, dt, P);
+    const bool split = whole && n_steps > 0 && !chain_applies(c, dt, P) && split_chain_applies(c, dt, P);   // dye grid != sim grid
+    const bool chains = whole && n_steps > 0 && (split || chain_applies(c, dt, P));
     out->pending_adopted = chains && c->pend_valid && dt == c->pend_dt && P->curl == c->pend_curl_strength;
-    out->runs_ahead = chains && run_ahead_enabled((long)c->sim_ncols * c->sim_rows);
+    out->runs_ahead = chains && (split || run_ahead_enabled((long)c->sim_ncols * c->sim_rows));
     const bool chain = chains && (n_steps > 1 || out->runs_ahead || out->pending_adopted);
     out->chained = chain ? n_steps - 1 + out->runs_ahead : 0;
     const bool fused_cvd = fluid_impl::fused_cvd_applies(c);
