@@ -490,3 +490,57 @@ def test_packed_dye_is_not_tried_where_its_kernel_does_not_apply():
         assert np.array_equal(a.read("dye"), b.read("dye"))
     finally:
         a.close(); b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sim_res,dye_res,seed", [(700, 700, 1), (1100, 1100, 2), (3200, 3200, 3), (96, 700, 4), (200, 3100, 5)])
+def test_random_call_sequences_leave_what_the_passes_leave(sim_res, dye_res, seed):
+    """The library keeps state a caller cannot see — the next step's curl / vorticity / divergence computed ahead, the dye packed to three
+    floats with its alpha as a scalar, the hold-off counters — and every entry point has to keep it honest.  A seeded random sequence of
+    calls (steps of 1 / 2 / 5, splats, reads, writes of single fields, dt and CURL changes, a render, a raw pointer) on the fused
+    schedule against the same sequence on the per-pass schedule: all five fields bit for bit at every read and at the end.  Sizes on both
+    sides of every threshold: chained + working ahead (700), chained without (1100 … is below 1536: with), packed dye (3200), dye != sim
+    chained (96 / 700), dye != sim with the dye packed (200 / 3100)."""
+    import fluid_hip
+    rng = np.random.default_rng(seed)
+    side = max(sim_res, dye_res)
+    mk = lambda sched: fluid_hip.FluidSim(canvas=(side, side), config={"SIM_RESOLUTION": sim_res, "DYE_RESOLUTION": dye_res, "PRESSURE_ITERATIONS": 20},
+                                          schedule=sched, random=fluid_hip.mulberry32(99))
+    a, b = mk("passes"), mk("fused")
+    fields = ("velocity", "pressure", "divergence", "curl", "dye")
+    dt = 0.016666
+    try:
+        a.multipleSplats(4); b.multipleSplats(4)
+        for op_i in range(40):
+            op = rng.integers(0, 10)
+            if op <= 3:
+                n = int(rng.choice([1, 1, 2, 5]))
+                a.step(dt, n); b.step(dt, n)
+            elif op == 4:
+                x, y = float(rng.random()), float(rng.random())
+                col = {"r": float(rng.random()), "g": float(rng.random()), "b": float(rng.random())}
+                for s_ in (a, b):
+                    s_.splat(x, y, 500.0 * (x - 0.5), -300.0 * (y - 0.5), col)
+            elif op == 5:
+                f = fields[int(rng.integers(0, 5))]
+                assert np.array_equal(a.read(f), b.read(f)), (op_i, "read", f)
+            elif op == 6:
+                f = ("velocity", "dye", "pressure")[int(rng.integers(0, 3))]
+                v = b.read(f) * np.float32(0.75)
+                if f == "dye" and rng.random() < 0.5:
+                    v[..., 3] = np.float32(rng.random())          # a dye with ANOTHER uniform alpha: still one value
+                a.write(f, v); b.write(f, v)
+            elif op == 7:
+                dt = float(rng.choice([0.016666, 0.01, 0.016666]))
+            elif op == 8:
+                c_ = int(rng.choice([30, 10, 0]))
+                a.config["CURL"] = b.config["CURL"] = c_
+            else:
+                if rng.random() < 0.5:
+                    assert np.array_equal(a.render(128, 128), b.render(128, 128)), (op_i, "render")
+                else:
+                    b.device_view("dye")                           # a raw pointer: the library forgets what it knew about the dye
+        for f in fields:
+            assert np.array_equal(a.read(f), b.read(f)), ("end", f)
+    finally:
+        a.close(); b.close()
