@@ -493,7 +493,8 @@ def test_packed_dye_is_not_tried_where_its_kernel_does_not_apply():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sim_res,dye_res,seed", [(700, 700, 1), (1100, 1100, 2), (3200, 3200, 3), (96, 700, 4), (200, 3100, 5)])
+@pytest.mark.parametrize("sim_res,dye_res,seed", [(700, 700, 1), (700, 700, 11), (1100, 1100, 2), (3200, 3200, 3), (3200, 3200, 13), (96, 700, 4), (96, 700, 14),
+                                                  (200, 3100, 5), (2100, 2100, 6)])
 def test_random_call_sequences_leave_what_the_passes_leave(sim_res, dye_res, seed):
     """The library keeps state a caller cannot see — the next step's curl / vorticity / divergence computed ahead, the dye packed to three
     floats with its alpha as a scalar, the hold-off counters — and every entry point has to keep it honest.  A seeded random sequence of
@@ -511,7 +512,7 @@ def test_random_call_sequences_leave_what_the_passes_leave(sim_res, dye_res, see
     dt = 0.016666
     try:
         a.multipleSplats(4); b.multipleSplats(4)
-        for op_i in range(40):
+        for op_i in range(90):
             op = rng.integers(0, 10)
             if op <= 3:
                 n = int(rng.choice([1, 1, 2, 5]))
