@@ -16,7 +16,7 @@ def test_product_kernels_do_not_spill():
     assert len(res) >= 85, sorted(res)                      # every kernel of the three sources was seen
     names = " ".join(res)
     for must in ("k_jacobi_tb_mix<8, 10, 7, 12, 10, 2>", "k_jacobi_tb<8, 5, 12, 10, 2>", "k_jacobi_tb2<8, 5, 12, 10, 3>", "k_curl_vort_div_mix<8, 5, 3>",
-                 "k_advect_both_fast<4>", "k_advect_cvd<4, 8, 3, 2>", "k_gradsub4", "k_display"):
+                 "k_advect_both_fast<4>", "k_advect_cvd<4, 8, 3, 2, true>", "k_advect_cvd<4, 8, 3, 2, false>", "k_advect_both_fast_rgb<4>", "k_gradsub4", "k_display"):
         assert must in res, must
     # lab shapes stay out of the product
     for lab in ("k_jacobi_tb<8, 12, 12, 10, 2>", "k_jacobi_tb_mix2", "k_advect_both_fast<8>", "k_advect_cvd<16, 8, 4"):
