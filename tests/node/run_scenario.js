@@ -7,12 +7,17 @@ const fluid = require(path.join(__dirname, '..', '..', 'webgl-fluid-simulation_a
 const args = JSON.parse(process.argv[2]);
 const sim = fluid.createFluid({ canvas: args.canvas, config: args.config, random: fluid.mulberry32(args.seed), schedule: args.schedule, storage: args.storage });
 sim.multipleSplats(args.randomSplats);
+sim.setStepMarks(4);
 for (let i = 0; i < args.steps; i++) sim.step(args.dt);
+const stepMarks = sim.stepMarks();          // the last call's steps (one step per call here)
+sim.setStepMarks(0);
+const scheduleInfo = sim.scheduleInfo(args.dt, 1);
 if (args.resizeTo) { Object.assign(sim.config, args.resizeTo); sim.initFramebuffers(); }
 const names = ['velocity', 'pressure', 'divergence', 'curl', 'dye'];
 const bufs = names.map(n => Buffer.from(sim.readField(n).buffer));
 fs.writeFileSync(args.out, Buffer.concat(bufs));
 const meta = { sim: [sim.velocity.width, sim.velocity.height], dye: [sim.dye.width, sim.dye.height],
-               f2t_len: sim.framebufferToTexture(sim.pressure.read).length };
+               f2t_len: sim.framebufferToTexture(sim.pressure.read).length, schedule_info: scheduleInfo, step_marks: Array.from(stepMarks),
+               build_flavor: require(path.join(__dirname, '..', '..', 'webgl-fluid-simulation_amd', 'addon', 'fluid_napi.node')).buildFlavor };
 sim.destroy();
 console.log(JSON.stringify(meta));

@@ -110,7 +110,8 @@ def test_addon_loads_and_fails_loudly_without_device(addon):
     r = subprocess.run([NODE, "-e", code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])
-    for k in ("create", "destroy", "resize", "splat", "step", "sync", "readField", "writeField", "fieldInfo"):
+    for k in ("create", "destroy", "resize", "splat", "step", "sync", "readField", "writeField", "fieldInfo", "scheduleInfo", "setStepMarks",
+              "getStepMarks", "abiVersion", "buildFlavor"):
         assert k in out["keys"]
     if out["n"] == 0:
         assert out["threw"] and out["code"] == "-3" and "no CPU path" in out["msg"]
@@ -129,10 +130,17 @@ def test_node_and_python_hosts_agree_bitwise(addon, tmp_path, schedule):
         sim.multipleSplats(6)
         for _ in range(3):
             sim.step(0.016666)
+        want_info = sim.schedule_info(1, 0.016666)
         sim.config.update({"DYE_RESOLUTION": 200})
         sim.initFramebuffers()
         want = sim.fields()
     assert meta["sim"] == [192, 96] and meta["dye"] == [400, 200]
+    # the ABI 8 diagnostics through the addon: what the next step would launch (nothing runs) and the per-step device times of the last call
+    info = meta["schedule_info"]
+    camel = lambda k: "".join(w.capitalize() if i else w for i, w in enumerate(k.split("_")))
+    assert info == {camel(k): v for k, v in want_info.items()} and info["fused"] == (1 if schedule == "fused" else 0)
+    assert len(meta["step_marks"]) == 1 and 0.0 < meta["step_marks"][0] < 1000.0
+    assert meta["build_flavor"] == "product"
     assert meta["f2t_len"] == 192 * 96 * 4
     raw = np.fromfile(args["out"], dtype=np.float32)
     off = 0

@@ -447,6 +447,15 @@ function createFluid (options) {
     sim.exchangeCount = function () { return native.exchangeCount(handle); };
     sim.setTiming = function (on) { native.setTiming(handle, on ? 1 : 0); };
     sim.getTimings = function () { return native.getTimings(handle); };
+    // what the next step(dt, n) would launch with the CURRENT config (nothing runs): { fused, jacobiLaunches, chained, runsAhead, dyePacked, ... }
+    sim.scheduleInfo = function (dt, n) {
+        const c = sim.config;
+        return native.scheduleInfo(handle, n === undefined ? 1 : n, dt, c.CURL, c.PRESSURE, c.PRESSURE_ITERATIONS,
+            c.VELOCITY_DISSIPATION, c.DENSITY_DISSIPATION);
+    };
+    // device time of each step of the next step(dt, n) calls, without a sync per step (the first `capacity` steps of a call; 0 = off)
+    sim.setStepMarks = function (capacity) { native.setStepMarks(handle, capacity); };
+    sim.stepMarks = function () { return native.getStepMarks(handle); };
     sim.destroy = function () { if (handle != null) { native.destroy(handle); handle = null; } };
 
     sim.initFramebuffers();

@@ -485,6 +485,65 @@ static napi_value n_get_timings(napi_env env, napi_callback_info info)
     return obj;
 }
 
+/* scheduleInfo(h, n, dt, curl, pressure, iterations, velocityDissipation, densityDissipation) -> what the next step(h, n, ...) with these
+ * arguments would launch (fluid_schedule_info_get, since ABI 8); nothing runs */
+static napi_value n_schedule_info(napi_env env, napi_callback_info info)
+{
+    napi_value a[8], obj, v;
+    fluid_ctx *c;
+    int n;
+    float dt;
+    fluid_params P;
+    fluid_schedule_info S;
+    memset(&P, 0, sizeof P);
+    if (!get_args(env, info, 8, a) || !get_ctx(env, a[0], &c)) return NULL;
+    if (!get_i(env, a[1], &n) || !get_f(env, a[2], &dt) || !get_f(env, a[3], &P.curl) || !get_f(env, a[4], &P.pressure) ||
+        !get_i(env, a[5], &P.iterations) || !get_f(env, a[6], &P.velocity_dissipation) || !get_f(env, a[7], &P.density_dissipation))
+        return NULL;
+    int rc = fluid_schedule_info_get(c, n, dt, &P, &S);
+    if (rc != FLUID_OK) return throw_status(env, c, rc);
+    NAPI_OK(napi_create_object(env, &obj));
+    const char *names[] = { "fused", "jacobiShape", "jacobiLaunches", "gradsubFolded", "chained", "curlStores", "launches", "runsAhead",
+                            "pendingAdopted", "dyePacked" };
+    const int vals[] = { S.fused, S.jacobi_shape, S.jacobi_launches, S.gradsub_folded, S.chained, S.curl_stores, S.launches, S.runs_ahead,
+                         S.pending_adopted, S.dye_packed };
+    for (int k = 0; k < 10; k++) {
+        NAPI_OK(napi_create_int32(env, vals[k], &v));
+        NAPI_OK(napi_set_named_property(env, obj, names[k], v));
+    }
+    return obj;
+}
+
+/* setStepMarks(h, capacity): an event in front of the first and behind every step of the next step() calls (fluid_set_step_marks) */
+static napi_value n_set_step_marks(napi_env env, napi_callback_info info)
+{
+    napi_value a[2];
+    fluid_ctx *c;
+    int cap;
+    if (!get_args(env, info, 2, a) || !get_ctx(env, a[0], &c) || !get_i(env, a[1], &cap)) return NULL;
+    int rc = fluid_set_step_marks(c, cap);
+    return rc == FLUID_OK ? NULL : throw_status(env, c, rc);
+}
+
+/* getStepMarks(h) -> [ms of each marked step of the last step() call] (waits for the last mark) */
+static napi_value n_get_step_marks(napi_env env, napi_callback_info info)
+{
+    napi_value a[1], arr, v;
+    fluid_ctx *c;
+    float ms[256];
+    int n = 0;
+    if (!get_args(env, info, 1, a) || !get_ctx(env, a[0], &c)) return NULL;
+    int rc = fluid_get_step_marks(c, ms, 256, &n);
+    if (rc != FLUID_OK) return throw_status(env, c, rc);
+    if (n > 256) n = 256;
+    NAPI_OK(napi_create_array_with_length(env, (size_t)n, &arr));
+    for (int k = 0; k < n; k++) {
+        NAPI_OK(napi_create_double(env, ms[k], &v));
+        NAPI_OK(napi_set_element(env, arr, (uint32_t)k, v));
+    }
+    return arr;
+}
+
 static napi_value init(napi_env env, napi_value exports)
 {
     const struct { const char *name; napi_callback fn; } fns[] = {
@@ -494,6 +553,7 @@ static napi_value init(napi_env env, napi_value exports)
         { "readField", n_read_field }, { "writeField", n_write_field }, { "deviceCount", n_device_count },
         { "setTiming", n_set_timing }, { "getTimings", n_get_timings },
         { "setDither", n_set_dither }, { "render", n_render }, { "readFrame", n_read_frame }, { "readFrameRgba8", n_read_frame_rgba8 },
+        { "scheduleInfo", n_schedule_info }, { "setStepMarks", n_set_step_marks }, { "getStepMarks", n_get_step_marks },
     };
     for (size_t k = 0; k < sizeof fns / sizeof fns[0]; k++) {
         napi_value f;
@@ -502,6 +562,7 @@ static napi_value init(napi_env env, napi_value exports)
     }
     napi_value v;
     if (napi_create_int32(env, fluid_abi_version(), &v) == napi_ok) napi_set_named_property(env, exports, "abiVersion", v);
+    if (napi_create_string_utf8(env, fluid_build_flavor(), NAPI_AUTO_LENGTH, &v) == napi_ok) napi_set_named_property(env, exports, "buildFlavor", v);
     return exports;
 }
 
