@@ -277,10 +277,13 @@ def test_native_tile_group_back_trace_beyond_reach_is_reported():
 
 @pytest.mark.parametrize("ty,tx,halo,cfg", [(2, 2, 56, {"SIM_RESOLUTION": 512, "DYE_RESOLUTION": 512, "PRESSURE_ITERATIONS": 50}),
                                             (2, 2, 16, {"SIM_RESOLUTION": 128, "DYE_RESOLUTION": 256, "PRESSURE_ITERATIONS": 20}),
-                                            (1, 3, 16, {"SIM_RESOLUTION": 192, "DYE_RESOLUTION": 192, "PRESSURE_ITERATIONS": 20})])
+                                            (1, 3, 16, {"SIM_RESOLUTION": 192, "DYE_RESOLUTION": 192, "PRESSURE_ITERATIONS": 20}),
+                                            # a centre tile with all EIGHT neighbours; halo 24: three pressure blocks, the exchanges between them
+                                            # and the step's first one covered by cut Jacobi launches (two of them at this size)
+                                            (3, 3, 24, {"SIM_RESOLUTION": 384, "DYE_RESOLUTION": 384, "PRESSURE_ITERATIONS": 50})])
 def test_native_rccl_path_2d_tiles_with_several_ranks_bitwise(ty, tx, halo, cfg):
-    """the RCCL leg of the 2-D decomposition (two grouped phases, staged column blocks, one message per neighbour) with
-    ty x tx rank threads against tests/fake_rccl"""
+    """the RCCL leg of the 2-D decomposition (ONE grouped round to up to eight neighbours — sides and corners —, staged blocks, one
+    message per neighbour) with ty x tx rank threads against tests/fake_rccl"""
     import json
     import os
     import subprocess

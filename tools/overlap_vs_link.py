@@ -31,7 +31,7 @@ DT = 0.016666
 CONFIGS = {
     # name: (canvas, SIM = DYE resolution, iterations, world, tiles_x, rank, halo, steps)
     "stripe": ((4096, 12288), 4096, 50, 3, 1, 1, 56, 60),       # weak scaling of configs[2]: the middle one of three 4096^2 stripes, 2 exchanges / step
-    "tile": ((12288, 12288), 12288, 50, 9, 3, 4, 56, 60),       # configs[3]'s per-rank shape: the centre 4096^2 tile of 3 x 3, two-phase exchange
+    "tile": ((12288, 12288), 12288, 50, 9, 3, 4, 56, 60),       # configs[3]'s per-rank shape: the centre 4096^2 tile of 3 x 3 (eight neighbours)
     "deep": ((8192, 6144), 6144, 200, 3, 1, 1, 56, 16),         # configs[4]'s regime: 8192 x 2048 per rank, 200 iterations -> 5 exchanges / step
 }
 
@@ -77,7 +77,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", action="append", default=None)
     ap.add_argument("--rounds", type=int, default=2)
+    ap.add_argument("--quick", action="store_true", help="overlap on only; links: none, 60 us, 20 us + 100 GB/s, 20 us + 40 GB/s")
     args = ap.parse_args()
+    knobs = {k: v for k, v in os.environ.items() if k.startswith("FLUID_") and k not in ("FLUID_RCCL_LIB",)}
+    if knobs:
+        print("## environment: %s" % knobs, flush=True)
     lib = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
     for name in (args.config or list(CONFIGS)):
         canvas, res, iters, world, tx, rk, halo, steps = CONFIGS[name]
@@ -85,8 +89,8 @@ def main():
               % (name, rk, world, "%dx%d tiles" % (world // tx, tx) if tx > 1 else "stripes", canvas[0], canvas[1], iters, halo, steps), flush=True)
         base = {}
         for rnd in range(args.rounds):
-            for overlap in (1, 0):
-                for delay, gbps in ((0, 0), (60, 0), (200, 0), (20, 100), (20, 40)):
+            for overlap in ((1,) if args.quick else (1, 0)):
+                for delay, gbps in (((0, 0), (60, 0), (20, 100), (20, 40)) if args.quick else ((0, 0), (60, 0), (200, 0), (20, 100), (20, 40))):
                     env = dict(os.environ, FLUID_RCCL_LIB=lib, FAKE_RCCL_LOOPBACK="1", _OVL_CHILD=json.dumps({"config": name, "overlap": overlap}))
                     env.pop("FAKE_RCCL_DELAY_US", None); env.pop("FAKE_RCCL_GBPS", None)
                     if delay:

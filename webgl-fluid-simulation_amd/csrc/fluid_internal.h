@@ -75,8 +75,8 @@ struct fluid_ctx {
     hipEvent_t ev_ready = nullptr;       // context stream -> comm stream: the rows to send exist
     hipEvent_t ev_landed = nullptr;      // comm stream -> context stream: the ghost rows have arrived
     hipEvent_t ev_mid = nullptr;         // 2-D tiles: this tile's ghost columns are in (phase A), ghost rows may follow
-    void* stage[8] = {};                 // 2-D tiles: contiguous staging of the strided column / row blocks, per direction
-    size_t stage_bytes[8] = {};
+    void* stage[16] = {};                // 2-D tiles: contiguous staging of the strided blocks, send and receive per direction (4 sides + 4 corners)
+    size_t stage_bytes[16] = {};
     long exchanges = 0;
     int reach = 24;                      // rows an advection back-trace may span (dt*|v| + 2); see fluid_set_reach
     int overlap = 1;                     // interior-first overlap of exchanges (FLUID_STRIPE_OVERLAP=0 turns it off)
@@ -156,8 +156,17 @@ int pass_divergence(fluid_ctx* c, int ext);
 int pass_curl_vort_div(fluid_ctx* c, float curl, float dt, int ext, Timer* t);
 int pass_clear(fluid_ctx* c, float value, int ext);
 struct Timer;
-int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launches, bool* gradsub, Timer* t, int split = 0);
-bool jacobi_split_ok(const fluid_ctx* c, int iters, bool wants_gradsub);
+// how the stripe / tile driver cuts the leading launches of a pressure block around an exchange in flight (pass_jacobi)
+struct JacobiSplit {
+    int mode = 0;         // 1 = the interiors only (while the exchange travels), 2 = the rest of the block (after it landed)
+    int margin = 0;       // texels the interiors stay inside the owned rectangle beyond their apron (0, or 3 behind the curl / vorticity / divergence interior)
+    int cover = 1;        // leading launches cut (1 or 2)
+    int guard_rows = 0, guard_cols = 0;   // pressure rows / columns next to the tile border that the exchange in flight is SENDING: the second
+                                          // cut launch writes into the buffer they are read from and stays clear of them
+};
+int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launches, bool* gradsub, Timer* t, const JacobiSplit* split = nullptr);
+bool jacobi_split_ok(const fluid_ctx* c, int iters, bool wants_gradsub, int margin = 0);
+int jacobi_split_launches(const fluid_ctx* c, int iters, bool wants_gradsub, const JacobiSplit& sp);   // leading launches that can be cut (<= sp.cover)
 bool gradsub_fold_enabled(long owned_texels);
 int pass_clear_jacobi(fluid_ctx* c, float value, int iters, int ext_out, int* launches, bool* gradsub);
 int pass_gradsub(fluid_ctx* c, int ext);

@@ -125,18 +125,25 @@ hipError_t launch_splat_dye(hipStream_t s, Win w, const float4* base, float4* ou
 hipError_t launch_resample(hipStream_t s, Win sw, const float* src, int nc, Win dw, float* dst);
 hipError_t launch_fill(hipStream_t s, float* dst, size_t n_vec, int nc, float v0, float v1, float v2, float v3);
 
-// Strided block copies for the ghost-column exchange of 2-D tiles (fluid_stripes.cpp): up to 8 rectangles — every field and
-// direction of one exchange phase — packed into (or unpacked from) contiguous staging in ONE launch on the comm stream.
-// `unit` = bytes per element moved (the channel size: 4, or 2 with fp16 storage); pitches and lines are multiples of it.
+// Strided block copies for the ghost-column exchange of 2-D tiles (fluid_stripes.cpp): up to 16 rectangles — every field and
+// direction of one exchange (four sides + four corners, two fields) — packed into (or unpacked from) contiguous staging in ONE launch
+// on the comm stream.  `unit` = bytes a thread moves at a time: the widest of 16 / 8 / 4 / 2 that both addresses, both pitches and the
+// line are multiples of (copy_rect_of picks it; a velocity block of 56 columns moves as 16-byte pieces, a pressure block of 51 as 4-byte ones).
 struct CopyRect {
     const char* src;
     char* dst;
     size_t spitch, dpitch;  // bytes between rows
-    unsigned line_units, nrows;
+    unsigned line_units, nrows, unit;
 };
+inline CopyRect copy_rect_of(const void* src, void* dst, size_t spitch, size_t dpitch, size_t line_bytes, int nrows)
+{
+    const size_t all = (size_t)src | (size_t)dst | spitch | dpitch | line_bytes;
+    const unsigned unit = (all & 15) == 0 ? 16 : (all & 7) == 0 ? 8 : (all & 3) == 0 ? 4 : 2;
+    return CopyRect{ (const char*)src, (char*)dst, spitch, dpitch, (unsigned)(line_bytes / unit), (unsigned)nrows, unit };
+}
 struct CopyRects {
-    CopyRect r[8];
-    int n, unit;
+    CopyRect r[16];
+    int n;
 };
 hipError_t launch_copy_rects(hipStream_t s, const CopyRects& R);
 
@@ -151,6 +158,9 @@ hipError_t launch_advect_both_rects(hipStream_t s, Win w, const __half2* vel, __
                                     float vel_dissipation, float dye_dissipation, const BandRects& B, unsigned int* miss);
 hipError_t launch_curl_vort_div_rects(hipStream_t s, Win w, const float2* vel, float* curl, float2* vel_out, float* div, float curl_strength,
                                       float dt, const BandRects& B);
+// launch_jacobi_tb over several rectangles in one launch (fp32 fields, iters <= 10): the frame of a block's first launch around the interior
+// that ran while an exchange was in flight.  Bitwise equal to launch_jacobi_tb over the same texels, whatever shape that one takes.
+hipError_t launch_jacobi_tb_rects(hipStream_t s, Win w, const float* p, const float* div, float* p_out, float pscale, int iters, const BandRects& B);
 hipError_t launch_curl_vort_div_rects(hipStream_t s, Win w, const __half2* vel, __half* curl, __half2* vel_out, __half* div, float curl_strength,
                                       float dt, const BandRects& B);
 
@@ -180,6 +190,7 @@ hipError_t launch_curl_vort_div(hipStream_t s, Win w, const float2* vel, float* 
 // number of owned texels (jacobi_tb_pick: small grids take smaller, deeper tiles; FLUID_TB_VARIANT forces one).
 int jacobi_tb_pick(long owned_texels);
 int jacobi_tb_depth(int shape);
+int jacobi_tb_apron_cols(int shape);   // columns of apron a tile of that shape loads on each side
 bool jacobi_tb_has_gradsub(int shape);
 bool jacobi_tb_supported(Win w);
 hipError_t launch_jacobi_tb(hipStream_t s, Win w, const float* p, const float* div, float* p_out, float pscale,

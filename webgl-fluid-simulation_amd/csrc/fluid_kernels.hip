@@ -634,15 +634,25 @@ __global__ void __launch_bounds__(BX) k_fill(float* __restrict__ dst, size_t n, 
         for (int k = 0; k < NC; k++) dst[i * NC + k] = vals[k];
 }
 
-// ghost-column blocks of 2-D tiles: strided rectangle -> contiguous staging and back, all rectangles of a phase in one launch
+// ghost-column blocks of 2-D tiles: strided rectangle -> contiguous staging and back, all rectangles of an exchange in one launch
 template <class U>
-__global__ void __launch_bounds__(BX) k_copy_rects(CopyRects R)
+__device__ __forceinline__ void copy_rect_body(const CopyRect& q)
 {
-    const CopyRect q = R.r[blockIdx.y];
     const size_t n = (size_t)q.line_units * q.nrows;
     for (size_t idx = (size_t)blockIdx.x * BX + threadIdx.x; idx < n; idx += (size_t)gridDim.x * BX) {
         const size_t row = idx / q.line_units, k = idx - row * q.line_units;
         reinterpret_cast<U*>(q.dst + row * q.dpitch)[k] = reinterpret_cast<const U*>(q.src + row * q.spitch)[k];
+    }
+}
+
+__global__ void __launch_bounds__(BX) k_copy_rects(CopyRects R)
+{
+    const CopyRect q = R.r[blockIdx.y];
+    switch (q.unit) {   // block-uniform
+    case 16: copy_rect_body<uint4>(q); break;
+    case 8: copy_rect_body<uint2>(q); break;
+    case 4: copy_rect_body<unsigned int>(q); break;
+    default: copy_rect_body<unsigned short>(q); break;
     }
 }
 
@@ -1541,6 +1551,22 @@ __global__ void __launch_bounds__(64 * NW, VD_WAVES_PER_EU) k_curl_vort_div_rect
     w.x0 = R.x0[k];
     w.x1 = R.x1[k];
     vort_div_tile<NW, RY>(w, vel, curl_out, vel_out, div_out, curl_strength, dt, R.ga[k], R.gb[k], R.xs[k], R.ys[k], R.nx[k], R.ny[k], b - R.blk0[k], remap, mail);
+}
+
+// The temporally blocked Jacobi tile over several rectangles in one launch: the FRAME of a block's first launch around the interior that
+// computed while the ghost rows / columns of an exchange were in flight (fluid_solver.cpp pass_jacobi, split 2; fluid_stripes.cpp).  The
+// frame of a 4096^2 tile is a few hundred tiles, so the launch is one tile's latency: it takes the 56-row tile (7 rows per wave).
+template <int NW, int RY, int HX, int HY, int BPC>
+__global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_rects(Win w, TileRects R, const float* __restrict__ p, const float* __restrict__ div,
+                                                              float* __restrict__ p_out, float pscale, int iters, int remap)
+{
+    __shared__ float4 mail[2][NW][2][64];
+    const int b = (int)blockIdx.x;
+    int k = 0;
+    while (k + 1 < R.n && b >= R.blk0[k + 1]) k++;
+    w.x0 = R.x0[k];
+    w.x1 = R.x1[k];
+    jacobi_tb_tile<NW, RY, HX, HY>(w, p, div, p_out, pscale, iters, R.ga[k], R.gb[k], R.xs[k], R.ys[k], R.nx[k], R.ny[k], b - R.blk0[k], remap, mail);
 }
 
 // the same kernel with smaller tiles for a launch's first and last rows (see k_jacobi_tb_mix: a launch is its bytes over the bandwidth
@@ -2532,13 +2558,16 @@ hipError_t launch_resample(hipStream_t s, Win sw, const float* src, int nc, Win 
 hipError_t launch_copy_rects(hipStream_t s, const CopyRects& R)
 {
     if (R.n < 1) return hipSuccess;
-    if (R.n > 8 || (R.unit != 2 && R.unit != 4)) return hipErrorInvalidValue;
+    if (R.n > 16) return hipErrorInvalidValue;
     size_t most = 0;
-    for (int k = 0; k < R.n; k++) most = std::max(most, (size_t)R.r[k].line_units * R.r[k].nrows);
+    for (int k = 0; k < R.n; k++) {
+        const unsigned u = R.r[k].unit;
+        if (u != 16 && u != 8 && u != 4 && u != 2) return hipErrorInvalidValue;
+        most = std::max(most, (size_t)R.r[k].line_units * R.r[k].nrows);
+    }
     if (most == 0) return hipSuccess;
     const unsigned gx = (unsigned)std::min<size_t>((most + BX - 1) / BX, 2048);
-    if (R.unit == 4) k_copy_rects<unsigned int><<<dim3(gx, R.n, 1), BX, 0, s>>>(R);
-    else k_copy_rects<unsigned short><<<dim3(gx, R.n, 1), BX, 0, s>>>(R);
+    k_copy_rects<<<dim3(gx, R.n, 1), BX, 0, s>>>(R);
     return hipGetLastError();
 }
 
@@ -2713,6 +2742,7 @@ int jacobi_tb_pick(long texels)
     return kDefaultTB;
 }
 int jacobi_tb_depth(int shape) { return kTB[shape].hy; }
+int jacobi_tb_apron_cols(int shape) { return kTB[shape].hx; }
 bool jacobi_tb_has_gradsub(int shape) { return tb_gs_built(shape); }
 
 bool jacobi_tb_supported(Win w) { return fused_supported(w); }
@@ -2882,6 +2912,31 @@ hipError_t launch_curl_vort_div_rects_any(hipStream_t s, Win w, const V2* vel, S
     R.blk0[R.n] = total;
     if (R.n == 0) return hipSuccess;
     k_curl_vort_div_rects<VD_NW, VD_RY><<<dim3(total, 1, 1), dim3(64, VD_NW, 1), 0, s>>>(w, R, vel, curl, vel_out, div, curl_strength, dt, cvd_remap());
+    return hipGetLastError();
+}
+
+// every product shape has a 12-column / 10-row apron (kTB); the frame launch runs the four-texel tile with 7 rows per wave whatever
+// shape the pass picked — same arithmetic per texel, hence the same bits
+hipError_t launch_jacobi_tb_rects(hipStream_t s, Win w, const float* p, const float* div, float* p_out, float pscale, int iters, const BandRects& B)
+{
+    constexpr int NW = 8, RY = 7, HX = 12, HY = 10;
+    using G = JacobiTB<NW, RY, HX, HY>;
+    if (!jacobi_tb_supported(w) || iters < 1 || iters > HY) return hipErrorInvalidValue;
+    TileRects R{};
+    int total = 0;
+    for (int k = 0; k < B.n; k++) {
+        const BandRect& q = B.r[k];
+        if (q.gb <= q.ga || q.xb <= q.xa) continue;
+        const int i = R.n++;
+        const Axis ax = make_axis(q.xa, q.xb, w.W, G::TX, HX), ay = make_axis(q.ga, q.gb, w.H, G::TY, HY);
+        R.x0[i] = q.xa; R.x1[i] = q.xb; R.ga[i] = q.ga; R.gb[i] = q.gb;
+        R.xs[i] = ax.S; R.ys[i] = ay.S; R.nx[i] = ax.n; R.ny[i] = ay.n;
+        R.blk0[i] = total;
+        total += ax.n * ay.n;
+    }
+    R.blk0[R.n] = total;
+    if (R.n == 0) return hipSuccess;
+    k_jacobi_tb_rects<NW, RY, HX, HY, 2><<<dim3(total, 1, 1), dim3(64, NW, 1), 0, s>>>(w, R, p, div, p_out, pscale, iters, xcd_remap());
     return hipGetLastError();
 }
 

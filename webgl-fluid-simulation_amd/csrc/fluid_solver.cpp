@@ -212,22 +212,73 @@ int pass_clear(fluid_ctx* c, float value, int ext)
 // `gradsub` (in: fold K6 into the last launch if that launch has the instantiation; out: whether it was): the last block then writes
 // the pressure AND velocity - grad(pressure) for the owned rows / columns (ext 0), and the caller skips pass_gradsub.  The blocks in
 // front of it leave the pressure valid one ring further out (ext_out >= 1), which is what the separate pass needs as well.
-// `split` (stripe driver, a pressure-only exchange in front of this block — fluid_stripes.cpp): 1 = ONLY the rows of the block's first
-// launch whose inputs are all owned (they compute while the ghost rows travel; no ping-pong swap yet), 2 = the rest of the block: the
-// first launch's strips next to the ghost rows, then every further launch.  1 then 2 leave exactly what 0 leaves (same launches over
-// the same rows, cut differently).  jacobi_split_ok() says whether a block can be cut this way.
-bool jacobi_split_ok(const fluid_ctx* c, int iters, bool wants_gradsub)
+// `split` (stripe / tile driver, an exchange in flight — fluid_stripes.cpp): 1 = ONLY the texels of the block's first launch whose inputs
+// are all owned and `margin` texels inside the owned rectangle (they compute while the ghost rows / columns travel; no ping-pong swap
+// yet), 2 = the rest of the block: the first launch's frame around that interior (ONE launch over its up to four rectangles,
+// launch_jacobi_tb_rects), then every further launch.  1 then 2 leave exactly what 0 leaves (the same iterations over the same texels,
+// cut differently).  `margin` = 0 behind a pressure-only exchange (the divergence is complete); 3 when the divergence itself is only
+// there on the interior of the curl / vorticity / divergence pass in front (a divergence texel reads velocity 3 texels away; columns go
+// by whole float4 groups: 4).  jacobi_split_ok() says whether a block can be cut this way.
+struct JacobiCut {
+    int ia, ib, ja, jb;   // the interior of the first launch: rows [ia, ib) x columns [ja, jb)
+};
+
+// `level`: 1 for the block's first launch, 2 for its second (cut too when the exchange needs a longer cover: its interior reads what the
+// first launch's interior wrote, one more apron further in — and writes into the buffer the exchange is sending from: it stays clear
+// of the rows / columns in flight)
+static JacobiCut jacobi_cut(const fluid_ctx* c, const Win& w, int ga, int gb, int shape, const JacobiSplit& sp, int level)
 {
-    if (!jacobi_tb_applies(c) || c->desc.parts_x != 1 || iters < 1) return false;
-    const long owned = (long)c->sim_ncols * c->sim_rows;
-    const int shape = jacobi_tb_pick(owned), depth = jacobi_tb_depth(shape);
-    const bool fold = wants_gradsub && jacobi_tb_has_gradsub(shape) && gradsub_fold_enabled(owned);
-    if (fold && iters <= depth) return false;            // the block's only launch carries the gradient subtract: not cut
-    return c->sim_rows > 4 * depth;                      // an interior worth a launch of its own
+    const fluid_desc& d = c->desc;
+    // a tile loads its whole apron whatever k is
+    int dep = level * jacobi_tb_depth(shape) + sp.margin, depx = level * jacobi_tb_apron_cols(shape) + ((sp.margin + 3) & ~3);
+    if (level > 1) {
+        dep = std::max(dep, sp.guard_rows);
+        depx = std::max(depx, (sp.guard_cols + 3) & ~3);
+    }
+    const int r0 = c->sim_row0, r1 = r0 + c->sim_rows, c0 = c->sim_col0, c1 = c0 + c->sim_ncols;
+    JacobiCut q;
+    q.ia = d.part > 0 ? std::min(std::max(r0 + dep, ga), gb) : ga;
+    q.ib = d.part < d.parts - 1 ? std::max(std::min(r1 - dep, gb), q.ia) : gb;
+    q.ja = d.part_x > 0 ? std::min(std::max(c0 + depx, w.x0), w.x1) : w.x0;
+    q.jb = d.part_x < d.parts_x - 1 ? std::max(std::min(c1 - depx, w.x1), q.ja) : w.x1;
+    return q;
 }
 
-int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launches, bool* gradsub, Timer* t, int split)
+// how many leading launches of a block of `iters` iterations can be cut this way, at most sp.cover (0: none)
+int jacobi_split_launches(const fluid_ctx* c, int iters, bool wants_gradsub, const JacobiSplit& sp)
 {
+    if (!jacobi_tb_applies(c) || iters < 1 || sp.cover < 1) return 0;
+    const long owned = (long)c->sim_ncols * c->sim_rows;
+    const int shape = jacobi_tb_pick(owned), depth = jacobi_tb_depth(shape), hx = jacobi_tb_apron_cols(shape);
+    const bool fold = wants_gradsub && jacobi_tb_has_gradsub(shape) && gradsub_fold_enabled(owned);
+    int m = (iters + depth - 1) / depth - (fold ? 1 : 0);   // the launch that carries the gradient subtract is not cut
+    if (m > sp.cover) m = sp.cover;
+    if (m > 2) m = 2;
+    const bool tiles = c->desc.parts_x > 1;
+    if (tiles) {   // the frame has left / right parts — the rectangle launch (fp32 fields, the 10-row apron) or nothing
+        if (c->storage != FLUID_STORE_F32 || depth > 10) return 0;
+        if ((c->sim_col0 & 3) != 0 || (c->sim_ncols & 3) != 0) return 0;   // interior columns as whole float4 groups
+    }
+    // an interior worth a launch of its own, at every level
+    auto worth = [&](int level) {
+        const int dep = std::max(level * depth + sp.margin, level > 1 ? sp.guard_rows : 0);
+        const int depx = std::max(level * hx + 4 + sp.margin, level > 1 ? sp.guard_cols + 4 : 0);
+        return c->sim_rows > 4 * dep && (!tiles || c->sim_ncols > 4 * depx);
+    };
+    while (m > 0 && !worth(m)) m--;
+    return m;
+}
+
+bool jacobi_split_ok(const fluid_ctx* c, int iters, bool wants_gradsub, int margin)
+{
+    JacobiSplit sp;
+    sp.margin = margin;
+    return jacobi_split_launches(c, iters, wants_gradsub, sp) > 0;
+}
+
+int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launches, bool* gradsub, Timer* t, const JacobiSplit* sp)
+{
+    const int split = sp ? sp->mode : 0;
     if (iters < 0) return c->fail(FLUID_ERR_INVALID, "negative iteration count");
     const bool tb = jacobi_tb_applies(c);
     const long owned = (long)c->sim_ncols * c->sim_rows;
@@ -241,12 +292,16 @@ int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launche
     // balanced blocks: ceil(iters / max) launches of nearly equal depth (50 with max 8 -> 8,7,7,7,7,7,7)
     const int tb_max = tb ? jacobi_tb_depth(shape) : 1;
     int launches_left = tb ? (iters + tb_max - 1) / tb_max : iters;
+    int cut_left = split && tb ? sp->cover : 0, level = 0;   // leading launches still to cut (split 1 / 2)
+    void *pa = c->prs[0], *pb = c->prs[1];               // split 1: the interiors ping-pong here; the context's pair swaps when the frames run
     while (done < iters) {
         int ga, gb;
         if (tb) {
             const int k = (iters - done + launches_left - 1) / launches_left;
             launches_left--;
+            if (split == 1 && cut_left == 0) return FLUID_OK;
             if (done + k == iters && fold) {
+                if (split == 1) return FLUID_OK;
                 row_range(c->sim, c->sim_row0, c->sim_rows, 0, ga, gb);
                 if (t) t->mark(P_JACOBI);  // the launches so far; this one is timed as P_GRADSUB by the caller
                 CK(c->hip(STORE_CALL(c, launch_jacobi_tb_gradsub(c->stream, sim_cols(c, 0), (const S::T1*)c->prs[0], (const S::T1*)c->div,
@@ -260,20 +315,40 @@ int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launche
                 return FLUID_OK;
             }
             row_range(c->sim, c->sim_row0, c->sim_rows, ext_out + (iters - done - k), ga, gb);
-            if (split && done == 0) {
-                // rows of this launch that read nothing of the ghost rows: a tile loads its apron (tb_max rows) whatever k is
-                const int r0 = c->sim_row0, r1 = r0 + c->sim_rows;
-                const int ia = c->desc.part > 0 ? std::min(std::max(r0 + tb_max, ga), gb) : ga;
-                const int ib = c->desc.part < c->desc.parts - 1 ? std::max(std::min(r1 - tb_max, gb), ia) : gb;
-                auto band = [&](int a, int b) {
-                    return b > a ? c->hip(STORE_CALL(c, launch_jacobi_tb(c->stream, sim_cols(c, ext_out + (iters - k)), (const S::T1*)c->prs[0],
-                                                                         (const S::T1*)c->div, (S::T1*)c->prs[1], pscale, k, a, b, shape)),
-                                          "jacobi_tb")
-                                 : (int)FLUID_OK;
+            if (cut_left > 0) {
+                cut_left--;
+                level++;
+                const Win w = sim_cols(c, ext_out + (iters - done - k));
+                const JacobiCut q = jacobi_cut(c, w, ga, gb, shape, *sp, level);
+                const float ps = done == 0 ? pscale : 1.0f;
+                auto band = [&](const void* src, void* dst, int a, int b, int xa, int xb) {
+                    if (b <= a || xb <= xa) return (int)FLUID_OK;
+                    Win wb = w;
+                    wb.x0 = xa;
+                    wb.x1 = xb;
+                    return c->hip(STORE_CALL(c, launch_jacobi_tb(c->stream, wb, (const S::T1*)src, (const S::T1*)c->div, (S::T1*)dst, ps, k, a, b, shape)),
+                                  "jacobi_tb");
                 };
-                if (split == 1) return band(ia, ib);      // interior only; the caller comes back with split == 2 once the ghost rows are in
-                CK(band(ga, ia));
-                CK(band(ib, gb));
+                if (split == 1) {   // interiors only; the caller comes back with split == 2 once the ghost texels are in
+                    CK(band(pa, pb, q.ia, q.ib, q.ja, q.jb));
+                    std::swap(pa, pb);
+                    done += k;
+                    continue;
+                }
+                // the frame around that interior.  (With two launches cut, this one reads pressure up to one apron inside the first
+                // interior, from the buffer the SECOND interior has already written into — further in: from 2 aprons + margin on.)
+                if (c->storage == FLUID_STORE_F32 && k <= 10) {        // one launch
+                    fluid::BandRects B{};
+                    B.r[B.n++] = fluid::BandRect{ w.x0, w.x1, ga, q.ia };
+                    B.r[B.n++] = fluid::BandRect{ w.x0, w.x1, q.ib, gb };
+                    B.r[B.n++] = fluid::BandRect{ w.x0, q.ja, q.ia, q.ib };
+                    B.r[B.n++] = fluid::BandRect{ q.jb, w.x1, q.ia, q.ib };
+                    CK(c->hip(fluid::launch_jacobi_tb_rects(c->stream, w, (const float*)c->prs[0], (const float*)c->div, (float*)c->prs[1], ps, k, B),
+                              "jacobi_tb (frame)"));
+                } else {   // fp16 storage / a deeper lab shape: stripes only (jacobi_split_launches), one launch per band
+                    CK(band(c->prs[0], c->prs[1], ga, q.ia, w.x0, w.x1));
+                    CK(band(c->prs[0], c->prs[1], q.ib, gb, w.x0, w.x1));
+                }
                 if (launches) (*launches)++;
                 std::swap(c->prs[0], c->prs[1]);
                 done += k;

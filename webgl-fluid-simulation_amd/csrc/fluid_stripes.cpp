@@ -25,6 +25,10 @@
 // all owned — and only the thin strips next to the ghost rows wait for the transfer (events both ways).  The
 // advection kernels count every tap outside the rows that are fresh for that launch, so a back-trace longer than
 // the reach is reported (FLUID_ERR_HALO) instead of reading a row that is still in flight.
+// The pressure blocks are cover as well (round 4): the leading launch(es) of a block behind an exchange — a pressure-only exchange
+// between two blocks, or the step's first exchange, behind the curl pass's interior — are cut the same way (pass_jacobi, JacobiSplit):
+// their interiors, one apron per launch inside the owned rectangle, compute while the ghost texels travel; the frame of each follows in
+// one launch.  How many launches are cut is sized per exchange with a link model (exchange_us): a cut costs a thin frame launch.
 //
 // RCCL is loaded at run time (dlopen): the single-GPU path does not depend on it, and a process that already
 // holds an RCCL (PyTorch bundles one) shares that copy instead of pulling in a second HIP runtime.
@@ -34,6 +38,8 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -352,12 +358,17 @@ int group_exchange_end(fluid_ctx** cs, int n)
 }
 
 // ---- 2-D tiles (parts_x > 1): ghost COLUMNS as well ---------------------------------------------------------------
-// Rank = part * parts_x + part_x.  An exchange has two phases: A moves ghost columns between left / right neighbours
-// (owned rows only), B then moves ghost rows between lower / upper neighbours over the owned columns PLUS the ghost
-// columns that phase A just filled — so the corner blocks arrive without diagonal messages.  The blocks are strided in the
-// tile's arrays (pitch = owned + ghost columns): they travel through contiguous staging buffers, packed and unpacked by ONE
-// kernel launch each per phase (launch_copy_rects: every field and direction of the phase).  One message per neighbour and
-// phase carries all the fields of the exchange.  The interior-first overlap works as for stripes, with four strips around the interior.
+// Rank = part * parts_x + part_x.  The blocks are strided in the tile's arrays (pitch = owned + ghost columns): they travel through
+// contiguous staging buffers, packed and unpacked by ONE kernel launch each (launch_copy_rects: every field and direction).  One
+// message per neighbour carries all the fields of the exchange.  The interior-first overlap works as for stripes, with four strips
+// around the interior.
+//   * over RCCL (rccl_exchange_2d_begin): ONE message round to up to EIGHT neighbours — ghost columns from LEFT / RIGHT, ghost rows
+//     from DOWN / UP over the owned columns, and the four corner blocks straight from the diagonal neighbours;
+//   * inside one process (group_exchange_2d_begin): two phases — A moves ghost columns between left / right neighbours (owned rows
+//     only), B then moves ghost rows between lower / upper neighbours over the owned columns PLUS the ghost columns phase A just
+//     filled, so the corner blocks arrive without diagonal copies.
+// Same bytes into the same ghost texels either way (a corner block of the diagonal neighbour's OWNED texels; tests/test_stripes_gpu.py
+// holds both drivers to the single domain bit for bit).
 struct Rect {
     char* p;             // first texel
     size_t pitch, line;  // bytes between rows, bytes per row of the block
@@ -365,15 +376,14 @@ struct Rect {
     size_t bytes() const { return line * (size_t)nrows; }
 };
 
-enum Dir { LEFT = 0, RIGHT = 1, DOWN = 2, UP = 3 };
+enum Dir { LEFT = 0, RIGHT = 1, DOWN = 2, UP = 3, DOWN_LEFT = 4, DOWN_RIGHT = 5, UP_LEFT = 6, UP_RIGHT = 7 };
 
 struct Blocks {
-    Rect send[4], recv[4];
-    // the same DOWN / UP rows cut for the RCCL driver, whose phases run side by side: `core` = over the owned columns only (needs nothing
-    // of phase A), `corner[dir][side]` = the part over the left (0) / right (1) ghost columns, forwarded once phase A has filled them
+    Rect send[4], recv[4];   // the in-process driver's two phases (DOWN / UP span owned + ghost columns)
+    // the RCCL driver's single round: `core` = DOWN / UP over the owned columns only, `diag` = the corner blocks (index dir - DOWN_LEFT):
+    // nx x n texels of this tile's OWNED corner out, the matching corner of its ghost frame in
     Rect send_core[4], recv_core[4];
-    Rect send_corner[4][2], recv_corner[4][2];
-    bool corner_side[2];   // the tile has ghost columns on that side
+    Rect send_diag[4], recv_diag[4];
 };
 
 int col_depth(const fluid_ctx* c, const FieldRef& f, int n)  // ghost columns that go with n ghost rows of this field
@@ -412,28 +422,46 @@ int blocks_of(fluid_ctx* c, int field, int n, Blocks* b)
     b->recv_core[DOWN] = rect(h - n, n, c0, c1 - c0);
     b->send_core[UP] = rect(h + R - n, n, c0, c1 - c0);
     b->recv_core[UP] = rect(h + R, n, c0, c1 - c0);
-    b->corner_side[0] = c->desc.part_x > 0;
-    b->corner_side[1] = c->desc.part_x < c->desc.parts_x - 1;
-    const int side_col[2] = { c0 - nx, c1 };
-    for (int sd = 0; sd < 2; sd++) {
-        b->send_corner[DOWN][sd] = rect(h, n, side_col[sd], nx);
-        b->recv_corner[DOWN][sd] = rect(h - n, n, side_col[sd], nx);
-        b->send_corner[UP][sd] = rect(h + R - n, n, side_col[sd], nx);
-        b->recv_corner[UP][sd] = rect(h + R, n, side_col[sd], nx);
-    }
+    b->send_diag[DOWN_LEFT - DOWN_LEFT] = rect(h, n, c0, nx);
+    b->recv_diag[DOWN_LEFT - DOWN_LEFT] = rect(h - n, n, c0 - nx, nx);
+    b->send_diag[DOWN_RIGHT - DOWN_LEFT] = rect(h, n, c1 - nx, nx);
+    b->recv_diag[DOWN_RIGHT - DOWN_LEFT] = rect(h - n, n, c1, nx);
+    b->send_diag[UP_LEFT - DOWN_LEFT] = rect(h + R - n, n, c0, nx);
+    b->recv_diag[UP_LEFT - DOWN_LEFT] = rect(h + R, n, c0 - nx, nx);
+    b->send_diag[UP_RIGHT - DOWN_LEFT] = rect(h + R - n, n, c1 - nx, nx);
+    b->recv_diag[UP_RIGHT - DOWN_LEFT] = rect(h + R, n, c1, nx);
     return FLUID_OK;
 }
 
 bool has_neighbour(const fluid_ctx* c, int dir)
 {
     const fluid_desc& d = c->desc;
-    return dir == LEFT ? d.part_x > 0 : dir == RIGHT ? d.part_x < d.parts_x - 1 : dir == DOWN ? d.part > 0 : d.part < d.parts - 1;
+    const bool l = d.part_x > 0, r = d.part_x < d.parts_x - 1, dn = d.part > 0, up = d.part < d.parts - 1;
+    switch (dir) {
+    case LEFT: return l;
+    case RIGHT: return r;
+    case DOWN: return dn;
+    case UP: return up;
+    case DOWN_LEFT: return dn && l;
+    case DOWN_RIGHT: return dn && r;
+    case UP_LEFT: return up && l;
+    default: return up && r;
+    }
 }
 
 int neighbour_rank(const fluid_ctx* c, int dir)
 {
-    const int r = c->desc.part * c->desc.parts_x + c->desc.part_x;
-    return dir == LEFT ? r - 1 : dir == RIGHT ? r + 1 : dir == DOWN ? r - c->desc.parts_x : r + c->desc.parts_x;
+    const int r = c->desc.part * c->desc.parts_x + c->desc.part_x, px = c->desc.parts_x;
+    switch (dir) {
+    case LEFT: return r - 1;
+    case RIGHT: return r + 1;
+    case DOWN: return r - px;
+    case UP: return r + px;
+    case DOWN_LEFT: return r - px - 1;
+    case DOWN_RIGHT: return r - px + 1;
+    case UP_LEFT: return r + px - 1;
+    default: return r + px + 1;
+    }
 }
 
 // `from`: the context that owns the source block.  On the same device the copy is one k_copy_rects launch on c's comm stream; a
@@ -448,8 +476,7 @@ int copy_rect(fluid_ctx* c, const fluid_ctx* from, const Rect& dst, const Rect& 
     }
     fluid::CopyRects one{};
     one.n = 1;
-    one.unit = (int)c->esz;
-    one.r[0] = { src.p, dst.p, src.pitch, dst.pitch, (unsigned)(src.line / c->esz), (unsigned)src.nrows };
+    one.r[0] = fluid::copy_rect_of(src.p, dst.p, src.pitch, dst.pitch, src.line, src.nrows);
     HIPCK(c, fluid::launch_copy_rects(s, one));
     return FLUID_OK;
 }
@@ -465,14 +492,12 @@ int ensure_stage(fluid_ctx* c, int slot, size_t bytes)
     return FLUID_OK;
 }
 
-// The whole exchange over RCCL on the comm stream (begun here, ended by rccl_exchange_end).  Two message rounds, but only the first
-// carries weight (round 4: the two-phase form — columns, THEN rows over owned + fresh ghost columns — put two full link times on
-// every exchange; against a link of 60 us the centre tile of 3 x 3 paid +25 % per step, profiles/r04/overlap_vs_link_latency.txt):
-//   round 1: ghost columns from LEFT / RIGHT (owned rows) and ghost rows from DOWN / UP over the OWNED columns — four neighbours, four
-//            links, side by side in one ncclGroup;
-//   round 2: the corner blocks (nx x n texels per field: a few tens of KB): what round 1 put into this tile's ghost columns next to its
-//            bottom / top rows is forwarded DOWN / UP — the diagonal neighbours' data arrives in two hops without diagonal messages.
-// Same bytes into the same ghost texels as the two-phase form (which the in-process group driver keeps).
+// The whole exchange over RCCL on the comm stream (begun here, ended by rccl_exchange_end): pack, ONE ncclGroup with a send and a
+// receive per neighbour — up to eight of them, every link side by side — unpack.  (Round 4 started with the two-phase form on this
+// path too: columns, THEN rows over owned + fresh ghost columns put two full link times on every exchange, and against a link of 60 us
+// the centre tile of 3 x 3 paid +25 % per step; a second, tiny round that forwarded the corner blocks still paid the latency twice —
+// profiles/r04/overlap_vs_link_latency.txt.  The corner blocks now come straight from the diagonal neighbours: on an xGMI node every
+// pair of GPUs has its own link.)
 int rccl_exchange_2d_begin(fluid_ctx* c, const fluid_stripe_op& op)
 {
     const Rccl* R = rccl(nullptr);
@@ -482,51 +507,38 @@ int rccl_exchange_2d_begin(fluid_ctx* c, const fluid_stripe_op& op)
     for (int i = 0; i < op.n_items; i++) CK(blocks_of(c, op.field[i], op.rows[i], &blk[i]));
     HIPCK(c, hipEventRecord(c->ev_ready, c->stream));
     HIPCK(c, hipStreamWaitEvent(c->comm_stream, c->ev_ready, 0));
-    const int unit = (int)c->esz;  // every line, pitch and staging offset is a multiple of the channel size
-    for (int round = 0; round < 2; round++) {
-        size_t total[4] = { 0, 0, 0, 0 };
-        fluid::CopyRects pack{}, unpack{};
-        pack.unit = unpack.unit = unit;
-        // the rectangles one direction carries in this round, in the order both ends agree on (items, then sides)
-        auto rects_of = [&](int dir, int i, const Rect** sr, const Rect** rr) -> int {
-            int n = 0;
-            if (round == 0) {
-                sr[n] = dir >= DOWN ? &blk[i].send_core[dir] : &blk[i].send[dir];
-                rr[n++] = dir >= DOWN ? &blk[i].recv_core[dir] : &blk[i].recv[dir];
-            } else if (dir >= DOWN) {
-                for (int sd = 0; sd < 2; sd++)
-                    if (blk[i].corner_side[sd]) {
-                        sr[n] = &blk[i].send_corner[dir][sd];
-                        rr[n++] = &blk[i].recv_corner[dir][sd];
-                    }
-            }
-            return n;
-        };
-        for (int dir = 0; dir < 4; dir++) {
-            if (!has_neighbour(c, dir)) continue;
-            const Rect *sr[2], *rr[2];
-            for (int i = 0; i < op.n_items; i++) {
-                const int n = rects_of(dir, i, sr, rr);
-                for (int k = 0; k < n; k++) total[dir] += sr[k]->bytes();
-            }
-            if (!total[dir]) continue;
-            CK(ensure_stage(c, 2 * dir, total[dir]));      // send staging of this direction (round 2 reuses it: stream order)
-            CK(ensure_stage(c, 2 * dir + 1, total[dir]));  // receive staging (the neighbour's blocks have the same shapes)
-            size_t off = 0;
-            for (int i = 0; i < op.n_items; i++) {
-                const int n = rects_of(dir, i, sr, rr);
-                for (int k = 0; k < n; k++) {
-                    if (pack.n >= 8) return c->fail(FLUID_ERR_INVALID, "tile exchange: more blocks than one copy launch takes");
-                    pack.r[pack.n++] = { sr[k]->p, (char*)c->stage[2 * dir] + off, sr[k]->pitch, sr[k]->line, (unsigned)(sr[k]->line / unit), (unsigned)sr[k]->nrows };
-                    unpack.r[unpack.n++] = { (char*)c->stage[2 * dir + 1] + off, rr[k]->p, rr[k]->line, rr[k]->pitch, (unsigned)(rr[k]->line / unit), (unsigned)rr[k]->nrows };
-                    off += sr[k]->bytes();
-                }
-            }
+    size_t total[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    fluid::CopyRects pack{}, unpack{};
+    auto rects_of = [&](int dir, int i, const Rect** sr, const Rect** rr) {
+        *sr = dir >= DOWN_LEFT ? &blk[i].send_diag[dir - DOWN_LEFT] : dir >= DOWN ? &blk[i].send_core[dir] : &blk[i].send[dir];
+        *rr = dir >= DOWN_LEFT ? &blk[i].recv_diag[dir - DOWN_LEFT] : dir >= DOWN ? &blk[i].recv_core[dir] : &blk[i].recv[dir];
+    };
+    auto aligned = [](size_t off) { return (off + 15) & ~(size_t)15; };   // every block starts on 16 bytes of the staging: wide copies
+    for (int dir = 0; dir < 8; dir++) {
+        if (!has_neighbour(c, dir)) continue;
+        const Rect *sr, *rr;
+        // the message of one direction: the fields of the exchange in item order — both ends cut the same shapes, hence the same layout
+        for (int i = 0; i < op.n_items; i++) {
+            rects_of(dir, i, &sr, &rr);
+            total[dir] = aligned(total[dir]) + sr->bytes();
         }
-        if (!(total[0] | total[1] | total[2] | total[3])) continue;
-        HIPCK(c, fluid::launch_copy_rects(c->comm_stream, pack));      // every field and direction of the round: one launch
+        if (!total[dir]) continue;
+        CK(ensure_stage(c, 2 * dir, total[dir]));      // send staging of this direction
+        CK(ensure_stage(c, 2 * dir + 1, total[dir]));  // receive staging (the neighbour's blocks have the same shapes)
+        size_t off = 0;
+        for (int i = 0; i < op.n_items; i++) {
+            rects_of(dir, i, &sr, &rr);
+            off = aligned(off);
+            if (pack.n >= 16) return c->fail(FLUID_ERR_INVALID, "tile exchange: more blocks than one copy launch takes");
+            pack.r[pack.n++] = fluid::copy_rect_of(sr->p, (char*)c->stage[2 * dir] + off, sr->pitch, sr->line, sr->line, sr->nrows);
+            unpack.r[unpack.n++] = fluid::copy_rect_of((char*)c->stage[2 * dir + 1] + off, rr->p, rr->line, rr->pitch, rr->line, rr->nrows);
+            off += sr->bytes();
+        }
+    }
+    if (pack.n) {
+        HIPCK(c, fluid::launch_copy_rects(c->comm_stream, pack));      // every field and direction: one launch
         NCCLCK(c, R, R->GroupStart());
-        for (int dir = 0; dir < 4; dir++)
+        for (int dir = 0; dir < 8; dir++)
             if (total[dir]) {
                 NCCLCK(c, R, R->Send(c->stage[2 * dir], total[dir], ncclChar, neighbour_rank(c, dir), comm, c->comm_stream));
                 NCCLCK(c, R, R->Recv(c->stage[2 * dir + 1], total[dir], ncclChar, neighbour_rank(c, dir), comm, c->comm_stream));
@@ -750,14 +762,119 @@ bool jacobi_overlap_ok(const fluid_ctx* c, const std::vector<fluid_stripe_op>& o
     return ops[i + 1].kind == FLUID_OP_JACOBI && jacobi_split_ok(c, ops[i + 1].iters, folds_gradsub(ops, i + 1));
 }
 
-int jacobi_block_interior(fluid_ctx* c, const fluid_stripe_op& blk) { return pass_jacobi(c, blk.iters, blk.ext, 1.0f, nullptr, nullptr, nullptr, 1); }
+// ---- how much cover an exchange needs --------------------------------------------------------------------------------
+// A cut launch costs a thin frame launch (~10 us at 4096^2 per rank: one tile's latency), so a block's launches are cut only as far as the
+// exchange is expected to last: its largest message over ONE link (the neighbours' links run side by side) at an assumed
+// 20 us + bytes / 50 GB/s — the order of an RCCL point-to-point message of a few MB over one xGMI link — plus the pack / unpack launches
+// of a tile exchange, against what a launch takes at the rates this library measures on the MI355X (profiles/r04: the Jacobi launch moves
+// 13.2 B/texel at 5.0 TB/s, the curl / vorticity / divergence pass 20 B/texel at 5.0 TB/s).  Nothing breaks when the guess is off: a
+// longer exchange shows, a shorter one has paid for a frame launch it did not need (profiles/r04/overlap_vs_link_latency.txt has both).
+// FLUID_LINK_MODEL="us,GB/s" (lab build) replaces the two constants.
+struct LinkModel {
+    double lat_us, gbps;
+};
 
-// the rest of the block; `gs` = the gradient-subtract op behind it, or null
-int jacobi_block_rest(fluid_ctx* c, const fluid_stripe_op& blk, const fluid_stripe_op* gs)
+LinkModel link_model()
 {
-    if (!gs) return pass_jacobi(c, blk.iters, blk.ext, 1.0f, nullptr, nullptr, nullptr, 2);
+    static const LinkModel m = [] {
+        LinkModel v{ 20.0, 50.0 };
+        if (const char* e = fluid::lab_env("FLUID_LINK_MODEL")) {
+            double a = 0, b = 0;
+            if (sscanf(e, "%lf,%lf", &a, &b) == 2 && a >= 0 && b > 0) v = LinkModel{ a, b };
+        }
+        return v;
+    }();
+    return m;
+}
+
+double exchange_us(fluid_ctx* c, const fluid_stripe_op& op)
+{
+    const bool tiles = c->desc.parts_x > 1;
+    double rows_msg = 0, cols_msg = 0;   // bytes to a DOWN / UP neighbour, to a LEFT / RIGHT one
+    for (int i = 0; i < op.n_items; i++) {
+        FieldRef f;
+        if (field_ref(c, op.field[i], &f, true) != FLUID_OK) return 0;
+        const double texel = (double)f.texel();
+        rows_msg += (double)op.rows[i] * (tiles ? f.cols : f.win->P) * texel;
+        if (tiles) cols_msg += (double)f.rows * col_depth(c, f, op.rows[i]) * texel;
+    }
+    const LinkModel m = link_model();
+    return m.lat_us + std::max(rows_msg, cols_msg) / (m.gbps * 1e3) + (tiles ? 30.0 : 0.0);
+}
+
+double jacobi_launch_us(const fluid_ctx* c) { return (double)c->sim_ncols * c->sim_rows * 13.2 / 5.0e6; }
+double cvd_interior_us(const fluid_ctx* c) { return (double)c->sim_ncols * c->sim_rows * 20.0 / 5.0e6; }
+
+int launches_for(double us, const fluid_ctx* c)   // Jacobi launches that take at least `us`, 0 .. 2
+{
+    if (us <= 0) return 0;
+    const int n = (int)std::ceil(us / jacobi_launch_us(c));
+    return n > 2 ? 2 : n;
+}
+
+// the pressure rows / columns an exchange is sending (0 if it carries no pressure): what a second cut launch must stay clear of
+void pressure_in_flight(fluid_ctx* c, const fluid_stripe_op& op, JacobiSplit* sp)
+{
+    for (int i = 0; i < op.n_items; i++)
+        if (op.field[i] == FLUID_PRESSURE) {
+            FieldRef f;
+            sp->guard_rows = op.rows[i];
+            if (c->desc.parts_x > 1 && field_ref(c, FLUID_PRESSURE, &f, true) == FLUID_OK) sp->guard_cols = col_depth(c, f, op.rows[i]);
+        }
+}
+
+// how to cut the Jacobi block behind a pressure-only exchange (cover >= 1: jacobi_overlap_ok said the block can be cut)
+JacobiSplit jacobi_overlap_split(fluid_ctx* c, const std::vector<fluid_stripe_op>& ops, size_t i)
+{
+    JacobiSplit sp;
+    pressure_in_flight(c, ops[i], &sp);
+    sp.cover = std::max(1, launches_for(exchange_us(c, ops[i]), c));
+    sp.cover = std::max(1, jacobi_split_launches(c, ops[i + 1].iters, folds_gradsub(ops, i + 1), sp));
+    return sp;
+}
+
+int jacobi_block_interior(fluid_ctx* c, const fluid_stripe_op& blk, JacobiSplit sp)
+{
+    sp.mode = 1;
+    return pass_jacobi(c, blk.iters, blk.ext, 1.0f, nullptr, nullptr, nullptr, &sp);
+}
+
+// The step's FIRST exchange (velocity + pressure) has the interior of the curl / vorticity / divergence pass as its cover — 65 us at
+// 4096^2 per rank, against pack + link + unpack of a tile exchange (profiles/r04/overlap_vs_link_latency.txt).  The first launch(es) of
+// the pressure block behind it are cut the same way and join the cover: their texels 3 (4 columns) + one apron inside the owned rectangle
+// read only divergence the interior launch already wrote and pressure nobody is exchanging into.  Then: the exchange lands, the strips of
+// the curl / vorticity / divergence pass, the frames of those Jacobi launches, every further launch.
+// cover = the launches to cut (0: the block is not cut).  FLUID_COVER_JACOBI=0 (lab build): off (A/B knob; same bits either way)
+JacobiSplit jacobi_cover_split(fluid_ctx* c, const std::vector<fluid_stripe_op>& ops, size_t i)
+{
+    static const bool on = [] {
+        const char* e = fluid::lab_env("FLUID_COVER_JACOBI");
+        return !(e && atoi(e) == 0);
+    }();
+    JacobiSplit sp;
+    sp.margin = 3;
+    sp.cover = 0;
+    if (!on || i + 2 >= ops.size() || ops[i + 1].kind != FLUID_OP_CURL_VORT_DIV || ops[i + 2].kind != FLUID_OP_CLEAR_JACOBI) return sp;
+    pressure_in_flight(c, ops[i], &sp);
+    sp.cover = launches_for(exchange_us(c, ops[i]) - cvd_interior_us(c), c);
+    sp.cover = jacobi_split_launches(c, ops[i + 2].iters, folds_gradsub(ops, i + 2), sp);
+    return sp;
+}
+
+int clear_jacobi_interior(fluid_ctx* c, const fluid_stripe_op& blk, const fluid_params* P, JacobiSplit sp)
+{
+    sp.mode = 1;
+    return pass_jacobi(c, blk.iters, blk.ext, P->pressure, nullptr, nullptr, nullptr, &sp);
+}
+
+// the rest of a cut block (pscale: config.PRESSURE for the step's first block, whose first launch carries the clear; 1 otherwise);
+// `gs` = the gradient-subtract op behind it, or null
+int jacobi_block_rest(fluid_ctx* c, const fluid_stripe_op& blk, const fluid_stripe_op* gs, float pscale, JacobiSplit sp)
+{
+    sp.mode = 2;
+    if (!gs) return pass_jacobi(c, blk.iters, blk.ext, pscale, nullptr, nullptr, nullptr, &sp);
     bool folded = true;
-    CK(pass_jacobi(c, blk.iters, blk.ext, 1.0f, nullptr, &folded, nullptr, 2));
+    CK(pass_jacobi(c, blk.iters, blk.ext, pscale, nullptr, &folded, nullptr, &sp));
     return folded ? (int)FLUID_OK : pass_gradsub(c, gs->ext);
 }
 
@@ -803,15 +920,23 @@ int stripe_step_n(fluid_ctx* c, int n, float dt, const fluid_params* P)
             if (c->desc.parts_x > 1) CK(rccl_exchange_2d_begin(c, op));
             else CK(rccl_exchange_begin(c, op));
             if (i + 1 < ops.size() && overlap_ok(c, ops[i + 1])) {
+                const JacobiSplit deep = jacobi_cover_split(c, ops, i);
                 CK(pass_interior(c, ops[i + 1], dt, P));  // computes while the ghost rows travel
+                if (deep.cover) CK(clear_jacobi_interior(c, ops[i + 2], P, deep));
                 CK(rccl_exchange_end(c));
                 CK(pass_strips(c, ops[i + 1], dt, P));
                 i++;
+                if (deep.cover) {
+                    const bool gs = folds_gradsub(ops, i + 1);
+                    CK(jacobi_block_rest(c, ops[i + 1], gs ? &ops[i + 2] : nullptr, P->pressure, deep));
+                    i += gs ? 2 : 1;
+                }
             } else if (jacobi_overlap_ok(c, ops, i)) {
                 const bool gs = folds_gradsub(ops, i + 1);
-                CK(jacobi_block_interior(c, ops[i + 1]));
+                const JacobiSplit sp = jacobi_overlap_split(c, ops, i);
+                CK(jacobi_block_interior(c, ops[i + 1], sp));
                 CK(rccl_exchange_end(c));
-                CK(jacobi_block_rest(c, ops[i + 1], gs ? &ops[i + 2] : nullptr));
+                CK(jacobi_block_rest(c, ops[i + 1], gs ? &ops[i + 2] : nullptr, 1.0f, sp));
                 i += gs ? 2 : 1;
             } else {
                 CK(rccl_exchange_end(c));
@@ -838,7 +963,7 @@ void stripes_release(fluid_ctx* c)
     if (c->ev_landed) (void)hipEventDestroy(c->ev_landed);
     if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
     c->ev_ready = c->ev_landed = c->ev_mid = nullptr;
-    for (int k = 0; k < 8; k++) {
+    for (int k = 0; k < 16; k++) {
         if (c->stage[k]) (void)hipFree(c->stage[k]);
         c->stage[k] = nullptr;
         c->stage_bytes[k] = 0;
@@ -1022,16 +1147,28 @@ int fluid_group_step_n(fluid_ctx** cs, int n_ctx, int steps, float dt, const flu
             else CK(group_exchange_begin(cs, n_ctx, op));
             if (i + 1 < ops.size() && overlap_ok(cs[0], ops[i + 1])) {
                 const fluid_stripe_op& next = ops[i + 1];
+                // the pressure block's first launch(es) join the cover as far as every tile of the group can cut them
+                JacobiSplit deep = jacobi_cover_split(cs[0], ops, i);
+                for (int r = 1; r < n_ctx; r++) deep.cover = std::min(deep.cover, jacobi_cover_split(cs[r], ops, i).cover);
                 CK(each([&](fluid_ctx* c) { return pass_interior(c, next, dt, P); }));
+                if (deep.cover) CK(each([&](fluid_ctx* c) { return clear_jacobi_interior(c, ops[i + 2], P, deep); }));
                 CK(tiles ? group_exchange_2d_end(cs, n_ctx) : group_exchange_end(cs, n_ctx));
                 CK(each([&](fluid_ctx* c) { return pass_strips(c, next, dt, P); }));
                 i++;
+                if (deep.cover) {
+                    const bool gs = folds_gradsub(ops, i + 1);
+                    const fluid_stripe_op& blk = ops[i + 1];
+                    CK(each([&](fluid_ctx* c) { return jacobi_block_rest(c, blk, gs ? &ops[i + 2] : nullptr, P->pressure, deep); }));
+                    i += gs ? 2 : 1;
+                }
             } else if (jacobi_overlap_ok(cs[0], ops, i)) {   // every stripe of a group has the same rows: the same answer
                 const bool gs = folds_gradsub(ops, i + 1);
                 const fluid_stripe_op& blk = ops[i + 1];
-                CK(each([&](fluid_ctx* c) { return jacobi_block_interior(c, blk); }));
-                CK(group_exchange_end(cs, n_ctx));
-                CK(each([&](fluid_ctx* c) { return jacobi_block_rest(c, blk, gs ? &ops[i + 2] : nullptr); }));
+                JacobiSplit sp = jacobi_overlap_split(cs[0], ops, i);
+                for (int r = 1; r < n_ctx; r++) sp.cover = std::min(sp.cover, jacobi_overlap_split(cs[r], ops, i).cover);
+                CK(each([&](fluid_ctx* c) { return jacobi_block_interior(c, blk, sp); }));
+                CK(tiles ? group_exchange_2d_end(cs, n_ctx) : group_exchange_end(cs, n_ctx));
+                CK(each([&](fluid_ctx* c) { return jacobi_block_rest(c, blk, gs ? &ops[i + 2] : nullptr, 1.0f, sp); }));
                 i += gs ? 2 : 1;
             } else {
                 CK(tiles ? group_exchange_2d_end(cs, n_ctx) : group_exchange_end(cs, n_ctx));
