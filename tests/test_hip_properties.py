@@ -288,6 +288,8 @@ def test_every_knob_of_the_fused_schedule_yields_the_same_bits():
     settings += [{"FLUID_TB2": t, "FLUID_FOLD_GRADSUB": f} for t in ("8,4", "8,5", "8,6", "4,10", "16,3") for f in ("0", "1")]   # rows / waves of the two-texel Jacobi tile
     settings += [{"FLUID_CHAIN": "0"}] + [{"FLUID_CHAIN_TILE": t} for t in ("8,8,4", "4,8,4", "8,8,3", "16,8,4", "8,4,3", "4,4,3", "16,4,3")]   # advection + the next step's curl / vorticity / divergence in one launch, or not
     settings += [{"FLUID_ADVECT_WY": "2"}, {"FLUID_ADVECT_WY": "4"}, {"FLUID_ADVECT_WY": "4", "FLUID_ADVECT_ROWS": "2", "FLUID_ADVECT_SPLIT_ROWS": "4"}]   # the advection block's waves stacked in y
+    # the dye != sim advection: velocity taps gathered (0) or read from the wave's LDS run (the product), one / two / four rows per thread
+    settings += [{"FLUID_VTILE": "0"}, {"FLUID_VTILE": "0", "FLUID_ADVECT_SPLIT_ROWS": "4"}, {"FLUID_VTILE": "1", "FLUID_ADVECT_SPLIT_ROWS": "2"}]
     settings += [{"FLUID_ADVECT_FAST": "0"}, {"FLUID_ADVECT_SPLIT_ROWS": "4"}, {"FLUID_ADVECT_SPLIT_ROWS": "1"}, {"FLUID_ADVECT_ROWS": "2"},
                  {"FLUID_TB_VARIANT": "1", "FLUID_FOLD_GRADSUB": "1"}, {"FLUID_TB_VARIANT": "5"}]
     ref = None

@@ -496,11 +496,21 @@ __device__ __forceinline__ void advect_velocity_fast_body(const Win& w, const V2
     if (miss) atomicAdd(miss_out, (unsigned)miss);
 }
 
-template <int ROWS, class V2, class D4, int WY = 1>
+// VT (fp32 velocity, WY == 1): the velocity is sampled at the dye texel's own position — a regular lattice, so the taps of a wave's 64
+// dye columns x ROWS dye rows are a run of at most 64 / ratio + 2 sim columns in 2 or 3 sim rows (ratio = dye width / sim width: 8 in the
+// reference's default configuration, script.js:60-61).  The wave fetches that run ONCE (one 8-byte load per lane, 60 lanes) into its own
+// 480 bytes of LDS and every lane reads its four taps from there — two ds_read2_b64 — instead of gathering them through the texture
+// addresser with four 16-byte loads per lane and row pair: the dye taps, which follow the flow, are the only gathers left.  A lane whose
+// taps are not all inside that run, or touch the domain edge / the window's stale part (taps32's slow path), gathers as before.
+// Same texels into the same arithmetic, hence the same bits.
+constexpr int VT_COLS = 20, VT_ROWS = 3;
+
+template <int ROWS, class V2, class D4, int WY = 1, bool VT = false>
 __device__ __forceinline__ void advect_dye_fast_body(const Win& vw, const V2* __restrict__ vel, const Win& dw, const D4* __restrict__ dye,
                                                      D4* __restrict__ dye_out, float dt, double rW, double rH, double rdd, float tsx, float tsy,
-                                                     int ga, int gb, unsigned int* __restrict__ miss_out)
+                                                     int ga, int gb, unsigned int* __restrict__ miss_out, float2* vtile = nullptr)
 {
+    static_assert(!VT || (WY == 1 && sizeof(V2) == sizeof(float2)), "the velocity tile: fp32 fields, waves side by side");
     constexpr int CW = BX / WY;  // columns per block (advect_both_fast_body)
     const int tx = WY == 1 ? (int)threadIdx.x : (int)threadIdx.x % CW, ty = WY == 1 ? 0 : (int)threadIdx.x / CW;
     const int lane_i = dw.x0 + (int)blockIdx.x * CW + tx;
@@ -521,11 +531,56 @@ __device__ __forceinline__ void advect_dye_fast_body(const Win& vw, const V2* __
         const int gjc = gj < gb ? gj : gb - 1;
         v[k] = div_uniform((float)gjc + 0.5f, rH);
         c[k] = (unsigned)((gjc - dw.g0) * dw.P + (i - dw.c0));
-        t[k] = taps32<sizeof(V2)>(vw, Bv, u, v[k]);  // uVelocity sampled at vUv: a LINEAR fetch on the sim grid
-        if (on[k]) miss += t[k].miss;
+        if constexpr (!VT) {
+            t[k] = taps32<sizeof(V2)>(vw, Bv, u, v[k]);  // uVelocity sampled at vUv: a LINEAR fetch on the sim grid
+            if (on[k]) miss += t[k].miss;
+        }
     }
     Fetch2 f2[ROWS];
-    gather_taps<ROWS>(vel, t, f2);
+    if constexpr (VT) {
+        // first taps (i0, j0[k]) and weights exactly as taps32 computes them
+        const float x = u * (float)vw.W - 0.5f, fi = floorf(x);
+        const int i0 = (int)fi;
+        int j0[ROWS];
+        float fyv[ROWS];
+#pragma unroll
+        for (int k = 0; k < ROWS; k++) {
+            const float y = v[k] * (float)vw.H - 0.5f, fj = floorf(y);
+            j0[k] = (int)fj;
+            fyv[k] = y - fj;
+        }
+        // the wave's run of sim texels: origin = the first lane's first tap (columns and rows only grow from there)
+        const int ib = __builtin_amdgcn_readfirstlane(i0), jb = __builtin_amdgcn_readfirstlane(j0[0]);
+        const int lane = (int)threadIdx.x & 63;
+        if (lane < VT_ROWS * VT_COLS) {
+            const int r = lane / VT_COLS, q = lane - r * VT_COLS;
+            const int lr = clampi(jb + r - vw.g0, 0, vw.rows - 1), lc = clampi(ib + q - vw.c0, 0, vw.P - 1);   // inside the array; a texel outside the tap box is never used
+            vtile[lane] = ld(vel, (size_t)lr * (size_t)vw.P + (size_t)lc);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int k = 0; k < ROWS; k++) {
+            const bool hit = (unsigned)(i0 - Bv.xlo) < Bv.nx && (unsigned)(j0[k] - Bv.ylo) < Bv.ny && (unsigned)(i0 - ib) < (unsigned)(VT_COLS - 1) &&
+                             (unsigned)(j0[k] - jb) < (unsigned)(VT_ROWS - 1);
+            if (hit) {
+                const int o = (j0[k] - jb) * VT_COLS + (i0 - ib);
+                f2[k].a = vtile[o];
+                f2[k].b = vtile[o + 1];
+                f2[k].c = vtile[o + VT_COLS];
+                f2[k].d = vtile[o + VT_COLS + 1];
+            } else {
+                const Tap4 tv = taps32<sizeof(V2)>(vw, Bv, u, v[k]);
+                if (on[k]) miss += tv.miss;
+                f2[k].a = ld(at_byte(vel, tv.a), 0); f2[k].b = ld(at_byte(vel, tv.b), 0); f2[k].c = ld(at_byte(vel, tv.c), 0); f2[k].d = ld(at_byte(vel, tv.d), 0);
+            }
+            f2[k].fx = x - fi;
+            f2[k].fy = fyv[k];
+        }
+    } else {
+        gather_taps<ROWS>(vel, t, f2);
+    }
 #pragma unroll
     for (int k = 0; k < ROWS; k++) {
         const Fetch2& f = f2[k];
@@ -566,6 +621,16 @@ __global__ void __launch_bounds__(BX) k_advect_dye_fast(Win vw, const V2* __rest
     advect_dye_fast_body<ROWS>(vw, vel, dw, dye, dye_out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss_out);
 }
 
+// ... with the velocity taps from the wave's LDS run (advect_dye_fast_body, VT)
+template <int ROWS>
+__global__ void __launch_bounds__(BX) k_advect_dye_fast_vt(Win vw, const float2* __restrict__ vel, Win dw, const float4* __restrict__ dye,
+                                                            float4* __restrict__ dye_out, float dt, double rW, double rH, double rdd, float tsx,
+                                                            float tsy, int ga, int gb, unsigned int* __restrict__ miss_out)
+{
+    __shared__ float2 vt[BX / 64][VT_ROWS * VT_COLS];
+    advect_dye_fast_body<ROWS, float2, float4, 1, true>(vw, vel, dw, dye, dye_out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss_out, vt[threadIdx.x >> 6]);
+}
+
 #ifdef FLUID_PROBES
 template <int ROWS, int WY>
 __global__ void __launch_bounds__(BX) k_advect_dye_fast_wy(Win vw, const float2* __restrict__ vel, Win dw, const float4* __restrict__ dye,
@@ -583,6 +648,15 @@ __global__ void __launch_bounds__(BX) k_advect_dye_fast_rgb(Win vw, const float2
                                                              float tsy, int ga, int gb, unsigned int* __restrict__ miss_out)
 {
     advect_dye_fast_body<ROWS>(vw, vel, dw, dye, dye_out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss_out);
+}
+
+template <int ROWS>
+__global__ void __launch_bounds__(BX) k_advect_dye_fast_rgb_vt(Win vw, const float2* __restrict__ vel, Win dw, const rgb3* __restrict__ dye,
+                                                                rgb3* __restrict__ dye_out, float dt, double rW, double rH, double rdd, float tsx,
+                                                                float tsy, int ga, int gb, unsigned int* __restrict__ miss_out)
+{
+    __shared__ float2 vt[BX / 64][VT_ROWS * VT_COLS];
+    advect_dye_fast_body<ROWS, float2, rgb3, 1, true>(vw, vel, dw, dye, dye_out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss_out, vt[threadIdx.x >> 6]);
 }
 
 template <int ROWS>
@@ -2287,6 +2361,16 @@ static int advect_wy()   // FLUID_ADVECT_WY (lab): 1 (default), 2 or 4 waves of 
 
 // texels per thread of the separate fast kernels: four, or fewer on small grids so that the launch still spreads over the chip
 // (FLUID_ADVECT_SPLIT_ROWS=1 / 2 / 4 forces one: A/B knob)
+// FLUID_VTILE=0 / 1 (lab build): the dye != sim advection gathers its velocity taps / reads them from the wave's LDS run (same bits)
+static bool velocity_tile()
+{
+    static const int mode = [] {
+        const char* e = lab_env("FLUID_VTILE");
+        return e ? (atoi(e) != 0 ? 1 : 0) : -1;
+    }();
+    return mode >= 0 ? mode == 1 : true;
+}
+
 static int split_advect_rows(long texels)
 {
     static const int forced = [] {
@@ -2296,6 +2380,16 @@ static int split_advect_rows(long texels)
     }();
     if (forced) return forced;
     return texels >= (1l << 20) ? 2 : 1;  // four rows per thread measured 10 % slower at 4096^2 (profiles/r03/shipping_rows.txt)
+}
+
+// ... of the kernels that read their velocity taps from the wave's LDS run (one run per wave whatever the rows): four rows from 6 M dye
+// texels (2816^2: 51.3 us against 54.7 with two; 4096^2 packed: 106.4 against 108.2), two from 1 M (2048^2: 26.0 against 27.6 with four),
+// one below (profiles/r04/dye_ne_sim_velocity_run_ab.txt)
+static int split_advect_rows_vt(long texels)
+{
+    static const bool forced = lab_env("FLUID_ADVECT_SPLIT_ROWS") != nullptr;   // (lab build)
+    if (forced) return split_advect_rows(texels);
+    return texels >= (6l << 20) ? 4 : (texels >= (1l << 20) ? 2 : 1);
 }
 
 template <class V2>
@@ -2339,14 +2433,30 @@ hipError_t launch_advect_dye_any(hipStream_t s, Win vw, const V2* vel, Win dw, c
             }
         }
 #endif
-        switch (split_advect_rows((long)(dw.x1 - dw.x0) * (gb - ga))) {
-#ifdef FLUID_PROBES
-        case 4: k_advect_dye_fast<4><<<dim3(gx, (gb - ga + 3) / 4, 1), BX, 0, s>>>(vw, vel, dw, dye, out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss); break;
-#endif
-        case 2: k_advect_dye_fast<2><<<dim3(gx, (gb - ga + 1) / 2, 1), BX, 0, s>>>(vw, vel, dw, dye, out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss); break;
-        default: k_advect_dye_fast<1><<<dim3(gx, gb - ga, 1), BX, 0, s>>>(vw, vel, dw, dye, out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss); break;
+        if constexpr (sizeof(V2) == sizeof(float2)) {
+            if (velocity_tile()) {
+                switch (split_advect_rows_vt((long)(dw.x1 - dw.x0) * (gb - ga))) {
+                case 4: k_advect_dye_fast_vt<4><<<dim3(gx, (gb - ga + 3) / 4, 1), BX, 0, s>>>(vw, vel, dw, dye, out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss); break;
+                case 2: k_advect_dye_fast_vt<2><<<dim3(gx, (gb - ga + 1) / 2, 1), BX, 0, s>>>(vw, vel, dw, dye, out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss); break;
+                default: k_advect_dye_fast_vt<1><<<dim3(gx, gb - ga, 1), BX, 0, s>>>(vw, vel, dw, dye, out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss); break;
+                }
+                return hipGetLastError();
+            }
         }
-        return hipGetLastError();
+#ifndef FLUID_PROBES
+        if constexpr (sizeof(V2) == sizeof(float2)) return hipErrorNotReady;   // (unreachable: the product library has no FLUID_VTILE=0)
+        else
+#endif
+        {
+            switch (split_advect_rows((long)(dw.x1 - dw.x0) * (gb - ga))) {
+#ifdef FLUID_PROBES
+            case 4: k_advect_dye_fast<4><<<dim3(gx, (gb - ga + 3) / 4, 1), BX, 0, s>>>(vw, vel, dw, dye, out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss); break;
+#endif
+            case 2: k_advect_dye_fast<2><<<dim3(gx, (gb - ga + 1) / 2, 1), BX, 0, s>>>(vw, vel, dw, dye, out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss); break;
+            default: k_advect_dye_fast<1><<<dim3(gx, gb - ga, 1), BX, 0, s>>>(vw, vel, dw, dye, out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss); break;
+            }
+            return hipGetLastError();
+        }
     }
     return hipErrorNotReady;
 }
@@ -2501,11 +2611,23 @@ hipError_t launch_advect_dye_rgb(hipStream_t s, Win vw, const float2* vel, Win d
         return hipErrorNotReady;
     const double rW = udiv_recip((float)dw.W), rH = udiv_recip((float)dw.H), rdd = udiv_recip(decay);
     const unsigned gx = (dw.x1 - dw.x0 + BX - 1) / BX;
+    if (velocity_tile()) {
+        switch (split_advect_rows_vt((long)(dw.x1 - dw.x0) * (gb - ga))) {
+        case 4: k_advect_dye_fast_rgb_vt<4><<<dim3(gx, (gb - ga + 3) / 4, 1), BX, 0, s>>>(vw, vel, dw, dye, out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss); break;
+        case 2: k_advect_dye_fast_rgb_vt<2><<<dim3(gx, (gb - ga + 1) / 2, 1), BX, 0, s>>>(vw, vel, dw, dye, out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss); break;
+        default: k_advect_dye_fast_rgb_vt<1><<<dim3(gx, gb - ga, 1), BX, 0, s>>>(vw, vel, dw, dye, out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss); break;
+        }
+        return hipGetLastError();
+    }
+#ifdef FLUID_PROBES
     if (split_advect_rows((long)(dw.x1 - dw.x0) * (gb - ga)) == 1)
         k_advect_dye_fast_rgb<1><<<dim3(gx, gb - ga, 1), BX, 0, s>>>(vw, vel, dw, dye, out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss);
     else
         k_advect_dye_fast_rgb<2><<<dim3(gx, (gb - ga + 1) / 2, 1), BX, 0, s>>>(vw, vel, dw, dye, out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss);
     return hipGetLastError();
+#else
+    return hipErrorNotReady;   // (unreachable: the product library has no FLUID_VTILE=0)
+#endif
 }
 
 hipError_t launch_splat_dye_rgb(hipStream_t s, Win w, const rgb3* base, rgb3* out, float x, float y, float aspect, float radius, float c0,
