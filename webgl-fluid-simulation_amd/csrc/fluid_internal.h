@@ -72,6 +72,9 @@ struct fluid_ctx {
     // stripe driver (fluid_stripes.cpp): RCCL communicator of the stripe set, exchange bookkeeping
     void* comm = nullptr;                // ncclComm_t, rank == desc.part, nranks == desc.parts
     hipStream_t comm_stream = nullptr;   // ghost rows travel here while the interior rows of the next pass compute
+    // lab (FLUID_JACOBI_CHAINS): a second stream and its events for the pressure loop cut into two row chains (pass_jacobi)
+    hipStream_t chain_stream = nullptr;
+    std::vector<hipEvent_t> chain_ev;
     hipEvent_t ev_ready = nullptr;       // context stream -> comm stream: the rows to send exist
     hipEvent_t ev_landed = nullptr;      // comm stream -> context stream: the ghost rows have arrived
     hipEvent_t ev_mid = nullptr;         // 2-D tiles: this tile's ghost columns are in (phase A), ghost rows may follow

@@ -276,6 +276,61 @@ bool jacobi_split_ok(const fluid_ctx* c, int iters, bool wants_gradsub, int marg
     return jacobi_split_launches(c, iters, wants_gradsub, sp) > 0;
 }
 
+#ifdef FLUID_PROBES
+// Lab (FLUID_JACOBI_CHAINS="rows fraction", e.g. 0.5): the pressure loop of a whole-domain context as TWO row chains on two streams.  Launch j
+// is cut at row m_j = M - 10 j: the lower part T_j = rows [0, m_j) reads nothing outside T_(j-1)'s output (one apron further up each
+// launch), so the T chain runs on its own; the upper part B_j = rows [m_j, H) follows B_(j-1) and T_(j-1).  What it is for: a launch is its
+// bytes over the bandwidth PLUS a fill / drain latency nothing overlaps (profiles/r03/jacobi_tail_probe.txt: ~10 us of 43.5) — with two
+// chains out of phase, one chain's fill / drain falls into the other's steady state.  Same iterations over the same texels, same bits.
+static double jacobi_chains()
+{
+    static const double f = [] {
+        const char* e = fluid::lab_env("FLUID_JACOBI_CHAINS");
+        const double v = e ? atof(e) : 0.0;
+        return v > 0.0 && v < 1.0 ? v : 0.0;
+    }();
+    return f;
+}
+
+static int pass_jacobi_chains(fluid_ctx* c, int iters, float pscale, int shape, int* launches)
+{
+    const int depth = jacobi_tb_depth(shape), L = (iters + depth - 1) / depth;
+    if (!c->chain_stream) {
+        HIPCK(c, hipStreamCreateWithFlags(&c->chain_stream, hipStreamNonBlocking));
+    }
+    while ((int)c->chain_ev.size() < L + 2) {
+        hipEvent_t e;
+        HIPCK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->chain_ev.push_back(e);
+    }
+    int ga, gb;
+    row_range(c->sim, c->sim_row0, c->sim_rows, 0, ga, gb);
+    const int M = ga + (int)((gb - ga) * jacobi_chains());
+    const Win w = sim_cols(c, 0);
+    HIPCK(c, hipEventRecord(c->chain_ev[L], c->stream));           // everything in front of the loop
+    HIPCK(c, hipStreamWaitEvent(c->chain_stream, c->chain_ev[L], 0));
+    int done = 0, left = L;
+    void *src = c->prs[0], *dst = c->prs[1];
+    for (int j = 0; j < L; j++) {
+        const int k = (iters - done + left - 1) / left;
+        left--;
+        const int m = M - depth * j;
+        const float ps = j == 0 ? pscale : 1.0f;
+        CK(c->hip(fluid::launch_jacobi_tb(c->stream, w, (const float*)src, (const float*)c->div, (float*)dst, ps, k, ga, m, shape), "jacobi_tb (lower chain)"));
+        HIPCK(c, hipEventRecord(c->chain_ev[j], c->stream));
+        if (j > 0) HIPCK(c, hipStreamWaitEvent(c->chain_stream, c->chain_ev[j - 1], 0));
+        CK(c->hip(fluid::launch_jacobi_tb(c->chain_stream, w, (const float*)src, (const float*)c->div, (float*)dst, ps, k, m, gb, shape), "jacobi_tb (upper chain)"));
+        std::swap(src, dst);
+        done += k;
+        if (launches) (*launches)++;
+    }
+    HIPCK(c, hipEventRecord(c->chain_ev[L + 1], c->chain_stream));
+    HIPCK(c, hipStreamWaitEvent(c->stream, c->chain_ev[L + 1], 0));
+    if (L & 1) std::swap(c->prs[0], c->prs[1]);
+    return FLUID_OK;
+}
+#endif
+
 int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launches, bool* gradsub, Timer* t, const JacobiSplit* sp)
 {
     const int split = sp ? sp->mode : 0;
@@ -292,6 +347,12 @@ int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launche
     // balanced blocks: ceil(iters / max) launches of nearly equal depth (50 with max 8 -> 8,7,7,7,7,7,7)
     const int tb_max = tb ? jacobi_tb_depth(shape) : 1;
     int launches_left = tb ? (iters + tb_max - 1) / tb_max : iters;
+#ifdef FLUID_PROBES
+    if (tb && !split && !fold && !c->timing && jacobi_chains() > 0.0 && c->storage == FLUID_STORE_F32 && c->desc.parts == 1 && c->desc.parts_x == 1 && ext_out == 0 &&
+        launches_left >= 2 && (int)(c->sim_rows * jacobi_chains()) > tb_max * (launches_left + 4) &&
+        (int)(c->sim_rows * (1.0 - jacobi_chains())) > 4 * tb_max)
+        return pass_jacobi_chains(c, iters, pscale, shape, launches);
+#endif
     int cut_left = split && tb ? sp->cover : 0, level = 0;   // leading launches still to cut (split 1 / 2)
     void *pa = c->prs[0], *pb = c->prs[1];               // split 1: the interiors ping-pong here; the context's pair swaps when the frames run
     while (done < iters) {
@@ -867,6 +928,8 @@ int fluid_destroy(fluid_ctx* c)
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
     for (auto& e : c->marks) (void)hipEventDestroy(e);
+    for (auto& e : c->chain_ev) (void)hipEventDestroy(e);
+    if (c->chain_stream) (void)hipStreamDestroy(c->chain_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return FLUID_OK;
