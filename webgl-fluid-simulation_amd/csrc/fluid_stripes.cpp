@@ -259,16 +259,28 @@ int nccl_fail(fluid_ctx* c, const Rccl* R, ncclResult_t e, const char* what)
 // whatever does not read the ghost rows in flight.  begin + end back to back is the plain synchronous exchange.
 int ensure_comm_stream(fluid_ctx* c)
 {
-    if (c->comm_stream) return FLUID_OK;
+    // A context that exchanges over RCCL (one process per GPU) gets its comm stream at the HIGHEST stream priority: what runs there — the
+    // pack / unpack launches of a tile exchange, RCCL's own send / receive kernels — is small and sits on the step's critical path, while
+    // the context stream floods the chip with the interior rows of the next pass.  At equal priority those few workgroups wait for the big
+    // launch's workgroups to retire one by one (every register of a CU is taken), and a 60 us link cost the centre tile of 3 x 3 +29 %
+    // per step instead of +24.5 % (profiles/r04/overlap_vs_link_latency_visit6_two_rounds.txt).
+    // The contexts of an in-process group (fluid_group_step_n: a whole stripe set on ONE device) keep the default priority: a priority
+    // stream takes hardware queues of its own, and four contexts with two queues each oversubscribe them — the same group stepped 21 %
+    // slower with overlap and 74 % slower without (2.02 -> 2.44 / 2.00 -> 3.48 ms, profiles/r04/group_priority_streams.txt).
+    const bool high = c->comm != nullptr;
+    if (c->comm_stream && c->comm_stream_high == high) return FLUID_OK;
     HIPCK(c, hipSetDevice(c->device));
-    // The HIGHEST stream priority: what runs here — the pack / unpack launches of a tile exchange, RCCL's own send / receive kernels — is
-    // small and sits on the step's critical path, while the context stream floods the chip with the interior rows of the next pass.  At
-    // equal priority those few workgroups wait for the big launch's workgroups to retire one by one (every register of a CU is taken), and a
-    // 60 us link costs the centre tile of 3 x 3 +29 % per step instead of the +10 % its interior compute leaves exposed
-    // (profiles/r04/overlap_vs_link_latency.txt).
+    if (c->comm_stream) {   // created before the communicator was (fluid_set_overlap): once more, at the other priority
+        HIPCK(c, hipStreamSynchronize(c->comm_stream));
+        HIPCK(c, hipStreamDestroy(c->comm_stream));
+        c->comm_stream = nullptr;
+    }
     int prio_least = 0, prio_greatest = 0;
     HIPCK(c, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-    HIPCK(c, hipStreamCreateWithPriority(&c->comm_stream, hipStreamNonBlocking, prio_greatest));
+    if (high) HIPCK(c, hipStreamCreateWithPriority(&c->comm_stream, hipStreamNonBlocking, prio_greatest));
+    else HIPCK(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    c->comm_stream_high = high;
+    if (c->ev_ready) return FLUID_OK;   // the events outlive the stream
     HIPCK(c, hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
     HIPCK(c, hipEventCreateWithFlags(&c->ev_landed, hipEventDisableTiming));
     HIPCK(c, hipEventCreateWithFlags(&c->ev_mid, hipEventDisableTiming));
