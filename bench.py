@@ -276,19 +276,33 @@ class Watchdog:
     def __init__(self, fd, seconds, base):
         import threading
         self.fd, self.seconds, self.base, self.stage = fd, seconds, base, "start"
+        self.result = None   # the finished headline measurement: what hangs BEHIND it (an extra configuration) must not take it away
+        self.deadline = time.time() + seconds   # every stage gets `seconds` of its own (at() moves it)
         self.done = threading.Event()
         self.t = threading.Thread(target=self._run, daemon=True)
         self.t.start()
 
     def _run(self):
-        if not self.done.wait(self.seconds):
-            out = dict(self.base, value=None, error="watchdog: stage '%s' did not complete within %.0f s on rank %s"
-                       % (self.stage, self.seconds, os.environ.get("RANK", "0")))
+        while not self.done.wait(0.5):
+            if time.time() < self.deadline:
+                continue
+            msg = "watchdog: stage '%s' did not complete within %.0f s on rank %s" % (self.stage, self.seconds, os.environ.get("RANK", "0"))
+            if self.result is not None:   # the weak-scaling number stands; the line says what did not finish behind it
+                if os.environ.get("RANK", "0") == "0":
+                    out = dict(self.result)
+                    out["extra_configs"] = list(out.get("extra_configs", [])) + [{"error": msg}]
+                    out.setdefault("parity_in_run", "not run: " + msg)
+                    os.write(self.fd, (json.dumps(out) + "\n").encode())
+                    os._exit(0)
+                time.sleep(3.0)   # rank 0 prints the line first; a launcher that sees a failed worker ends the others
+                os._exit(3)
+            out = dict(self.base, value=None, error=msg)
             os.write(self.fd, (json.dumps(out) + "\n").encode())
             os._exit(3)
 
     def at(self, stage):
         self.stage = stage
+        self.deadline = time.time() + self.seconds
 
     def stop(self):
         self.done.set()
@@ -518,8 +532,9 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         eng = getattr(sm, "engine", None)
         return eng if (eng is not None and hasattr(eng, "set_step_marks") and getattr(sm, "native", False)) else None
 
-    def measure(sm, warmup, steps, label):
-        """`warmup` untimed steps, then EXACTLY `steps` steps bracketed by sync + barrier + sync; MAX over ranks"""
+    def measure(sm, warmup, steps, label, fatal=True):
+        """`warmup` untimed steps, then EXACTLY `steps` steps bracketed by sync + barrier + sync; MAX over ranks.
+        fatal=False (the extra configurations behind the headline measurement): a failure comes back as a string instead of ending the run"""
         def sync():
             sm.sync()
             dev_sync()
@@ -540,10 +555,12 @@ def main(argv=None, engine_factory=None, backend="nccl"):
             elapsed = time.perf_counter() - t0
             if N > 1:
                 sm.check_halo()
-        except fluid_hip.FluidError as ex:
-            err, elapsed = "step failed on rank %d: %s" % (rank, ex), 0.0
+        except Exception as ex:   # FluidError from the library, or anything a hosted driver raises: ONE line either way
+            err, elapsed = "step failed on rank %d: %s: %s" % (rank, type(ex).__name__, str(ex)[:300]), 0.0
         err = agree(err)
         if err:
+            if not fatal:
+                return err
             if dog:
                 dog.stop()
             fail(err, code=5)
@@ -629,6 +646,8 @@ def main(argv=None, engine_factory=None, backend="nccl"):
             plans = {4: ["8192,50,2"], 8: ["16384,200,1"]}.get(N, [])
         plans = [] if plans == ["none"] else plans
         extra = []
+        if dog:
+            dog.result = out   # from here on a hang or a failure belongs to an extra configuration: the headline number above is kept
         for spec in plans:
             f = [int(x) for x in spec.split(",")]
             esize, eiters, etx = f[0], f[1], max(1, f[2] if len(f) > 2 else 1)
@@ -653,7 +672,11 @@ def main(argv=None, engine_factory=None, backend="nccl"):
                 if problem.startswith("set-up failed"):
                     sim = None
                 break
-            el = measure(sim, entry["warmup"], esteps, name)
+            el = measure(sim, entry["warmup"], esteps, name, fatal=False)
+            if isinstance(el, str):
+                entry["error"] = el
+                extra.append(entry)
+                break
             sps = esteps / el
             eb = algorithmic_bytes_per_cell(eiters) * float(esize) * esize * half
             entry.update({"value": round(float(esize) * esize * sps / 1e9, 4), "unit": "GLUPS", "steps_per_sec": round(sps, 3),

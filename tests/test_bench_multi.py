@@ -125,3 +125,37 @@ def test_bench_refuses_an_rccl_stand_in(tmp_path):
     assert r.returncode != 0 and len(lines) == 1
     d = json.loads(lines[0])
     assert d["value"] is None and "FLUID_RCCL_LIB" in d["error"]
+
+
+def test_bench_extra_config_that_cannot_be_set_up_leaves_the_headline_alone(oracle, tmp_path):
+    """an extra configuration whose set-up fails (here: stripes thinner than the ghost zone) is reported under `extra_configs`; the
+    weak-scaling number measured in front of it stands"""
+    import torch.multiprocessing as mp
+    argv = ["--gpus", "2", "--size", "64", "--iters", "20", "--steps", "3", "--warmup", "1", "--halo", "8", "--cpu-budget", "0", "--comm-timeout", "100",
+            "--extra-config", "8,10,1,2"]
+    mp.spawn(_rank, args=(2, _free_port(), str(tmp_path), argv), nprocs=2, join=True)
+    lines0 = [l for l in open(os.path.join(str(tmp_path), "stdout_0.txt")).read().splitlines() if l.strip()]
+    assert len(lines0) == 1
+    d = json.loads(lines0[0])
+    assert "error" not in d and d["value"] > 0 and abs(d["value"] - 64 * 128 * d["steps_per_sec"] / 1e9) <= 1e-4
+    (e,) = d["extra_configs"]
+    assert "error" in e and "value" not in e
+
+
+@pytest.mark.parametrize("with_result", [False, True])
+def test_bench_watchdog_keeps_a_finished_headline(with_result):
+    """N > 1: a stage that does not complete ends the run with ONE line.  In front of the headline measurement that line is an error
+    record; behind it (an extra configuration that hangs) it is the headline line, with the stage that hung under `extra_configs`"""
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "d = bench.Watchdog(1, 0.3, {'metric': 'm', 'n_gpus': 2})\n"
+            "d.at('set-up')\n"
+            "%s"
+            "time.sleep(20)\n") % (ROOT, "d.result = {'metric': 'm', 'n_gpus': 2, 'value': 1.5}; d.at('configs[4]: the timed 10 steps')\n" if with_result else "")
+    r = subprocess.run([sys.executable, "-c", code], env=dict(_clean_env(), RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, (lines, r.stderr.decode()[-500:])
+    d = json.loads(lines[0])
+    if with_result:
+        assert r.returncode == 0 and d["value"] == 1.5 and "configs[4]" in d["extra_configs"][0]["error"] and "not run" in d["parity_in_run"]
+    else:
+        assert r.returncode == 3 and d["value"] is None and "set-up" in d["error"]
