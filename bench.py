@@ -406,6 +406,8 @@ def main(argv=None, engine_factory=None, backend="nccl"):
                          "of >= 1 ms the MI355X answers a load step by dropping its shader clock from 2.4 to ~1.8 GHz for a few milliseconds and "
                          "ramping back over ~15 ms (profiles/r04/first_steps.txt: measured from inside the stream, touched or untouched buffers "
                          "alike); `--steps 20 --warmup 5` is 13 ms of work, all of it inside that dip.  The line reports the window without it as well (`cold_start`)")
+    ap.add_argument("--no-step-marks", action="store_true", help="no events between the timed steps (`timed_window_regime` is then absent): "
+                                                                  "the A/B of what the marks cost")
     ap.add_argument("--comm-timeout", type=float, default=120.0, help="N > 1: seconds the communicator set-up and the warm-up steps may take "
                                                                      "before the watchdog reports which stage hung")
     args = ap.parse_args(argv)
@@ -542,7 +544,7 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         if dog:
             dog.at("%s: warm-up, %d steps (the first ghost-row exchanges over RCCL / xGMI)" % (label, warmup))
         try:
-            if marks_of(sm) is not None and steps <= 512:
+            if marks_of(sm) is not None and steps <= 512 and not args.no_step_marks:
                 marks_of(sm).set_step_marks(steps)   # events between the steps, nobody waits for them: `timed_window_regime`
             preload()
             sm.step(DT, warmup)   # N > 1, native driver: the plan and its RCCL exchanges run inside libfluid_hip.so
@@ -579,7 +581,7 @@ def main(argv=None, engine_factory=None, backend="nccl"):
 
     elapsed = measure(sim, args.warmup, args.steps, "headline")
     regime = None
-    if rank == 0 and marks_of(sim) is not None and args.steps <= 512:
+    if rank == 0 and marks_of(sim) is not None and args.steps <= 512 and not args.no_step_marks:
         per = marks_of(sim).step_marks()
         marks_of(sim).set_step_marks(0)
         if per:

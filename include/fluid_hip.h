@@ -323,7 +323,8 @@ typedef struct fluid_schedule_info {
 int fluid_schedule_info_get(fluid_ctx *ctx, int n_steps, float dt, const fluid_params *params, fluid_schedule_info *out);
 
 /* Step marks (since ABI 8): one event on the context's stream in front of the first and behind every step of the NEXT fluid_step_n /
- * fluid_group_step_n calls (the first `capacity` steps of each call; 0 switches the marks off).  Unlike fluid_set_timing nothing waits:
+ * fluid_group_step_n calls (the first `capacity` steps of each call; 0 switches the marks off).  Timing-only events (no system-scope
+ * fence when one is recorded: with default events every mark cost the stream 6 us).  Unlike fluid_set_timing nothing waits:
  * the stream runs exactly as it does unmarked, so the marks show how a step's time develops INSIDE a timed window (bench.py
  * `timed_window_regime`: the first steps after an idle run slower than the steady state).  fluid_get_step_marks waits for the last
  * mark of the last call and returns the device time of each of its marked steps in milliseconds. */
