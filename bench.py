@@ -406,6 +406,9 @@ def main(argv=None, engine_factory=None, backend="nccl"):
                          "of >= 1 ms the MI355X answers a load step by dropping its shader clock from 2.4 to ~1.8 GHz for a few milliseconds and "
                          "ramping back over ~15 ms (profiles/r04/first_steps.txt: measured from inside the stream, touched or untouched buffers "
                          "alike); `--steps 20 --warmup 5` is 13 ms of work, all of it inside that dip.  The line reports the window without it as well (`cold_start`)")
+    ap.add_argument("--link-model", default=None, metavar="US,GBPS", help="N > 1: what one neighbour message costs on this machine's links (latency in us, "
+                    "GB/s; fluid_set_link_model — sizes how much compute the driver puts in front of an exchange's arrival; default: the "
+                    "library's 20 us, 50 GB/s).  Recorded in config.link_model")
     ap.add_argument("--no-step-marks", action="store_true", help="no events between the timed steps (`timed_window_regime` is then absent): "
                                                                   "the A/B of what the marks cost")
     ap.add_argument("--comm-timeout", type=float, default=120.0, help="N > 1: seconds the communicator set-up and the warm-up steps may take "
@@ -459,7 +462,8 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         from fluid_hip.stripes import StripeSim
         c = dict(cfg, SIM_RESOLUTION=min(gw, gh), DYE_RESOLUTION=min(gw, gh), PRESSURE_ITERATIONS=its)
         kw = dict(engine_factory=engine_factory) if on_cpu else dict(native=not args.hosted, tiles_x=tx, storage=args.storage,
-                                                                    reach=min(args.reach, args.halo))
+                                                                    reach=min(args.reach, args.halo),
+                                                                    link_model=tuple(float(x) for x in args.link_model.split(",")) if args.link_model else None)
         return StripeSim(canvas=(gw, gh), config=c, halo=args.halo, schedule=args.schedule, random=fluid_hip.mulberry32(1234),
                          device=local_rank, **kw)
 
@@ -639,6 +643,7 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         out["config"]["driver"] = "native plan + ncclSend/ncclRecv inside libfluid_hip.so" if sim.native else "hosted: torch.distributed batch_isend_irecv"
         if sim.native:
             out["config"]["advect_exchange_rows"] = list(sim.engine.advect_exchange_rows())
+            out["config"]["link_model"] = args.link_model or "library default (20 us + bytes / 50 GB/s per neighbour message)"
 
     # ---- N > 1: BASELINE.json's own multi-GPU configurations, strong scaling, after the weak-scaling measurement (`value` above is
     #      untouched: the driver's scaling curve is computed from it) ----

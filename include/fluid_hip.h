@@ -252,6 +252,12 @@ int fluid_set_reach(fluid_ctx *ctx, int rows);
 int fluid_advect_exchange_rows(const fluid_ctx *ctx, int *velocity_rows, int *dye_rows);
 /* interior-first overlap of the exchanges with the curl/vorticity/divergence and advection kernels (default on) */
 int fluid_set_overlap(fluid_ctx *ctx, int enabled);
+/* What one neighbour message costs on this machine's links: latency_us + bytes / gbytes_per_s (default 20 us, 50 GB/s: an RCCL
+ * point-to-point message of a few MB over one xGMI link).  With the overlap on, the driver also cuts the leading launch(es) of a
+ * pressure block behind an exchange — their interior computes while the ghost texels travel — and sizes that cut (0, 1 or 2
+ * launches, each at the price of one thin launch) with this figure; nothing but speed depends on it.  Every rank of a set may
+ * keep its own.  Since ABI 8. */
+int fluid_set_link_model(fluid_ctx *ctx, float latency_us, float gbytes_per_s);
 
 typedef struct fluid_comm_id {
     char bytes[128]; /* an ncclUniqueId */

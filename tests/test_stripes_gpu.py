@@ -362,3 +362,40 @@ def test_overlap_probe_runs_one_rank_in_loopback():
         out[delay] = json.loads(lines[-1])
         assert out[delay]["ok"] and out[delay]["exchanges_per_step"] == 2.0
     assert out[200]["ms_per_step"] - out[0]["ms_per_step"] > 0.35, out
+
+
+@pytest.mark.parametrize("link", [(0.0, 1e6), (5000.0, 1.0)])
+@pytest.mark.parametrize("ty,tx,halo,iters", [(4, 1, 24, 50), (2, 2, 56, 50), (3, 3, 16, 30)])
+def test_link_model_changes_the_schedule_not_the_bits(ty, tx, halo, iters, link):
+    """fluid_set_link_model sizes how many leading Jacobi launches are cut around an exchange (an instantaneous link: none behind the
+    step's first exchange, one behind a pressure exchange; a very slow one: two wherever the tile is large enough) — speed only: the
+    decomposed run equals the single domain bit for bit either way"""
+    import fluid_hip
+    from fluid_hip.stripes import StripeGroup
+    cfg = {"SIM_RESOLUTION": 576, "DYE_RESOLUTION": 576, "PRESSURE_ITERATIONS": iters}
+    with fluid_hip.FluidSim(canvas=(576, 576), config=cfg, random=fluid_hip.mulberry32(11)) as one:
+        one.multipleSplats(6)
+        one.step(0.016666, 2)
+        want = one.fields()
+    g = StripeGroup(ty * tx, canvas=(576, 576), config=cfg, halo=halo, random=fluid_hip.mulberry32(11), tiles_x=tx, link_model=link)
+    try:
+        g.multipleSplats(6)
+        g.step(0.016666, 2)
+        g.check_halo()
+        for k in S.FIELDS:
+            assert np.array_equal(g.read(k), want[k]), (k, ty, tx, link)
+    finally:
+        g.close()
+
+
+def test_link_model_rejects_nonsense():
+    import fluid_hip
+    from fluid_hip.stripes import StripeGroup
+    g = StripeGroup(2, canvas=(256, 256), config={"SIM_RESOLUTION": 256, "DYE_RESOLUTION": 256}, halo=16)
+    try:
+        with pytest.raises(fluid_hip.FluidError):
+            g.engines[0].set_link_model(-1.0, 50.0)
+        with pytest.raises(fluid_hip.FluidError):
+            g.engines[0].set_link_model(20.0, 0.0)
+    finally:
+        g.close()

@@ -72,6 +72,7 @@ struct fluid_ctx {
     // stripe driver (fluid_stripes.cpp): RCCL communicator of the stripe set, exchange bookkeeping
     void* comm = nullptr;                // ncclComm_t, rank == desc.part, nranks == desc.parts
     hipStream_t comm_stream = nullptr;   // ghost rows travel here while the interior rows of the next pass compute
+    float link_lat_us = 20.0f, link_gbps = 50.0f;   // one neighbour message: latency + bytes / bandwidth (fluid_set_link_model)
     bool comm_stream_high = false;       // created at the highest stream priority (contexts with an RCCL communicator: ensure_comm_stream)
     // lab (FLUID_JACOBI_CHAINS): a second stream and its events for the pressure loop cut into two row chains (pass_jacobi)
     hipStream_t chain_stream = nullptr;

@@ -781,22 +781,22 @@ bool jacobi_overlap_ok(const fluid_ctx* c, const std::vector<fluid_stripe_op>& o
 // of a tile exchange, against what a launch takes at the rates this library measures on the MI355X (profiles/r04: the Jacobi launch moves
 // 13.2 B/texel at 5.0 TB/s, the curl / vorticity / divergence pass 20 B/texel at 5.0 TB/s).  Nothing breaks when the guess is off: a
 // longer exchange shows, a shorter one has paid for a frame launch it did not need (profiles/r04/overlap_vs_link_latency.txt has both).
-// FLUID_LINK_MODEL="us,GB/s" (lab build) replaces the two constants.
+// fluid_set_link_model() replaces the two constants for a context; FLUID_LINK_MODEL="us,GB/s" (lab build) for the process.
 struct LinkModel {
     double lat_us, gbps;
 };
 
-LinkModel link_model()
+LinkModel link_model(const fluid_ctx* c)
 {
-    static const LinkModel m = [] {
-        LinkModel v{ 20.0, 50.0 };
+    static const LinkModel forced = [] {
+        LinkModel v{ -1.0, -1.0 };
         if (const char* e = fluid::lab_env("FLUID_LINK_MODEL")) {
             double a = 0, b = 0;
             if (sscanf(e, "%lf,%lf", &a, &b) == 2 && a >= 0 && b > 0) v = LinkModel{ a, b };
         }
         return v;
     }();
-    return m;
+    return forced.gbps > 0 ? forced : LinkModel{ (double)c->link_lat_us, (double)c->link_gbps };
 }
 
 double exchange_us(fluid_ctx* c, const fluid_stripe_op& op)
@@ -810,7 +810,7 @@ double exchange_us(fluid_ctx* c, const fluid_stripe_op& op)
         rows_msg += (double)op.rows[i] * (tiles ? f.cols : f.win->P) * texel;
         if (tiles) cols_msg += (double)f.rows * col_depth(c, f, op.rows[i]) * texel;
     }
-    const LinkModel m = link_model();
+    const LinkModel m = link_model(c);
     return m.lat_us + std::max(rows_msg, cols_msg) / (m.gbps * 1e3) + (tiles ? 30.0 : 0.0);
 }
 
@@ -1007,6 +1007,15 @@ int fluid_set_reach(fluid_ctx* c, int rows)
     if (!c) return FLUID_ERR_INVALID;
     if (rows < 1) return c->fail(FLUID_ERR_INVALID, "reach must be >= 1 row");
     c->reach = rows;
+    return FLUID_OK;
+}
+
+int fluid_set_link_model(fluid_ctx* c, float latency_us, float gbytes_per_s)
+{
+    if (!c) return FLUID_ERR_INVALID;
+    if (!(latency_us >= 0.0f) || !(gbytes_per_s > 0.0f)) return c->fail(FLUID_ERR_INVALID, "link model: latency >= 0 us, bandwidth > 0 GB/s");
+    c->link_lat_us = latency_us;
+    c->link_gbps = gbytes_per_s;
     return FLUID_OK;
 }
 

@@ -118,6 +118,7 @@ SYMBOLS = {
     "fluid_set_reach": (_I, [_CTX, _I]),
     "fluid_advect_exchange_rows": (_I, [_CTX, C.POINTER(_I), C.POINTER(_I)]),
     "fluid_set_overlap": (_I, [_CTX, _I]),
+    "fluid_set_link_model": (_I, [_CTX, _F, _F]),
     "fluid_comm_set_library": (_I, [C.c_char_p]),
     "fluid_comm_unique_id": (_I, [C.POINTER(CommId)]),
     "fluid_comm_init": (_I, [_CTX, C.POINTER(CommId)]),

@@ -178,6 +178,7 @@ class HipStripeEngine:
 
     def set_reach(self, rows): self._ck(self.lib.fluid_set_reach(self.ctx, int(rows)))
     def set_overlap(self, on): self._ck(self.lib.fluid_set_overlap(self.ctx, 1 if on else 0))
+    def set_link_model(self, latency_us, gbytes_per_s): self._ck(self.lib.fluid_set_link_model(self.ctx, float(latency_us), float(gbytes_per_s)))
 
     def advect_exchange_rows(self):
         a, b = C.c_int(0), C.c_int(0)
@@ -287,9 +288,11 @@ class StripeSim:
     def __init__(self, canvas=(512, 512), config: Optional[dict] = None, halo: int = 32, schedule: str = "fused",
                  random: Optional[Callable[[], float]] = None, device: int = 0, comm=None,
                  engine_factory: Optional[Callable] = None, native: Optional[bool] = None, reach: Optional[int] = None,
-                 overlap: Optional[bool] = None, tiles_x: int = 1, storage: str = "f32"):
+                 overlap: Optional[bool] = None, tiles_x: int = 1, storage: str = "f32", link_model=None):
         """tiles_x > 1: 2-D decomposition, world // tiles_x row stripes x tiles_x column tiles, rank = stripe * tiles_x +
-        tile column (native driver only; the hosted schedule below is 1-D)"""
+        tile column (native driver only; the hosted schedule below is 1-D).  link_model = (latency_us, GB/s) of one neighbour
+        message (fluid_set_link_model: sizes how much compute the native driver puts in front of an exchange's arrival)"""
+        self._link_model = link_model
         self.canvas = canvas if isinstance(canvas, Canvas) else Canvas(*canvas)
         self.config = dict(DEFAULT_CONFIG)
         if config:
@@ -345,6 +348,8 @@ class StripeSim:
             self.engine.set_reach(reach)
         if overlap is not None:
             self.engine.set_overlap(overlap)
+        if getattr(self, "_link_model", None) is not None:
+            self.engine.set_link_model(*self._link_model)
         payload = None
         if self.rank == 0:   # a failure on rank 0 must reach every rank, or they would wait in the broadcast forever
             try:
@@ -477,8 +482,9 @@ class StripeGroup:
 
     def __init__(self, world: int, canvas=(512, 512), config: Optional[dict] = None, halo: int = 32, schedule: str = "fused",
                  random: Optional[Callable[[], float]] = None, device: int = 0, reach: Optional[int] = None,
-                 overlap: Optional[bool] = None, tiles_x: int = 1, storage: str = "f32"):
-        """`world` contexts: world // tiles_x row stripes x tiles_x column tiles (tiles_x = 1: the 1-D stripe set)"""
+                 overlap: Optional[bool] = None, tiles_x: int = 1, storage: str = "f32", link_model=None):
+        """`world` contexts: world // tiles_x row stripes x tiles_x column tiles (tiles_x = 1: the 1-D stripe set);
+        link_model = (latency_us, GB/s): fluid_set_link_model on every context"""
         if world % tiles_x:
             raise ValueError("world must be a multiple of tiles_x")
         self.tiles_x, self.tiles_y = tiles_x, world // tiles_x
@@ -500,6 +506,8 @@ class StripeGroup:
                 e.set_reach(reach)
             if overlap is not None:
                 e.set_overlap(overlap)
+            if link_model is not None:
+                e.set_link_model(*link_model)
         self.lib = _abi.lib()
 
     def close(self):
