@@ -196,6 +196,7 @@ function createFluid (options) {
             handle = native.createTile(simRes.width, simRes.height, dyeRes.width, dyeRes.height, device, schedule,
                 Math.floor(t.rank / tilesX), t.world / tilesX, t.rank % tilesX, tilesX, t.halo === undefined ? 56 : t.halo, storage);
             if (t.reach !== undefined) native.setReach(handle, t.reach);
+            if (t.linkModel !== undefined) native.setLinkModel(handle, t.linkModel[0], t.linkModel[1]);   // [latency us, GB/s] of one neighbour message
             // FLUID_TRACE_COMM: marker lines on stderr around the one call that talks to RCCL (ncclCommInitRank), so that a wedged
             // communicator bootstrap on a box can be told from a hang in this library (tests/test_node_shim.py)
             const trace = !!process.env.FLUID_TRACE_COMM;

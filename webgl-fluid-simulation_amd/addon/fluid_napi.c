@@ -204,6 +204,17 @@ static napi_value n_set_reach(napi_env env, napi_callback_info info)
     return rc == FLUID_OK ? NULL : throw_status(env, c, rc);
 }
 
+/* setLinkModel(h, latencyUs, gbytesPerS): what one neighbour message costs on this machine's links (fluid_set_link_model) */
+static napi_value n_set_link_model(napi_env env, napi_callback_info info)
+{
+    napi_value a[3];
+    fluid_ctx *c;
+    float lat, gbps;
+    if (!get_args(env, info, 3, a) || !get_ctx(env, a[0], &c) || !get_f(env, a[1], &lat) || !get_f(env, a[2], &gbps)) return NULL;
+    int rc = fluid_set_link_model(c, lat, gbps);
+    return rc == FLUID_OK ? NULL : throw_status(env, c, rc);
+}
+
 /* haloCheck(h): throws (code -5) if an advection back-trace left the refreshed ghost rows / columns */
 static napi_value n_halo_check(napi_env env, napi_callback_info info)
 {
@@ -554,6 +565,7 @@ static napi_value init(napi_env env, napi_value exports)
         { "setTiming", n_set_timing }, { "getTimings", n_get_timings },
         { "setDither", n_set_dither }, { "render", n_render }, { "readFrame", n_read_frame }, { "readFrameRgba8", n_read_frame_rgba8 },
         { "scheduleInfo", n_schedule_info }, { "setStepMarks", n_set_step_marks }, { "getStepMarks", n_get_step_marks },
+        { "setLinkModel", n_set_link_model },
     };
     for (size_t k = 0; k < sizeof fns / sizeof fns[0]; k++) {
         napi_value f;
