@@ -281,9 +281,16 @@ int ensure_comm_stream(fluid_ctx* c)
     else HIPCK(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
     c->comm_stream_high = high;
     if (c->ev_ready) return FLUID_OK;   // the events outlive the stream
-    HIPCK(c, hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
-    HIPCK(c, hipEventCreateWithFlags(&c->ev_landed, hipEventDisableTiming));
-    HIPCK(c, hipEventCreateWithFlags(&c->ev_mid, hipEventDisableTiming));
+    // FLUID_EVENT_SCOPE=device (lab build): the three events without a system-scope fence (hipEventDisableSystemFence).  On one GPU that
+    // removes the 6-7 us of idle each record / wait on the context stream costs (profiles/r04/stripe_rank_timeline.txt); whether it is
+    // safe between GPUs depends on RCCL never letting the peer device touch the field memory directly, which no one-GPU test can see —
+    // a probe for the first multi-GPU box, not a product setting.
+    unsigned ev_flags = hipEventDisableTiming;
+    if (const char* e = fluid::lab_env("FLUID_EVENT_SCOPE"))
+        if (e[0] == 'd') ev_flags |= hipEventDisableSystemFence;
+    HIPCK(c, hipEventCreateWithFlags(&c->ev_ready, ev_flags));
+    HIPCK(c, hipEventCreateWithFlags(&c->ev_landed, ev_flags));
+    HIPCK(c, hipEventCreateWithFlags(&c->ev_mid, ev_flags));
     if (const char* e = fluid::lab_env("FLUID_STRIPE_OVERLAP")) c->overlap = atoi(e) != 0;
     return FLUID_OK;
 }
