@@ -7,6 +7,7 @@
 // There is NO CPU path here: without a HIP device fluid_create() fails.
 #include "../../include/fluid_hip.h"
 #include "fluid_internal.h"
+#include "fluid_cut.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -219,29 +220,13 @@ int pass_clear(fluid_ctx* c, float value, int ext)
 // cut differently).  `margin` = 0 behind a pressure-only exchange (the divergence is complete); 3 when the divergence itself is only
 // there on the interior of the curl / vorticity / divergence pass in front (a divergence texel reads velocity 3 texels away; columns go
 // by whole float4 groups: 4).  jacobi_split_ok() says whether a block can be cut this way.
-struct JacobiCut {
-    int ia, ib, ja, jb;   // the interior of the first launch: rows [ia, ib) x columns [ja, jb)
-};
-
-// `level`: 1 for the block's first launch, 2 for its second (cut too when the exchange needs a longer cover: its interior reads what the
-// first launch's interior wrote, one more apron further in — and writes into the buffer the exchange is sending from: it stays clear
-// of the rows / columns in flight)
-static JacobiCut jacobi_cut(const fluid_ctx* c, const Win& w, int ga, int gb, int shape, const JacobiSplit& sp, int level)
+static fluid::BlockCut jacobi_cut(const fluid_ctx* c, const Win& w, int ga, int gb, int shape, const JacobiSplit& sp, int level)
 {
     const fluid_desc& d = c->desc;
-    // a tile loads its whole apron whatever k is
-    int dep = level * jacobi_tb_depth(shape) + sp.margin, depx = level * jacobi_tb_apron_cols(shape) + ((sp.margin + 3) & ~3);
-    if (level > 1) {
-        dep = std::max(dep, sp.guard_rows);
-        depx = std::max(depx, (sp.guard_cols + 3) & ~3);
-    }
-    const int r0 = c->sim_row0, r1 = r0 + c->sim_rows, c0 = c->sim_col0, c1 = c0 + c->sim_ncols;
-    JacobiCut q;
-    q.ia = d.part > 0 ? std::min(std::max(r0 + dep, ga), gb) : ga;
-    q.ib = d.part < d.parts - 1 ? std::max(std::min(r1 - dep, gb), q.ia) : gb;
-    q.ja = d.part_x > 0 ? std::min(std::max(c0 + depx, w.x0), w.x1) : w.x0;
-    q.jb = d.part_x < d.parts_x - 1 ? std::max(std::min(c1 - depx, w.x1), q.ja) : w.x1;
-    return q;
+    int dep, depx;
+    fluid::cut_depths(level, jacobi_tb_depth(shape), jacobi_tb_apron_cols(shape), sp.margin, sp.guard_rows, sp.guard_cols, dep, depx);
+    return fluid::block_cut(ga, gb, w.x0, w.x1, c->sim_row0, c->sim_row0 + c->sim_rows, c->sim_col0, c->sim_col0 + c->sim_ncols, d.part > 0,
+                            d.part < d.parts - 1, d.part_x > 0, d.part_x < d.parts_x - 1, dep, depx);
 }
 
 // how many leading launches of a block of `iters` iterations can be cut this way, at most sp.cover (0: none)
@@ -261,8 +246,8 @@ int jacobi_split_launches(const fluid_ctx* c, int iters, bool wants_gradsub, con
     }
     // an interior worth a launch of its own, at every level
     auto worth = [&](int level) {
-        const int dep = std::max(level * depth + sp.margin, level > 1 ? sp.guard_rows : 0);
-        const int depx = std::max(level * hx + 4 + sp.margin, level > 1 ? sp.guard_cols + 4 : 0);
+        int dep, depx;
+        fluid::cut_depths(level, depth, hx, sp.margin, sp.guard_rows, sp.guard_cols, dep, depx);
         return c->sim_rows > 4 * dep && (!tiles || c->sim_ncols > 4 * depx);
     };
     while (m > 0 && !worth(m)) m--;
@@ -380,7 +365,7 @@ int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launche
                 cut_left--;
                 level++;
                 const Win w = sim_cols(c, ext_out + (iters - done - k));
-                const JacobiCut q = jacobi_cut(c, w, ga, gb, shape, *sp, level);
+                const fluid::BlockCut q = jacobi_cut(c, w, ga, gb, shape, *sp, level);
                 const float ps = done == 0 ? pscale : 1.0f;
                 auto band = [&](const void* src, void* dst, int a, int b, int xa, int xb) {
                     if (b <= a || xb <= xa) return (int)FLUID_OK;
@@ -399,11 +384,10 @@ int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launche
                 // the frame around that interior.  (With two launches cut, this one reads pressure up to one apron inside the first
                 // interior, from the buffer the SECOND interior has already written into — further in: from 2 aprons + margin on.)
                 if (c->storage == FLUID_STORE_F32 && k <= 10) {        // one launch
+                    fluid::CutRect fr[4];
+                    fluid::cut_frame(ga, gb, w.x0, w.x1, q, fr);
                     fluid::BandRects B{};
-                    B.r[B.n++] = fluid::BandRect{ w.x0, w.x1, ga, q.ia };
-                    B.r[B.n++] = fluid::BandRect{ w.x0, w.x1, q.ib, gb };
-                    B.r[B.n++] = fluid::BandRect{ w.x0, q.ja, q.ia, q.ib };
-                    B.r[B.n++] = fluid::BandRect{ q.jb, w.x1, q.ia, q.ib };
+                    for (const fluid::CutRect& r : fr) B.r[B.n++] = fluid::BandRect{ r.xa, r.xb, r.ga, r.gb };
                     CK(c->hip(fluid::launch_jacobi_tb_rects(c->stream, w, (const float*)c->prs[0], (const float*)c->div, (float*)c->prs[1], ps, k, B),
                               "jacobi_tb (frame)"));
                 } else {   // fp16 storage / a deeper lab shape: stripes only (jacobi_split_launches), one launch per band
