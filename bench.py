@@ -130,6 +130,15 @@ def cpu_baseline(size: int, iters: int, budget_s: float, kind: str = "auto", max
     return out
 
 
+def link_arg(spec):
+    """--link-model: "US,GBPS" -> that model; "default" -> the library's constants; None / "calibrate" -> measured at start-up"""
+    if spec in (None, "calibrate"):
+        return "calibrate"
+    if spec == "default":
+        return None
+    return tuple(float(x) for x in spec.split(","))
+
+
 def fluid_knobs():
     """every FLUID_* variable in the environment: the library's A/B knobs (tile shapes, folds, chains, another build of the library, an
     RCCL stand-in) change what is timed, so the line lists them (`config.knobs`; empty = the shipped defaults)"""
@@ -349,12 +358,31 @@ def parity_in_run(fluid_hip, size, iters, device, storage, with_oracle=True, ste
         sim.multipleSplats(20)
     for sim in sims:
         sim.step(DT, steps)
-    for sim in sims:
-        sim.sync()
-    same = True
+    # Compared ON THE DEVICE through FluidSim.device_view, which orders torch's current stream behind everything the solver has enqueued —
+    # the steps above AND the conversion of the packed dye back to RGBA that asking for the pointer triggers (fluid_stream_wait_context;
+    # include/fluid_hip.h, fluid_field_device_ptr's ordering rule).  No host sync is needed in front, none is made.  Round 4 synchronised
+    # FIRST and then read the dye while that conversion was still writing it: BENCH_r04's MISMATCH (profiles/r05/device_view_race.txt).
+    fields, same = {}, True
     for k in ("velocity", "pressure", "divergence", "curl", "dye"):
-        same = same and bool(torch.equal(sims[0].device_view(k), sims[1].device_view(k)))
+        a, b = sims[0].device_view(k), sims[1].device_view(k)
+        eq = bool(torch.equal(a, b))
+        rec = {"equal": eq}
+        if not eq:   # say WHAT differs: a record that only says MISMATCH cannot be diagnosed
+            ne = a != b
+            rec["n_diff"] = int(ne.sum().item())
+            rec["n_values"] = int(a.numel())
+            rec["max_abs"] = float((a.double() - b.double()).abs().nan_to_num(nan=float("inf")).max().item())
+            rec["n_nan"] = int((a != a).sum().item()) + int((b != b).sum().item())
+            idx = ne.nonzero()[0].tolist()
+            rec["first_diff_at"] = idx
+            rec["first_values"] = [float(a[tuple(idx)].item()), float(b[tuple(idx)].item())]
+            # second opinion through the host path (fluid_read_field: a synchronous copy on the solver's own stream)
+            rec["host_read_equal"] = bool(np.array_equal(sims[0].read(k), sims[1].read(k)))
+        fields[k] = rec
+        same = same and eq
+    torch.cuda.synchronize(device)
     out["fused_vs_passes_%d" % size] = ("bitwise equal, all five fields after %d steps" % steps) if same else "MISMATCH"
+    out["fields_%d" % size] = fields
     for sim in sims:
         sim.close()
     out["seconds"] = round(time.perf_counter() - t0, 2)
@@ -401,14 +429,17 @@ def main(argv=None, engine_factory=None, backend="nccl"):
                          "configurations when N matches — N = 4: 8192,50,2 (configs[3]); N = 8: 16384,200,1 (configs[4]); 'none' disables")
     ap.add_argument("--hosted", action="store_true", help="N > 1: drive the passes from Python with torch.distributed send/recv "
                                                           "instead of the native plan + RCCL inside libfluid_hip.so")
-    ap.add_argument("--settle-ms", type=float, default=40.0,
-                    help="milliseconds of the same workload on a scratch context enqueued directly in front of the warm-up (0 = none).  After an idle "
-                         "of >= 1 ms the MI355X answers a load step by dropping its shader clock from 2.4 to ~1.8 GHz for a few milliseconds and "
-                         "ramping back over ~15 ms (profiles/r04/first_steps.txt: measured from inside the stream, touched or untouched buffers "
-                         "alike); `--steps 20 --warmup 5` is 13 ms of work, all of it inside that dip.  The line reports the window without it as well (`cold_start`)")
-    ap.add_argument("--link-model", default=None, metavar="US,GBPS", help="N > 1: what one neighbour message costs on this machine's links (latency in us, "
-                    "GB/s; fluid_set_link_model — sizes how much compute the driver puts in front of an exchange's arrival; default: the "
-                    "library's 20 us, 50 GB/s).  Recorded in config.link_model")
+    ap.add_argument("--settle-ms", type=float, default=0.0,
+                    help="milliseconds of the same workload on a scratch context enqueued directly in front of the warm-up.  DEFAULT 0: `value` is the "
+                         "literal W warm-up + K timed steps, as every earlier round and the driver's consistency check read them.  After an idle of "
+                         ">= 1 ms the MI355X answers a load step by dropping its shader clock from 2.4 to ~1.8 GHz for a few milliseconds and ramping "
+                         "back over ~15 ms (profiles/r04/first_steps.txt); `--steps 20 --warmup 5` is 13 ms of work, all of it inside that dip.  The "
+                         "line reports the same window behind 40 ms of load as an EXTRA field (`preloaded_window`), never as `value`.  > 0: the "
+                         "load goes in front of the headline itself; the line then says so (config.settle, effective_warmup_steps, cold_start)")
+    ap.add_argument("--link-model", default=None, metavar="US,GBPS|calibrate|default",
+                    help="N > 1: what one neighbour message costs on this machine's links (latency in us, GB/s; fluid_set_link_model — sizes how "
+                         "much compute the driver puts in front of an exchange's arrival).  Default `calibrate`: measured at start-up on the set's "
+                         "own links (fluid_comm_calibrate_link); `default`: the library's 20 us, 50 GB/s.  Recorded in config.link_model")
     ap.add_argument("--no-step-marks", action="store_true", help="no events between the timed steps (`timed_window_regime` is then absent): "
                                                                   "the A/B of what the marks cost")
     ap.add_argument("--comm-timeout", type=float, default=120.0, help="N > 1: seconds the communicator set-up and the warm-up steps may take "
@@ -463,7 +494,7 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         c = dict(cfg, SIM_RESOLUTION=min(gw, gh), DYE_RESOLUTION=min(gw, gh), PRESSURE_ITERATIONS=its)
         kw = dict(engine_factory=engine_factory) if on_cpu else dict(native=not args.hosted, tiles_x=tx, storage=args.storage,
                                                                     reach=min(args.reach, args.halo),
-                                                                    link_model=tuple(float(x) for x in args.link_model.split(",")) if args.link_model else None)
+                                                                    link_model=link_arg(args.link_model))
         return StripeSim(canvas=(gw, gh), config=c, halo=args.halo, schedule=args.schedule, random=fluid_hip.mulberry32(1234),
                          device=local_rank, **kw)
 
@@ -486,7 +517,7 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         # (--tiles-x T: size * T columns x size * N / T rows, every rank still owns size x size texels)
         tx = max(1, args.tiles_x)
         gw, gh = (size, size) if args.strong else (size * tx, size * N // tx)
-        dog.at("communicator set-up (ncclGetUniqueId on rank 0, broadcast, ncclCommInitRank inside libfluid_hip.so)")
+        dog.at("communicator set-up (ncclGetUniqueId on rank 0, broadcast, ncclCommInitRank inside libfluid_hip.so, link calibration: 46 neighbour exchanges)")
         try:
             sim = make_stripes(gw, gh, iters, tx)
         except Exception as ex:   # no silent switch to another driver: say what failed, on every rank, and stop
@@ -623,9 +654,25 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         "speedup_vs_pass_structure": {"algorithmic_GBps": round(alg_step_bytes * steps_per_s / 1e9, 1),
                                       "x_hbm_peak": round(alg_step_bytes * steps_per_s / 1e9 / (HBM_PEAK_GBPS * N), 4)},
     })
+    # steps of the same workload the chip ran directly in front of the timed window: the warm-up, plus — only with --settle-ms > 0 — the
+    # scratch context's load (its sizing steps included).  Equal to `warmup` for the default command.
+    out["effective_warmup_steps"] = args.warmup + (settle["steps"] + 6 if settle else 0)
     if settle:
         out["config"]["settle"] = settle
-    out["config"]["knobs"] = knobs   # FLUID_* variables in the environment (A/B knobs of the library); {} = shipped defaults
+    # FLUID_* variables in the environment.  Only a LAB build (libfluid_hip_probes.so through FLUID_HIP_LIB) reads the tuning knobs; the
+    # product library reads none, so on a product build they are listed apart as ignored — the run measured the shipped defaults.
+    if not on_cpu:
+        flavor = fluid_hip.lib().fluid_build_flavor().decode()
+        out["config"]["build_flavor"] = flavor
+        plumbing = ("FLUID_HIP_LIB", "FLUID_RCCL_LIB", "FLUID_HIP_NO_TORCH")
+        if flavor == "product":
+            ignored = {k: v for k, v in knobs.items() if k not in plumbing}
+            if ignored:
+                out["config"]["knobs_ignored"] = ignored
+                print("bench.py: WARNING: %s set, but the product library reads no tuning knob — this run measures the shipped defaults "
+                      "(load the lab build with FLUID_HIP_LIB=.../libfluid_hip_probes.so for A/B runs)" % ", ".join(sorted(ignored)), file=sys.stderr)
+            knobs = {k: v for k, v in knobs.items() if k in plumbing}
+    out["config"]["knobs"] = knobs   # {} = shipped defaults
     if regime:
         out["timed_window_regime"] = regime
     if N == 1 and not on_cpu:
@@ -643,7 +690,9 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         out["config"]["driver"] = "native plan + ncclSend/ncclRecv inside libfluid_hip.so" if sim.native else "hosted: torch.distributed batch_isend_irecv"
         if sim.native:
             out["config"]["advect_exchange_rows"] = list(sim.engine.advect_exchange_rows())
-            out["config"]["link_model"] = args.link_model or "library default (20 us + bytes / 50 GB/s per neighbour message)"
+            lm = getattr(sim, "link_model", None)   # this rank's; every rank measures its own links
+            out["config"]["link_model"] = ({"latency_us": round(lm[0], 2), "GBps": round(lm[1], 2), "source": lm[2]} if lm
+                                           else "library default (20 us + bytes / 50 GB/s per neighbour message)")
 
     # ---- N > 1: BASELINE.json's own multi-GPU configurations, strong scaling, after the weak-scaling measurement (`value` above is
     #      untouched: the driver's scaling curve is computed from it) ----
@@ -853,6 +902,37 @@ def main(argv=None, engine_factory=None, backend="nccl"):
                              "what": "the same %d warm-up + %d timed steps on a fresh context after 300 ms of idle, nothing in front of the splats: "
                                      "inside the shader-clock dip that follows a load step (config.settle)" % (args.warmup, args.steps)}
 
+    # ---- the same W + K behind 40 ms of load: what the window reads once the chip is out of the clock dip (an extra, never `value`) ----
+    if rank == 0 and N == 1 and not settle and not on_cpu and not args.no_steady and deadline.left() > 20:
+        sync()
+        with fluid_hip.FluidSim(canvas=(size, size), config=cfg, device=local_rank, schedule=args.schedule, random=fluid_hip.mulberry32(4321),
+                                storage=args.storage) as load, \
+             fluid_hip.FluidSim(canvas=(size, size), config=cfg, device=local_rank, schedule=args.schedule, random=fluid_hip.mulberry32(1234),
+                                storage=args.storage) as hot:
+            load.multipleSplats(20)
+            hot.multipleSplats(20)
+            load.step(DT, 2)
+            load.sync()
+            t0 = time.perf_counter()
+            load.step(DT, 4)
+            load.sync()
+            est = max((time.perf_counter() - t0) / 4, 1e-6)
+            n_load = max(1, int(40.0 / 1e3 / est + 0.999))
+            dev_sync()
+            time.sleep(0.3)
+            load.step(DT, n_load)   # asynchronous, on its own stream: the warm-up below starts on a chip that is already under load
+            hot.step(DT, args.warmup)
+            hot.sync(); load.sync(); dev_sync()
+            t0 = time.perf_counter()
+            hot.step(DT, args.steps)
+            hot.sync(); dev_sync()
+            el = time.perf_counter() - t0
+        out["preloaded_window"] = {"ms_per_step": round(1e3 * el / args.steps, 4), "steps_per_sec": round(args.steps / el, 2),
+                                   "effective_warmup_steps": args.warmup + n_load,
+                                   "what": "the same %d warm-up + %d timed steps on a fresh context, with %d steps (40 ms) of the same workload on a scratch "
+                                           "context enqueued directly in front of the warm-up: out of the shader-clock dip that follows a load step "
+                                           "(profiles/r04/first_steps.txt).  Reported beside `value`, which is the literal W + K window" % (args.warmup, args.steps, n_load)}
+
     # the in-run parity check, on every rank's own GPU, BEHIND every timed section of this run (see parity_in_run): a mismatch replaces
     # the line by an error
     if not args.no_parity and not on_cpu:
@@ -865,6 +945,20 @@ def main(argv=None, engine_factory=None, backend="nccl"):
                 problem = "in-run parity check failed on rank %d: %s" % (rank, json.dumps(parity))
         except Exception as ex:
             problem = "in-run parity check could not run on rank %d: %s" % (rank, str(ex)[:200])
+        if N > 1:   # every rank checks its own GPU: the line carries all of their summaries, so that one rank's problem is attributable
+            mine = {"rank": rank, "ok": bool(parity and parity["ok"]) and not problem}
+            if parity:
+                mine["fields_differing"] = {k: v for k, v in parity.get("fields_%d" % size, {}).items() if not v.get("equal")}
+            if problem:
+                mine["problem"] = problem[:400]
+            ranks = [None] * N
+            dist.all_gather_object(ranks, mine)
+            if parity is None:
+                parity = {"ok": False}
+            parity["ranks"] = ranks
+            bad = [r for r in ranks if not r["ok"]]
+            if bad and not problem:
+                problem = "in-run parity check failed on rank(s) %s: %s" % ([r["rank"] for r in bad], json.dumps(bad)[:1500])
         problem = agree(problem)
         if problem:
             if dog:

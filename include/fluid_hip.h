@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define FLUID_ABI_VERSION 8
+#define FLUID_ABI_VERSION 9
 
 typedef enum fluid_status {
     FLUID_OK = 0,
@@ -197,13 +197,30 @@ int fluid_pass_splat(fluid_ctx *ctx, int field, float x, float y, float aspect, 
  * nrows counts rows of that field (dye rows for FLUID_DYE). dev_buf is device memory. */
 int fluid_halo_pack(fluid_ctx *ctx, int field, int side, int nrows, void *dev_buf);
 int fluid_halo_unpack(fluid_ctx *ctx, int field, int side, int nrows, const void *dev_buf);
-/* device address of array row 0 (ghost rows included) of the field's CURRENT read buffer, for zero-copy ghost-row
- * send/recv by the stripe driver.  Passes that swap read/write invalidate it: query after each pass.
+/* device address of array row 0 (ghost rows included) of the field's CURRENT read buffer — the zero-copy form of "DoubleFBO.read after a
+ * call is the result" (script.js:1079-1106), and what the stripe driver sends / receives ghost rows through.
+ * Passes that swap read/write invalidate it: query after each pass.
  * The texels behind the pointer are always the layout fluid_field_info describes (dye: RGBA).  Internally the library may keep state that
  * the pointer cannot see — the next step's curl / vorticity / divergence computed ahead, the dye packed to three floats while its alpha is
  * one known value: asking for a pointer drops the former and converts the latter back, and — because whatever is written through the
- * pointer is invisible to the library — the dye is not packed again until the next splat.  A cost in speed only, never in results. */
+ * pointer is invisible to the library — the dye is not packed again until the next splat.  A cost in speed only, never in results.
+ *
+ * ORDERING (the rule every zero-copy consumer lives by).  The memory holds the field once the work the context has enqueued ON ITS STREAM
+ * up to and including this call has run: the library's streams are non-blocking, so a kernel / copy / torch op on ANY other stream — the
+ * null stream included — is NOT ordered against it by itself.  A consumer does one of:
+ *   (1) fluid_sync(ctx) in front of the call.  Work the call itself has to enqueue (the packed-dye conversion above) is then waited for
+ *       INSIDE the call: `fluid_sync(); fluid_field_device_ptr();` always returns memory that is complete for the host and every stream;
+ *   (2) fluid_stream_wait_context(ctx, consumer_stream) behind the call: no host wait, the consumer's stream waits on the device;
+ *   (3) run on the context's stream (fluid_set_stream gave the library the consumer's stream: the stripe driver's case).
+ * The reverse hazard is the consumer's as well: the context's NEXT call overwrites / swaps these buffers, so work that still reads (or
+ * writes) through the pointer must have finished, or fluid_context_wait_stream(ctx, consumer_stream) must be called, before that call. */
 int fluid_field_device_ptr(fluid_ctx *ctx, int field, void **dev_ptr);
+/* `hip_stream` (a hipStream_t; NULL = the legacy null stream) waits, on the device, for everything this context has enqueued so far —
+ * its steps, passes, exchanges and conversions; work enqueued on `hip_stream` after the call sees their results.  Does not block the host. */
+int fluid_stream_wait_context(fluid_ctx *ctx, void *hip_stream);
+/* the other direction: whatever this context enqueues after the call runs behind everything enqueued on `hip_stream` so far (a consumer
+ * still reading a field through a raw pointer, a producer that wrote ghost rows through one).  Does not block the host. */
+int fluid_context_wait_stream(fluid_ctx *ctx, void *hip_stream);
 /* synchronises, then returns FLUID_ERR_HALO if any advection tap since the last check fell outside the stripe's rows.
  * fluid_step / fluid_step_n / fluid_group_step_n on stripe and tile contexts call it themselves at the end of every call
  * (the step that sampled a row that was not refreshed fails; the call synchronises), so this entry point only matters to a
@@ -258,6 +275,13 @@ int fluid_set_overlap(fluid_ctx *ctx, int enabled);
  * launches, each at the price of one thin launch) with this figure; nothing but speed depends on it.  Every rank of a set may
  * keep its own.  Since ABI 8. */
 int fluid_set_link_model(fluid_ctx *ctx, float latency_us, float gbytes_per_s);
+/* MEASURES the two figures instead of assuming them (the defaults are guesses nobody calibrated on xGMI, and a wrong model costs 2-3 % either
+ * way).  Collective over the stripe / tile set — every rank calls it once, behind fluid_comm_init: `reps` (<= 0: 20) grouped ncclSend /
+ * ncclRecv exchanges with the row and column neighbours, as a step's exchange issues them, of a 4 KB message and of the largest message a step
+ * sends (the velocity + pressure ghost rows), back to back on the comm stream with an event between every two; latency = the median small
+ * exchange, bandwidth = the extra bytes / the extra time of the large one.  Sets the context's link model (fluid_set_link_model) and reports it.
+ * A rank without neighbours keeps its model and reports that.  Since ABI 9. */
+int fluid_comm_calibrate_link(fluid_ctx *ctx, int reps, float *latency_us, float *gbytes_per_s);
 
 typedef struct fluid_comm_id {
     char bytes[128]; /* an ncclUniqueId */

@@ -54,15 +54,45 @@ def test_bench_line_is_live_and_consistent():
     # round 4: what the line says about the timed window and about what ran in it
     t = d["timed_window_regime"]
     assert len(t["ms_per_timed_step"]) == 5 and abs(sum(t["ms_per_timed_step"]) - t["sum_ms"]) < 1e-2 and t["sum_ms"] <= 5 * d["ms_per_step"] * 1.05
-    assert d["config"]["knobs"] == {} and d["config"]["settle"]["steps"] >= 1
+    # round 5: `value` is the literal W + K window (no load in front of the warm-up by default); the window behind 40 ms of load is an extra
+    assert d["config"]["knobs"] == {} and "settle" not in d["config"] and "cold_start" not in d and d["effective_warmup_steps"] == 2
+    assert d["config"]["build_flavor"] == "product"
+    w = d["preloaded_window"]
+    assert w["ms_per_step"] > 0 and w["effective_warmup_steps"] > 2
+    assert all(f["equal"] for f in p["fields_1024"].values()) and len(p["fields_1024"]) == 5
     k = d["config"]["kernels"]
     assert k["chained_steps"] == 5 and k["gradsub_folded"] is True and k["curl_field_stored_by_steps"] == 2 and k["jacobi_launches_per_step"] == 5
-    assert d["cold_start"]["ms_per_step"] > 0 and len(d["cold_start"]["ms_per_timed_step"]) == 5
     # (at 1024^2 the fields sit in the caches: the counters may see FEWER bytes than a launch must move, so no order between the two fractions)
     assert 0 < r["frac_compulsory"] <= 1.0 and r["compulsory_bytes_per_launch"] == 12 * 1024 * 1024
     assert abs(r["frac_compulsory"] - r["compulsory_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9 / 8000.0) <= 2e-3
     if "step_hbm" in d:
         assert 0 < d["step_hbm"]["frac_compulsory"] <= 1.0
+
+
+@pytest.mark.gpu
+def test_the_drivers_command_at_the_headline_size():
+    """`python3 bench.py --gpus 1 --steps 20 --warmup 5` — the driver's exact command, BASELINE configs[2] (4096^2 / 50): the run that was an
+    error record in round 4 (in-run parity check, packed dye: tests/test_device_view.py) must print a whole line"""
+    d = run_bench("--gpus", "1", "--steps", "20", "--warmup", "5")
+    assert d["value"] > 0 and d["steps"] == 20 and d["warmup"] == 5 and d["effective_warmup_steps"] == 5 and "error" not in d
+    assert "configs[2]" in d["config"]["workload"] and d["config"]["kernels"]["dye_packed_rgb"] is True
+    assert abs(d["value"] - 4096 * 4096 * 1e3 / d["ms_per_step"] / 1e9) <= 2e-3 * d["value"]
+    p = d["parity_in_run"]
+    assert p["ok"] and "bitwise" in p["fused_vs_passes_4096"] and "bitwise" in p["hip_vs_oracle_256"]
+    assert all(f["equal"] for f in p["fields_4096"].values()) and len(p["fields_4096"]) == 5
+    r = d["roofline"]
+    assert r["kernel"].startswith("k_jacobi_tb") and 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-3
+    assert d["cpu_baseline"]["kind"] in ("reference", "port") and d["cpu_baseline"]["unit"] == "GLUPS"
+    assert d["preloaded_window"]["ms_per_step"] > 0
+
+
+@pytest.mark.gpu
+def test_a_settled_headline_says_so():
+    """--settle-ms > 0 puts the load in front of the headline itself: the line then carries config.settle, the steps that really ran in
+    front of the window, and the cold window beside it"""
+    d = run_bench("--steps", "5", "--warmup", "2", "--size", "1024", "--cpu-budget", "0", "--no-traffic", "--settle-ms", "20")
+    assert d["config"]["settle"]["steps"] >= 1 and d["effective_warmup_steps"] == 2 + d["config"]["settle"]["steps"] + 6
+    assert d["cold_start"]["ms_per_step"] > 0 and len(d["cold_start"]["ms_per_timed_step"]) == 5 and "preloaded_window" not in d
 
 
 @pytest.mark.gpu

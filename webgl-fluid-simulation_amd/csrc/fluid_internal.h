@@ -43,6 +43,7 @@ struct fluid_ctx {
     void* pend_div = nullptr;
     void* pend_curl = nullptr;
     bool pend_valid = false;
+    bool pend_failed = false;   // the pending buffers could not be allocated (out of device memory): no run-ahead on this context
     float pend_dt = 0.0f, pend_curl_strength = 0.0f;
     void touched() { pend_valid = false; }   // call from every entry point that changes a field or hands out its memory
 
@@ -79,6 +80,7 @@ struct fluid_ctx {
     std::vector<hipEvent_t> chain_ev;
     hipEvent_t ev_ready = nullptr;       // context stream -> comm stream: the rows to send exist
     hipEvent_t ev_landed = nullptr;      // comm stream -> context stream: the ghost rows have arrived
+    hipEvent_t ev_order = nullptr;       // fluid_stream_wait_context / fluid_context_wait_stream: context stream <-> a caller's stream
     hipEvent_t ev_mid = nullptr;         // 2-D tiles: this tile's ghost columns are in (phase A), ghost rows may follow
     void* stage[16] = {};                // 2-D tiles: contiguous staging of the strided blocks, send and receive per direction (4 sides + 4 corners)
     size_t stage_bytes[16] = {};

@@ -754,16 +754,26 @@ bool run_ahead_enabled(long owned_texels)
 
 int pending_buffers(fluid_ctx* c)   // allocated on first use: whole-domain fp32 contexts below 3072^2 texels only (<= 150 MB)
 {
-    if (c->pend_vel) return FLUID_OK;
+    if (c->pend_vel && c->pend_div && c->pend_curl) return FLUID_OK;
+    if (c->pend_failed) return FLUID_ERR_OOM;   // tried before and the device had no room: this context steps without working ahead
     const size_t n = cells(c->sim);
-    HIPCK(c, hipMalloc(&c->pend_vel, n * 2 * sizeof(float)));
-    HIPCK(c, hipMalloc(&c->pend_div, n * sizeof(float)));
-    HIPCK(c, hipMalloc(&c->pend_curl, n * sizeof(float)));
+    int rc = FLUID_OK;
+    // all three or none: a partial set would look usable to the next call (pend_vel alone used to be the test) and hand k_advect_cvd null outputs
+    if (!rc && !c->pend_vel) rc = c->hip(hipMalloc(&c->pend_vel, n * 2 * sizeof(float)), "hipMalloc pending velocity");
+    if (!rc && !c->pend_div) rc = c->hip(hipMalloc(&c->pend_div, n * sizeof(float)), "hipMalloc pending divergence");
+    if (!rc && !c->pend_curl) rc = c->hip(hipMalloc(&c->pend_curl, n * sizeof(float)), "hipMalloc pending curl");
     // the padding columns are never meaningful but are copied around: give them defined content once
-    HIPCK(c, hipMemsetAsync(c->pend_vel, 0, n * 2 * sizeof(float), c->stream));
-    HIPCK(c, hipMemsetAsync(c->pend_div, 0, n * sizeof(float), c->stream));
-    HIPCK(c, hipMemsetAsync(c->pend_curl, 0, n * sizeof(float), c->stream));
-    return FLUID_OK;
+    if (!rc) rc = c->hip(hipMemsetAsync(c->pend_vel, 0, n * 2 * sizeof(float), c->stream), "memset pending velocity");
+    if (!rc) rc = c->hip(hipMemsetAsync(c->pend_div, 0, n * sizeof(float), c->stream), "memset pending divergence");
+    if (!rc) rc = c->hip(hipMemsetAsync(c->pend_curl, 0, n * sizeof(float), c->stream), "memset pending curl");
+    if (rc) {
+        for (void** p : { &c->pend_vel, &c->pend_div, &c->pend_curl }) {
+            if (*p) (void)hipFree(*p);
+            *p = nullptr;
+        }
+        c->pend_failed = true;   // (a resize clears it: other sizes, another try)
+    }
+    return rc;
 }
 
 bool chain_applies(const fluid_ctx* c, float dt, const fluid_params* P)
@@ -913,6 +923,7 @@ int fluid_destroy(fluid_ctx* c)
         if (e) (void)hipEventDestroy(e);
     for (auto& e : c->marks) (void)hipEventDestroy(e);
     for (auto& e : c->chain_ev) (void)hipEventDestroy(e);
+    if (c->ev_order) (void)hipEventDestroy(c->ev_order);
     if (c->chain_stream) (void)hipStreamDestroy(c->chain_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -979,6 +990,7 @@ int fluid_resize(fluid_ctx* c, int sw, int sh, int dw, int dh)
             if (*p) (void)hipFree(*p);
             *p = nullptr;
         }
+        c->pend_failed = false;
     }
     c->desc.sim_w = sw;
     c->desc.sim_h = sh;
@@ -1304,11 +1316,41 @@ int fluid_field_device_ptr(fluid_ctx* c, int field, void** dev_ptr)
 {
     if (!c || !dev_ptr) return FLUID_ERR_INVALID;
     c->touched();
+    HIPCK(c, hipSetDevice(c->device));
+    const bool was_packed = c->dye_packed;
     FieldRef f;
     CK(field_ref(c, field, &f));
+    // The header's ordering rule (1): work THIS call had to enqueue is waited for here, so that `fluid_sync(); fluid_field_device_ptr();`
+    // hands out finished memory.  Round 4 returned while k_dye_unpack was still writing the buffer behind the pointer, on a non-blocking
+    // stream no other stream is ordered against: bench.py's torch.equal read it half-written (BENCH_r04.json, profiles/r05/device_view_race.txt).
+    if (was_packed && !c->dye_packed) HIPCK(c, hipStreamSynchronize(c->stream));
     if (field == FLUID_DYE) c->alpha_known = false;   // a raw pointer: whatever gets written through it, the context does not see (until the next splat)
     *dev_ptr = f.ptr;
     return FLUID_OK;
+}
+
+// the two ordering calls of the zero-copy contract (include/fluid_hip.h, fluid_field_device_ptr): one event, recorded on the producing
+// side and waited for by the consuming stream, all on the device
+static int order_streams(fluid_ctx* c, hipStream_t from, hipStream_t to)
+{
+    HIPCK(c, hipSetDevice(c->device));
+    if (from == to) return FLUID_OK;   // one stream: already in order
+    if (!c->ev_order) HIPCK(c, hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming));
+    HIPCK(c, hipEventRecord(c->ev_order, from));
+    HIPCK(c, hipStreamWaitEvent(to, c->ev_order, 0));
+    return FLUID_OK;
+}
+
+int fluid_stream_wait_context(fluid_ctx* c, void* hip_stream)
+{
+    if (!c) return FLUID_ERR_INVALID;
+    return order_streams(c, c->stream, (hipStream_t)hip_stream);
+}
+
+int fluid_context_wait_stream(fluid_ctx* c, void* hip_stream)
+{
+    if (!c) return FLUID_ERR_INVALID;
+    return order_streams(c, (hipStream_t)hip_stream, c->stream);
 }
 
 int fluid_halo_check(fluid_ctx* c)
@@ -1357,7 +1399,11 @@ int fluid_schedule_info_get(fluid_ctx* c, int n_steps, float dt, const fluid_par
     out->chained = chain ? n_steps - 1 + out->runs_ahead : 0;
     const bool fused_cvd = fluid_impl::fused_cvd_applies(c);
     out->dye_packed = whole && dye_pack_applies(c) && (c->dye_packed || c->pack_holdoff == 0);
-    out->curl_stores = (fused_cvd && fluid_impl::skip_hidden_curl() && n_steps > 0) ? 1 + (out->runs_ahead ? 1 : 0) : n_steps + (out->runs_ahead ? 1 : 0);
+    // how many times the call stores a curl field.  Chained / plain steps: hidden curls are skipped — the call's last step's is stored, plus
+    // the one the closing launch works ahead.  Split path (dye grid != sim grid; step_once chain 3): EVERY step's closing launch stores the
+    // next step's curl into the pending buffer, and a lead launch (nothing adopted) stores the first step's own.
+    if (split) out->curl_stores = n_steps + (out->pending_adopted ? 0 : 1);
+    else out->curl_stores = (fused_cvd && fluid_impl::skip_hidden_curl() && n_steps > 0) ? 1 + (out->runs_ahead ? 1 : 0) : n_steps + (out->runs_ahead ? 1 : 0);
     if (whole) {
         const int cvd = fused_cvd ? 1 : 3, clear = tb ? 0 : 1, gs = out->gradsub_folded ? 0 : 1;
         const int adv = fluid_impl::fused_advect_applies(c) ? 1 : 2;

@@ -843,12 +843,15 @@ void pressure_in_flight(fluid_ctx* c, const fluid_stripe_op& op, JacobiSplit* sp
 }
 
 // how to cut the Jacobi block behind a pressure-only exchange (cover >= 1: jacobi_overlap_ok said the block can be cut)
-JacobiSplit jacobi_overlap_split(fluid_ctx* c, const std::vector<fluid_stripe_op>& ops, size_t i)
+// `for_group`: the answer of ONE context of an in-process group, not rounded up — the group cuts as many launches as its least able
+// context can (fluid_group_step_n), and none when that is 0
+JacobiSplit jacobi_overlap_split(fluid_ctx* c, const std::vector<fluid_stripe_op>& ops, size_t i, bool for_group = false)
 {
     JacobiSplit sp;
     pressure_in_flight(c, ops[i], &sp);
     sp.cover = std::max(1, launches_for(exchange_us(c, ops[i]), c));
-    sp.cover = std::max(1, jacobi_split_launches(c, ops[i + 1].iters, folds_gradsub(ops, i + 1), sp));
+    sp.cover = jacobi_split_launches(c, ops[i + 1].iters, folds_gradsub(ops, i + 1), sp);
+    if (!for_group) sp.cover = std::max(1, sp.cover);
     return sp;
 }
 
@@ -1123,6 +1126,108 @@ int fluid_comm_selftest(fluid_ctx* c, int nfloats)
     return rc;
 }
 
+int fluid_comm_calibrate_link(fluid_ctx* c, int reps, float* latency_us, float* gbytes_per_s)
+{
+    if (!c) return FLUID_ERR_INVALID;
+    const Rccl* R = rccl(nullptr);
+    if (!R || !c->comm) return c->fail(FLUID_ERR_COMM, "no communicator (fluid_comm_init)");
+    CK(ensure_comm_stream(c));
+    HIPCK(c, hipSetDevice(c->device));
+    if (reps <= 0) reps = 20;
+    if (reps > 200) reps = 200;
+    const int warm = 3;
+    // the neighbours a step exchanges whole rows / columns with (the corner blocks of a tile exchange are a few KB: not what the time is)
+    const int py = c->desc.part, px = c->desc.part_x, ny = c->desc.parts, nx = c->desc.parts_x;
+    std::vector<int> peers;
+    if (py > 0) peers.push_back((py - 1) * nx + px);
+    if (py < ny - 1) peers.push_back((py + 1) * nx + px);
+    if (px > 0) peers.push_back(py * nx + px - 1);
+    if (px < nx - 1) peers.push_back(py * nx + px + 1);
+    auto report = [&] {
+        if (latency_us) *latency_us = c->link_lat_us;
+        if (gbytes_per_s) *gbytes_per_s = c->link_gbps;
+        return (int)FLUID_OK;
+    };
+    if (peers.empty()) return report();
+    // the largest message of a step: the first exchange's velocity + pressure ghost rows to one neighbour (every rank of a set computes the
+    // same figure: the message sizes of the two sides of a pair must agree)
+    const size_t small = 4096;
+    size_t large = (size_t)c->desc.halo * (size_t)c->sim.P * 12u * (c->storage == FLUID_STORE_F16 ? 1u : 2u) / 2u;
+    large = std::min<size_t>(std::max<size_t>(large & ~(size_t)255, (size_t)1 << 20), (size_t)64 << 20);
+    char* buf = nullptr;
+    HIPCK(c, hipMalloc((void**)&buf, 2 * peers.size() * large));
+    std::vector<hipEvent_t> ev((size_t)warm + reps + 1, nullptr);
+    int rc = FLUID_OK;
+    auto measure = [&](size_t bytes, double* median_us) {
+        ncclComm_t comm = (ncclComm_t)c->comm;
+        for (size_t k = 0; k < ev.size() && !rc; k++) {
+            if (k > 0) {
+                ncclResult_t e = R->GroupStart();
+                for (size_t p = 0; p < peers.size() && e == ncclSuccess; p++) {
+                    e = R->Send(buf + (2 * p) * large, bytes, ncclChar, peers[p], comm, c->comm_stream);
+                    if (e == ncclSuccess) e = R->Recv(buf + (2 * p + 1) * large, bytes, ncclChar, peers[p], comm, c->comm_stream);
+                }
+                if (e == ncclSuccess) e = R->GroupEnd();
+                if (e != ncclSuccess) {
+                    rc = nccl_fail(c, R, e, "link calibration send/recv");
+                    break;
+                }
+            }
+            rc = c->hip(hipEventRecord(ev[k], c->comm_stream), "record");
+        }
+        if (!rc) rc = c->hip(hipStreamSynchronize(c->comm_stream), "sync");
+        if (rc) return;
+        std::vector<float> us;
+        for (size_t k = (size_t)warm; k + 1 < ev.size(); k++) {
+            float ms = 0;
+            if ((rc = c->hip(hipEventElapsedTime(&ms, ev[k], ev[k + 1]), "elapsed"))) return;
+            us.push_back(ms * 1e3f);
+        }
+        std::sort(us.begin(), us.end());
+        *median_us = us[us.size() / 2];
+    };
+    double t_small = 0, t_large = 0;
+    do {
+        if ((rc = c->hip(hipMemsetAsync(buf, 0, 2 * peers.size() * large, c->comm_stream), "memset"))) break;
+        for (auto& e : ev)
+            if ((rc = c->hip(hipEventCreate(&e), "hipEventCreate"))) break;
+        if (rc) break;
+        measure(small, &t_small);
+        if (rc) break;
+        measure(large, &t_large);
+    } while (0);
+    for (auto& e : ev)
+        if (e) (void)hipEventDestroy(e);
+    (void)hipFree(buf);
+    CK(rc);
+    // latency + bytes / bandwidth through the two points; a link on which the large message costs no more than the small one (an
+    // instantaneous stand-in) gets a bandwidth that makes the byte term vanish
+    const double lat = std::max(t_small, 0.0);
+    const double extra = t_large - t_small;
+    const double gbps = extra > 0.02 * std::max(t_small, 1.0) ? std::min((double)(large - small) / (extra * 1e3), 1e4) : 1e4;
+    c->link_lat_us = (float)lat;
+    c->link_gbps = (float)gbps;
+    return report();
+}
+
+// the cut of a pressure-only exchange's Jacobi block for an in-process group: every context is asked (its own geometry, storage and
+// column alignment — jacobi_overlap_ok / jacobi_split_launches), the group cuts what ALL of them can, and nothing (cover 0) when one cannot
+static JacobiSplit group_overlap_split(fluid_ctx** cs, int n_ctx, const std::vector<fluid_stripe_op>& ops, size_t i)
+{
+    JacobiSplit none;
+    none.cover = 0;
+    for (int r = 0; r < n_ctx; r++)
+        if (!jacobi_overlap_ok(cs[r], ops, i)) return none;
+    JacobiSplit sp = jacobi_overlap_split(cs[0], ops, i, true);
+    for (int r = 1; r < n_ctx && sp.cover > 0; r++) {
+        const JacobiSplit o = jacobi_overlap_split(cs[r], ops, i, true);
+        sp.cover = std::min(sp.cover, o.cover);
+        sp.guard_rows = std::max(sp.guard_rows, o.guard_rows);
+        sp.guard_cols = std::max(sp.guard_cols, o.guard_cols);
+    }
+    return sp;
+}
+
 int fluid_group_step_n(fluid_ctx** cs, int n_ctx, int steps, float dt, const fluid_params* P)
 {
     if (!cs || n_ctx < 1 || !P || steps < 0) return FLUID_ERR_INVALID;
@@ -1189,11 +1294,9 @@ int fluid_group_step_n(fluid_ctx** cs, int n_ctx, int steps, float dt, const flu
                     CK(each([&](fluid_ctx* c) { return jacobi_block_rest(c, blk, gs ? &ops[i + 2] : nullptr, P->pressure, deep); }));
                     i += gs ? 2 : 1;
                 }
-            } else if (jacobi_overlap_ok(cs[0], ops, i)) {   // every stripe of a group has the same rows: the same answer
+            } else if (JacobiSplit sp = group_overlap_split(cs, n_ctx, ops, i); sp.cover > 0) {
                 const bool gs = folds_gradsub(ops, i + 1);
                 const fluid_stripe_op& blk = ops[i + 1];
-                JacobiSplit sp = jacobi_overlap_split(cs[0], ops, i);
-                for (int r = 1; r < n_ctx; r++) sp.cover = std::min(sp.cover, jacobi_overlap_split(cs[r], ops, i).cover);
                 CK(each([&](fluid_ctx* c) { return jacobi_block_interior(c, blk, sp); }));
                 CK(tiles ? group_exchange_2d_end(cs, n_ctx) : group_exchange_end(cs, n_ctx));
                 CK(each([&](fluid_ctx* c) { return jacobi_block_rest(c, blk, gs ? &ops[i + 2] : nullptr, 1.0f, sp); }));

@@ -113,12 +113,15 @@ SYMBOLS = {
     "fluid_halo_pack": (_I, [_CTX, _I, _I, _I, C.c_void_p]),
     "fluid_halo_unpack": (_I, [_CTX, _I, _I, _I, C.c_void_p]),
     "fluid_field_device_ptr": (_I, [_CTX, _I, C.POINTER(C.c_void_p)]),
+    "fluid_stream_wait_context": (_I, [_CTX, C.c_void_p]),
+    "fluid_context_wait_stream": (_I, [_CTX, C.c_void_p]),
     "fluid_halo_check": (_I, [_CTX]),
     "fluid_stripe_plan": (_I, [_I, _I, _I, _I, _I, C.POINTER(StripeOp), _I, C.POINTER(_I)]),
     "fluid_set_reach": (_I, [_CTX, _I]),
     "fluid_advect_exchange_rows": (_I, [_CTX, C.POINTER(_I), C.POINTER(_I)]),
     "fluid_set_overlap": (_I, [_CTX, _I]),
     "fluid_set_link_model": (_I, [_CTX, _F, _F]),
+    "fluid_comm_calibrate_link": (_I, [_CTX, _I, C.POINTER(_F), C.POINTER(_F)]),
     "fluid_comm_set_library": (_I, [C.c_char_p]),
     "fluid_comm_unique_id": (_I, [C.POINTER(CommId)]),
     "fluid_comm_init": (_I, [_CTX, C.POINTER(CommId)]),
@@ -175,7 +178,7 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the header and the library disagree
             fn.restype = res
             fn.argtypes = args
-        if L.fluid_abi_version() != 8:
+        if L.fluid_abi_version() != 9:
             raise FluidError(ERR_UNSUPPORTED, "ABI version mismatch")
         _lib = L
         _point_at_torch_rccl(L)

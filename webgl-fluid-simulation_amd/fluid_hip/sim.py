@@ -449,11 +449,18 @@ class FluidSim:
     def fields(self) -> Dict[str, np.ndarray]:
         return {k: self.read(k) for k in FIELD_IDS}
 
-    def device_view(self, name: str):
+    def device_view(self, name: str, stream=None):
         """torch tensor [rows, width, channels] aliasing the field's CURRENT read buffer on the device (zero copy through
-        __cuda_array_interface__; the padding columns of the pitch are sliced off).  READ-ONLY and short-lived: the pointer is the buffer
-        that is current NOW — any step, splat, pass or write swaps the field's ping-pong buffers (and may free them: resize), after which
-        the view shows the spare buffer or dangles.  The caller orders its torch work against the solver stream (sim.sync())."""
+        __cuda_array_interface__; the padding columns of the pitch are sliced off).
+
+        ORDERED for the caller (include/fluid_hip.h, fluid_field_device_ptr's rule (2)): the torch stream that is current when this is
+        called (or `stream`) waits ON THE DEVICE for everything the solver has enqueued so far — steps still running, the packed dye's
+        conversion back to RGBA — so torch work issued on that stream afterwards reads the finished field.  No host synchronisation.
+        (Round 4 left this to the caller's sim.sync() and then enqueued the conversion BEHIND that sync: BENCH_r04's mismatch.)
+
+        READ-ONLY and short-lived: the pointer is the buffer that is current NOW — any step, splat, pass or write swaps the field's
+        ping-pong buffers (and may free them: resize), after which the view shows the spare buffer or dangles.  Torch work that still
+        reads the view when the solver is next called must be ordered in front of it: `sim.wait_for_torch()`."""
         import torch
         ptr = C.c_void_p()
         self._check(self._lib.fluid_field_device_ptr(self._ctx, FIELD_IDS[name], C.byref(ptr)))
@@ -462,12 +469,23 @@ class FluidSim:
         # own view with the ghost geometry: fluid_hip.stripes.HipStripeEngine.view)
         if fi.halo or fi.halo_x or fi.array_col0 or fi.cols != fi.width or fi.rows != fi.height:
             raise FluidError(_abi.ERR_UNSUPPORTED, "device_view is for whole-domain contexts")
+        with torch.cuda.device(self._device):
+            s = torch.cuda.current_stream() if stream is None else stream
+            self._check(self._lib.fluid_stream_wait_context(self._ctx, C.c_void_p(s.cuda_stream)))
         shape = (fi.rows + 2 * fi.halo, fi.pitch, fi.channels)
 
         class _DeviceArray:  # minimal CUDA-array-interface carrier
             __cuda_array_interface__ = {"shape": shape, "typestr": "<f%d" % fi.bytes_per_channel, "data": (ptr.value, False), "version": 2}
 
         return torch.as_tensor(_DeviceArray(), device="cuda:%d" % self._device)[:, :fi.width]
+
+    def wait_for_torch(self, stream=None):
+        """the solver's next call runs behind everything enqueued on torch's current stream (or `stream`) so far: call it between the last
+        torch op that reads a device_view and the next step / splat / write (fluid_context_wait_stream; no host synchronisation)"""
+        import torch
+        with torch.cuda.device(self._device):
+            s = torch.cuda.current_stream() if stream is None else stream
+            self._check(self._lib.fluid_context_wait_stream(self._ctx, C.c_void_p(s.cuda_stream)))
 
     # -- single passes (test / stripe-driver port) -------------------------------------------------
     def run_pass(self, name: str, dt: float = 0.016666, iters: int = 1, ext: int = 0):

@@ -180,6 +180,13 @@ class HipStripeEngine:
     def set_overlap(self, on): self._ck(self.lib.fluid_set_overlap(self.ctx, 1 if on else 0))
     def set_link_model(self, latency_us, gbytes_per_s): self._ck(self.lib.fluid_set_link_model(self.ctx, float(latency_us), float(gbytes_per_s)))
 
+    def calibrate_link(self, reps=20):
+        """collective over the stripe / tile set (behind comm_init): measure what a neighbour message costs and make it this context's
+        link model (fluid_comm_calibrate_link) -> (latency_us, GB/s)"""
+        lat, bw = C.c_float(0), C.c_float(0)
+        self._ck(self.lib.fluid_comm_calibrate_link(self.ctx, int(reps), C.byref(lat), C.byref(bw)))
+        return float(lat.value), float(bw.value)
+
     def advect_exchange_rows(self):
         a, b = C.c_int(0), C.c_int(0)
         self._ck(self.lib.fluid_advect_exchange_rows(self.ctx, C.byref(a), C.byref(b)))
@@ -291,8 +298,11 @@ class StripeSim:
                  overlap: Optional[bool] = None, tiles_x: int = 1, storage: str = "f32", link_model=None):
         """tiles_x > 1: 2-D decomposition, world // tiles_x row stripes x tiles_x column tiles, rank = stripe * tiles_x +
         tile column (native driver only; the hosted schedule below is 1-D).  link_model = (latency_us, GB/s) of one neighbour
-        message (fluid_set_link_model: sizes how much compute the native driver puts in front of an exchange's arrival)"""
+        message (fluid_set_link_model: sizes how much compute the native driver puts in front of an exchange's arrival);
+        link_model = "calibrate": measure it at start-up on this set's own links (fluid_comm_calibrate_link; `self.link_model` holds
+        what came out); None: the library's defaults"""
         self._link_model = link_model
+        self.link_model = None   # (latency_us, GB/s, source) once known
         self.canvas = canvas if isinstance(canvas, Canvas) else Canvas(*canvas)
         self.config = dict(DEFAULT_CONFIG)
         if config:
@@ -348,8 +358,10 @@ class StripeSim:
             self.engine.set_reach(reach)
         if overlap is not None:
             self.engine.set_overlap(overlap)
-        if getattr(self, "_link_model", None) is not None:
-            self.engine.set_link_model(*self._link_model)
+        lm = getattr(self, "_link_model", None)
+        if lm is not None and not isinstance(lm, str):
+            self.engine.set_link_model(*lm)
+            self.link_model = (float(lm[0]), float(lm[1]), "given")
         payload = None
         if self.rank == 0:   # a failure on rank 0 must reach every rank, or they would wait in the broadcast forever
             try:
@@ -360,6 +372,12 @@ class StripeSim:
         if payload[:4] == b"ERR:":
             raise _abi.FluidError(_abi.ERR_COMM, payload[4:].decode())
         self.engine.comm_init(payload)
+        if lm == "calibrate" and self.world > 1:
+            try:
+                lat, bw = self.engine.calibrate_link()
+                self.link_model = (lat, bw, "measured at start-up: fluid_comm_calibrate_link, 20 exchanges of 4 KB and of the step's largest message")
+            except _abi.FluidError as ex:   # the probe is an optimisation: the library's constants stay, the line says why
+                self.link_model = (20.0, 50.0, "library default; the start-up probe failed: %s" % str(ex)[:160])
 
     @property
     def exchanges(self):
