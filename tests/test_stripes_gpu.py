@@ -388,6 +388,29 @@ def test_link_model_changes_the_schedule_not_the_bits(ty, tx, halo, iters, link)
         g.close()
 
 
+@pytest.mark.parametrize("delay_us,gbps", [(40, 25), (80, 50), (150, 100)])
+def test_link_calibration_finds_the_link_it_is_given(delay_us, gbps):
+    """fluid_comm_calibrate_link against tests/fake_rccl with a synthetic link (latency + bytes / bandwidth per exchange): the measured model
+    is within 20 % of the injected one.  One rank of three in the stand-in's loopback mode (the middle stripe: two neighbours), its own
+    process per link because the stand-in reads its environment once.  (The defaults the probe replaces — 20 us, 50 GB/s — decide how many
+    Jacobi launches the driver cuts around an exchange; a wrong guess costs 2-3 % either way: profiles/r04/overlap_vs_link_latency.txt.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    tool = os.path.join(os.path.dirname(here), "tools", "overlap_vs_link.py")
+    lib = fake_rccl_lib()
+    env = dict(os.environ, FLUID_RCCL_LIB=lib, FAKE_RCCL_LOOPBACK="1", FAKE_RCCL_DELAY_US=str(delay_us), FAKE_RCCL_GBPS=str(gbps),
+               _OVL_CHILD=json.dumps({"config": "stripe", "overlap": 1, "calibrate": True}))
+    r = subprocess.run([sys.executable, tool], env=env, capture_output=True, text=True, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert lines, r.stderr[-800:]
+    d = json.loads(lines[-1])
+    assert abs(d["latency_us"] - delay_us) <= 0.2 * delay_us, d
+    assert abs(d["GBps"] - gbps) <= 0.2 * gbps, d
+
+
 def test_link_model_rejects_nonsense():
     import fluid_hip
     from fluid_hip.stripes import StripeGroup

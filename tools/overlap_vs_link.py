@@ -56,6 +56,11 @@ def child(a):
     e.use_own_stream()
     e.set_overlap(a["overlap"])
     e.comm_init(new_comm_id())      # loopback: returns at once
+    if a.get("calibrate"):          # tests/test_stripes_gpu.py: does the start-up probe find the link the stand-in was given?
+        lat, bw = e.calibrate_link(int(a.get("reps", 20)))
+        e.close()
+        print(json.dumps({"ok": True, "latency_us": lat, "GBps": bw}))
+        return
     for s in splats:
         e.splat(*s, aspect, radius)
     e.step_n(40, DT, cfg)            # past the shader-clock dip of a load step (profiles/r04/first_steps.txt)

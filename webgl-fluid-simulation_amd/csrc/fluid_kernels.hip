@@ -253,13 +253,33 @@ __device__ __forceinline__ void load_pair(const float2* F, unsigned o, float2& a
     a = make_float2(v.x, v.y);
     b = make_float2(v.z, v.w);
 }
+// two horizontally adjacent PACKED dye texels — 24 contiguous bytes, dword-aligned — in a 16-byte and an 8-byte load instead of two
+// 12-byte ones: the texture addresser spends its cycles per instruction and lane group, not per byte, and a dwordx3 costs what a dwordx4 does
+typedef float quad_u4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef float pair_u4 __attribute__((ext_vector_type(2), aligned(4)));
+__device__ __forceinline__ void load_pair(const rgb3* F, unsigned o, float4& a, float4& b)
+{
+    const char* p = reinterpret_cast<const char*>(F) + (size_t)o;
+    const quad_u4 lo = *reinterpret_cast<const quad_u4*>(p);
+    const pair_u4 hi = *reinterpret_cast<const pair_u4*>(p + 16);
+    a = make_float4(lo.x, lo.y, lo.z, 0.0f);
+    b = make_float4(lo.w, hi.x, hi.y, 0.0f);
+}
 // f[k].a .. f[k].d = the texels at byte offsets t[k].a .. t[k].d of field F
-template <int ROWS, class T, class FT>
+// PAIR3: the packed dye's two taps of a row in one 16-byte + one 8-byte load (load_pair above) wherever no clamp separates them
+template <int ROWS, bool PAIR3 = false, class T, class FT>
 __device__ __forceinline__ void gather_taps(const T* __restrict__ F, const Tap4 (&t)[ROWS], FT (&f)[ROWS])
 {
 #pragma unroll
     for (int k = 0; k < ROWS; k++) {
         bool paired = false;
+        if constexpr (PAIR3 && sizeof(T) == sizeof(rgb3) && sizeof(f[k].a) == sizeof(float4)) {   // packed fp32 dye
+            paired = t[k].b == t[k].a + 12u && t[k].d == t[k].c + 12u;
+            if (paired) {
+                load_pair(reinterpret_cast<const rgb3*>(F), t[k].a, f[k].a, f[k].b);
+                load_pair(reinterpret_cast<const rgb3*>(F), t[k].c, f[k].c, f[k].d);
+            }
+        }
         if constexpr (sizeof(T) == sizeof(float2) && sizeof(f[k].a) == sizeof(float2)) {   // fp32 velocity
             paired = t[k].b == t[k].a + 8u && t[k].d == t[k].c + 8u;                       // no clamp between the two taps of a row
             if (paired) {
@@ -277,7 +297,7 @@ __device__ __forceinline__ void gather_taps(const T* __restrict__ F, const Tap4 
 
 // WY: waves of a block stacked in y (1 = the four waves side by side: 256 columns x ROWS rows per block; 4 = one wave wide: 64 columns x
 // 4 ROWS rows — the block's waves then share the rows between them in the CU's L1, at the price of more column seams between XCDs)
-template <int ROWS, class V2, class D4, int WY = 1>
+template <int ROWS, class V2, class D4, int WY = 1, bool PAIR3 = false>
 __device__ __forceinline__ void advect_both_fast_body(const Win& w, const V2* __restrict__ vel, V2* __restrict__ vel_out,
                                                       const D4* __restrict__ dye, D4* __restrict__ dye_out, float dt, double rW, double rH,
                                                       double rvd, double rdd, float tsx, float tsy, int ga, int gb,
@@ -327,7 +347,7 @@ __device__ __forceinline__ void advect_both_fast_body(const Win& w, const V2* __
         if (on[k]) miss += t[k].miss;
     }
     Fetch4 f4[ROWS];
-    gather_taps<ROWS>(dye, t, f4);
+    gather_taps<ROWS, PAIR3>(dye, t, f4);
 #pragma unroll
     for (int k = 0; k < ROWS; k++) {
         const Fetch4& f = f4[k];
@@ -387,6 +407,16 @@ __global__ void __launch_bounds__(BX) k_dye_unpack(const rgb3* __restrict__ rgb,
 }
 
 #ifdef FLUID_PROBES
+// lab (FLUID_RGB_PAIR=1): the packed-dye advection with the two dye taps of a row in a 16-byte + an 8-byte load (gather_taps PAIR3)
+template <int ROWS>
+__global__ void __launch_bounds__(BX) k_advect_both_fast_rgb_pair(Win w, const float2* __restrict__ vel, float2* __restrict__ vel_out,
+                                                                   const rgb3* __restrict__ dye, rgb3* __restrict__ dye_out, float dt, double rW,
+                                                                   double rH, double rvd, double rdd, float tsx, float tsy, int ga, int gb,
+                                                                   unsigned int* __restrict__ miss_out)
+{
+    advect_both_fast_body<ROWS, float2, rgb3, 1, true>(w, vel, vel_out, dye, dye_out, dt, rW, rH, rvd, rdd, tsx, tsy, ga, gb, miss_out, (int)blockIdx.x, (int)blockIdx.y);
+}
+
 // lab: the packed-dye advection with its block's waves stacked in y (WY) AND the blocks handed to the XCDs in contiguous column ranges
 // (block b runs on XCD b % 8: with the plain (bx, by) grid horizontally adjacent blocks never share an L2; here XCD k takes the k-th
 // eighth of every block row, so that a tap row displaced across a block seam is refetched at 8 seams per row instead of at every one)
@@ -505,7 +535,7 @@ __device__ __forceinline__ void advect_velocity_fast_body(const Win& w, const V2
 // Same texels into the same arithmetic, hence the same bits.
 constexpr int VT_COLS = 20, VT_ROWS = 3;
 
-template <int ROWS, class V2, class D4, int WY = 1, bool VT = false>
+template <int ROWS, class V2, class D4, int WY = 1, bool VT = false, bool PAIR3 = false>
 __device__ __forceinline__ void advect_dye_fast_body(const Win& vw, const V2* __restrict__ vel, const Win& dw, const D4* __restrict__ dye,
                                                      D4* __restrict__ dye_out, float dt, double rW, double rH, double rdd, float tsx, float tsy,
                                                      int ga, int gb, unsigned int* __restrict__ miss_out, float2* vtile = nullptr)
@@ -590,7 +620,7 @@ __device__ __forceinline__ void advect_dye_fast_body(const Win& vw, const V2* __
         if (on[k]) miss += t[k].miss;
     }
     Fetch4 f4[ROWS];
-    gather_taps<ROWS>(dye, t, f4);
+    gather_taps<ROWS, PAIR3>(dye, t, f4);
 #pragma unroll
     for (int k = 0; k < ROWS; k++) {
         const Fetch4& f = f4[k];
@@ -658,6 +688,17 @@ __global__ void __launch_bounds__(BX) k_advect_dye_fast_rgb_vt(Win vw, const flo
     __shared__ float2 vt[BX / 64][VT_ROWS * VT_COLS];
     advect_dye_fast_body<ROWS, float2, rgb3, 1, true>(vw, vel, dw, dye, dye_out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss_out, vt[threadIdx.x >> 6]);
 }
+
+#ifdef FLUID_PROBES
+template <int ROWS>   // lab (FLUID_RGB_PAIR=1): the dye pass on the packed field with paired tap loads
+__global__ void __launch_bounds__(BX) k_advect_dye_fast_rgb_vt_pair(Win vw, const float2* __restrict__ vel, Win dw, const rgb3* __restrict__ dye,
+                                                                     rgb3* __restrict__ dye_out, float dt, double rW, double rH, double rdd, float tsx,
+                                                                     float tsy, int ga, int gb, unsigned int* __restrict__ miss_out)
+{
+    __shared__ float2 vt[BX / 64][VT_ROWS * VT_COLS];
+    advect_dye_fast_body<ROWS, float2, rgb3, 1, true, true>(vw, vel, dw, dye, dye_out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss_out, vt[threadIdx.x >> 6]);
+}
+#endif
 
 template <int ROWS>
 __global__ void __launch_bounds__(BX) k_advect_both(Win w, const float2* __restrict__ vel, float2* __restrict__ vel_out,
@@ -2579,6 +2620,11 @@ hipError_t launch_advect_both_rgb(hipStream_t s, Win w, const float2* vel, float
 #undef WY_CASE
         return hipGetLastError();
     }
+    static const bool pair3 = [] { const char* e = lab_env("FLUID_RGB_PAIR"); return e && atoi(e) != 0; }();
+    if (pair3 && rows == 4) {
+        k_advect_both_fast_rgb_pair<4><<<dim3(gx, (gb - ga + 3) / 4, 1), BX, 0, s>>>(w, vel, vel_out, dye, dye_out, dt, rW, rH, rvd, rdd, tsx, tsy, ga, gb, miss);
+        return hipGetLastError();
+    }
     switch (rows) {
         ADVECT_FAST_CASE(k_advect_both_fast_rgb, 2)
         ADVECT_FAST_CASE(k_advect_both_fast_rgb, 3)
@@ -2611,6 +2657,13 @@ hipError_t launch_advect_dye_rgb(hipStream_t s, Win vw, const float2* vel, Win d
         return hipErrorNotReady;
     const double rW = udiv_recip((float)dw.W), rH = udiv_recip((float)dw.H), rdd = udiv_recip(decay);
     const unsigned gx = (dw.x1 - dw.x0 + BX - 1) / BX;
+#ifdef FLUID_PROBES
+    static const bool pair3 = [] { const char* e = lab_env("FLUID_RGB_PAIR"); return e && atoi(e) != 0; }();
+    if (pair3 && velocity_tile() && split_advect_rows_vt((long)(dw.x1 - dw.x0) * (gb - ga)) == 4) {
+        k_advect_dye_fast_rgb_vt_pair<4><<<dim3(gx, (gb - ga + 3) / 4, 1), BX, 0, s>>>(vw, vel, dw, dye, out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss);
+        return hipGetLastError();
+    }
+#endif
     if (velocity_tile()) {
         switch (split_advect_rows_vt((long)(dw.x1 - dw.x0) * (gb - ga))) {
         case 4: k_advect_dye_fast_rgb_vt<4><<<dim3(gx, (gb - ga + 3) / 4, 1), BX, 0, s>>>(vw, vel, dw, dye, out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss); break;
