@@ -231,7 +231,18 @@ int fluid_halo_check(fluid_ctx *ctx);
  * The reference is single-GPU, so nothing in script.js corresponds to this block; it is how step() (1231-1294)
  * runs when `parts` > 1.  fluid_step / fluid_step_n on a stripe context execute the plan below: pass groups on the
  * stripe's window with neighbour ncclSend / ncclRecv (one ncclGroup per exchange, in place on the ghost rows)
- * between them, all on the context stream.  No global collective is on the data path. */
+ * between them, all on the context stream.  No global collective is on the data path.
+ *
+ * WHAT IS COLLECTIVE ON A SET (every rank makes the call, with the same arguments, in the same order): fluid_step / fluid_step_n (they
+ * exchange), fluid_comm_init, fluid_comm_calibrate_link — and, since ABI 9, everything that puts dye texels into a context behind the
+ * library's back or resets their alpha: fluid_splat / fluid_pass_splat on FLUID_DYE (the reference's splat() draws into the whole dye
+ * texture: every rank draws it on its window), fluid_write_field(FLUID_DYE), fluid_halo_unpack(FLUID_DYE), fluid_field_device_ptr(FLUID_DYE).
+ * Reason: a rank of at least 3072^2 owned texels whose dye grid is its sim grid keeps the dye packed to three floats per texel through the
+ * fused advection, as a whole-domain context does, and its ghost texels then travel as 12-byte texels, in place — the field's FORMAT is
+ * part of the message layout two neighbours cut.  The library derives it from nothing but those calls and the steps' arguments, so ranks
+ * that make them alike agree by construction (fluid_group_step_n checks format and alpha across an in-process set and refuses a set that
+ * disagrees).  READS are not collective: fluid_read_field(FLUID_DYE) on one rank converts into the field's spare buffer and changes
+ * nothing. */
 typedef enum fluid_stripe_op_kind {
     FLUID_OP_EXCHANGE = 0,       /* refresh n_items fields' ghost rows from both neighbours                  */
     FLUID_OP_CURL_VORT_DIV = 1,  /* script.js:1234-1251, ghost rows out to `ext`                               */

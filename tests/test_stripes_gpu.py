@@ -411,6 +411,55 @@ def test_link_calibration_finds_the_link_it_is_given(delay_us, gbps):
     assert abs(d["GBps"] - gbps) <= 0.2 * gbps, d
 
 
+@pytest.mark.parametrize("world,tiles_x,canvas", [(2, 1, (4096, 4608)), (4, 2, (6144, 6144))])
+def test_packed_dye_on_a_stripe_or_tile_set_leaves_the_same_bits(world, tiles_x, canvas):
+    """Round 5: stripe / tile contexts of at least 3072^2 owned texels keep their dye PACKED (three floats per texel) through the fused
+    advection like a whole domain does, and the ghost texels travel as 12-byte texels, in place.  The set must leave what the single domain
+    leaves, bit for bit — through splats into a packed field, a READ of one context only in mid-run (which must not change that context's
+    format: the format is part of the message layout both ends of an exchange cut), and steps behind it."""
+    import fluid_hip
+    from fluid_hip.stripes import StripeGroup
+    res = min(canvas)
+    cfg = {"SIM_RESOLUTION": res, "DYE_RESOLUTION": res, "PRESSURE_ITERATIONS": 12}
+    DT = 0.016666
+    g = StripeGroup(world, canvas=canvas, config=cfg, halo=24, random=fluid_hip.mulberry32(77), tiles_x=tiles_x)
+    try:
+        with fluid_hip.FluidSim(canvas=canvas, config=cfg, random=fluid_hip.mulberry32(77)) as one:
+            for sim in (g, one):
+                sim.multipleSplats(4)
+                sim.step(DT, 3)
+            info = [e.schedule_info(3, DT, g.config) for e in g.engines]
+            assert all(i["dye_packed"] for i in info), info               # the set really runs the packed path
+            peek = g.engines[0].read("dye")                               # ONE context read: converts into the spare buffer, changes nothing
+            assert peek[..., 3].min() == peek[..., 3].max() and 0.9 < float(peek[0, 0, 3]) < 1.0   # the decayed alpha, one value
+            assert g.engines[0].schedule_info(3, DT, g.config)["dye_packed"]
+            for sim in (g, one):
+                sim.multipleSplats(2)                                     # splats into the packed field
+                sim.step(DT, 4)
+            for k in ("velocity", "pressure", "divergence", "curl", "dye"):
+                assert np.array_equal(g.read(k), one.read(k)), k
+    finally:
+        g.close()
+
+
+def test_a_set_that_disagrees_on_the_dye_is_refused():
+    """what "splats are collective on a set" means where one process can see it: a splat into ONE context of an in-process set leaves the
+    contexts with different alphas (1 against the decayed value) — fluid_group_step_n refuses to exchange instead of mixing texel formats"""
+    import fluid_hip
+    from fluid_hip.stripes import StripeGroup
+    cfg = {"SIM_RESOLUTION": 4096, "DYE_RESOLUTION": 4096, "PRESSURE_ITERATIONS": 4}
+    g = StripeGroup(2, canvas=(4096, 4608), config=cfg, halo=24, random=fluid_hip.mulberry32(5))
+    try:
+        g.multipleSplats(2)
+        g.step(0.016666, 2)
+        g.engines[1].splat(0.5, 0.5, 10.0, 10.0, 1.0, 0.5, 0.25, 4096 / 4608, 0.0025)
+        with pytest.raises(fluid_hip.FluidError) as e:
+            g.step(0.016666, 1)
+        assert "collective" in str(e.value)
+    finally:
+        g.close()
+
+
 def test_link_model_rejects_nonsense():
     import fluid_hip
     from fluid_hip.stripes import StripeGroup

@@ -133,8 +133,17 @@ struct FieldRef {
     size_t esz;              // bytes per channel of the device array (4, or 2 with fp16 storage)
     size_t texel() const { return (size_t)nc * esz; }
 };
-int field_ref(fluid_ctx* c, int field, FieldRef* f, bool geometry_only = false);
+int field_ref(fluid_ctx* c, int field, FieldRef* f, bool geometry_only = false, bool keep_packed = false);
 int ensure_rgba(fluid_ctx* c);   // the dye buffers hold RGBA texels from here on (unpacks a packed dye field: fluid_ctx::dye_packed)
+// Stripe / tile contexts pack their dye too (round 5): the ghost texels then travel as 12-byte texels, in place, and the FORMAT of the field is
+// part of the message layout two neighbours must agree on.  It is therefore a function of nothing but what every rank of a set does alike:
+// the splats (alpha becomes 1: packing may start), the steps (dye_prepare in front of every dye exchange: one predicate on dt, the decays
+// and the packing state), and the calls that write dye texels behind the library's back (fluid_write_field, fluid_halo_unpack, a raw pointer:
+// alpha unknown until the next splat) — which the header declares collective on such sets.  A READ converts into the spare buffer and
+// changes nothing.  fluid_group_step_n asserts format and alpha equal across an in-process set.
+bool dye_wants_packed(const fluid_ctx* c, float dt, float vel_diss, float dye_diss);
+int dye_prepare(fluid_ctx* c, float dt, const fluid_params* P);          // the field in the format this step's advection takes
+void advect_both_note(fluid_ctx* c, float dt, float dye_diss);           // one advection of the dye happened (band / rects forms: once per step)
 
 // per-pass device time (fluid_set_timing): events on the context stream around each pass group
 struct Timer {

@@ -156,6 +156,8 @@ hipError_t launch_advect_both_rects(hipStream_t s, Win w, const float2* vel, flo
                                     float vel_dissipation, float dye_dissipation, const BandRects& B, unsigned int* miss);
 hipError_t launch_advect_both_rects(hipStream_t s, Win w, const __half2* vel, __half2* vel_out, const half4* dye, half4* dye_out, float dt,
                                     float vel_dissipation, float dye_dissipation, const BandRects& B, unsigned int* miss);
+hipError_t launch_advect_both_rects_rgb(hipStream_t s, Win w, const float2* vel, float2* vel_out, const rgb3* dye, rgb3* dye_out, float dt,
+                                        float vel_dissipation, float dye_dissipation, const BandRects& B, unsigned int* miss);   // packed dye (hipErrorNotReady: see launch_advect_both_rgb)
 hipError_t launch_curl_vort_div_rects(hipStream_t s, Win w, const float2* vel, float* curl, float2* vel_out, float* div, float curl_strength,
                                       float dt, const BandRects& B);
 // launch_jacobi_tb over several rectangles in one launch (fp32 fields, iters <= 10): the frame of a block's first launch around the interior

@@ -3065,6 +3065,31 @@ hipError_t launch_advect_both_rects(hipStream_t s, Win w, const __half2* vel, __
 {
     return launch_advect_both_rects_any(s, w, vel, vel_out, dye, dye_out, dt, vel_dissipation, dye_dissipation, B, miss);
 }
+// the strips of a stripe / tile on the PACKED dye field (the caller checked advect_rgb_supported: the fast kernel applies)
+hipError_t launch_advect_both_rects_rgb(hipStream_t s, Win w, const float2* vel, float2* vel_out, const rgb3* dye, rgb3* dye_out, float dt,
+                                        float vel_dissipation, float dye_dissipation, const BandRects& B, unsigned int* miss)
+{
+    const float vdecay = 1.0f + vel_dissipation * dt, ddecay = 1.0f + dye_dissipation * dt;
+    if (!advect_fast_ok(w, sizeof(float4), vdecay, ddecay)) return hipErrorNotReady;
+    AdvRects R{};
+    constexpr int ROWS = 4;
+    int total = 0;
+    for (int k = 0; k < B.n; k++) {
+        const BandRect& q = B.r[k];
+        if (q.gb <= q.ga || q.xb <= q.xa) continue;
+        const int i = R.n++;
+        R.xa[i] = q.xa; R.xb[i] = q.xb; R.ga[i] = q.ga; R.gb[i] = q.gb;
+        R.nbx[i] = (q.xb - q.xa + BX - 1) / BX;
+        R.blk0[i] = total;
+        total += R.nbx[i] * ((q.gb - q.ga + ROWS - 1) / ROWS);
+    }
+    R.blk0[R.n] = total;
+    if (R.n == 0) return hipSuccess;
+    const float tsx = (float)(1.0 / w.W), tsy = (float)(1.0 / w.H);
+    const double rW = udiv_recip((float)w.W), rH = udiv_recip((float)w.H), rvd = udiv_recip(vdecay), rdd = udiv_recip(ddecay);
+    k_advect_both_fast_rects<ROWS><<<dim3(total, 1, 1), BX, 0, s>>>(w, R, vel, vel_out, dye, dye_out, dt, rW, rH, rvd, rdd, tsx, tsy, miss);
+    return hipGetLastError();
+}
 
 template <class V2, class S1>
 hipError_t launch_curl_vort_div_rects_any(hipStream_t s, Win w, const V2* vel, S1* curl, V2* vel_out, S1* div, float curl_strength, float dt,

@@ -456,7 +456,9 @@ int ensure_rgba(fluid_ctx* c)
     CK(c->hip(fluid::launch_dye_unpack(c->stream, (const fluid::rgb3*)c->dyeb[0], (float4*)c->dyeb[1], cells(c->dye), c->dye_alpha), "unpack dye"));
     std::swap(c->dyeb[0], c->dyeb[1]);
     c->dye_packed = false;
-    if (c->packed_advects < 16) c->pack_holdoff = 256;   // somebody needs RGBA texels every few steps: packing would cost more than it saves
+    // somebody needs RGBA texels every few steps: packing would cost more than it saves.  Whole-domain contexts only: on a stripe / tile the
+    // format of the dye is part of the exchange's message layout, so it may depend on nothing one rank does alone (fluid_internal.h)
+    if (c->packed_advects < 16 && c->desc.parts == 1 && c->desc.parts_x == 1) c->pack_holdoff = 256;
     return FLUID_OK;
 }
 
@@ -476,11 +478,13 @@ void note_dye_advected(fluid_ctx* c, float dt, float dissipation)
     if (c->alpha_known) c->dye_alpha = c->dye_alpha / (1.0f + dissipation * dt);
 }
 
-// a whole-domain fp32 context whose DYE passes are bandwidth-bound (a dye grid of at least kSmallGridTexels: on the sim grid that is where no
-// launches are chained either) and whose alpha is known; fused schedule (the per-pass kernels read RGBA)
+// an fp32 context whose DYE passes are bandwidth-bound (at least kSmallGridTexels owned dye texels: on the sim grid that is where no launches
+// are chained either) and whose alpha is known; fused schedule (the per-pass kernels read RGBA).  A stripe / tile context packs where the one
+// fused advection kernel applies (dye grid = sim grid): its ghost rows then travel as 12-byte texels too (fluid_stripes.cpp).
 bool dye_pack_applies(const fluid_ctx* c)
 {
-    return dye_pack_enabled() && c->alpha_known && c->storage == FLUID_STORE_F32 && c->desc.parts == 1 && c->desc.parts_x == 1 &&
+    const bool whole = c->desc.parts == 1 && c->desc.parts_x == 1;
+    return dye_pack_enabled() && c->alpha_known && c->storage == FLUID_STORE_F32 && (whole || fused_advect_applies(c)) &&
            c->desc.schedule == FLUID_SCHED_FUSED && (long)c->dye_ncols * c->dye_rows >= fluid::kSmallGridTexels;
 }
 
@@ -530,8 +534,7 @@ int pass_advect(fluid_ctx* c, float dt, float vel_diss, float dye_diss, Timer* t
         int ga, gb;
         row_range(c->sim, c->sim_row0, c->sim_rows, 0, ga, gb);
         if (c->pack_holdoff > 0 && !c->dye_packed) c->pack_holdoff--;
-        if (dye_pack_applies(c) && (c->dye_packed || c->pack_holdoff == 0) &&
-            fluid::advect_rgb_supported(sim_cols(c, 0), sim_cols(c, 0), dt, vel_diss, dye_diss)) {   // 40 instead of 48 B/texel: the dye as three floats, its uniform alpha as a scalar
+        if (dye_wants_packed(c, dt, vel_diss, dye_diss)) {   // 40 instead of 48 B/texel: the dye as three floats, its uniform alpha as a scalar
             CK(ensure_packed(c));
             c->packed_advects++;
             const hipError_t e = fluid::launch_advect_both_rgb(c->stream, sim_cols(c, 0), (const float2*)c->vel[0], (float2*)c->vel[1],
@@ -620,9 +623,30 @@ int cvd_rects(fluid_ctx* c, float curl, float dt, const BandRects& B)
 
 void cvd_swap(fluid_ctx* c) { std::swap(c->vel[0], c->vel[1]); }
 
+// the format the dye takes through THIS step's advection, decided once per step in front of the exchange that refreshes its ghost rows
+// (fluid_stripes.cpp) — and by pass_advect for a whole domain: packed where packing applies, the fast kernel takes these decays and the
+// field is not in a hold-off
+bool dye_wants_packed(const fluid_ctx* c, float dt, float vel_diss, float dye_diss)
+{
+    if (!dye_pack_applies(c) || !(c->dye_packed || c->pack_holdoff == 0)) return false;
+    const bool same = c->sim.W == c->dye.W && c->sim.H == c->dye.H;
+    return same ? fluid::advect_rgb_supported(sim_cols(c, 0), sim_cols(c, 0), dt, vel_diss, dye_diss)
+                : fluid::advect_rgb_supported(c->sim, dye_cols(c, 0), dt, dye_diss, dye_diss);
+}
+
+int dye_prepare(fluid_ctx* c, float dt, const fluid_params* P)
+{
+    return dye_wants_packed(c, dt, P->velocity_dissipation, P->density_dissipation) ? ensure_packed(c) : ensure_rgba(c);
+}
+
+void advect_both_note(fluid_ctx* c, float dt, float dye_diss)
+{
+    if (c->dye_packed) c->packed_advects++;
+    note_dye_advected(c, dt, dye_diss);
+}
+
 int advect_both_band(fluid_ctx* c, float dt, float vel_diss, float dye_diss, int ga, int gb, int xa, int xb, int v0, int v1, int u0, int u1)
 {
-    CK(ensure_rgba(c));
     Win w = c->sim;  // dye grid == sim grid: one window serves both gathers
     w.x0 = xa;
     w.x1 = xb;
@@ -630,18 +654,27 @@ int advect_both_band(fluid_ctx* c, float dt, float vel_diss, float dye_diss, int
     w.v1 = v1;
     w.u0 = u0;
     w.u1 = u1;
+    if (c->dye_packed) {   // (dye_prepare left it packed because the fast kernel takes these decays: never hipErrorNotReady)
+        return c->hip(fluid::launch_advect_both_rgb(c->stream, w, (const float2*)c->vel[0], (float2*)c->vel[1], (const fluid::rgb3*)c->dyeb[0],
+                                                    (fluid::rgb3*)c->dyeb[1], dt, vel_diss, dye_diss, ga, gb, c->miss),
+                      "advect");
+    }
     return c->hip(STORE_CALL(c, launch_advect_both(c->stream, w, VEL(c, 0), VEL(c, 1), DYE(c, 0), DYE(c, 1), dt, vel_diss, dye_diss, ga, gb, c->miss)),
                   "advect");
 }
 
 int advect_both_rects(fluid_ctx* c, float dt, float vel_diss, float dye_diss, const BandRects& B, int v0, int v1, int u0, int u1)
 {
-    CK(ensure_rgba(c));
     Win w = c->sim;  // dye grid == sim grid: one window serves both gathers
     w.v0 = v0;
     w.v1 = v1;
     w.u0 = u0;
     w.u1 = u1;
+    if (c->dye_packed) {
+        return c->hip(fluid::launch_advect_both_rects_rgb(c->stream, w, (const float2*)c->vel[0], (float2*)c->vel[1], (const fluid::rgb3*)c->dyeb[0],
+                                                          (fluid::rgb3*)c->dyeb[1], dt, vel_diss, dye_diss, B, c->miss),
+                      "advect");
+    }
     return c->hip(STORE_CALL(c, launch_advect_both_rects(c->stream, w, VEL(c, 0), VEL(c, 1), DYE(c, 0), DYE(c, 1), dt, vel_diss, dye_diss, B, c->miss)),
                   "advect");
 }
@@ -796,7 +829,7 @@ bool split_chain_applies(const fluid_ctx* c, float dt, const fluid_params* P)
 
 namespace fluid_impl {
 
-int field_ref(fluid_ctx* c, int field, FieldRef* f, bool geometry_only)
+int field_ref(fluid_ctx* c, int field, FieldRef* f, bool geometry_only, bool keep_packed)
 {
     const int h = c->desc.parts > 1 ? c->desc.halo : 0, hx = c->desc.parts_x > 1 ? c->desc.halo : 0;
     switch (field) {
@@ -805,8 +838,12 @@ int field_ref(fluid_ctx* c, int field, FieldRef* f, bool geometry_only)
     case FLUID_DIVERGENCE: *f = { c->div, &c->sim, c->sim_row0, c->sim_rows, h, 1, c->sim_col0, c->sim_ncols, hx, c->esz }; break;
     case FLUID_CURL: *f = { c->curl, &c->sim, c->sim_row0, c->sim_rows, h, 1, c->sim_col0, c->sim_ncols, hx, c->esz }; break;
     case FLUID_DYE:
-        if (!geometry_only) CK(ensure_rgba(c));   // whoever asks for the dye field's MEMORY (read, write, ghost rows, a raw pointer) gets RGBA texels
-        *f = { c->dyeb[0], &c->dye, c->dye_row0, c->dye_rows, c->dye_halo, 4, c->dye_col0, c->dye_ncols, c->dye_halo_x, c->esz }; break;
+        // whoever asks for the dye field's MEMORY (read, write, ghost rows, a raw pointer) gets RGBA texels — except the stripe / tile driver's
+        // own exchanges (keep_packed), which move the ghost texels in whatever format the field is in: 3 channels while it is packed
+        if (!geometry_only && !keep_packed) CK(ensure_rgba(c));
+        *f = { c->dyeb[0], &c->dye, c->dye_row0, c->dye_rows, c->dye_halo, (keep_packed && !geometry_only && c->dye_packed) ? 3 : 4,
+               c->dye_col0, c->dye_ncols, c->dye_halo_x, c->esz };
+        break;
     default: return c->fail(FLUID_ERR_INVALID, "unknown field id");
     }
     return FLUID_OK;
@@ -904,7 +941,7 @@ int fluid_create(const fluid_desc* desc, fluid_ctx** out)
         fluid_destroy(c);
         return rc;
     }
-    c->alpha_known = c->desc.parts == 1 && c->desc.parts_x == 1 && c->storage == FLUID_STORE_F32;   // alloc_fields filled alpha = 1
+    c->alpha_known = c->storage == FLUID_STORE_F32;   // alloc_fields filled alpha = 1, ghost rows and columns included
     c->dye_alpha = 1.0f;
     *out = c;
     return FLUID_OK;
@@ -1041,9 +1078,10 @@ int fluid_pass_splat(fluid_ctx* c, int field, float x, float y, float aspect, fl
             CK(c->hip(STORE_CALL(c, launch_splat_dye(c->stream, dye_cols(c, c->dye_halo_x), DYE(c, 0), DYE(c, 1), x, y, aspect, radius, c0, c1, c2, ga, gb)),
                       "splat dye"));
         std::swap(c->dyeb[0], c->dyeb[1]);
-        // the splat writes alpha = 1 into every texel it covers — all of them on a whole-domain fp32 context (a stripe's ranks are splatted one
-        // by one by their host; fp16 storage rounds the decayed alpha: neither tracks it)
-        if (c->desc.parts == 1 && c->desc.parts_x == 1 && c->storage == FLUID_STORE_F32) {
+        // the splat writes alpha = 1 into every texel of the context's window, ghost rows and columns included (fp16 storage rounds the decayed
+        // alpha and does not track it).  On a stripe / tile set the value is the same on every rank because every rank gets every splat — the
+        // header's contract for splats, writes and raw pointers on such sets (collective), asserted by fluid_group_step_n for in-process sets
+        if (c->storage == FLUID_STORE_F32) {
             c->alpha_known = true;
             c->dye_alpha = 1.0f;
         }
@@ -1145,9 +1183,17 @@ struct HostBlock {
     char* first_row;      // device address of the first owned row (array column 0)
 };
 
-int host_block(fluid_ctx* c, int field, size_t bytes, const char* who, HostBlock* b)
+// `peek`: a READ of a stripe / tile context's packed dye converts into the field's spare buffer and leaves the field as it is — on such a
+// set the dye's format is part of the exchange's message layout and must not change because ONE rank was read (fluid_internal.h)
+int host_block(fluid_ctx* c, int field, size_t bytes, const char* who, HostBlock* b, bool peek = false)
 {
-    CK(field_ref(c, field, &b->f));
+    if (peek && field == FLUID_DYE && c->dye_packed && (c->desc.parts > 1 || c->desc.parts_x > 1)) {
+        CK(field_ref(c, field, &b->f, true));   // RGBA geometry
+        CK(c->hip(fluid::launch_dye_unpack(c->stream, (const fluid::rgb3*)c->dyeb[0], (float4*)c->dyeb[1], cells(c->dye), c->dye_alpha), "unpack dye (read)"));
+        b->f.ptr = c->dyeb[1];
+    } else {
+        CK(field_ref(c, field, &b->f));
+    }
     const FieldRef& f = b->f;
     b->line = (size_t)f.cols * f.nc * sizeof(float);
     if (bytes != (size_t)f.rows * b->line) return c->fail(FLUID_ERR_INVALID, std::string(who) + ": byte count does not match the owned rows x columns (fp32)");
@@ -1162,7 +1208,7 @@ int fluid_read_field(fluid_ctx* c, int field, float* host, size_t bytes)
 {
     if (!c || !host) return FLUID_ERR_INVALID;
     HostBlock b;
-    CK(host_block(c, field, bytes, "read_field", &b));
+    CK(host_block(c, field, bytes, "read_field", &b, true));
     HIPCK(c, hipSetDevice(c->device));
     const size_t pitch32 = (size_t)b.f.win->P * b.f.nc * sizeof(float);
     const size_t col = (size_t)(b.f.col0 - b.f.win->c0);  // array column of the first owned column
@@ -1189,7 +1235,8 @@ int fluid_write_field(fluid_ctx* c, int field, const float* host, size_t bytes)
     HIPCK(c, hipSetDevice(c->device));
     const size_t pitch32 = (size_t)b.f.win->P * b.f.nc * sizeof(float);
     const size_t col = (size_t)(b.f.col0 - b.f.win->c0);  // array column of the first owned column
-    if (field == FLUID_DYE && c->alpha_known) {   // does the caller's dye keep ONE alpha?  (whole-domain fp32 contexts only ever know theirs)
+    if (field == FLUID_DYE && (c->desc.parts > 1 || c->desc.parts_x > 1)) c->alpha_known = false;   // the ghost texels keep what they held: no ONE alpha until the next splat
+    if (field == FLUID_DYE && c->alpha_known) {   // does the caller's dye keep ONE alpha?
         const size_t n = (size_t)b.f.rows * b.f.cols;
         const float a0 = n ? host[3] : c->dye_alpha;
         bool uniform = true;
@@ -1309,6 +1356,7 @@ int fluid_halo_pack(fluid_ctx* c, int field, int side, int nrows, void* dev_buf)
 int fluid_halo_unpack(fluid_ctx* c, int field, int side, int nrows, const void* dev_buf)
 {
     if (c) c->touched();
+    if (c && field == FLUID_DYE) c->alpha_known = false;   // ghost texels from a buffer of the caller's: whatever alpha they carry
     return halo_copy(c, field, side, nrows, const_cast<void*>(dev_buf), false);
 }
 
@@ -1398,7 +1446,7 @@ int fluid_schedule_info_get(fluid_ctx* c, int n_steps, float dt, const fluid_par
     const bool chain = chains && (n_steps > 1 || out->runs_ahead || out->pending_adopted);
     out->chained = chain ? n_steps - 1 + out->runs_ahead : 0;
     const bool fused_cvd = fluid_impl::fused_cvd_applies(c);
-    out->dye_packed = whole && dye_pack_applies(c) && (c->dye_packed || c->pack_holdoff == 0);
+    out->dye_packed = dye_pack_applies(c) && (c->dye_packed || c->pack_holdoff == 0);
     // how many times the call stores a curl field.  Chained / plain steps: hidden curls are skipped — the call's last step's is stored, plus
     // the one the closing launch works ahead.  Split path (dye grid != sim grid; step_once chain 3): EVERY step's closing launch stores the
     // next step's curl into the pending buffer, and a lead launch (nothing adopted) stores the first step's own.

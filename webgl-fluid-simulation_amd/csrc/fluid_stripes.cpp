@@ -166,7 +166,7 @@ struct Rows {
 int rows_of(fluid_ctx* c, int field, int n, Rows* r)
 {
     FieldRef f;
-    CK(field_ref(c, field, &f));
+    CK(field_ref(c, field, &f, false, true));   // the dye in the format it is in (dye_prepare ran in front of the exchange): 12-byte texels while packed
     if (n < 1 || n > f.halo || n > f.rows) return c->fail(FLUID_ERR_INVALID, "exchange rows exceed the ghost rows / the stripe");
     const size_t rowf = (size_t)f.win->P * f.texel();  // bytes per array row (pitch)
     char* base = (char*)f.ptr;
@@ -407,7 +407,7 @@ struct Blocks {
 
 int col_depth(const fluid_ctx* c, const FieldRef& f, int n)  // ghost columns that go with n ghost rows of this field
 {
-    if (f.nc != 4) return n < f.halo_x ? n : f.halo_x;      // sim fields: same depth both ways
+    if (f.win != &c->dye) return n < f.halo_x ? n : f.halo_x;      // sim fields: same depth both ways
     const long num = (long)n * c->dye.W * c->sim.H, den = (long)c->dye.H * c->sim.W;  // dye: same physical distance
     long nx = (num + den - 1) / den + 1;
     if (nx > f.halo_x) nx = f.halo_x;
@@ -417,7 +417,7 @@ int col_depth(const fluid_ctx* c, const FieldRef& f, int n)  // ghost columns th
 int blocks_of(fluid_ctx* c, int field, int n, Blocks* b)
 {
     FieldRef f;
-    CK(field_ref(c, field, &f));
+    CK(field_ref(c, field, &f, false, true));   // (as rows_of)
     if (n < 1 || (c->desc.parts > 1 && (n > f.halo || n > f.rows))) return c->fail(FLUID_ERR_INVALID, "exchange rows exceed the ghost rows / the tile");
     const size_t texel = f.texel(), pitch = (size_t)f.win->P * texel;
     const int nx = col_depth(c, f, n);
@@ -740,6 +740,7 @@ int pass_strips(fluid_ctx* c, const fluid_stripe_op& op, float dt, const fluid_p
             return advect_both_band(c, dt, P->velocity_dissipation, P->density_dissipation, ga, gb, xa, xb, v0, v1, u0, u1);
         }));
     }
+    advect_both_note(c, dt, P->density_dissipation);   // interior + strips = this step's one advection of the dye
     advect_both_swap(c);
     return FLUID_OK;
 }
@@ -900,6 +901,15 @@ int jacobi_block_rest(fluid_ctx* c, const fluid_stripe_op& blk, const fluid_stri
     return folded ? (int)FLUID_OK : pass_gradsub(c, gs->ext);
 }
 
+// in front of an exchange that carries dye ghost texels: the field goes into the format this step's advection takes (packed or RGBA — one
+// predicate, the same on every rank of the set: fluid_internal.h), so that both ends of every message cut the same texel size
+int prepare_exchange(fluid_ctx* c, const fluid_stripe_op& op, float dt, const fluid_params* P)
+{
+    for (int i = 0; i < op.n_items; i++)
+        if (op.field[i] == FLUID_DYE) return dye_prepare(c, dt, P);
+    return FLUID_OK;
+}
+
 int plan_for(fluid_ctx* c, const fluid_params* P, std::vector<fluid_stripe_op>& ops)
 {
     int va, vd;
@@ -939,6 +949,7 @@ int stripe_step_n(fluid_ctx* c, int n, float dt, const fluid_params* P)
                 CK(pass_whole(c, op, dt, P));
                 continue;
             }
+            CK(prepare_exchange(c, op, dt, P));
             if (c->desc.parts_x > 1) CK(rccl_exchange_2d_begin(c, op));
             else CK(rccl_exchange_begin(c, op));
             if (i + 1 < ops.size() && overlap_ok(c, ops[i + 1])) {
@@ -1276,6 +1287,11 @@ int fluid_group_step_n(fluid_ctx** cs, int n_ctx, int steps, float dt, const flu
                 continue;
             }
             const bool tiles = cs[0]->desc.parts_x > 1;
+            CK(each([&](fluid_ctx* c) { return prepare_exchange(c, op, dt, P); }));
+            for (int r = 1; r < n_ctx; r++)   // what "collective" buys on an RCCL set, checked where one process sees every rank
+                if (cs[r]->dye_packed != cs[0]->dye_packed || (cs[0]->dye_packed && std::memcmp(&cs[r]->dye_alpha, &cs[0]->dye_alpha, sizeof(float)) != 0))
+                    return cs[r]->fail(FLUID_ERR_INVALID, "the contexts of a set disagree on the dye's format or alpha: splats, dye writes and raw dye pointers "
+                                                          "are collective on a stripe / tile set");
             if (tiles) CK(group_exchange_2d_begin(cs, n_ctx, op));
             else CK(group_exchange_begin(cs, n_ctx, op));
             if (i + 1 < ops.size() && overlap_ok(cs[0], ops[i + 1])) {

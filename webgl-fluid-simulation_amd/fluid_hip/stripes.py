@@ -176,6 +176,14 @@ class HipStripeEngine:
     def exchange_count(self):
         return int(self.lib.fluid_exchange_count(self.ctx))
 
+    def schedule_info(self, n_steps, dt, config):
+        """fluid_schedule_info_get for this context (tile shape, folds, whether the dye is / would be packed)"""
+        p = _abi.Params(float(config["CURL"]), float(config["PRESSURE"]), int(config["PRESSURE_ITERATIONS"]),
+                        float(config["VELOCITY_DISSIPATION"]), float(config["DENSITY_DISSIPATION"]))
+        info = _abi.ScheduleInfo()
+        self._ck(self.lib.fluid_schedule_info_get(self.ctx, int(n_steps), float(dt), C.byref(p), C.byref(info)))
+        return {k: getattr(info, k) for k, _ in _abi.ScheduleInfo._fields_}
+
     def set_reach(self, rows): self._ck(self.lib.fluid_set_reach(self.ctx, int(rows)))
     def set_overlap(self, on): self._ck(self.lib.fluid_set_overlap(self.ctx, 1 if on else 0))
     def set_link_model(self, latency_us, gbytes_per_s): self._ck(self.lib.fluid_set_link_model(self.ctx, float(latency_us), float(gbytes_per_s)))
