@@ -81,6 +81,8 @@ struct fluid_ctx {
     hipEvent_t ev_ready = nullptr;       // context stream -> comm stream: the rows to send exist
     hipEvent_t ev_landed = nullptr;      // comm stream -> context stream: the ghost rows have arrived
     hipEvent_t ev_order = nullptr;       // fluid_stream_wait_context / fluid_context_wait_stream: context stream <-> a caller's stream
+    hipEvent_t ev_inner = nullptr;       // context stream -> comm stream, device scope: the interiors a cut Jacobi launch's frame reads are written
+    hipEvent_t ev_joined = nullptr;      // comm stream -> context stream: the strips (and frames) that ran on the comm stream are done
     hipEvent_t ev_mid = nullptr;         // 2-D tiles: this tile's ghost columns are in (phase A), ghost rows may follow
     void* stage[16] = {};                // 2-D tiles: contiguous staging of the strided blocks, send and receive per direction (4 sides + 4 corners)
     size_t stage_bytes[16] = {};
@@ -179,6 +181,10 @@ struct JacobiSplit {
     int cover = 1;        // leading launches cut (1 or 2)
     int guard_rows = 0, guard_cols = 0;   // pressure rows / columns next to the tile border that the exchange in flight is SENDING: the second
                                           // cut launch writes into the buffer they are read from and stays clear of them
+    // mode 2: the frames of the cut launches go on this stream (the comm stream, behind the exchange that just landed) instead of the context
+    // stream; `frame_done` is recorded there behind the last of them and the context stream waits for it before the block's further launches
+    hipStream_t frame_stream = nullptr;
+    hipEvent_t frame_done = nullptr;
 };
 int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launches, bool* gradsub, Timer* t, const JacobiSplit* split = nullptr);
 bool jacobi_split_ok(const fluid_ctx* c, int iters, bool wants_gradsub, int margin = 0);

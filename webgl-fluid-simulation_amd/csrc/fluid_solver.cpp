@@ -383,16 +383,26 @@ int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launche
                 }
                 // the frame around that interior.  (With two launches cut, this one reads pressure up to one apron inside the first
                 // interior, from the buffer the SECOND interior has already written into — further in: from 2 aprons + margin on.)
+                // sp->frame_stream: the frames run on the comm stream, behind the exchange that brought their ghost texels
+                hipStream_t main_stream = c->stream;
+                if (sp->frame_stream) c->stream = sp->frame_stream;
+                int rc_frame = FLUID_OK;
                 if (c->storage == FLUID_STORE_F32 && k <= 10) {        // one launch
                     fluid::CutRect fr[4];
                     fluid::cut_frame(ga, gb, w.x0, w.x1, q, fr);
                     fluid::BandRects B{};
                     for (const fluid::CutRect& r : fr) B.r[B.n++] = fluid::BandRect{ r.xa, r.xb, r.ga, r.gb };
-                    CK(c->hip(fluid::launch_jacobi_tb_rects(c->stream, w, (const float*)c->prs[0], (const float*)c->div, (float*)c->prs[1], ps, k, B),
-                              "jacobi_tb (frame)"));
+                    rc_frame = c->hip(fluid::launch_jacobi_tb_rects(c->stream, w, (const float*)c->prs[0], (const float*)c->div, (float*)c->prs[1], ps, k, B),
+                                      "jacobi_tb (frame)");
                 } else {   // fp16 storage / a deeper lab shape: stripes only (jacobi_split_launches), one launch per band
-                    CK(band(c->prs[0], c->prs[1], ga, q.ia, w.x0, w.x1));
-                    CK(band(c->prs[0], c->prs[1], q.ib, gb, w.x0, w.x1));
+                    rc_frame = band(c->prs[0], c->prs[1], ga, q.ia, w.x0, w.x1);
+                    if (!rc_frame) rc_frame = band(c->prs[0], c->prs[1], q.ib, gb, w.x0, w.x1);
+                }
+                c->stream = main_stream;
+                CK(rc_frame);
+                if (sp->frame_stream && cut_left == 0) {   // the last frame: the block's further launches (context stream) follow it
+                    HIPCK(c, hipEventRecord(sp->frame_done, sp->frame_stream));
+                    HIPCK(c, hipStreamWaitEvent(c->stream, sp->frame_done, 0));
                 }
                 if (launches) (*launches)++;
                 std::swap(c->prs[0], c->prs[1]);

@@ -291,6 +291,9 @@ int ensure_comm_stream(fluid_ctx* c)
     HIPCK(c, hipEventCreateWithFlags(&c->ev_ready, ev_flags));
     HIPCK(c, hipEventCreateWithFlags(&c->ev_landed, ev_flags));
     HIPCK(c, hipEventCreateWithFlags(&c->ev_mid, ev_flags));
+    HIPCK(c, hipEventCreateWithFlags(&c->ev_joined, ev_flags));
+    // context stream -> comm stream on ONE device, about texels this device wrote: no system-scope fence (as the step marks: fluid_solver.cpp)
+    HIPCK(c, hipEventCreateWithFlags(&c->ev_inner, hipEventDisableTiming | hipEventDisableSystemFence));
     if (const char* e = fluid::lab_env("FLUID_STRIPE_OVERLAP")) c->overlap = atoi(e) != 0;
     return FLUID_OK;
 }
@@ -901,6 +904,45 @@ int jacobi_block_rest(fluid_ctx* c, const fluid_stripe_op& blk, const fluid_stri
     return folded ? (int)FLUID_OK : pass_gradsub(c, gs->ext);
 }
 
+// ---- the thin launches of an overlapped exchange on the COMM stream (round 5) ----
+// Behind an exchange the context stream used to run, one after the other: the strips of the pass whose interior covered the exchange (11.7 us
+// for the curl / vorticity / divergence pass of a 4096^2 stripe, 6.5 us for the advection) and the frame of the cut Jacobi launch (10.9 us) —
+// launches of one tile's latency each, +5 % of the step (profiles/r04/stripe_rank_timeline.txt).  They depend on the ghost texels, not on the
+// interior that is still running: they now go on the comm stream, directly behind RCCL's receive, and run BESIDE the interior launches wherever
+// the link is faster than those (it is: 75 + 47 us of cover in front of the pressure loop, 147 us of advection).  The context stream then waits
+// once, for ev_joined, where it waited for ev_landed.  A frame reads pressure / divergence the interiors wrote: the comm stream waits for
+// ev_inner (device scope: same GPU) in front of it.  The strips' and frames' texels are disjoint from the interiors' (that is what makes them
+// strips and frames), so nothing but those two events orders the streams.  FLUID_STRIPS_ON_COMM=0 (lab build): as before (A/B knob; same bits).
+bool strips_on_comm(const fluid_ctx* c)
+{
+    static const bool on = [] {
+        const char* e = fluid::lab_env("FLUID_STRIPS_ON_COMM");
+        return !(e && atoi(e) == 0);
+    }();
+    return on && c->comm != nullptr && c->comm_stream != nullptr;
+}
+
+struct OnStream {   // the launchers enqueue on fluid_ctx::stream: point it somewhere else for a scope
+    fluid_ctx* c;
+    hipStream_t saved;
+    OnStream(fluid_ctx* ctx, hipStream_t s) : c(ctx), saved(ctx->stream) { c->stream = s; }
+    ~OnStream() { c->stream = saved; }
+};
+
+// the comm stream has the ghost texels (its own receive is done: the self-wait carries the acquire the context stream's wait used to make)
+int comm_has_landed(fluid_ctx* c)
+{
+    HIPCK(c, hipStreamWaitEvent(c->comm_stream, c->ev_landed, 0));
+    return FLUID_OK;
+}
+
+int join_comm(fluid_ctx* c)   // the context stream continues behind what the comm stream has been given so far
+{
+    HIPCK(c, hipEventRecord(c->ev_joined, c->comm_stream));
+    HIPCK(c, hipStreamWaitEvent(c->stream, c->ev_joined, 0));
+    return FLUID_OK;
+}
+
 // in front of an exchange that carries dye ghost texels: the field goes into the format this step's advection takes (packed or RGBA — one
 // predicate, the same on every rank of the set: fluid_internal.h), so that both ends of every message cut the same texel size
 int prepare_exchange(fluid_ctx* c, const fluid_stripe_op& op, float dt, const fluid_params* P)
@@ -952,12 +994,32 @@ int stripe_step_n(fluid_ctx* c, int n, float dt, const fluid_params* P)
             CK(prepare_exchange(c, op, dt, P));
             if (c->desc.parts_x > 1) CK(rccl_exchange_2d_begin(c, op));
             else CK(rccl_exchange_begin(c, op));
+            const bool side = strips_on_comm(c);   // strips and frames beside the interiors, on the comm stream
             if (i + 1 < ops.size() && overlap_ok(c, ops[i + 1])) {
-                const JacobiSplit deep = jacobi_cover_split(c, ops, i);
+                JacobiSplit deep = jacobi_cover_split(c, ops, i);
                 CK(pass_interior(c, ops[i + 1], dt, P));  // computes while the ghost rows travel
+                // what a frame reads of the interiors: the first frame the DIVERGENCE of the pass's interior (its pressure input is the
+                // step's old pressure), a second frame also the first Jacobi interior's output
+                if (side && deep.cover == 1) HIPCK(c, hipEventRecord(c->ev_inner, c->stream));
                 if (deep.cover) CK(clear_jacobi_interior(c, ops[i + 2], P, deep));
-                CK(rccl_exchange_end(c));
-                CK(pass_strips(c, ops[i + 1], dt, P));
+                if (side) {
+                    if (deep.cover >= 2) HIPCK(c, hipEventRecord(c->ev_inner, c->stream));
+                    CK(comm_has_landed(c));
+                    {
+                        OnStream on(c, c->comm_stream);
+                        CK(pass_strips(c, ops[i + 1], dt, P));
+                    }
+                    if (deep.cover) {
+                        HIPCK(c, hipStreamWaitEvent(c->comm_stream, c->ev_inner, 0));
+                        deep.frame_stream = c->comm_stream;
+                        deep.frame_done = c->ev_joined;   // pass_jacobi joins the streams behind the last frame
+                    } else {
+                        CK(join_comm(c));
+                    }
+                } else {
+                    CK(rccl_exchange_end(c));
+                    CK(pass_strips(c, ops[i + 1], dt, P));
+                }
                 i++;
                 if (deep.cover) {
                     const bool gs = folds_gradsub(ops, i + 1);
@@ -966,9 +1028,19 @@ int stripe_step_n(fluid_ctx* c, int n, float dt, const fluid_params* P)
                 }
             } else if (jacobi_overlap_ok(c, ops, i)) {
                 const bool gs = folds_gradsub(ops, i + 1);
-                const JacobiSplit sp = jacobi_overlap_split(c, ops, i);
+                JacobiSplit sp = jacobi_overlap_split(c, ops, i);
                 CK(jacobi_block_interior(c, ops[i + 1], sp));
-                CK(rccl_exchange_end(c));
+                if (side) {
+                    CK(comm_has_landed(c));
+                    if (sp.cover >= 2) {   // the second frame reads the first interior's output (one cut launch: its frame reads nothing the interior writes)
+                        HIPCK(c, hipEventRecord(c->ev_inner, c->stream));
+                        HIPCK(c, hipStreamWaitEvent(c->comm_stream, c->ev_inner, 0));
+                    }
+                    sp.frame_stream = c->comm_stream;
+                    sp.frame_done = c->ev_joined;
+                } else {
+                    CK(rccl_exchange_end(c));
+                }
                 CK(jacobi_block_rest(c, ops[i + 1], gs ? &ops[i + 2] : nullptr, 1.0f, sp));
                 i += gs ? 2 : 1;
             } else {
@@ -995,7 +1067,9 @@ void stripes_release(fluid_ctx* c)
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
     if (c->ev_landed) (void)hipEventDestroy(c->ev_landed);
     if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
-    c->ev_ready = c->ev_landed = c->ev_mid = nullptr;
+    if (c->ev_joined) (void)hipEventDestroy(c->ev_joined);
+    if (c->ev_inner) (void)hipEventDestroy(c->ev_inner);
+    c->ev_ready = c->ev_landed = c->ev_mid = c->ev_joined = c->ev_inner = nullptr;
     for (int k = 0; k < 16; k++) {
         if (c->stage[k]) (void)hipFree(c->stage[k]);
         c->stage[k] = nullptr;
