@@ -291,8 +291,12 @@ int ensure_comm_stream(fluid_ctx* c)
     HIPCK(c, hipEventCreateWithFlags(&c->ev_ready, ev_flags));
     HIPCK(c, hipEventCreateWithFlags(&c->ev_landed, ev_flags));
     HIPCK(c, hipEventCreateWithFlags(&c->ev_mid, ev_flags));
-    HIPCK(c, hipEventCreateWithFlags(&c->ev_joined, ev_flags));
-    // context stream -> comm stream on ONE device, about texels this device wrote: no system-scope fence (as the step marks: fluid_solver.cpp)
+    // between the two streams of ONE device, about texels this device wrote: no system-scope fence (as the step marks: fluid_solver.cpp).
+    // ev_joined hands the context stream what the comm stream did behind the exchange; the ghost texels themselves were acquired at system
+    // scope by the comm stream's own wait for ev_landed (comm_has_landed), in front of the first kernel that read them.  With a system-scope
+    // ev_joined the thin launches on the comm stream cost a slow link one more 6-7 us fence per exchange than round 4's schedule
+    // (profiles/r05/stripe_rank_strips_on_comm.txt, first form: the centre tile at 60 us per exchange +1 ... 2.5 %).
+    HIPCK(c, hipEventCreateWithFlags(&c->ev_joined, hipEventDisableTiming | hipEventDisableSystemFence));
     HIPCK(c, hipEventCreateWithFlags(&c->ev_inner, hipEventDisableTiming | hipEventDisableSystemFence));
     if (const char* e = fluid::lab_env("FLUID_STRIPE_OVERLAP")) c->overlap = atoi(e) != 0;
     return FLUID_OK;
