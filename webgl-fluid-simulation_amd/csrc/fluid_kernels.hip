@@ -232,6 +232,18 @@ __device__ __forceinline__ Tap4 taps32(const Win& w, const TapBox& B, float u, f
     }
     return t;
 }
+// taps32 that also says where the first tap is and whether the fetch took the interior path (the tap box of k_advect_dye_fast_rgb_box)
+template <unsigned SZ>
+__device__ __forceinline__ Tap4 taps32_ij(const Win& w, const TapBox& B, float u, float v, int& i0, int& j0, bool& interior)
+{
+    const float x = u * (float)w.W - 0.5f;
+    const float y = v * (float)w.H - 0.5f;
+    i0 = (int)floorf(x);
+    j0 = (int)floorf(y);
+    interior = (unsigned)(i0 - B.xlo) < B.nx && (unsigned)(j0 - B.ylo) < B.ny;
+    return taps32<SZ>(w, B, u, v);   // (the same expressions: the compiler merges them)
+}
+
 // the texel at a 32-bit byte offset from the (uniform) base pointer
 template <class T>
 __device__ __forceinline__ const T* at_byte(const T* p, unsigned o)
@@ -535,10 +547,38 @@ __device__ __forceinline__ void advect_velocity_fast_body(const Win& w, const V2
 // Same texels into the same arithmetic, hence the same bits.
 constexpr int VT_COLS = 20, VT_ROWS = 3;
 
-template <int ROWS, class V2, class D4, int WY = 1, bool VT = false, bool PAIR3 = false>
+// BOX (packed fp32 dye, lab: FLUID_DYE_BOX=1): the wave's dye taps through LDS.  The dye taps follow the flow, but on a dye grid FINER than
+// the sim grid the flow is smooth at the dye's scale: the taps of a wave's 64 columns x ROWS rows fill a box of about (64 + 2) x (ROWS + 2)
+// texels.  The wave finds the box (min / max of its lanes' first taps: four 6-step xor-shuffle reductions), fetches its rows with ONE aligned
+// 16-byte load per lane and row — 6 loads instead of the 16 twelve-byte gathers the texture addresser works off at 16 lanes per clock
+// (TA busy 0.65-0.75 in round 4's kernel: profiles/r04/advect_l1_l2_requests.txt) — and every lane reads its taps from the wave's own 6 KB
+// of LDS.  A lane whose taps are not interior (domain edge, stale window: taps32's slow path) gathers as before, as does a whole wave whose
+// box does not fit (BOX_ROWS rows x 64 16-byte chunks).  Same texels into the same arithmetic, hence the same bits.
+constexpr int BOX_ROWS = 6;
+// LDS pointers keep their address space through the call (round 5: as generic pointers the wave's reads of its velocity tile compiled to
+// flat_load — 28 of them per thread, every one a texture-addresser instruction, in the kernel whose bound IS the texture addresser)
+typedef __attribute__((address_space(3))) float2 lds_float2;
+typedef __attribute__((address_space(3))) float4 lds_float4;
+typedef __attribute__((address_space(3))) float lds_float;
+typedef __attribute__((address_space(3))) char lds_char;
+__device__ __forceinline__ int wave_min(int v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = min(v, __shfl_xor(v, m, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+template <int ROWS, class V2, class D4, int WY = 1, bool VT = false, bool PAIR3 = false, bool BOX = false>
 __device__ __forceinline__ void advect_dye_fast_body(const Win& vw, const V2* __restrict__ vel, const Win& dw, const D4* __restrict__ dye,
                                                      D4* __restrict__ dye_out, float dt, double rW, double rH, double rdd, float tsx, float tsy,
-                                                     int ga, int gb, unsigned int* __restrict__ miss_out, float2* vtile = nullptr)
+                                                     int ga, int gb, unsigned int* __restrict__ miss_out, lds_float2* vtile = nullptr,
+                                                     lds_float4* box = nullptr)
 {
     static_assert(!VT || (WY == 1 && sizeof(V2) == sizeof(float2)), "the velocity tile: fp32 fields, waves side by side");
     constexpr int CW = BX / WY;  // columns per block (advect_both_fast_body)
@@ -585,7 +625,8 @@ __device__ __forceinline__ void advect_dye_fast_body(const Win& vw, const V2* __
         if (lane < VT_ROWS * VT_COLS) {
             const int r = lane / VT_COLS, q = lane - r * VT_COLS;
             const int lr = clampi(jb + r - vw.g0, 0, vw.rows - 1), lc = clampi(ib + q - vw.c0, 0, vw.P - 1);   // inside the array; a texel outside the tap box is never used
-            vtile[lane] = ld(vel, (size_t)lr * (size_t)vw.P + (size_t)lc);
+            const float2 tv0 = ld(vel, (size_t)lr * (size_t)vw.P + (size_t)lc);
+            vtile[lane] = tv0;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -611,16 +652,60 @@ __device__ __forceinline__ void advect_dye_fast_body(const Win& vw, const V2* __
     } else {
         gather_taps<ROWS>(vel, t, f2);
     }
+    int di0[ROWS], dj0[ROWS];
+    bool dint[ROWS];
 #pragma unroll
     for (int k = 0; k < ROWS; k++) {
         const Fetch2& f = f2[k];
         const float vx = mixf(mixf(f.a.x, f.b.x, f.fx), mixf(f.c.x, f.d.x, f.fx), f.fy);
         const float vy = mixf(mixf(f.a.y, f.b.y, f.fx), mixf(f.c.y, f.d.y, f.fx), f.fy);
-        t[k] = taps32<sizeof(D4)>(dw, Bd, u - dt * vx * tsx, v[k] - dt * vy * tsy);
+        if constexpr (BOX) t[k] = taps32_ij<sizeof(D4)>(dw, Bd, u - dt * vx * tsx, v[k] - dt * vy * tsy, di0[k], dj0[k], dint[k]);
+        else t[k] = taps32<sizeof(D4)>(dw, Bd, u - dt * vx * tsx, v[k] - dt * vy * tsy);
         if (on[k]) miss += t[k].miss;
     }
     Fetch4 f4[ROWS];
-    gather_taps<ROWS, PAIR3>(dye, t, f4);
+    bool boxed = false;
+    if constexpr (BOX && sizeof(D4) == sizeof(rgb3)) {
+        int lo_i = 0x7fffffff, hi_i = -0x7fffffff, lo_j = 0x7fffffff, hi_j = -0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < ROWS; k++)
+            if (dint[k]) {
+                lo_i = min(lo_i, di0[k]); hi_i = max(hi_i, di0[k] + 1);
+                lo_j = min(lo_j, dj0[k]); hi_j = max(hi_j, dj0[k] + 1);
+            }
+        lo_i = wave_min(lo_i); hi_i = wave_max(hi_i); lo_j = wave_min(lo_j); hi_j = wave_max(hi_j);
+        const unsigned row_bytes = (unsigned)dw.P * 12u;
+        const unsigned first16 = ((unsigned)(lo_i - dw.c0) * 12u) & ~15u;               // row pitch and array base are multiples of 16
+        const unsigned chunks = hi_i >= lo_i ? (((unsigned)(hi_i - dw.c0) * 12u + 12u - first16 + 15u) >> 4) : 65u;
+        const int bh = hi_j - lo_j + 1;
+        boxed = hi_i >= lo_i && bh <= BOX_ROWS && chunks <= 64u;                        // wave-uniform
+        if (boxed) {
+            const int lane = (int)threadIdx.x & 63;
+            const char* row0 = reinterpret_cast<const char*>(dye) + (size_t)(unsigned)(lo_j - dw.g0) * row_bytes + first16 + 16u * (unsigned)lane;
+#pragma unroll
+            for (int r = 0; r < BOX_ROWS; r++)
+                if (r < bh && (unsigned)lane < chunks) box[r * 64 + lane] = *reinterpret_cast<const float4*>(row0 + (size_t)r * row_bytes);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int k = 0; k < ROWS; k++) {
+                if (dint[k]) {
+                    const unsigned o = (unsigned)(dj0[k] - lo_j) * 1024u + ((unsigned)(di0[k] - dw.c0) * 12u - first16);
+                    const lds_float* p = reinterpret_cast<const lds_float*>(reinterpret_cast<const lds_char*>(box) + o);
+                    f4[k].a = make_float4(p[0], p[1], p[2], 0.0f);
+                    f4[k].b = make_float4(p[3], p[4], p[5], 0.0f);
+                    f4[k].c = make_float4(p[256], p[257], p[258], 0.0f);
+                    f4[k].d = make_float4(p[259], p[260], p[261], 0.0f);
+                } else {
+                    f4[k].a = ld(at_byte(dye, t[k].a), 0); f4[k].b = ld(at_byte(dye, t[k].b), 0); f4[k].c = ld(at_byte(dye, t[k].c), 0); f4[k].d = ld(at_byte(dye, t[k].d), 0);
+                }
+                f4[k].fx = t[k].fx;
+                f4[k].fy = t[k].fy;
+            }
+        }
+    }
+    if (!boxed) gather_taps<ROWS, PAIR3>(dye, t, f4);
 #pragma unroll
     for (int k = 0; k < ROWS; k++) {
         const Fetch4& f = f4[k];
@@ -658,7 +743,7 @@ __global__ void __launch_bounds__(BX) k_advect_dye_fast_vt(Win vw, const float2*
                                                             float tsy, int ga, int gb, unsigned int* __restrict__ miss_out)
 {
     __shared__ float2 vt[BX / 64][VT_ROWS * VT_COLS];
-    advect_dye_fast_body<ROWS, float2, float4, 1, true>(vw, vel, dw, dye, dye_out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss_out, vt[threadIdx.x >> 6]);
+    advect_dye_fast_body<ROWS, float2, float4, 1, true>(vw, vel, dw, dye, dye_out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss_out, (lds_float2*)vt[threadIdx.x >> 6]);
 }
 
 #ifdef FLUID_PROBES
@@ -686,7 +771,18 @@ __global__ void __launch_bounds__(BX) k_advect_dye_fast_rgb_vt(Win vw, const flo
                                                                 float tsy, int ga, int gb, unsigned int* __restrict__ miss_out)
 {
     __shared__ float2 vt[BX / 64][VT_ROWS * VT_COLS];
-    advect_dye_fast_body<ROWS, float2, rgb3, 1, true>(vw, vel, dw, dye, dye_out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss_out, vt[threadIdx.x >> 6]);
+    advect_dye_fast_body<ROWS, float2, rgb3, 1, true>(vw, vel, dw, dye, dye_out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss_out, (lds_float2*)vt[threadIdx.x >> 6]);
+}
+
+template <int ROWS>   // the dye pass on the packed field with the wave's tap box staged through LDS (advect_dye_fast_body BOX)
+__global__ void __launch_bounds__(BX) k_advect_dye_fast_rgb_box(Win vw, const float2* __restrict__ vel, Win dw, const rgb3* __restrict__ dye,
+                                                                 rgb3* __restrict__ dye_out, float dt, double rW, double rH, double rdd, float tsx,
+                                                                 float tsy, int ga, int gb, unsigned int* __restrict__ miss_out)
+{
+    __shared__ float2 vt[BX / 64][VT_ROWS * VT_COLS];
+    __shared__ float4 box[BX / 64][BOX_ROWS][64];
+    advect_dye_fast_body<ROWS, float2, rgb3, 1, true, false, true>(vw, vel, dw, dye, dye_out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss_out, (lds_float2*)vt[threadIdx.x >> 6],
+                                                                   (lds_float4*)&box[threadIdx.x >> 6][0][0]);
 }
 
 #ifdef FLUID_PROBES
@@ -696,7 +792,7 @@ __global__ void __launch_bounds__(BX) k_advect_dye_fast_rgb_vt_pair(Win vw, cons
                                                                      float tsy, int ga, int gb, unsigned int* __restrict__ miss_out)
 {
     __shared__ float2 vt[BX / 64][VT_ROWS * VT_COLS];
-    advect_dye_fast_body<ROWS, float2, rgb3, 1, true, true>(vw, vel, dw, dye, dye_out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss_out, vt[threadIdx.x >> 6]);
+    advect_dye_fast_body<ROWS, float2, rgb3, 1, true, true>(vw, vel, dw, dye, dye_out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss_out, (lds_float2*)vt[threadIdx.x >> 6]);
 }
 #endif
 
@@ -2426,6 +2522,18 @@ static int split_advect_rows(long texels)
 // ... of the kernels that read their velocity taps from the wave's LDS run (one run per wave whatever the rows): four rows from 6 M dye
 // texels (2816^2: 51.3 us against 54.7 with two; 4096^2 packed: 106.4 against 108.2), two from 1 M (2048^2: 26.0 against 27.6 with four),
 // one below (profiles/r04/dye_ne_sim_velocity_run_ab.txt)
+// FLUID_DYE_BOX (lab build): 1 = the packed dye pass stages each wave's tap box through LDS (k_advect_dye_fast_rgb_box), 0 = gathers.
+// The product library takes kDyeBoxDefault.
+constexpr bool kDyeBoxDefault = false;
+static bool dye_box()
+{
+    static const int mode = [] {
+        const char* e = lab_env("FLUID_DYE_BOX");
+        return e ? (atoi(e) != 0 ? 1 : 0) : -1;
+    }();
+    return mode >= 0 ? mode == 1 : kDyeBoxDefault;
+}
+
 static int split_advect_rows_vt(long texels)
 {
     static const bool forced = lab_env("FLUID_ADVECT_SPLIT_ROWS") != nullptr;   // (lab build)
@@ -2657,6 +2765,10 @@ hipError_t launch_advect_dye_rgb(hipStream_t s, Win vw, const float2* vel, Win d
         return hipErrorNotReady;
     const double rW = udiv_recip((float)dw.W), rH = udiv_recip((float)dw.H), rdd = udiv_recip(decay);
     const unsigned gx = (dw.x1 - dw.x0 + BX - 1) / BX;
+    if (dye_box() && velocity_tile() && split_advect_rows_vt((long)(dw.x1 - dw.x0) * (gb - ga)) == 4) {
+        k_advect_dye_fast_rgb_box<4><<<dim3(gx, (gb - ga + 3) / 4, 1), BX, 0, s>>>(vw, vel, dw, dye, out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss);
+        return hipGetLastError();
+    }
 #ifdef FLUID_PROBES
     static const bool pair3 = [] { const char* e = lab_env("FLUID_RGB_PAIR"); return e && atoi(e) != 0; }();
     if (pair3 && velocity_tile() && split_advect_rows_vt((long)(dw.x1 - dw.x0) * (gb - ga)) == 4) {

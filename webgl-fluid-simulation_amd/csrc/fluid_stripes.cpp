@@ -765,8 +765,8 @@ int pass_whole(fluid_ctx* c, const fluid_stripe_op& op, float dt, const fluid_pa
     c->dye.v1 = c->dye_row0 + c->dye_rows + vd;
     if (c->desc.parts_x > 1) {  // 2-D tiles: the same for the columns
         FieldRef fv, fd;
-        CK(field_ref(c, FLUID_VELOCITY, &fv));
-        CK(field_ref(c, FLUID_DYE, &fd));
+        CK(field_ref(c, FLUID_VELOCITY, &fv, true));
+        CK(field_ref(c, FLUID_DYE, &fd, true));   // geometry only: asking for the dye's MEMORY here unpacked a packed field every step (2 x 2 tiles without overlap: +30 %)
         const int ax = col_depth(c, fv, va), dx = col_depth(c, fd, vd);
         c->sim.u0 = c->sim_col0 - ax;
         c->sim.u1 = c->sim_col0 + c->sim_ncols + ax;
@@ -1002,21 +1002,24 @@ int stripe_step_n(fluid_ctx* c, int n, float dt, const fluid_params* P)
             if (i + 1 < ops.size() && overlap_ok(c, ops[i + 1])) {
                 JacobiSplit deep = jacobi_cover_split(c, ops, i);
                 CK(pass_interior(c, ops[i + 1], dt, P));  // computes while the ghost rows travel
-                // what a frame reads of the interiors: the first frame the DIVERGENCE of the pass's interior (its pressure input is the
-                // step's old pressure), a second frame also the first Jacobi interior's output
-                if (side && deep.cover == 1) HIPCK(c, hipEventRecord(c->ev_inner, c->stream));
+                // ONE cut Jacobi launch: its frame reads the DIVERGENCE of the pass's interior (its pressure input is the step's old
+                // pressure) and nothing the Jacobi interior writes — it runs on the comm stream beside that interior.  With TWO cut
+                // launches the second frame reads the first interior's output: the frames would wait for both interiors anyway, and a
+                // hop to the comm stream and back costs more than it hides (the 200-iteration regime: +2 %, profiles/r05) — they stay
+                // on the context stream, behind the strips.
+                const bool frames_on_comm = side && deep.cover == 1;
+                if (frames_on_comm) HIPCK(c, hipEventRecord(c->ev_inner, c->stream));
                 if (deep.cover) CK(clear_jacobi_interior(c, ops[i + 2], P, deep));
                 if (side) {
-                    if (deep.cover >= 2) HIPCK(c, hipEventRecord(c->ev_inner, c->stream));
                     CK(comm_has_landed(c));
                     {
                         OnStream on(c, c->comm_stream);
                         CK(pass_strips(c, ops[i + 1], dt, P));
                     }
-                    if (deep.cover) {
+                    if (frames_on_comm) {
                         HIPCK(c, hipStreamWaitEvent(c->comm_stream, c->ev_inner, 0));
                         deep.frame_stream = c->comm_stream;
-                        deep.frame_done = c->ev_joined;   // pass_jacobi joins the streams behind the last frame
+                        deep.frame_done = c->ev_joined;   // pass_jacobi joins the streams behind the frame
                     } else {
                         CK(join_comm(c));
                     }
@@ -1034,12 +1037,8 @@ int stripe_step_n(fluid_ctx* c, int n, float dt, const fluid_params* P)
                 const bool gs = folds_gradsub(ops, i + 1);
                 JacobiSplit sp = jacobi_overlap_split(c, ops, i);
                 CK(jacobi_block_interior(c, ops[i + 1], sp));
-                if (side) {
+                if (side && sp.cover == 1) {   // one cut launch: its frame reads nothing the interior writes, and runs beside it (two: see above)
                     CK(comm_has_landed(c));
-                    if (sp.cover >= 2) {   // the second frame reads the first interior's output (one cut launch: its frame reads nothing the interior writes)
-                        HIPCK(c, hipEventRecord(c->ev_inner, c->stream));
-                        HIPCK(c, hipStreamWaitEvent(c->comm_stream, c->ev_inner, 0));
-                    }
                     sp.frame_stream = c->comm_stream;
                     sp.frame_done = c->ev_joined;
                 } else {
