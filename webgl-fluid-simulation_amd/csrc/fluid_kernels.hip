@@ -269,7 +269,7 @@ __device__ __forceinline__ void load_pair(const float2* F, unsigned o, float2& a
 // 12-byte ones: the texture addresser spends its cycles per instruction and lane group, not per byte, and a dwordx3 costs what a dwordx4 does
 typedef float quad_u4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef float pair_u4 __attribute__((ext_vector_type(2), aligned(4)));
-__device__ __forceinline__ void load_pair(const rgb3* F, unsigned o, float4& a, float4& b)
+[[maybe_unused]] __device__ __forceinline__ void load_pair(const rgb3* F, unsigned o, float4& a, float4& b)
 {
     const char* p = reinterpret_cast<const char*>(F) + (size_t)o;
     const quad_u4 lo = *reinterpret_cast<const quad_u4*>(p);
@@ -557,17 +557,25 @@ constexpr int VT_COLS = 20, VT_ROWS = 3;
 constexpr int BOX_ROWS = 6;
 // LDS pointers keep their address space through the call (round 5: as generic pointers the wave's reads of its velocity tile compiled to
 // flat_load — 28 of them per thread, every one a texture-addresser instruction, in the kernel whose bound IS the texture addresser)
-typedef __attribute__((address_space(3))) float2 lds_float2;
-typedef __attribute__((address_space(3))) float4 lds_float4;
+// (clang's own vector types: HIP's float2 / float4 are classes whose operator= takes a generic `this`)
+typedef float lds_v2 __attribute__((ext_vector_type(2)));
+typedef float lds_v4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) lds_v2 lds_float2;
+typedef __attribute__((address_space(3))) lds_v4 lds_float4;
 typedef __attribute__((address_space(3))) float lds_float;
 typedef __attribute__((address_space(3))) char lds_char;
-__device__ __forceinline__ int wave_min(int v)
+__device__ __forceinline__ float2 lds_get(const lds_float2* p, int i)
+{
+    const lds_v2 q = p[i];
+    return make_float2(q.x, q.y);
+}
+[[maybe_unused]] __device__ __forceinline__ int wave_min(int v)
 {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v = min(v, __shfl_xor(v, m, 64));
     return v;
 }
-__device__ __forceinline__ int wave_max(int v)
+[[maybe_unused]] __device__ __forceinline__ int wave_max(int v)
 {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m, 64));
@@ -626,7 +634,7 @@ __device__ __forceinline__ void advect_dye_fast_body(const Win& vw, const V2* __
             const int r = lane / VT_COLS, q = lane - r * VT_COLS;
             const int lr = clampi(jb + r - vw.g0, 0, vw.rows - 1), lc = clampi(ib + q - vw.c0, 0, vw.P - 1);   // inside the array; a texel outside the tap box is never used
             const float2 tv0 = ld(vel, (size_t)lr * (size_t)vw.P + (size_t)lc);
-            vtile[lane] = tv0;
+            vtile[lane] = lds_v2{ tv0.x, tv0.y };
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -637,10 +645,10 @@ __device__ __forceinline__ void advect_dye_fast_body(const Win& vw, const V2* __
                              (unsigned)(j0[k] - jb) < (unsigned)(VT_ROWS - 1);
             if (hit) {
                 const int o = (j0[k] - jb) * VT_COLS + (i0 - ib);
-                f2[k].a = vtile[o];
-                f2[k].b = vtile[o + 1];
-                f2[k].c = vtile[o + VT_COLS];
-                f2[k].d = vtile[o + VT_COLS + 1];
+                f2[k].a = lds_get(vtile, o);
+                f2[k].b = lds_get(vtile, o + 1);
+                f2[k].c = lds_get(vtile, o + VT_COLS);
+                f2[k].d = lds_get(vtile, o + VT_COLS + 1);
             } else {
                 const Tap4 tv = taps32<sizeof(V2)>(vw, Bv, u, v[k]);
                 if (on[k]) miss += tv.miss;
@@ -684,7 +692,10 @@ __device__ __forceinline__ void advect_dye_fast_body(const Win& vw, const V2* __
             const char* row0 = reinterpret_cast<const char*>(dye) + (size_t)(unsigned)(lo_j - dw.g0) * row_bytes + first16 + 16u * (unsigned)lane;
 #pragma unroll
             for (int r = 0; r < BOX_ROWS; r++)
-                if (r < bh && (unsigned)lane < chunks) box[r * 64 + lane] = *reinterpret_cast<const float4*>(row0 + (size_t)r * row_bytes);
+                if (r < bh && (unsigned)lane < chunks) {
+                    const float4 q = *reinterpret_cast<const float4*>(row0 + (size_t)r * row_bytes);
+                    box[r * 64 + lane] = lds_v4{ q.x, q.y, q.z, q.w };
+                }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -774,7 +785,8 @@ __global__ void __launch_bounds__(BX) k_advect_dye_fast_rgb_vt(Win vw, const flo
     advect_dye_fast_body<ROWS, float2, rgb3, 1, true>(vw, vel, dw, dye, dye_out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss_out, (lds_float2*)vt[threadIdx.x >> 6]);
 }
 
-template <int ROWS>   // the dye pass on the packed field with the wave's tap box staged through LDS (advect_dye_fast_body BOX)
+#ifdef FLUID_PROBES
+template <int ROWS>   // lab (FLUID_DYE_BOX=1): the dye pass on the packed field with the wave's tap box staged through LDS (advect_dye_fast_body BOX)
 __global__ void __launch_bounds__(BX) k_advect_dye_fast_rgb_box(Win vw, const float2* __restrict__ vel, Win dw, const rgb3* __restrict__ dye,
                                                                  rgb3* __restrict__ dye_out, float dt, double rW, double rH, double rdd, float tsx,
                                                                  float tsy, int ga, int gb, unsigned int* __restrict__ miss_out)
@@ -785,7 +797,6 @@ __global__ void __launch_bounds__(BX) k_advect_dye_fast_rgb_box(Win vw, const fl
                                                                    (lds_float4*)&box[threadIdx.x >> 6][0][0]);
 }
 
-#ifdef FLUID_PROBES
 template <int ROWS>   // lab (FLUID_RGB_PAIR=1): the dye pass on the packed field with paired tap loads
 __global__ void __launch_bounds__(BX) k_advect_dye_fast_rgb_vt_pair(Win vw, const float2* __restrict__ vel, Win dw, const rgb3* __restrict__ dye,
                                                                      rgb3* __restrict__ dye_out, float dt, double rW, double rH, double rdd, float tsx,
@@ -2522,17 +2533,14 @@ static int split_advect_rows(long texels)
 // ... of the kernels that read their velocity taps from the wave's LDS run (one run per wave whatever the rows): four rows from 6 M dye
 // texels (2816^2: 51.3 us against 54.7 with two; 4096^2 packed: 106.4 against 108.2), two from 1 M (2048^2: 26.0 against 27.6 with four),
 // one below (profiles/r04/dye_ne_sim_velocity_run_ab.txt)
-// FLUID_DYE_BOX (lab build): 1 = the packed dye pass stages each wave's tap box through LDS (k_advect_dye_fast_rgb_box), 0 = gathers.
-// The product library takes kDyeBoxDefault.
-constexpr bool kDyeBoxDefault = false;
+#ifdef FLUID_PROBES
+// FLUID_DYE_BOX=1 (lab build): the packed dye pass stages each wave's tap box through LDS (k_advect_dye_fast_rgb_box; measured +53 %: profiles/r05)
 static bool dye_box()
 {
-    static const int mode = [] {
-        const char* e = lab_env("FLUID_DYE_BOX");
-        return e ? (atoi(e) != 0 ? 1 : 0) : -1;
-    }();
-    return mode >= 0 ? mode == 1 : kDyeBoxDefault;
+    static const bool on = [] { const char* e = lab_env("FLUID_DYE_BOX"); return e && atoi(e) != 0; }();
+    return on;
 }
+#endif
 
 static int split_advect_rows_vt(long texels)
 {
@@ -2765,11 +2773,11 @@ hipError_t launch_advect_dye_rgb(hipStream_t s, Win vw, const float2* vel, Win d
         return hipErrorNotReady;
     const double rW = udiv_recip((float)dw.W), rH = udiv_recip((float)dw.H), rdd = udiv_recip(decay);
     const unsigned gx = (dw.x1 - dw.x0 + BX - 1) / BX;
+#ifdef FLUID_PROBES
     if (dye_box() && velocity_tile() && split_advect_rows_vt((long)(dw.x1 - dw.x0) * (gb - ga)) == 4) {
         k_advect_dye_fast_rgb_box<4><<<dim3(gx, (gb - ga + 3) / 4, 1), BX, 0, s>>>(vw, vel, dw, dye, out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss);
         return hipGetLastError();
     }
-#ifdef FLUID_PROBES
     static const bool pair3 = [] { const char* e = lab_env("FLUID_RGB_PAIR"); return e && atoi(e) != 0; }();
     if (pair3 && velocity_tile() && split_advect_rows_vt((long)(dw.x1 - dw.x0) * (gb - ga)) == 4) {
         k_advect_dye_fast_rgb_vt_pair<4><<<dim3(gx, (gb - ga + 3) / 4, 1), BX, 0, s>>>(vw, vel, dw, dye, out, dt, rW, rH, rdd, tsx, tsy, ga, gb, miss);
