@@ -31,7 +31,7 @@ def main():
     sim = getResolution(full["SIM_RESOLUTION"], *canvas)
     dye = getResolution(full["DYE_RESOLUTION"], *canvas)
     cid = new_comm_id()
-    out, errs = [None] * world, []
+    out, errs, links = [None] * world, [], [None] * world
     aspect = canvas[0] / canvas[1]
     radius = full["SPLAT_RADIUS"] / 100.0 * (aspect if aspect > 1 else 1.0)
 
@@ -43,6 +43,8 @@ def main():
             if "overlap" in a:
                 e.set_overlap(a["overlap"])
             e.comm_init(cid)                       # collective: blocks until every rank thread has called it
+            if a.get("calibrate"):                 # the start-up link probe between real rank threads (collective as well): it must leave the
+                links[r] = e.calibrate_link(5)     # communicator in step with its neighbours' and return a model
             for x, y, dx, dy, cr, cg, cb in splats:
                 e.splat(x, y, dx, dy, cr, cg, cb, aspect, radius)
             e.step_n(steps, 0.016666, full)
@@ -64,7 +66,7 @@ def main():
     def assemble(k):
         return np.concatenate([np.concatenate([out[y * tx + x][0][k] for x in range(tx)], axis=1) for y in range(ty)], axis=0)
     bad = [k for k in want if not np.array_equal(assemble(k), want[k])]
-    print(json.dumps({"ok": not bad, "mismatch": bad, "exchanges": out[0][1], "rccl": os.environ.get("FLUID_RCCL_LIB")}))
+    print(json.dumps({"ok": not bad, "mismatch": bad, "exchanges": out[0][1], "rccl": os.environ.get("FLUID_RCCL_LIB"), "links": links}))
 
 
 if __name__ == "__main__":

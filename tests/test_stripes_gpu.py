@@ -222,6 +222,28 @@ def test_native_rccl_path_with_several_ranks_bitwise(world, halo, overlap, cfg, 
     assert out["exchanges"] == steps * sum(1 for op in plan if op[0] == "exchange")
 
 
+@pytest.mark.parametrize("world,tiles_x,canvas,res", [(3, 1, (256, 768), 256), (4, 2, (512, 512), 512)])
+def test_link_calibration_between_rank_threads_then_steps_bitwise(world, tiles_x, canvas, res):
+    """fluid_comm_calibrate_link as `bench.py --gpus N` runs it: every rank thread of a set (tests/fake_rccl, real matching between the
+    ranks, not loopback) probes its neighbours right behind comm_init — 2 x 23 grouped exchanges with up to four of them — and the set then
+    steps: the probe must leave every pair's send / receive order in step (else the first exchange hangs or mismatches) and hand every rank
+    a model; the fields are still the single domain's, bit for bit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = fake_rccl_lib()
+    cfg = {"SIM_RESOLUTION": res, "DYE_RESOLUTION": res, "PRESSURE_ITERATIONS": 30}
+    args = {"world": world, "tiles_x": tiles_x, "halo": 24, "overlap": True, "config": cfg, "canvas": list(canvas), "steps": 2, "calibrate": True}
+    r = subprocess.run([sys.executable, os.path.join(here, "fake_rccl", "run_ranks.py"), json.dumps(args)], env=dict(os.environ, FLUID_RCCL_LIB=lib),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["ok"], out
+    assert len(out["links"]) == world and all(l is not None and l[0] >= 0 and l[1] > 0 for l in out["links"]), out["links"]
+
+
 # ---- 2-D tile decomposition (BASELINE configs[3]: 2 x 2 on four GPUs): ghost columns as well -------------------------------
 TILE_CASES = [
     # canvas, config, halo, tiles_y, tiles_x, steps

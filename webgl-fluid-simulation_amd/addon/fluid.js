@@ -196,13 +196,18 @@ function createFluid (options) {
             handle = native.createTile(simRes.width, simRes.height, dyeRes.width, dyeRes.height, device, schedule,
                 Math.floor(t.rank / tilesX), t.world / tilesX, t.rank % tilesX, tilesX, t.halo === undefined ? 56 : t.halo, storage);
             if (t.reach !== undefined) native.setReach(handle, t.reach);
-            if (t.linkModel !== undefined) native.setLinkModel(handle, t.linkModel[0], t.linkModel[1]);   // [latency us, GB/s] of one neighbour message
+            if (Array.isArray(t.linkModel)) native.setLinkModel(handle, t.linkModel[0], t.linkModel[1]);   // [latency us, GB/s] of one neighbour message
             // FLUID_TRACE_COMM: marker lines on stderr around the one call that talks to RCCL (ncclCommInitRank), so that a wedged
             // communicator bootstrap on a box can be told from a hang in this library (tests/test_node_shim.py)
             const trace = !!process.env.FLUID_TRACE_COMM;
             if (trace) process.stderr.write('[fluid.js] commInit begin rank ' + t.rank + '/' + t.world + '\n');
             native.commInit(handle, t.commId);          // collective: every rank of the run calls it
             if (trace) process.stderr.write('[fluid.js] commInit done rank ' + t.rank + '\n');
+            // linkModel: [latency us, GB/s] given, or 'calibrate' — measured now, on this set's own links (collective like commInit;
+            // what came out is sim.linkModel).  A probe that fails leaves the library's constants in place.
+            if (t.linkModel === 'calibrate' && t.world > 1) {
+                try { sim.linkModel = native.calibrateLink(handle, 20); } catch (e) { sim.linkModel = null; sim.linkModelError = String(e.message || e); }
+            }
         } else if (handle == null) handle = native.create(simRes.width, simRes.height, dyeRes.width, dyeRes.height, device, schedule, storage);
         else native.resize(handle, simRes.width, simRes.height, dyeRes.width, dyeRes.height);
     };

@@ -215,6 +215,25 @@ static napi_value n_set_link_model(napi_env env, napi_callback_info info)
     return rc == FLUID_OK ? NULL : throw_status(env, c, rc);
 }
 
+/* calibrateLink(h, reps) -> [latencyUs, gbytesPerS]: collective over the tile set, behind commInit — measures what a neighbour message
+ * costs on this node's links and makes it the context's link model (fluid_comm_calibrate_link, ABI 9) */
+static napi_value n_calibrate_link(napi_env env, napi_callback_info info)
+{
+    napi_value a[2], arr, v;
+    fluid_ctx *c;
+    int reps;
+    float lat = 0.0f, gbps = 0.0f;
+    if (!get_args(env, info, 2, a) || !get_ctx(env, a[0], &c) || !get_i(env, a[1], &reps)) return NULL;
+    int rc = fluid_comm_calibrate_link(c, reps, &lat, &gbps);
+    if (rc != FLUID_OK) return throw_status(env, c, rc);
+    NAPI_OK(napi_create_array_with_length(env, 2, &arr));
+    NAPI_OK(napi_create_double(env, (double)lat, &v));
+    NAPI_OK(napi_set_element(env, arr, 0, v));
+    NAPI_OK(napi_create_double(env, (double)gbps, &v));
+    NAPI_OK(napi_set_element(env, arr, 1, v));
+    return arr;
+}
+
 /* haloCheck(h): throws (code -5) if an advection back-trace left the refreshed ghost rows / columns */
 static napi_value n_halo_check(napi_env env, napi_callback_info info)
 {
@@ -566,6 +585,7 @@ static napi_value init(napi_env env, napi_value exports)
         { "setDither", n_set_dither }, { "render", n_render }, { "readFrame", n_read_frame }, { "readFrameRgba8", n_read_frame_rgba8 },
         { "scheduleInfo", n_schedule_info }, { "setStepMarks", n_set_step_marks }, { "getStepMarks", n_get_step_marks },
         { "setLinkModel", n_set_link_model },
+        { "calibrateLink", n_calibrate_link },
     };
     for (size_t k = 0; k < sizeof fns / sizeof fns[0]; k++) {
         napi_value f;

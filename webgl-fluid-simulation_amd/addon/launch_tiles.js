@@ -46,7 +46,9 @@ function launchTiles (options) {
                 }
             });
             child.on('exit', code => { if (code !== 0 && results[rank] === undefined) fail(new Error('rank ' + rank + ' exited with code ' + code)); });
-            child.send({ type: 'init', rank, world, tilesX, device: options.isolate ? 0 : devices[rank], halo: options.halo === undefined ? 56 : options.halo, reach: options.reach,
+            // linkModel: [latency us, GB/s], or 'calibrate' (the default on more than one GPU): every rank measures its links behind commInit
+            const linkModel = options.linkModel !== undefined ? options.linkModel : (world > 1 ? 'calibrate' : undefined);
+            child.send({ type: 'init', rank, world, tilesX, device: options.isolate ? 0 : devices[rank], halo: options.halo === undefined ? 56 : options.halo, reach: options.reach, linkModel,
                          worker: path.resolve(options.worker), fluid: options.fluid || {}, args: options.args || {} });
         }
     });
@@ -64,6 +66,7 @@ function childMain () {
                 const commId = Buffer.from(m.id, 'base64');
                 const tile = { rank: init.rank, world: init.world, tilesX: init.tilesX, halo: init.world > 1 ? init.halo : 0, commId };
                 if (init.reach !== undefined) tile.reach = init.reach;
+                if (init.linkModel !== undefined) tile.linkModel = init.linkModel;
                 const sim = fluid.createFluid(Object.assign({}, init.fluid, { tile, device: init.device }));
                 const work = require(init.worker);
                 const value = await work(sim, { rank: init.rank, world: init.world, tilesX: init.tilesX, args: init.args, fluid });

@@ -1240,7 +1240,8 @@ int fluid_comm_calibrate_link(fluid_ctx* c, int reps, float* latency_us, float* 
     // the largest message of a step: the first exchange's velocity + pressure ghost rows to one neighbour (every rank of a set computes the
     // same figure: the message sizes of the two sides of a pair must agree)
     const size_t small = 4096;
-    size_t large = (size_t)c->desc.halo * (size_t)c->sim.P * 12u * (c->storage == FLUID_STORE_F16 ? 1u : 2u) / 2u;
+    // (from the descriptor only — the global width, the decomposition, the ghost depth: a tile's own pitch differs between border and inner tiles)
+    size_t large = (size_t)c->desc.halo * ((size_t)c->desc.sim_w / (size_t)c->desc.parts_x) * 12u * (c->storage == FLUID_STORE_F16 ? 1u : 2u) / 2u;
     large = std::min<size_t>(std::max<size_t>(large & ~(size_t)255, (size_t)1 << 20), (size_t)64 << 20);
     char* buf = nullptr;
     HIPCK(c, hipMalloc((void**)&buf, 2 * peers.size() * large));
