@@ -390,6 +390,59 @@ def parity_in_run(fluid_hip, size, iters, device, storage, with_oracle=True, ste
     return out
 
 
+def compare_with_single_domain(one, engines, device):
+    """every context of a stripe / tile set against the rows x columns it owns of the single domain `one` (a FluidSim over the GLOBAL grid that
+    ran the same splats and steps), all five fields, bit for bit, on the device -> {field: {equal, ...}}.  `engines`: HipStripeEngine-like
+    objects (info(name) with row0 / rows / col0 / cols, read(name)) — this rank's one context under RCCL, every context of an in-process set
+    in tests/test_bench_live.py."""
+    import torch
+    fields = {}
+    for k in ("velocity", "pressure", "divergence", "curl", "dye"):
+        ref, rec = one.device_view(k), {"equal": True}
+        for e in engines:
+            fi = e.info(k)
+            mine = torch.from_numpy(e.read(k)).to(ref.device)            # this context's owned block through the host path
+            want = ref[fi.row0:fi.row0 + fi.rows, fi.col0:fi.col0 + fi.cols]
+            if want.dtype != mine.dtype:
+                want = want.to(mine.dtype)   # fp16 storage: the host path widens exactly
+            if mine.dim() == 2:
+                mine = mine.unsqueeze(-1)
+            if not bool(torch.equal(mine, want)):
+                ne = mine != want
+                rec.update(equal=False, n_diff=int(ne.sum().item()), n_values=int(mine.numel()),
+                           max_abs=float((mine.double() - want.double()).abs().nan_to_num(nan=float("inf")).max().item()),
+                           first_diff_at=[int(x) for x in ne.nonzero()[0].tolist()], rows=[fi.row0, fi.row0 + fi.rows], cols=[fi.col0, fi.col0 + fi.cols])
+                break
+        fields[k] = rec
+    torch.cuda.synchronize(device)
+    return fields
+
+
+def decomposition_in_run(fluid_hip, make_set, canvas, cfg, device, schedule, storage, steps=3, splats=6):
+    """N > 1: what the ranks exchange is right — on the hardware the number was measured on.  A FRESH stripe / tile set of the benchmark's own
+    geometry (collective: its own communicator, the same calibrated link model) takes `splats` seeded splats and `steps` steps over RCCL; every
+    rank then runs the single domain of the WHOLE grid itself (the global fields fit one MI355X many times over: 8 GB for 4096 x 32768) with
+    the same splats and steps and compares the rows x columns it owns, all five fields, bit for bit.  The library's decomposition is bitwise
+    invariant on one GPU (tests/test_stripes_gpu.py, test_baseline_sizes.py: in-process sets and rank threads against a stand-in RCCL); this is
+    the same statement over real links, where a stale ghost line or a mis-ordered exchange would show and nothing else in the run would."""
+    t0 = time.perf_counter()
+    st = make_set()
+    try:
+        st.multipleSplats(splats)
+        st.step(DT, steps)
+        st.sync()
+        st.check_halo()
+        with fluid_hip.FluidSim(canvas=canvas, config=cfg, device=device, schedule=schedule, random=fluid_hip.mulberry32(1234), storage=storage) as one:
+            one.multipleSplats(splats)
+            one.step(DT, steps)
+            fields = compare_with_single_domain(one, [st.engine], device)
+    finally:
+        st.close()
+    ok = all(f["equal"] for f in fields.values())
+    return {"set_vs_single_domain": ("bitwise equal on this rank's rows, all five fields after %d steps" % steps) if ok else "MISMATCH",
+            "fields": fields, "grid": list(canvas), "seconds": round(time.perf_counter() - t0, 2), "ok": ok}
+
+
 def main(argv=None, engine_factory=None, backend="nccl"):
     """`engine_factory` / `backend` are the hooks of tests/test_bench_multi.py: the N > 1 branch of THIS function — rendezvous,
     StripeSim set-up, barrier, max-over-ranks timing, the JSON line — runs on CPU ranks over gloo with an injected stripe engine.
@@ -415,6 +468,8 @@ def main(argv=None, engine_factory=None, backend="nccl"):
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the HIP-event instrumented pass")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child runs (HBM bytes per launch, VALU counters)")
     ap.add_argument("--no-steady", action="store_true", help="skip the long (>= 2000 steps) steady-state timing appended to the line")
+    ap.add_argument("--no-decomposition-check", action="store_true", help="N > 1: skip the in-run check of a fresh stripe / tile set against the single "
+                    "domain of the whole grid (every rank runs the global grid itself for three steps and compares its rows bit for bit)")
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run parity check (fused == per-pass schedule at the bench size, HIP == oracle on a small case) that follows the timed sections")
     ap.add_argument("--extras-budget", type=float, default=600.0, help="seconds everything BEHIND the timed section may take in total "
                     "(counter passes, steady timing, CPU baseline); an extra that no longer fits is skipped and says so in the line")
@@ -945,10 +1000,25 @@ def main(argv=None, engine_factory=None, backend="nccl"):
                 problem = "in-run parity check failed on rank %d: %s" % (rank, json.dumps(parity))
         except Exception as ex:
             problem = "in-run parity check could not run on rank %d: %s" % (rank, str(ex)[:200])
+        if N > 1 and not problem and not args.no_decomposition_check:
+            # ... and what the ranks EXCHANGE: a fresh set of the benchmark's geometry against the single domain of the whole grid, per rank
+            if dog:
+                dog.at("in-run decomposition check (a fresh set of %d ranks steps over RCCL; every rank compares its rows with the single domain)" % N)
+            try:
+                cgl = dict(cfg, SIM_RESOLUTION=min(grid_w, grid_h), DYE_RESOLUTION=min(grid_w, grid_h))
+                deco = decomposition_in_run(fluid_hip, lambda: make_stripes(grid_w, grid_h, iters, max(1, args.tiles_x)), (grid_w, grid_h), cgl,
+                                            local_rank, args.schedule, args.storage)
+                parity["decomposition"] = deco
+                if not deco["ok"]:
+                    problem = "in-run decomposition check failed on rank %d: %s" % (rank, json.dumps(deco)[:1200])
+            except Exception as ex:   # the check could not run (memory, set-up): say so; only a MISMATCH is an error of the run
+                parity["decomposition"] = {"set_vs_single_domain": "not run: %s: %s" % (type(ex).__name__, str(ex)[:200]), "ok": None}
         if N > 1:   # every rank checks its own GPU: the line carries all of their summaries, so that one rank's problem is attributable
             mine = {"rank": rank, "ok": bool(parity and parity["ok"]) and not problem}
             if parity:
                 mine["fields_differing"] = {k: v for k, v in parity.get("fields_%d" % size, {}).items() if not v.get("equal")}
+                if "decomposition" in parity:
+                    mine["decomposition"] = parity["decomposition"]["set_vs_single_domain"]
             if problem:
                 mine["problem"] = problem[:400]
             ranks = [None] * N

@@ -103,3 +103,37 @@ def test_bench_extras_budget_is_honoured():
     assert "model" in d["roofline"]["traffic_source"] and "budget" in d["roofline"]["traffic_source"]
     assert d["cpu_baseline"]["value"] is None and "budget" in d["cpu_baseline"]["sample"]
     assert d["skipped"]["steady_ms_per_step"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,tiles_x,canvas", [(4, 1, (256, 1024)), (4, 2, (512, 512))])
+def test_the_decomposition_checker_of_the_multi_gpu_line(world, tiles_x, canvas):
+    """bench.py N > 1 checks in the run that a fresh stripe / tile set over RCCL leaves the single domain's bits on every rank's own rows
+    (decomposition_in_run).  Its comparison — owned rows x columns of each context against the global field, on the device — runs here on an
+    in-process set: equal as the library's decomposition is, and a context that was tampered with is caught with its rows named."""
+    import numpy as np
+    import fluid_hip
+    from fluid_hip.stripes import StripeGroup
+    sys.path.insert(0, ROOT)
+    import bench
+    res = min(canvas)
+    cfg = {"SIM_RESOLUTION": res, "DYE_RESOLUTION": res, "PRESSURE_ITERATIONS": 20}
+    g = StripeGroup(world, canvas=canvas, config=cfg, halo=24, random=fluid_hip.mulberry32(1234), tiles_x=tiles_x)
+    try:
+        with fluid_hip.FluidSim(canvas=canvas, config=cfg, random=fluid_hip.mulberry32(1234)) as one:
+            for sim in (g, one):
+                sim.multipleSplats(6)
+                sim.step(bench.DT, 3)
+            f = bench.compare_with_single_domain(one, g.engines, 0)
+            assert set(f) == {"velocity", "pressure", "divergence", "curl", "dye"} and all(v["equal"] for v in f.values()), f
+            e = g.engines[world - 1]
+            p = e.read("pressure")
+            p[3, 5] += 1.0
+            e.write("pressure", p)
+            f = bench.compare_with_single_domain(one, g.engines, 0)
+            fi = e.info("pressure")
+            assert not f["pressure"]["equal"] and f["pressure"]["n_diff"] == 1 and f["pressure"]["rows"] == [fi.row0, fi.row0 + fi.rows]
+            assert f["pressure"]["first_diff_at"][:2] == [3, 5] and all(v["equal"] for k, v in f.items() if k != "pressure")
+    finally:
+        g.close()
+
