@@ -76,6 +76,7 @@ struct fluid_ctx {
     float link_lat_us = 20.0f, link_gbps = 50.0f;   // one neighbour message: latency + bytes / bandwidth (fluid_set_link_model)
     bool comm_stream_high = false;       // created at the highest stream priority (contexts with an RCCL communicator: ensure_comm_stream)
     // lab (FLUID_JACOBI_CHAINS): a second stream and its events for the pressure loop cut into two row chains (pass_jacobi)
+    unsigned int* chain_flags = nullptr;   // lab (FLUID_JACOBI_CHAIN): the (block, tile row) counters of k_jacobi_tb_chain
     hipStream_t chain_stream = nullptr;
     std::vector<hipEvent_t> chain_ev;
     hipEvent_t ev_ready = nullptr;       // context stream -> comm stream: the rows to send exist

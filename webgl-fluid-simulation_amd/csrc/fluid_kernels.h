@@ -195,6 +195,13 @@ int jacobi_tb_depth(int shape);
 int jacobi_tb_apron_cols(int shape);   // columns of apron a tile of that shape loads on each side
 bool jacobi_tb_has_gradsub(int shape);
 bool jacobi_tb_supported(Win w);
+#ifdef FLUID_PROBES
+// lab (FLUID_JACOBI_CHAIN=1): the pressure loop as ONE launch of chained blocks of iterations (fluid_kernels.hip, k_jacobi_tb_chain)
+bool jacobi_chain_enabled();
+size_t jacobi_chain_flag_bytes();
+hipError_t launch_jacobi_tb_chain(hipStream_t s, Win w, float* pa, float* pb, const float* div, float pscale, int iters, int ga, int gb,
+                                  unsigned int* flags, int* blocks, bool* result_in_b);
+#endif
 hipError_t launch_jacobi_tb(hipStream_t s, Win w, const float* p, const float* div, float* p_out, float pscale,
                             int iters, int ga, int gb, int shape);
 // The same launch with K6 (gradient subtract) folded in — for the LAST block of a step's loop: runs `iters` iterations, writes p_out rows

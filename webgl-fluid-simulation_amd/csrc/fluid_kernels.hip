@@ -1085,7 +1085,23 @@ __device__ __forceinline__ void jacobi_sweep(Quad (&P)[RY], const Quad (&D)[RY],
 }
 
 // T = float (fp32 fields) or __half (fp16 storage: the clear and every iteration round their output to fp16)
-template <int NW, int RY, int HX, int HY, int EDGE, class T, bool GS = false, class V2 = float2>
+// CHAIN (lab, k_jacobi_tb_chain): the pressure is read with `sc1` loads (past this CU's L1) and stored with `sc1` write-through stores, so
+// that a tile of the NEXT block of iterations, on any XCD, may read it inside the same launch once this tile has said it is done — the
+// guide's R1 hand-off (payload write-through, every storing wave drains, one flag), without a fence on either side.
+typedef unsigned int chain_u4 __attribute__((ext_vector_type(4)));
+[[maybe_unused]] __device__ __forceinline__ Quad load_quad_sc1(__amdgpu_buffer_rsrc_t r, size_t idx)
+{
+    const chain_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (unsigned)(idx * sizeof(float)), 0, 16);   // aux 16 = sc1
+    return quad_of(make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)));
+}
+[[maybe_unused]] __device__ __forceinline__ void store_quad_sc1(__amdgpu_buffer_rsrc_t r, size_t idx, Quad q)
+{
+    const float4 f = float4_of(q);
+    __builtin_amdgcn_raw_buffer_store_b128(chain_u4{ __float_as_uint(f.x), __float_as_uint(f.y), __float_as_uint(f.z), __float_as_uint(f.w) }, r,
+                                           (unsigned)(idx * sizeof(float)), 0, 16);
+}
+
+template <int NW, int RY, int HX, int HY, int EDGE, class T, bool GS = false, class V2 = float2, bool CHAIN = false>
 __device__ __forceinline__ void jacobi_tb_body(const Win& w, const T* __restrict__ p, const T* __restrict__ div,
                                                T* __restrict__ p_out, float pscale, int iters, int ga, int gb, int x0,
                                                int y0, float4 (*mail)[NW][2][64], const V2* __restrict__ vel = nullptr,
@@ -1108,11 +1124,18 @@ __device__ __forceinline__ void jacobi_tb_body(const Win& w, const T* __restrict
     Quad P[RY], D[RY];
     const unsigned cxs = (unsigned)(min(max(cx, w.c0), w.c0 + w.P - 4) - w.c0);  // array column of the lane's quad, kept inside the array
     const v2f ps = v2f{ pscale, pscale };
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t rin, rout;
+    if constexpr (CHAIN) {
+        const int bytes = (int)((size_t)w.rows * (size_t)w.P * sizeof(float));
+        rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(p), 0, bytes, 0x00020000);
+        rout = __builtin_amdgcn_make_buffer_rsrc(p_out, 0, bytes, 0x00020000);
+    }
 #pragma unroll
     for (int r = 0; r < RY; r++) {
         const int lr = min(max(gy + r - w.g0, 0), w.rows - 1);
         const size_t row = (size_t)lr * (size_t)w.P;  // wave-uniform
-        P[r] = load_quad(p, row + cxs);
+        if constexpr (CHAIN) P[r] = load_quad_sc1(rin, row + cxs);
+        else P[r] = load_quad(p, row + cxs);
         D[r] = load_quad(div, row + cxs);
     }
 #pragma unroll
@@ -1145,8 +1168,10 @@ __device__ __forceinline__ void jacobi_tb_body(const Win& w, const T* __restrict
 #pragma unroll
     for (int r = 0; r < RY; r++) {
         const int gj = gy + r;
-        if (col_store && gj >= out_lo && gj < out_hi)
-            store_quad(p_out, (size_t)at(w, gj, cx), P[r]);
+        if (col_store && gj >= out_lo && gj < out_hi) {
+            if constexpr (CHAIN) store_quad_sc1(rout, (size_t)at(w, gj, cx), P[r]);
+            else store_quad(p_out, (size_t)at(w, gj, cx), P[r]);
+        }
     }
 
     // K6 folded into the LAST launch of the loop (gradientSubtractShader script.js:895-913): the tile still holds the final pressure,
@@ -1235,6 +1260,75 @@ __device__ __forceinline__ void jacobi_tb_tile(const Win& w, const T* __restrict
     else if (xedge) jacobi_tb_body<NW, RY, HX, HYT, 1, T, GS, V2>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail, vel, vel_out);
     else jacobi_tb_body<NW, RY, HX, HYT, 0, T, GS, V2>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail, vel, vel_out);
 }
+
+#ifdef FLUID_PROBES
+// ---- lab (FLUID_JACOBI_CHAIN=1): the whole pressure loop as ONE launch ------------------------------------------
+// A launch of ten iterations is its bytes over the bandwidth plus ~8 us in which the chip fills and drains, five times per step.  Here the
+// five blocks of iterations are one grid of 5 x T workgroups: workgroup B = l T + b runs tile b of block l, reads the pressure buffer l % 2
+// and writes the other one.  A tile of block l may start when the three tile ROWS of block l - 1 around it are complete (the rows its
+// apron reads — and, because block l writes the buffer block l - 1 read, the rows whose readers must be through): one counter per
+// (block, tile row), bumped by every tile behind its drained write-through stores, polled by one lane.
+// The order that makes this pay: within a block every XCD takes a contiguous run of the row-major tile sequence (as k_jacobi_tb does), and
+// ODD blocks walk their runs BACKWARDS.  A front that finishes block l at the bottom of its run starts block l + 1 right there — the rows
+// it needs are its own last ones and the neighbouring front's FIRST ones, done long ago — and reaches the top of its run when the front
+// above has long finished block l.  No front ever waits for another one to end; the drain of block l is the fill of block l + 1.
+// Dependencies point to lower workgroup ids only: with workgroups dispatched in id order (what the hardware does; HIP does not promise it)
+// a waiting workgroup waits for one that is resident or done.  The poll is bounded all the same: a workgroup that gives up sets *err and
+// computes on stale data rather than hang the device.
+constexpr int CHAIN_MAX_BLOCKS = 8, CHAIN_MAX_ROWS = 128;
+struct ChainPlan {
+    int blocks, tiles;            // blocks of iterations, tiles per block (nx * ny)
+    int iters[CHAIN_MAX_BLOCKS];
+};
+
+template <int NW, int RY, int HX, int HY, int BPC>
+__global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_chain(Win w, float* __restrict__ pa, float* __restrict__ pb,
+                                                              const float* __restrict__ div, float pscale, ChainPlan C, int ga, int gb, int xs,
+                                                              int ys, int nx, int ny, unsigned int* __restrict__ done,
+                                                              unsigned int* __restrict__ err)
+{
+    __shared__ float4 mail[2][NW][2][64];
+    using G = JacobiTB<NW, RY, HX, HY>;
+    const int B = (int)blockIdx.x, l = B / C.tiles, b = B - l * C.tiles;
+    // tile of workgroup b: XCD b % 8 takes the (b / 8)-th tile of its contiguous run of the row-major sequence, from the far end in odd blocks
+    const int n = C.tiles, q = n >> 3, r8 = n & 7, xcd = b & 7, slot = b >> 3;
+    const int len = q + (xcd < r8 ? 1 : 0), start = xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q;
+    const int t = start + ((l & 1) ? len - 1 - slot : slot);
+    const int by = t / nx, bx = t - by * nx;
+    if (l > 0) {
+        if (threadIdx.x == 0 && threadIdx.y == 0) {
+            const int r0 = by > 0 ? by - 1 : 0, r1 = by < ny - 1 ? by + 1 : ny - 1;
+            const unsigned int* flag = done + (l - 1) * CHAIN_MAX_ROWS;
+            bool gave_up = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;   // somebody already did: nobody waits any more
+            unsigned spins = 0;
+            for (int r = r0; r <= r1 && !gave_up; r++) {
+                while (__hip_atomic_load(flag + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nx) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (++spins > (1u << 16)) {   // tens of milliseconds: something is not coming — say so and go on (never hang the device)
+                        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        gave_up = true;
+                        break;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const float* p = (l & 1) ? pb : pa;
+    float* p_out = (l & 1) ? pa : pb;
+    const int x0 = xs + bx * G::VX, y0 = ys + by * G::VY;
+    const bool xedge = (x0 <= 0) || (x0 + G::TX >= w.W), yedge = (y0 <= 0) || (y0 + G::TY >= w.H);
+    const bool ragged = (w.W & 3) != 0 && x0 + G::TX >= w.W;
+    const float ps = l == 0 ? pscale : 1.0f;
+    if (yedge || ragged) jacobi_tb_body<NW, RY, HX, HY, 2, float, false, float2, true>(w, p, div, p_out, ps, C.iters[l], ga, gb, x0, y0, mail);
+    else if (xedge) jacobi_tb_body<NW, RY, HX, HY, 1, float, false, float2, true>(w, p, div, p_out, ps, C.iters[l], ga, gb, x0, y0, mail);
+    else jacobi_tb_body<NW, RY, HX, HY, 0, float, false, float2, true>(w, p, div, p_out, ps, C.iters[l], ga, gb, x0, y0, mail);
+    // done: every storing wave drains its write-through stores, then ONE lane counts the tile (the guide's R1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0) __hip_atomic_fetch_add(done + l * CHAIN_MAX_ROWS + by, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#endif
 
 // BPC = workgroups that must fit on a CU together (their load / compute / store phases overlap each other):
 // the second __launch_bounds__ argument is waves per SIMD, i.e. the VGPR budget the compiler has to meet.
@@ -3124,6 +3218,45 @@ hipError_t launch_jacobi_tb(hipStream_t s, Win w, const float* p, const float* d
 {
     return launch_jacobi_tb_any(s, w, p, div, p_out, pscale, iters, ga, gb, shape);
 }
+
+#ifdef FLUID_PROBES
+bool jacobi_chain_enabled()
+{
+    static const bool on = [] { const char* e = lab_env("FLUID_JACOBI_CHAIN"); return e && atoi(e) != 0; }();
+    return on;
+}
+size_t jacobi_chain_flag_bytes() { return (size_t)(CHAIN_MAX_BLOCKS * CHAIN_MAX_ROWS + 1) * sizeof(unsigned int); }
+
+// `iters` iterations as ONE launch of ceil(iters / 10) chained blocks (k_jacobi_tb_chain; the 80-row tile of shape 0).  pa holds the input;
+// the result is in pb when the number of blocks is odd, in pa when it is even (*result_in_b).  hipErrorNotReady: does not apply here.
+hipError_t launch_jacobi_tb_chain(hipStream_t s, Win w, float* pa, float* pb, const float* div, float pscale, int iters, int ga, int gb,
+                                  unsigned int* flags, int* blocks, bool* result_in_b)
+{
+    using G = JacobiTB<8, 10, 12, 10>;
+    ROWS_OR_RETURN();
+    if (!jacobi_tb_supported(w) || iters < 1) return hipErrorNotReady;
+    const int depth = 10;
+    ChainPlan C{};
+    C.blocks = (iters + depth - 1) / depth;
+    if (C.blocks > CHAIN_MAX_BLOCKS) return hipErrorNotReady;
+    int done = 0, left = C.blocks;
+    for (int l = 0; l < C.blocks; l++) {   // balanced, as pass_jacobi cuts them
+        C.iters[l] = (iters - done + left - 1) / left;
+        done += C.iters[l];
+        left--;
+    }
+    const Axis ax = make_axis(w.x0, w.x1, w.W, G::TX, 12), ay = make_axis(ga, gb, w.H, G::TY, 10);
+    if (ay.n > CHAIN_MAX_ROWS) return hipErrorNotReady;
+    C.tiles = ax.n * ay.n;
+    hipError_t e = hipMemsetAsync(flags, 0, jacobi_chain_flag_bytes(), s);
+    if (e != hipSuccess) return e;
+    k_jacobi_tb_chain<8, 10, 12, 10, 2><<<dim3((unsigned)(C.blocks * C.tiles), 1, 1), dim3(64, 8, 1), 0, s>>>(
+        w, pa, pb, div, pscale, C, ga, gb, ax.S, ay.S, ax.n, ay.n, flags, flags + CHAIN_MAX_BLOCKS * CHAIN_MAX_ROWS);
+    *blocks = C.blocks;
+    *result_in_b = (C.blocks & 1) != 0;
+    return hipGetLastError();
+}
+#endif
 hipError_t launch_jacobi_tb(hipStream_t s, Win w, const __half* p, const __half* div, __half* p_out, float pscale, int iters, int ga, int gb, int shape)
 {
     return launch_jacobi_tb_any(s, w, p, div, p_out, pscale, iters, ga, gb, shape);

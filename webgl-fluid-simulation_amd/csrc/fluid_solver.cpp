@@ -338,6 +338,24 @@ int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launche
         (int)(c->sim_rows * (1.0 - jacobi_chains())) > 4 * tb_max)
         return pass_jacobi_chains(c, iters, pscale, shape, launches);
 #endif
+#ifdef FLUID_PROBES
+    // lab (FLUID_JACOBI_CHAIN=1): the whole loop as ONE launch of chained blocks (whole-domain fp32 contexts, the 80-row tile)
+    if (tb && !split && !fold && !c->timing && fluid::jacobi_chain_enabled() && c->storage == FLUID_STORE_F32 && c->desc.parts == 1 && c->desc.parts_x == 1 &&
+        ext_out == 0 && launches_left >= 2 && shape == 0) {
+        if (!c->chain_flags) HIPCK(c, hipMalloc((void**)&c->chain_flags, fluid::jacobi_chain_flag_bytes()));
+        int ga, gb, blocks = 0;
+        bool in_b = false;
+        row_range(c->sim, c->sim_row0, c->sim_rows, 0, ga, gb);
+        const hipError_t e = fluid::launch_jacobi_tb_chain(c->stream, sim_cols(c, 0), (float*)c->prs[0], (float*)c->prs[1], (const float*)c->div, pscale, iters, ga, gb,
+                                                           c->chain_flags, &blocks, &in_b);
+        if (e != hipErrorNotReady) {
+            CK(c->hip(e, "jacobi_tb (chain)"));
+            if (in_b) std::swap(c->prs[0], c->prs[1]);
+            if (launches) *launches += blocks;
+            return FLUID_OK;
+        }
+    }
+#endif
     int cut_left = split && tb ? sp->cover : 0, level = 0;   // leading launches still to cut (split 1 / 2)
     void *pa = c->prs[0], *pb = c->prs[1];               // split 1: the interiors ping-pong here; the context's pair swaps when the frames run
     while (done < iters) {
@@ -971,6 +989,7 @@ int fluid_destroy(fluid_ctx* c)
     for (auto& e : c->marks) (void)hipEventDestroy(e);
     for (auto& e : c->chain_ev) (void)hipEventDestroy(e);
     if (c->ev_order) (void)hipEventDestroy(c->ev_order);
+    if (c->chain_flags) (void)hipFree(c->chain_flags);
     if (c->chain_stream) (void)hipStreamDestroy(c->chain_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
