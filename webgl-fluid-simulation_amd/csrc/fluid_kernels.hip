@@ -1281,7 +1281,10 @@ struct ChainPlan {
     int iters[CHAIN_MAX_BLOCKS];
 };
 
-template <int NW, int RY, int HX, int HY, int BPC>
+// DIAG (FLUID_JACOBI_CHAIN=2 / 3 / 4: timing probes whose RESULTS ARE NOT VALID): 1 = a tile counts itself done without draining its stores
+// (what the wait for the write-through acknowledgements costs), 2 = plain pressure loads and stores instead of sc1 (what the cache policy
+// costs), 3 = nobody waits for anybody (what the dependency waits cost)
+template <int NW, int RY, int HX, int HY, int BPC, int DIAG = 0>
 __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_chain(Win w, float* __restrict__ pa, float* __restrict__ pb,
                                                               const float* __restrict__ div, float pscale, ChainPlan C, int ga, int gb, int xs,
                                                               int ys, int nx, int ny, unsigned int* __restrict__ done,
@@ -1295,7 +1298,7 @@ __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_chain
     const int len = q + (xcd < r8 ? 1 : 0), start = xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q;
     const int t = start + ((l & 1) ? len - 1 - slot : slot);
     const int by = t / nx, bx = t - by * nx;
-    if (l > 0) {
+    if (l > 0 && DIAG != 3) {
         if (threadIdx.x == 0 && threadIdx.y == 0) {
             const int r0 = by > 0 ? by - 1 : 0, r1 = by < ny - 1 ? by + 1 : ny - 1;
             const unsigned int* flag = done + (l - 1) * CHAIN_MAX_ROWS;
@@ -1320,11 +1323,12 @@ __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_chain
     const bool xedge = (x0 <= 0) || (x0 + G::TX >= w.W), yedge = (y0 <= 0) || (y0 + G::TY >= w.H);
     const bool ragged = (w.W & 3) != 0 && x0 + G::TX >= w.W;
     const float ps = l == 0 ? pscale : 1.0f;
-    if (yedge || ragged) jacobi_tb_body<NW, RY, HX, HY, 2, float, false, float2, true>(w, p, div, p_out, ps, C.iters[l], ga, gb, x0, y0, mail);
-    else if (xedge) jacobi_tb_body<NW, RY, HX, HY, 1, float, false, float2, true>(w, p, div, p_out, ps, C.iters[l], ga, gb, x0, y0, mail);
-    else jacobi_tb_body<NW, RY, HX, HY, 0, float, false, float2, true>(w, p, div, p_out, ps, C.iters[l], ga, gb, x0, y0, mail);
+    constexpr bool SC1 = DIAG != 2;
+    if (yedge || ragged) jacobi_tb_body<NW, RY, HX, HY, 2, float, false, float2, SC1>(w, p, div, p_out, ps, C.iters[l], ga, gb, x0, y0, mail);
+    else if (xedge) jacobi_tb_body<NW, RY, HX, HY, 1, float, false, float2, SC1>(w, p, div, p_out, ps, C.iters[l], ga, gb, x0, y0, mail);
+    else jacobi_tb_body<NW, RY, HX, HY, 0, float, false, float2, SC1>(w, p, div, p_out, ps, C.iters[l], ga, gb, x0, y0, mail);
     // done: every storing wave drains its write-through stores, then ONE lane counts the tile (the guide's R1)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (DIAG != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0 && threadIdx.y == 0) __hip_atomic_fetch_add(done + l * CHAIN_MAX_ROWS + by, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -3220,11 +3224,12 @@ hipError_t launch_jacobi_tb(hipStream_t s, Win w, const float* p, const float* d
 }
 
 #ifdef FLUID_PROBES
-bool jacobi_chain_enabled()
+static int jacobi_chain_mode()   // FLUID_JACOBI_CHAIN: 1 = the chained launch; 2, 3, 4 = its timing probes (k_jacobi_tb_chain DIAG 1, 2, 3: invalid results)
 {
-    static const bool on = [] { const char* e = lab_env("FLUID_JACOBI_CHAIN"); return e && atoi(e) != 0; }();
-    return on;
+    static const int m = [] { const char* e = lab_env("FLUID_JACOBI_CHAIN"); return e ? atoi(e) : 0; }();
+    return m;
 }
+bool jacobi_chain_enabled() { return jacobi_chain_mode() >= 1 && jacobi_chain_mode() <= 4; }
 size_t jacobi_chain_flag_bytes() { return (size_t)(CHAIN_MAX_BLOCKS * CHAIN_MAX_ROWS + 1) * sizeof(unsigned int); }
 
 // `iters` iterations as ONE launch of ceil(iters / 10) chained blocks (k_jacobi_tb_chain; the 80-row tile of shape 0).  pa holds the input;
@@ -3250,8 +3255,14 @@ hipError_t launch_jacobi_tb_chain(hipStream_t s, Win w, float* pa, float* pb, co
     C.tiles = ax.n * ay.n;
     hipError_t e = hipMemsetAsync(flags, 0, jacobi_chain_flag_bytes(), s);
     if (e != hipSuccess) return e;
-    k_jacobi_tb_chain<8, 10, 12, 10, 2><<<dim3((unsigned)(C.blocks * C.tiles), 1, 1), dim3(64, 8, 1), 0, s>>>(
-        w, pa, pb, div, pscale, C, ga, gb, ax.S, ay.S, ax.n, ay.n, flags, flags + CHAIN_MAX_BLOCKS * CHAIN_MAX_ROWS);
+    const dim3 grid((unsigned)(C.blocks * C.tiles), 1, 1), block(64, 8, 1);
+    unsigned int* err = flags + CHAIN_MAX_BLOCKS * CHAIN_MAX_ROWS;
+    switch (jacobi_chain_mode()) {
+    case 2: k_jacobi_tb_chain<8, 10, 12, 10, 2, 1><<<grid, block, 0, s>>>(w, pa, pb, div, pscale, C, ga, gb, ax.S, ay.S, ax.n, ay.n, flags, err); break;
+    case 3: k_jacobi_tb_chain<8, 10, 12, 10, 2, 2><<<grid, block, 0, s>>>(w, pa, pb, div, pscale, C, ga, gb, ax.S, ay.S, ax.n, ay.n, flags, err); break;
+    case 4: k_jacobi_tb_chain<8, 10, 12, 10, 2, 3><<<grid, block, 0, s>>>(w, pa, pb, div, pscale, C, ga, gb, ax.S, ay.S, ax.n, ay.n, flags, err); break;
+    default: k_jacobi_tb_chain<8, 10, 12, 10, 2, 0><<<grid, block, 0, s>>>(w, pa, pb, div, pscale, C, ga, gb, ax.S, ay.S, ax.n, ay.n, flags, err); break;
+    }
     *blocks = C.blocks;
     *result_in_b = (C.blocks & 1) != 0;
     return hipGetLastError();
