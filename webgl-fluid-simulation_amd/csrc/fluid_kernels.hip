@@ -1277,8 +1277,9 @@ __device__ __forceinline__ void jacobi_tb_tile(const Win& w, const T* __restrict
 // computes on stale data rather than hang the device.
 constexpr int CHAIN_MAX_BLOCKS = 8, CHAIN_MAX_ROWS = 128;
 struct ChainPlan {
-    int blocks, tiles;            // blocks of iterations, tiles per block (nx * ny)
+    int blocks, tiles;            // blocks of iterations; workgroups per block (mode 0: nx * ny tiles; band-cyclic: 8 G band nx, some without a tile)
     int iters[CHAIN_MAX_BLOCKS];
+    int band;                     // > 0: the band-cyclic order below, `band` tile rows per band
 };
 
 // DIAG (FLUID_JACOBI_CHAIN=2 / 3 / 4: timing probes whose RESULTS ARE NOT VALID): 1 = a tile counts itself done without draining its stores
@@ -1292,12 +1293,32 @@ __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_chain
 {
     __shared__ float4 mail[2][NW][2][64];
     using G = JacobiTB<NW, RY, HX, HY>;
-    const int B = (int)blockIdx.x, l = B / C.tiles, b = B - l * C.tiles;
-    // tile of workgroup b: XCD b % 8 takes the (b / 8)-th tile of its contiguous run of the row-major sequence, from the far end in odd blocks
-    const int n = C.tiles, q = n >> 3, r8 = n & 7, xcd = b & 7, slot = b >> 3;
-    const int len = q + (xcd < r8 ? 1 : 0), start = xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q;
-    const int t = start + ((l & 1) ? len - 1 - slot : slot);
-    const int by = t / nx, bx = t - by * nx;
+    // The workgroup's place in the ORDER is the order in which workgroups really start — a ticket — not blockIdx: a workgroup then only ever
+    // waits for workgroups that have started, whatever order the hardware dispatches in (the first form relied on id order)
+    __shared__ int ticket;
+    if (threadIdx.x == 0 && threadIdx.y == 0) ticket = (int)__hip_atomic_fetch_add(err + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int B = ticket, l = B / C.tiles, b = B - l * C.tiles;
+    int bx, by;
+    if (C.band > 0) {
+        // BAND-CYCLIC order, the same direction in every block: consecutive workgroups alternate XCDs (b % 8); XCD k walks bands of `band`
+        // tile rows — band k of every group of eight bands, group after group — so that the rows a tile of block l + 1 needs (its own
+        // band's and the neighbouring bands' of the SAME group) were finished a whole block ago, while the 8 x band x nx tiles in flight
+        // together still share their aprons inside one XCD's L2.  (The first form — each XCD one contiguous run of the whole sequence, odd
+        // blocks backwards — turned every front around on the tiles that had just been resident TOGETHER: a block's first 64 tiles per
+        // front waited for the previous block's last 64, i.e. for its drain; +10 % instead of -2 %: profiles/r05/jacobi_chain_ab.txt.)
+        const int xcd = b & 7, i = b >> 3, per_band = C.band * nx, g = i / per_band, j = i - g * per_band;
+        by = (g * 8 + xcd) * C.band + j / nx;
+        bx = j % nx;
+        if (by >= ny) return;   // the last group's bands beyond the grid: no tile (block-uniform)
+    } else {
+        // XCD b % 8 takes the (b / 8)-th tile of its contiguous run of the row-major sequence, from the far end in odd blocks
+        const int n = C.tiles, q = n >> 3, r8 = n & 7, xcd = b & 7, slot = b >> 3;
+        const int len = q + (xcd < r8 ? 1 : 0), start = xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q;
+        const int t = start + ((l & 1) ? len - 1 - slot : slot);
+        by = t / nx;
+        bx = t - by * nx;
+    }
     if (l > 0 && DIAG != 3) {
         if (threadIdx.x == 0 && threadIdx.y == 0) {
             const int r0 = by > 0 ? by - 1 : 0, r1 = by < ny - 1 ? by + 1 : ny - 1;
@@ -3230,7 +3251,7 @@ static int jacobi_chain_mode()   // FLUID_JACOBI_CHAIN: 1 = the chained launch; 
     return m;
 }
 bool jacobi_chain_enabled() { return jacobi_chain_mode() >= 1 && jacobi_chain_mode() <= 4; }
-size_t jacobi_chain_flag_bytes() { return (size_t)(CHAIN_MAX_BLOCKS * CHAIN_MAX_ROWS + 1) * sizeof(unsigned int); }
+size_t jacobi_chain_flag_bytes() { return (size_t)(CHAIN_MAX_BLOCKS * CHAIN_MAX_ROWS + 2) * sizeof(unsigned int); }   // counters, err, ticket
 
 // `iters` iterations as ONE launch of ceil(iters / 10) chained blocks (k_jacobi_tb_chain; the 80-row tile of shape 0).  pa holds the input;
 // the result is in pb when the number of blocks is odd, in pa when it is even (*result_in_b).  hipErrorNotReady: does not apply here.
@@ -3252,7 +3273,9 @@ hipError_t launch_jacobi_tb_chain(hipStream_t s, Win w, float* pa, float* pb, co
     }
     const Axis ax = make_axis(w.x0, w.x1, w.W, G::TX, 12), ay = make_axis(ga, gb, w.H, G::TY, 10);
     if (ay.n > CHAIN_MAX_ROWS) return hipErrorNotReady;
-    C.tiles = ax.n * ay.n;
+    static const int band = [] { const char* e = lab_env("FLUID_CHAIN_BAND"); return e ? atoi(e) : 4; }();   // 0 = the first form (contiguous runs, odd blocks backwards)
+    C.band = band > 0 ? band : 0;
+    C.tiles = C.band > 0 ? 8 * ((ay.n + 8 * C.band - 1) / (8 * C.band)) * C.band * ax.n : ax.n * ay.n;
     hipError_t e = hipMemsetAsync(flags, 0, jacobi_chain_flag_bytes(), s);
     if (e != hipSuccess) return e;
     const dim3 grid((unsigned)(C.blocks * C.tiles), 1, 1), block(64, 8, 1);
