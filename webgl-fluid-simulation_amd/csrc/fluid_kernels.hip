@@ -1280,6 +1280,7 @@ struct ChainPlan {
     int blocks, tiles;            // blocks of iterations; workgroups per block (mode 0: nx * ny tiles; band-cyclic: 8 G band nx, some without a tile)
     int iters[CHAIN_MAX_BLOCKS];
     int band;                     // > 0: the band-cyclic order below, `band` tile rows per band
+    int tickets;                  // 1: a workgroup's place in the order is a ticket it draws when it starts (independent of the dispatch order)
 };
 
 // DIAG (FLUID_JACOBI_CHAIN=2 / 3 / 4: timing probes whose RESULTS ARE NOT VALID): 1 = a tile counts itself done without draining its stores
@@ -1296,9 +1297,11 @@ __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_chain
     // The workgroup's place in the ORDER is the order in which workgroups really start — a ticket — not blockIdx: a workgroup then only ever
     // waits for workgroups that have started, whatever order the hardware dispatches in (the first form relied on id order)
     __shared__ int ticket;
-    if (threadIdx.x == 0 && threadIdx.y == 0) ticket = (int)__hip_atomic_fetch_add(err + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const int B = ticket, l = B / C.tiles, b = B - l * C.tiles;
+    if (C.tickets) {   // (one word for 6000 workgroups per step: 46 us of the step at 4096^2 — visit 12; off = blockIdx order, what the hardware dispatches in)
+        if (threadIdx.x == 0 && threadIdx.y == 0) ticket = (int)__hip_atomic_fetch_add(err + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+    }
+    const int B = C.tickets ? ticket : (int)blockIdx.x, l = B / C.tiles, b = B - l * C.tiles;
     int bx, by;
     if (C.band > 0) {
         // BAND-CYCLIC order, the same direction in every block: consecutive workgroups alternate XCDs (b % 8); XCD k walks bands of `band`
@@ -1320,19 +1323,17 @@ __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_chain
         bx = t - by * nx;
     }
     if (l > 0 && DIAG != 3) {
-        if (threadIdx.x == 0 && threadIdx.y == 0) {
-            const int r0 = by > 0 ? by - 1 : 0, r1 = by < ny - 1 ? by + 1 : ny - 1;
-            const unsigned int* flag = done + (l - 1) * CHAIN_MAX_ROWS;
-            bool gave_up = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;   // somebody already did: nobody waits any more
+        // three lanes, one row each: the three counters come back in ONE memory round trip (one lane after the other: three — visit 12)
+        const int r = by - 1 + (int)threadIdx.x;
+        if (threadIdx.y == 0 && threadIdx.x < 3 && r >= 0 && r < ny) {
+            const unsigned int* flag = done + (l - 1) * CHAIN_MAX_ROWS + r;
             unsigned spins = 0;
-            for (int r = r0; r <= r1 && !gave_up; r++) {
-                while (__hip_atomic_load(flag + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nx) {
-                    __builtin_amdgcn_s_sleep(4);
-                    if (++spins > (1u << 16)) {   // tens of milliseconds: something is not coming — say so and go on (never hang the device)
-                        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        gave_up = true;
-                        break;
-                    }
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nx) {
+                __builtin_amdgcn_s_sleep(2);
+                if ((++spins & 1023u) == 0 &&
+                    (spins > (1u << 16) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {   // never hang the device
+                    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
                 }
             }
         }
@@ -3274,7 +3275,9 @@ hipError_t launch_jacobi_tb_chain(hipStream_t s, Win w, float* pa, float* pb, co
     const Axis ax = make_axis(w.x0, w.x1, w.W, G::TX, 12), ay = make_axis(ga, gb, w.H, G::TY, 10);
     if (ay.n > CHAIN_MAX_ROWS) return hipErrorNotReady;
     static const int band = [] { const char* e = lab_env("FLUID_CHAIN_BAND"); return e ? atoi(e) : 4; }();   // 0 = the first form (contiguous runs, odd blocks backwards)
+    static const int tickets = [] { const char* e = lab_env("FLUID_CHAIN_TICKET"); return e ? atoi(e) : 0; }();
     C.band = band > 0 ? band : 0;
+    C.tickets = tickets != 0;
     C.tiles = C.band > 0 ? 8 * ((ay.n + 8 * C.band - 1) / (8 * C.band)) * C.band * ax.n : ax.n * ay.n;
     hipError_t e = hipMemsetAsync(flags, 0, jacobi_chain_flag_bytes(), s);
     if (e != hipSuccess) return e;
