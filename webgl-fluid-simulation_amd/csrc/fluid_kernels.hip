@@ -1275,7 +1275,7 @@ __device__ __forceinline__ void jacobi_tb_tile(const Win& w, const T* __restrict
 // Dependencies point to lower workgroup ids only: with workgroups dispatched in id order (what the hardware does; HIP does not promise it)
 // a waiting workgroup waits for one that is resident or done.  The poll is bounded all the same: a workgroup that gives up sets *err and
 // computes on stale data rather than hang the device.
-constexpr int CHAIN_MAX_BLOCKS = 8, CHAIN_MAX_ROWS = 128;
+constexpr int CHAIN_MAX_BLOCKS = 8, CHAIN_MAX_ROWS = 512;
 struct ChainPlan {
     int blocks, tiles;            // blocks of iterations; workgroups per block (mode 0: nx * ny tiles; band-cyclic: 8 G band nx, some without a tile)
     int iters[CHAIN_MAX_BLOCKS];
@@ -3274,7 +3274,10 @@ hipError_t launch_jacobi_tb_chain(hipStream_t s, Win w, float* pa, float* pb, co
     }
     const Axis ax = make_axis(w.x0, w.x1, w.W, G::TX, 12), ay = make_axis(ga, gb, w.H, G::TY, 10);
     if (ay.n > CHAIN_MAX_ROWS) return hipErrorNotReady;
-    static const int band = [] { const char* e = lab_env("FLUID_CHAIN_BAND"); return e ? atoi(e) : 4; }();   // 0 = the first form (contiguous runs, odd blocks backwards)
+    // rows per band: what keeps ONE band of an XCD inside the 64 workgroups resident there (32 CUs x 2): 4096-wide: 18 tiles per row -> 3 rows.
+    // (4 rows = 72 tiles spill and the order alone costs 12 %; 2 rows leave a third of the XCD to the next band: +2 %: profiles/r05/jacobi_chain_ab.txt)
+    static const int forced = [] { const char* e = lab_env("FLUID_CHAIN_BAND"); return e ? atoi(e) : -1; }();   // 0 = the first form (contiguous runs, odd blocks backwards)
+    const int band = forced >= 0 ? forced : std::max(1, 64 / ax.n);
     static const int tickets = [] { const char* e = lab_env("FLUID_CHAIN_TICKET"); return e ? atoi(e) : 0; }();
     C.band = band > 0 ? band : 0;
     C.tickets = tickets != 0;
