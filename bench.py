@@ -735,7 +735,7 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         # which kernels the timed call launched (the library picks by grid size): chained = steps whose advection launch also ran the next
         # step's curl / vorticity / divergence (fluid_step_n below 3072^2 texels); a per-frame fluid_step never chains
         out["config"]["kernels"] = {"jacobi_shape": si["jacobi_shape"], "jacobi_launches_per_step": si["jacobi_launches"],
-                                    "gradsub_folded": bool(si["gradsub_folded"]), "chained_steps": si["chained"],
+                                    "jacobi_chained": bool(si["jacobi_chained"]), "gradsub_folded": bool(si["gradsub_folded"]), "chained_steps": si["chained"],
                                     "curl_field_stored_by_steps": si["curl_stores"], "launches_in_timed_call": si["launches"],
                                     "dye_packed_rgb": bool(si["dye_packed"])}
     if on_cpu:
@@ -830,7 +830,9 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         # the kernel that runs the loop: the temporally blocked register tile, or one launch per iteration under --schedule passes
         if args.schedule == "fused":
             # (k_jacobi_tb_mix: the same tile kernel with smaller tiles for the launch's first and last rows — what large grids run)
-            cands = ["k_jacobi_tb_h<", "k_jacobi_tb<"] if args.storage == "f16" else ["k_jacobi_tb_mix<", "k_jacobi_tb<", "k_jacobi_tb2<"]
+            # (k_jacobi_tb_chain: the loop's blocks of ten iterations as ONE launch — 4096-wide grids since round 5; its counters are per
+            # dispatch, the line's figures per BLOCK, which is what a launch of the other kernels is: blocks_per_dispatch below)
+            cands = ["k_jacobi_tb_h<", "k_jacobi_tb<"] if args.storage == "f16" else ["k_jacobi_tb_chain<", "k_jacobi_tb_mix<", "k_jacobi_tb<", "k_jacobi_tb2<"]
         else:
             cands = ["k_h_jacobi", "k_jacobi"] if args.storage == "f16" else ["k_jacobi"]
         if only_folded and args.schedule == "fused":
@@ -846,8 +848,11 @@ def main(argv=None, engine_factory=None, backend="nccl"):
                     break
             if entry is None:
                 why = "no %s dispatch in the counter pass" % cands[0]
+        per_dispatch = 1
+        if entry and kname.startswith("k_jacobi_tb_chain"):
+            per_dispatch = max(1, int(round((launches / max(tm["steps"], 1)) / max(entry["launches_per_step"], 1e-9))))
         if entry:
-            bytes_launch, source = entry["bytes_per_launch"], "PMC FETCH_SIZE x2 + WRITE_SIZE, this run (rocprofv3 --pmc, separate passes)"
+            bytes_launch, source = int(entry["bytes_per_launch"] / per_dispatch), "PMC FETCH_SIZE x2 + WRITE_SIZE, this run (rocprofv3 --pmc, separate passes)"
         else:   # the least a launch must move: pressure in, divergence in, pressure out (no apron re-reads counted)
             bytes_launch, source = int(12.0 * size * size * half), "model: compulsory 12 B/texel per launch (PMC pass unavailable: %s)" % why
         achieved = bytes_launch / (avg_ms * 1e-3) / 1e9
@@ -860,6 +865,8 @@ def main(argv=None, engine_factory=None, backend="nccl"):
             "compulsory_bytes_per_launch": int((28.0 if only_folded else 12.0) * size * size * half),
             "frac_compulsory": round((28.0 if only_folded else 12.0) * size * size * half / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
             "avg_launch_ms": round(avg_ms, 5), "launches_per_step": launches / max(tm["steps"], 1),
+            # > 1: the kernel is ONE dispatch of that many chained blocks of iterations; traffic, avg_launch_ms and launches_per_step are per block
+            "blocks_per_dispatch": per_dispatch,
             "iterations_per_launch": iters * tm["steps"] / max(tm["jacobi_launches"], 1),
             "algorithmic_bytes_per_launch": int(alg_launch),
             "algorithmic_GBps": round(alg_launch / (avg_ms * 1e-3) / 1e9, 1),
@@ -882,15 +889,16 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         if not args.no_traffic and args.schedule == "fused":
             valu, vwhy = collect_valu(args, deadline, cands)
             if valu:
+                disp_ms = avg_ms * per_dispatch   # the counters are per dispatch
                 valu["busy_ms_at_max_clock"] = round(valu["simd_valu_cycles_per_launch"] / 2.4e6, 5)   # 2.4 GHz: a lower bound on the time
                 gui = valu.get("gui_active_cycles_per_launch", 0)
                 if gui:   # the counter may come summed over the 8 XCDs: its value per millisecond tells (the clock is 1.8-2.4 GHz)
-                    inst = 8 if gui / (avg_ms * 1e6) > 4.8 else 1
+                    inst = 8 if gui / (disp_ms * 1e6) > 4.8 else 1
                     valu["gui_instances_assumed"] = inst
                     valu["busy_frac"] = round(valu["simd_valu_cycles_per_launch"] / (gui / inst), 4)
-                    valu["effective_clock_GHz"] = round(gui / inst / (avg_ms * 1e6), 3)
+                    valu["effective_clock_GHz"] = round(gui / inst / (disp_ms * 1e6), 3)
                 else:
-                    valu["busy_frac"] = round(valu["busy_ms_at_max_clock"] / avg_ms, 4)
+                    valu["busy_frac"] = round(valu["busy_ms_at_max_clock"] / disp_ms, 4)
                 # busy_frac prices every instruction at one 4-cycle issue (the counter ticks once per instruction: cycles_per_inst reads 4.0).
                 # On gfx950 only v_fma_f32 costs that; the sweep's own mix — nine v_pk_add/mul_f32 and two v_add_f32_dpp per four texels —
                 # costs 1.65 x (tools/micro/valu_rate2.hip: v_pk_* 1.67, *_dpp 1.55 of a v_fma_f32 slot; profiles/r02/advect_experiments.txt).

@@ -1,0 +1,62 @@
+"""The pressure loop as ONE launch of chained blocks of iterations (k_jacobi_tb_chain, round 5): 4096-wide whole-domain fp32 grids run the
+step's 50 Jacobi iterations (pressureShader script.js:868-890, loop 1259-1266) as one grid of 5 x T workgroups in which a tile of block l
+waits for the three tile rows of block l - 1 around it — no fill / drain between the blocks.  Same iterations over the same texels, hence the
+same bits: held here to the one-kernel-per-pass schedule (which the goldens pin to the live reference) on the shapes the rule selects, the
+iteration counts that cut unevenly, and next to the shapes it must leave alone."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+DT = 0.016666
+
+
+@pytest.mark.parametrize("w,h,iters,chained", [
+    (4096, 4096, 50, True),      # the headline
+    (4096, 2048, 47, True),      # non-square, blocks of 10 / 10 / 9 / 9 / 9
+    (4200, 3000, 11, True),      # W % 4 == 0 but no power of two; two blocks (6 + 5)
+    (3800, 2100, 80, True),      # the narrow end of the rule (17 tiles per row), eight blocks
+    (4096, 4096, 10, False),     # one block: a plain launch
+    (4096, 1024, 50, False),     # too few rows
+    (3072, 3072, 50, False),     # four rows of tiles per XCD band: the plain launches (measured level)
+    (6144, 2048, 50, False),     # a tile row longer than an XCD holds: the chained order costs locality
+])
+def test_chained_pressure_loop_leaves_the_same_bits(w, h, iters, chained):
+    import fluid_hip
+    cfg = {"SIM_RESOLUTION": min(w, h), "DYE_RESOLUTION": min(w, h), "PRESSURE_ITERATIONS": iters}
+    sims = [fluid_hip.FluidSim(canvas=(w, h), config=cfg, schedule=s, random=fluid_hip.mulberry32(21)) for s in ("passes", "fused")]
+    try:
+        info = sims[1].schedule_info(3, DT)
+        assert bool(info["jacobi_chained"]) is chained and info["jacobi_launches"] == -(-iters // 10), info
+        assert info["launches"] == 3 * (1 + (1 if chained else info["jacobi_launches"]) + 1 + 1), info
+        for s in sims:
+            s.multipleSplats(5)
+            s.step(DT, 2)
+            s.multipleSplats(1)
+            s.step(DT, 1)            # a call of one step: the same loop again
+        for k in ("velocity", "pressure", "divergence", "curl", "dye"):
+            assert np.array_equal(sims[0].read(k), sims[1].read(k)), k
+        # the loop on its own, through the per-pass entry point (what the stripe driver's hosted form and the tests call)
+        for s in sims:
+            s.run_pass("jacobi", iters=iters)
+        assert np.array_equal(sims[0].read("pressure"), sims[1].read("pressure"))
+    finally:
+        for s in sims:
+            s.close()
+
+
+def test_a_long_run_through_the_chained_loop_stays_bitwise():
+    """300 steps at the headline size in calls of 1, 7 and 50 steps: fused (chained loop, packed dye) == per-pass after every burst"""
+    import fluid_hip
+    cfg = {"SIM_RESOLUTION": 4096, "DYE_RESOLUTION": 4096, "PRESSURE_ITERATIONS": 50}
+    sims = [fluid_hip.FluidSim(canvas=(4096, 4096), config=cfg, schedule=s, random=fluid_hip.mulberry32(3)) for s in ("passes", "fused")]
+    try:
+        for s in sims:
+            s.multipleSplats(12)
+        for n in (1, 7, 50, 1, 50, 50, 50, 41, 50):
+            for s in sims:
+                s.step(DT, n)
+            for k in ("velocity", "pressure", "dye"):
+                assert np.array_equal(sims[0].read(k), sims[1].read(k)), (n, k)
+    finally:
+        for s in sims:
+            s.close()

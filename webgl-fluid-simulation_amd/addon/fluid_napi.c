@@ -534,10 +534,10 @@ static napi_value n_schedule_info(napi_env env, napi_callback_info info)
     if (rc != FLUID_OK) return throw_status(env, c, rc);
     NAPI_OK(napi_create_object(env, &obj));
     const char *names[] = { "fused", "jacobiShape", "jacobiLaunches", "gradsubFolded", "chained", "curlStores", "launches", "runsAhead",
-                            "pendingAdopted", "dyePacked" };
+                            "pendingAdopted", "dyePacked", "jacobiChained" };
     const int vals[] = { S.fused, S.jacobi_shape, S.jacobi_launches, S.gradsub_folded, S.chained, S.curl_stores, S.launches, S.runs_ahead,
-                         S.pending_adopted, S.dye_packed };
-    for (int k = 0; k < 10; k++) {
+                         S.pending_adopted, S.dye_packed, S.jacobi_chained };
+    for (int k = 0; k < 11; k++) {
         NAPI_OK(napi_create_int32(env, vals[k], &v));
         NAPI_OK(napi_set_named_property(env, obj, names[k], v));
     }

@@ -76,7 +76,12 @@ struct fluid_ctx {
     float link_lat_us = 20.0f, link_gbps = 50.0f;   // one neighbour message: latency + bytes / bandwidth (fluid_set_link_model)
     bool comm_stream_high = false;       // created at the highest stream priority (contexts with an RCCL communicator: ensure_comm_stream)
     // lab (FLUID_JACOBI_CHAINS): a second stream and its events for the pressure loop cut into two row chains (pass_jacobi)
-    unsigned int* chain_flags = nullptr;   // lab (FLUID_JACOBI_CHAIN): the (block, tile row) counters of k_jacobi_tb_chain
+    // the chained Jacobi launch (k_jacobi_tb_chain; whole-domain fp32 contexts of 4096-wide grids): its (block, tile row) counters on the
+    // device, and two words of MAPPED HOST memory the kernel writes when a workgroup gives up waiting for a tile — read for free at every
+    // synchronising call (chain_check): a pressure loop that timed out is an error of that call, never a silently wrong field
+    unsigned int* chain_flags = nullptr;
+    unsigned int* chain_err_host = nullptr;
+    unsigned int* chain_err_dev = nullptr;
     hipStream_t chain_stream = nullptr;
     std::vector<hipEvent_t> chain_ev;
     hipEvent_t ev_ready = nullptr;       // context stream -> comm stream: the rows to send exist
@@ -137,6 +142,7 @@ struct FieldRef {
     size_t texel() const { return (size_t)nc * esz; }
 };
 int field_ref(fluid_ctx* c, int field, FieldRef* f, bool geometry_only = false, bool keep_packed = false);
+int chain_check(fluid_ctx* c);   // behind a stream synchronisation: did a chained Jacobi launch give up waiting (FLUID_ERR_HIP)?
 int ensure_rgba(fluid_ctx* c);   // the dye buffers hold RGBA texels from here on (unpacks a packed dye field: fluid_ctx::dye_packed)
 // Stripe / tile contexts pack their dye too (round 5): the ghost texels then travel as 12-byte texels, in place, and the FORMAT of the field is
 // part of the message layout two neighbours must agree on.  It is therefore a function of nothing but what every rank of a set does alike:

@@ -195,13 +195,14 @@ int jacobi_tb_depth(int shape);
 int jacobi_tb_apron_cols(int shape);   // columns of apron a tile of that shape loads on each side
 bool jacobi_tb_has_gradsub(int shape);
 bool jacobi_tb_supported(Win w);
-#ifdef FLUID_PROBES
-// lab (FLUID_JACOBI_CHAIN=1): the pressure loop as ONE launch of chained blocks of iterations (fluid_kernels.hip, k_jacobi_tb_chain)
-bool jacobi_chain_enabled();
+// The pressure loop as ONE launch of chained blocks of ten iterations (fluid_kernels.hip, k_jacobi_tb_chain; fp32 fields, the 80-row tile):
+// where jacobi_chain_applies() says so — 4096-wide grids — it is what pass_jacobi runs.  `flags`: jacobi_chain_flag_bytes() of device memory
+// (zeroed by the launcher); `err`: two words the device can write and the HOST can read (mapped host memory): err[0] != 0 = a workgroup gave up
+// waiting for a tile (the results of that call are not valid).  pa holds the input; the result is in pb when the number of blocks is odd.
+bool jacobi_chain_applies(const Win& w, int ga, int gb, int iters);
 size_t jacobi_chain_flag_bytes();
 hipError_t launch_jacobi_tb_chain(hipStream_t s, Win w, float* pa, float* pb, const float* div, float pscale, int iters, int ga, int gb,
-                                  unsigned int* flags, int* blocks, bool* result_in_b);
-#endif
+                                  unsigned int* flags, unsigned int* err, int* blocks, bool* result_in_b);
 hipError_t launch_jacobi_tb(hipStream_t s, Win w, const float* p, const float* div, float* p_out, float pscale,
                             int iters, int ga, int gb, int shape);
 // The same launch with K6 (gradient subtract) folded in — for the LAST block of a step's loop: runs `iters` iterations, writes p_out rows

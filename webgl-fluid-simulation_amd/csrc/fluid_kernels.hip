@@ -1261,8 +1261,7 @@ __device__ __forceinline__ void jacobi_tb_tile(const Win& w, const T* __restrict
     else jacobi_tb_body<NW, RY, HX, HYT, 0, T, GS, V2>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail, vel, vel_out);
 }
 
-#ifdef FLUID_PROBES
-// ---- lab (FLUID_JACOBI_CHAIN=1): the whole pressure loop as ONE launch ------------------------------------------
+// ---- the whole pressure loop as ONE launch (round 5) — shipped where it measured faster: 4096-wide grids --------
 // A launch of ten iterations is its bytes over the bandwidth plus ~8 us in which the chip fills and drains, five times per step.  Here the
 // five blocks of iterations are one grid of 5 x T workgroups: workgroup B = l T + b runs tile b of block l, reads the pressure buffer l % 2
 // and writes the other one.  A tile of block l may start when the three tile ROWS of block l - 1 around it are complete (the rows its
@@ -1354,7 +1353,6 @@ __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_chain
     __syncthreads();
     if (threadIdx.x == 0 && threadIdx.y == 0) __hip_atomic_fetch_add(done + l * CHAIN_MAX_ROWS + by, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-#endif
 
 // BPC = workgroups that must fit on a CU together (their load / compute / store phases overlap each other):
 // the second __launch_bounds__ argument is waves per SIMD, i.e. the VGPR budget the compiler has to meet.
@@ -3245,23 +3243,35 @@ hipError_t launch_jacobi_tb(hipStream_t s, Win w, const float* p, const float* d
     return launch_jacobi_tb_any(s, w, p, div, p_out, pscale, iters, ga, gb, shape);
 }
 
-#ifdef FLUID_PROBES
-static int jacobi_chain_mode()   // FLUID_JACOBI_CHAIN: 1 = the chained launch; 2, 3, 4 = its timing probes (k_jacobi_tb_chain DIAG 1, 2, 3: invalid results)
+static int jacobi_chain_mode()   // FLUID_JACOBI_CHAIN (lab build): 0 = never, 1 = wherever it can run; 2, 3, 4 = its timing probes (k_jacobi_tb_chain DIAG 1, 2, 3: invalid results); unset: the rule below
 {
-    static const int m = [] { const char* e = lab_env("FLUID_JACOBI_CHAIN"); return e ? atoi(e) : 0; }();
+    static const int m = [] { const char* e = lab_env("FLUID_JACOBI_CHAIN"); return e ? atoi(e) : -1; }();
     return m;
 }
-bool jacobi_chain_enabled() { return jacobi_chain_mode() >= 1 && jacobi_chain_mode() <= 4; }
-size_t jacobi_chain_flag_bytes() { return (size_t)(CHAIN_MAX_BLOCKS * CHAIN_MAX_ROWS + 2) * sizeof(unsigned int); }   // counters, err, ticket
+// Where the chained launch is the shipped path: it removes four of a step's five fill / drain phases (~8 us each at 4096^2) and pays one
+// memory round trip per tile for the three counters it polls — worth -2.6 ... -3.2 % of the step at 4096^2 and nothing at 3072^2; its
+// band-cyclic order costs locality where a tile row is longer than an XCD holds (6144^2: +2.8 %, 8192^2: +3.6 %).  So: the tile rows of
+// which exactly three fill an XCD's 64 workgroup slots (17 ... 21 tiles: widths 3740 ... 4890), up to 8192 rows
+// (profiles/r05/jacobi_chain_ab.txt).
+bool jacobi_chain_applies(const Win& w, int ga, int gb, int iters)
+{
+    using G = JacobiTB<8, 10, 12, 10>;
+    const int mode = jacobi_chain_mode();
+    if (mode == 0 || iters <= 10 || iters > 10 * CHAIN_MAX_BLOCKS || !jacobi_tb_supported(w)) return false;
+    if (mode >= 1) return true;
+    const Axis ax = make_axis(w.x0, w.x1, w.W, G::TX, 12);
+    return 64 / ax.n == 3 && gb - ga <= 8192 && gb - ga >= 2048;
+}
+size_t jacobi_chain_flag_bytes() { return (size_t)(CHAIN_MAX_BLOCKS * CHAIN_MAX_ROWS) * sizeof(unsigned int); }   // the (block, tile row) counters
 
 // `iters` iterations as ONE launch of ceil(iters / 10) chained blocks (k_jacobi_tb_chain; the 80-row tile of shape 0).  pa holds the input;
 // the result is in pb when the number of blocks is odd, in pa when it is even (*result_in_b).  hipErrorNotReady: does not apply here.
 hipError_t launch_jacobi_tb_chain(hipStream_t s, Win w, float* pa, float* pb, const float* div, float pscale, int iters, int ga, int gb,
-                                  unsigned int* flags, int* blocks, bool* result_in_b)
+                                  unsigned int* flags, unsigned int* err, int* blocks, bool* result_in_b)
 {
     using G = JacobiTB<8, 10, 12, 10>;
     ROWS_OR_RETURN();
-    if (!jacobi_tb_supported(w) || iters < 1) return hipErrorNotReady;
+    if (!jacobi_chain_applies(w, ga, gb, iters)) return hipErrorNotReady;
     const int depth = 10;
     ChainPlan C{};
     C.blocks = (iters + depth - 1) / depth;
@@ -3280,23 +3290,29 @@ hipError_t launch_jacobi_tb_chain(hipStream_t s, Win w, float* pa, float* pb, co
     const int band = forced >= 0 ? forced : std::max(1, 64 / ax.n);
     static const int tickets = [] { const char* e = lab_env("FLUID_CHAIN_TICKET"); return e ? atoi(e) : 0; }();
     C.band = band > 0 ? band : 0;
-    C.tickets = tickets != 0;
+    C.tickets = tickets != 0;   // (lab; err[1] is the ticket word: the caller zeroes it)
     C.tiles = C.band > 0 ? 8 * ((ay.n + 8 * C.band - 1) / (8 * C.band)) * C.band * ax.n : ax.n * ay.n;
     hipError_t e = hipMemsetAsync(flags, 0, jacobi_chain_flag_bytes(), s);
     if (e != hipSuccess) return e;
     const dim3 grid((unsigned)(C.blocks * C.tiles), 1, 1), block(64, 8, 1);
-    unsigned int* err = flags + CHAIN_MAX_BLOCKS * CHAIN_MAX_ROWS;
+#ifdef FLUID_PROBES
+    if (C.tickets) {
+        e = hipMemsetAsync(err + 1, 0, sizeof(unsigned int), s);
+        if (e != hipSuccess) return e;
+    }
+#endif
     switch (jacobi_chain_mode()) {
+#ifdef FLUID_PROBES
     case 2: k_jacobi_tb_chain<8, 10, 12, 10, 2, 1><<<grid, block, 0, s>>>(w, pa, pb, div, pscale, C, ga, gb, ax.S, ay.S, ax.n, ay.n, flags, err); break;
     case 3: k_jacobi_tb_chain<8, 10, 12, 10, 2, 2><<<grid, block, 0, s>>>(w, pa, pb, div, pscale, C, ga, gb, ax.S, ay.S, ax.n, ay.n, flags, err); break;
     case 4: k_jacobi_tb_chain<8, 10, 12, 10, 2, 3><<<grid, block, 0, s>>>(w, pa, pb, div, pscale, C, ga, gb, ax.S, ay.S, ax.n, ay.n, flags, err); break;
+#endif
     default: k_jacobi_tb_chain<8, 10, 12, 10, 2, 0><<<grid, block, 0, s>>>(w, pa, pb, div, pscale, C, ga, gb, ax.S, ay.S, ax.n, ay.n, flags, err); break;
     }
     *blocks = C.blocks;
     *result_in_b = (C.blocks & 1) != 0;
     return hipGetLastError();
 }
-#endif
 hipError_t launch_jacobi_tb(hipStream_t s, Win w, const __half* p, const __half* div, __half* p_out, float pscale, int iters, int ga, int gb, int shape)
 {
     return launch_jacobi_tb_any(s, w, p, div, p_out, pscale, iters, ga, gb, shape);

@@ -338,24 +338,29 @@ int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launche
         (int)(c->sim_rows * (1.0 - jacobi_chains())) > 4 * tb_max)
         return pass_jacobi_chains(c, iters, pscale, shape, launches);
 #endif
-#ifdef FLUID_PROBES
-    // lab (FLUID_JACOBI_CHAIN=1): the whole loop as ONE launch of chained blocks (whole-domain fp32 contexts, the 80-row tile)
-    if (tb && !split && !fold && !c->timing && fluid::jacobi_chain_enabled() && c->storage == FLUID_STORE_F32 && c->desc.parts == 1 && c->desc.parts_x == 1 &&
-        ext_out == 0 && launches_left >= 2 && shape == 0) {
-        if (!c->chain_flags) HIPCK(c, hipMalloc((void**)&c->chain_flags, fluid::jacobi_chain_flag_bytes()));
+    // the whole loop as ONE launch of chained blocks of ten iterations where that is the faster schedule (4096-wide whole-domain fp32 grids:
+    // fluid::jacobi_chain_applies); counted as its blocks — each moves the field once, as a launch does
+    if (tb && !split && !fold && c->storage == FLUID_STORE_F32 && c->desc.parts == 1 && c->desc.parts_x == 1 && ext_out == 0 && shape == 0) {
         int ga, gb, blocks = 0;
         bool in_b = false;
         row_range(c->sim, c->sim_row0, c->sim_rows, 0, ga, gb);
-        const hipError_t e = fluid::launch_jacobi_tb_chain(c->stream, sim_cols(c, 0), (float*)c->prs[0], (float*)c->prs[1], (const float*)c->div, pscale, iters, ga, gb,
-                                                           c->chain_flags, &blocks, &in_b);
-        if (e != hipErrorNotReady) {
-            CK(c->hip(e, "jacobi_tb (chain)"));
-            if (in_b) std::swap(c->prs[0], c->prs[1]);
-            if (launches) *launches += blocks;
-            return FLUID_OK;
+        if (fluid::jacobi_chain_applies(sim_cols(c, 0), ga, gb, iters)) {
+            if (!c->chain_flags) {
+                HIPCK(c, hipMalloc((void**)&c->chain_flags, fluid::jacobi_chain_flag_bytes()));
+                HIPCK(c, hipHostMalloc((void**)&c->chain_err_host, 2 * sizeof(unsigned int), hipHostMallocMapped));
+                c->chain_err_host[0] = c->chain_err_host[1] = 0;
+                HIPCK(c, hipHostGetDevicePointer((void**)&c->chain_err_dev, c->chain_err_host, 0));
+            }
+            const hipError_t e = fluid::launch_jacobi_tb_chain(c->stream, sim_cols(c, 0), (float*)c->prs[0], (float*)c->prs[1], (const float*)c->div, pscale, iters,
+                                                               ga, gb, c->chain_flags, c->chain_err_dev, &blocks, &in_b);
+            if (e != hipErrorNotReady) {
+                CK(c->hip(e, "jacobi_tb (chain)"));
+                if (in_b) std::swap(c->prs[0], c->prs[1]);
+                if (launches) *launches += blocks;
+                return FLUID_OK;
+            }
         }
     }
-#endif
     int cut_left = split && tb ? sp->cover : 0, level = 0;   // leading launches still to cut (split 1 / 2)
     void *pa = c->prs[0], *pb = c->prs[1];               // split 1: the interiors ping-pong here; the context's pair swaps when the frames run
     while (done < iters) {
@@ -857,6 +862,14 @@ bool split_chain_applies(const fluid_ctx* c, float dt, const fluid_params* P)
 
 namespace fluid_impl {
 
+int chain_check(fluid_ctx* c)
+{
+    if (!c->chain_err_host || c->chain_err_host[0] == 0) return FLUID_OK;
+    c->chain_err_host[0] = 0;
+    return c->fail(FLUID_ERR_HIP, "the chained Jacobi launch gave up waiting for a tile of the previous block of iterations (workgroups not dispatched in "
+                                  "id order?): the fields of the calls since the last synchronisation are not valid");
+}
+
 int field_ref(fluid_ctx* c, int field, FieldRef* f, bool geometry_only, bool keep_packed)
 {
     const int h = c->desc.parts > 1 ? c->desc.halo : 0, hx = c->desc.parts_x > 1 ? c->desc.halo : 0;
@@ -990,6 +1003,7 @@ int fluid_destroy(fluid_ctx* c)
     for (auto& e : c->chain_ev) (void)hipEventDestroy(e);
     if (c->ev_order) (void)hipEventDestroy(c->ev_order);
     if (c->chain_flags) (void)hipFree(c->chain_flags);
+    if (c->chain_err_host) (void)hipHostFree(c->chain_err_host);
     if (c->chain_stream) (void)hipStreamDestroy(c->chain_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -1190,7 +1204,7 @@ int fluid_sync(fluid_ctx* c)
     if (!c) return FLUID_ERR_INVALID;
     HIPCK(c, hipSetDevice(c->device));
     HIPCK(c, hipStreamSynchronize(c->stream));
-    return FLUID_OK;
+    return chain_check(c);
 }
 
 int fluid_field_info_get(const fluid_ctx* c, int field, fluid_field_info* out)
@@ -1244,7 +1258,7 @@ int fluid_read_field(fluid_ctx* c, int field, float* host, size_t bytes)
     if (c->storage == FLUID_STORE_F32) {
         HIPCK(c, hipMemcpy2DAsync(host, b.line, b.first_row + col * b.f.texel(), pitch32, b.line, b.f.rows, hipMemcpyDeviceToHost, c->stream));
         HIPCK(c, hipStreamSynchronize(c->stream));
-        return FLUID_OK;
+        return chain_check(c);
     }
     float* tmp = nullptr;
     HIPCK(c, hipMalloc((void**)&tmp, b.rows_n * sizeof(float)));
@@ -1467,6 +1481,12 @@ int fluid_schedule_info_get(fluid_ctx* c, int n_steps, float dt, const fluid_par
     out->jacobi_shape = tb ? fluid::jacobi_tb_pick(owned) : -1;
     const int depth = tb ? fluid::jacobi_tb_depth(out->jacobi_shape) : 1;
     out->jacobi_launches = tb ? (P->iterations + depth - 1) / depth : P->iterations;
+    {   // ... which are ONE launch of chained blocks where that schedule applies (pass_jacobi)
+        int ga, gb;
+        row_range(c->sim, c->sim_row0, c->sim_rows, 0, ga, gb);
+        out->jacobi_chained = tb && whole && c->storage == FLUID_STORE_F32 && out->jacobi_shape == 0 && !fluid_impl::gradsub_fold_enabled(owned) &&
+                              fluid::jacobi_chain_applies(sim_cols(c, 0), ga, gb, P->iterations);
+    }
     out->gradsub_folded = tb && fluid::jacobi_tb_has_gradsub(out->jacobi_shape) && fluid_impl::gradsub_fold_enabled(owned);
     const bool split = whole && n_steps > 0 && !chain_applies(c, dt, P) && split_chain_applies(c, dt, P);   // dye grid != sim grid
     const bool chains = whole && n_steps > 0 && (split || chain_applies(c, dt, P));
@@ -1484,7 +1504,7 @@ int fluid_schedule_info_get(fluid_ctx* c, int n_steps, float dt, const fluid_par
     if (whole) {
         const int cvd = fused_cvd ? 1 : 3, clear = tb ? 0 : 1, gs = out->gradsub_folded ? 0 : 1;
         const int adv = fluid_impl::fused_advect_applies(c) ? 1 : 2;
-        const int per_step = cvd + clear + out->jacobi_launches + gs + adv;
+        const int per_step = cvd + clear + (out->jacobi_chained ? 1 : out->jacobi_launches) + gs + adv;
         // a chained step has no curl launch of its own: only the call's first step does, unless the previous call already ran it ahead
         out->launches = chain ? n_steps * (per_step - 1) + (out->pending_adopted ? 0 : 1) : n_steps * per_step;
     }

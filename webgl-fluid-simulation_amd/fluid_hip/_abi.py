@@ -63,7 +63,7 @@ DISPLAY_BLOOM, DISPLAY_SUNRAYS = 0, 1
 
 
 class ScheduleInfo(C.Structure):
-    _fields_ = [(k, C.c_int) for k in ("fused", "jacobi_shape", "jacobi_launches", "gradsub_folded", "chained", "curl_stores", "launches", "runs_ahead", "pending_adopted", "dye_packed")]
+    _fields_ = [(k, C.c_int) for k in ("fused", "jacobi_shape", "jacobi_launches", "gradsub_folded", "chained", "curl_stores", "launches", "runs_ahead", "pending_adopted", "dye_packed", "jacobi_chained")]
 
 
 class StripeOp(C.Structure):
