@@ -872,7 +872,7 @@ def main(argv=None, engine_factory=None, backend="nccl"):
             "algorithmic_GBps": round(alg_launch / (avg_ms * 1e-3) / 1e9, 1),
             "note": "achieved = HBM bytes one launch really moves / its measured duration (bounded by the peak); "
                     "algorithmic_* = the reference's 12 B/cell/iteration for the iterations this launch performs (a speed-up over the "
-                    "pass structure, may exceed the peak); bound = the larger of the memory term (frac_of_attainable: achieved / the "
+                    "pass structure, may exceed the peak); bound = the roofline the path is priced against (HBM: no matrix work on it); co_bound = 'valu' when the arithmetic term exceeds the memory term (frac_of_attainable: achieved / the "
                     "guide's measured 6.29 TB/s streaming ceiling) and the arithmetic term (valu.busy_frac: the average SIMD's "
                     "VALU-issuing cycles / the launch's cycles, SQ counters of this run, x the issue cost of the sweep's instruction mix: "
                     "valu.busy_frac_issue_cost)",
@@ -906,8 +906,10 @@ def main(argv=None, engine_factory=None, backend="nccl"):
                 valu["issue_cost_factor_model"] = JACOBI_ISSUE_COST
                 valu["busy_frac_issue_cost"] = round(min(valu["busy_frac"] * JACOBI_ISSUE_COST, 1.0), 4)
                 roof["valu"] = valu
+                # `bound` names the roofline the path is priced against — HBM: there is no matrix work on it.  When the arithmetic term is the
+                # larger one the line says so beside it (the chained launch of round 5 keeps the VALU busy while its tiles wait for nothing)
                 if valu["busy_frac_issue_cost"] > roof["frac_of_attainable"]:
-                    roof["bound"] = "valu"
+                    roof["co_bound"] = "valu"
             else:
                 roof["valu"] = {"busy_frac": None, "why": vwhy}
         out["roofline"] = roof

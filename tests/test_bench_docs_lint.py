@@ -78,7 +78,7 @@ def test_the_headline_line_reproduces_from_the_committed_counter_files():
     busy = v.get("busy_frac_issue_cost", v["busy_frac"])   # lines since visit 39 weigh the count with the sweep's issue cost (bench.py JACOBI_ISSUE_COST)
     if "busy_frac_issue_cost" in v:
         assert abs(min(v["busy_frac"] * v["issue_cost_factor_model"], 1.0) - busy) <= 1e-4
-    assert r["bound"] == ("valu" if busy > r["frac_of_attainable"] else "hbm")
+    assert r["bound"] == "hbm" and (r.get("co_bound") == "valu") == (busy > r["frac_of_attainable"])
     # rocprofv3 --kernel-trace --stats of the same command: the kernel's average launch agrees with the HIP-event figure of the line (within 5 %)
     with open(os.path.join(P, "kernel_stats_fused_4096_50.csv")) as f:
         rows = [row for row in csv.DictReader(f) if k.split("<")[0] + "<" in row["Name"]]

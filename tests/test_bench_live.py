@@ -45,10 +45,10 @@ def test_bench_line_is_live_and_consistent():
         assert 0 < s["frac"] <= 1.0 and abs(s["frac"] - s["GBps"] / 8000.0) <= 1e-3
     v = r.get("valu")
     assert v is not None and ("why" in v or 0 < v["busy_frac"] <= 1.0)
-    assert r["bound"] in ("hbm", "valu")
+    assert r["bound"] == "hbm"
     if v.get("busy_frac"):
         assert abs(min(v["busy_frac"] * v["issue_cost_factor_model"], 1.0) - v["busy_frac_issue_cost"]) <= 1e-4
-        assert r["bound"] == ("valu" if v["busy_frac_issue_cost"] > r["frac_of_attainable"] else "hbm")
+        assert r["bound"] == "hbm" and (r.get("co_bound") == "valu") == (v["busy_frac_issue_cost"] > r["frac_of_attainable"])
     assert r["mem_phase_ms"] > 0 and r["valu_phase_ms"] >= 0
     assert d["steady_ms_per_step"] > 0 and d["speedup_vs_pass_structure"]["x_hbm_peak"] > 0
     # round 4: what the line says about the timed window and about what ran in it
