@@ -203,6 +203,9 @@ bool jacobi_chain_applies(const Win& w, int ga, int gb, int iters);
 size_t jacobi_chain_flag_bytes();
 hipError_t launch_jacobi_tb_chain(hipStream_t s, Win w, float* pa, float* pb, const float* div, float pscale, int iters, int ga, int gb,
                                   unsigned int* flags, unsigned int* err, int* blocks, bool* result_in_b);
+// ... with a row range per block (a stripe rank's launches behind its cut ones: each recomputes fewer ghost rows); <= 8 blocks of <= 10 iterations
+hipError_t launch_jacobi_tb_chain_ranges(hipStream_t s, Win w, float* pa, float* pb, const float* div, float pscale, int nblocks, const int* iters,
+                                         const int* ga, const int* gb, const int* xa, const int* xb, unsigned int* flags, unsigned int* err);
 hipError_t launch_jacobi_tb(hipStream_t s, Win w, const float* p, const float* div, float* p_out, float pscale,
                             int iters, int ga, int gb, int shape);
 // The same launch with K6 (gradient subtract) folded in — for the LAST block of a step's loop: runs `iters` iterations, writes p_out rows

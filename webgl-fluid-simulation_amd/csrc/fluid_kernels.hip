@@ -1278,6 +1278,9 @@ constexpr int CHAIN_MAX_BLOCKS = 8, CHAIN_MAX_ROWS = 512;
 struct ChainPlan {
     int blocks, tiles;            // blocks of iterations; workgroups per block (mode 0: nx * ny tiles; band-cyclic: 8 G band nx, some without a tile)
     int iters[CHAIN_MAX_BLOCKS];
+    int xa[CHAIN_MAX_BLOCKS], xb[CHAIN_MAX_BLOCKS];   // ... and columns (2-D tiles: the ghost columns shrink too; everywhere else the window's own)
+    int ga[CHAIN_MAX_BLOCKS], gb[CHAIN_MAX_BLOCKS];   // rows block l stores (a stripe's blocks recompute fewer ghost rows each: the ranges shrink; the
+                                                      // tiling is block 0's — the widest — for all of them, and a tile with nothing to store only counts itself)
     int band;                     // > 0: the band-cyclic order below, `band` tile rows per band
     int tickets;                  // 1: a workgroup's place in the order is a ticket it draws when it starts (independent of the dispatch order)
 };
@@ -1287,7 +1290,7 @@ struct ChainPlan {
 // costs), 3 = nobody waits for anybody (what the dependency waits cost)
 template <int NW, int RY, int HX, int HY, int BPC, int DIAG = 0>
 __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_chain(Win w, float* __restrict__ pa, float* __restrict__ pb,
-                                                              const float* __restrict__ div, float pscale, ChainPlan C, int ga, int gb, int xs,
+                                                              const float* __restrict__ div, float pscale, ChainPlan C, int xs,
                                                               int ys, int nx, int ny, unsigned int* __restrict__ done,
                                                               unsigned int* __restrict__ err)
 {
@@ -1321,7 +1324,15 @@ __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_chain
         by = t / nx;
         bx = t - by * nx;
     }
-    if (l > 0 && DIAG != 3) {
+    const int ga = C.ga[l], gb = C.gb[l];
+    w.x0 = C.xa[l];
+    w.x1 = C.xb[l];
+    const int y0t = ys + by * G::VY, x0t = xs + bx * G::VX;
+    int st_lo, st_hi, sx_lo, sx_hi;
+    tile_exact(y0t, G::TY, HY, w.H, ga, gb, st_lo, st_hi);
+    tile_exact(x0t, G::TX, HX, w.W, w.x0, w.x1, sx_lo, sx_hi);
+    const bool nothing = st_hi <= st_lo || sx_hi <= sx_lo;   // this block's ranges do not reach this tile (block-uniform): no reads, no writes — count and go
+    if (l > 0 && DIAG != 3 && !nothing) {
         // three lanes, one row each: the three counters come back in ONE memory round trip (one lane after the other: three — visit 12)
         const int r = by - 1 + (int)threadIdx.x;
         if (threadIdx.y == 0 && threadIdx.x < 3 && r >= 0 && r < ny) {
@@ -1345,7 +1356,8 @@ __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_chain
     const bool ragged = (w.W & 3) != 0 && x0 + G::TX >= w.W;
     const float ps = l == 0 ? pscale : 1.0f;
     constexpr bool SC1 = DIAG != 2;
-    if (yedge || ragged) jacobi_tb_body<NW, RY, HX, HY, 2, float, false, float2, SC1>(w, p, div, p_out, ps, C.iters[l], ga, gb, x0, y0, mail);
+    if (nothing) {
+    } else if (yedge || ragged) jacobi_tb_body<NW, RY, HX, HY, 2, float, false, float2, SC1>(w, p, div, p_out, ps, C.iters[l], ga, gb, x0, y0, mail);
     else if (xedge) jacobi_tb_body<NW, RY, HX, HY, 1, float, false, float2, SC1>(w, p, div, p_out, ps, C.iters[l], ga, gb, x0, y0, mail);
     else jacobi_tb_body<NW, RY, HX, HY, 0, float, false, float2, SC1>(w, p, div, p_out, ps, C.iters[l], ga, gb, x0, y0, mail);
     // done: every storing wave drains its write-through stores, then ONE lane counts the tile (the guide's R1)
@@ -3266,23 +3278,24 @@ size_t jacobi_chain_flag_bytes() { return (size_t)(CHAIN_MAX_BLOCKS * CHAIN_MAX_
 
 // `iters` iterations as ONE launch of ceil(iters / 10) chained blocks (k_jacobi_tb_chain; the 80-row tile of shape 0).  pa holds the input;
 // the result is in pb when the number of blocks is odd, in pa when it is even (*result_in_b).  hipErrorNotReady: does not apply here.
-hipError_t launch_jacobi_tb_chain(hipStream_t s, Win w, float* pa, float* pb, const float* div, float pscale, int iters, int ga, int gb,
-                                  unsigned int* flags, unsigned int* err, int* blocks, bool* result_in_b)
+// The general form: `nblocks` blocks of iters[l] (<= 10) iterations storing rows [ga[l], gb[l]) — ga non-decreasing, gb non-increasing (a stripe's
+// launches recompute fewer ghost rows each); block 0's range carries the tiling.  pa holds the input; the result is in pb when nblocks is odd.
+hipError_t launch_jacobi_tb_chain_ranges(hipStream_t s, Win w, float* pa, float* pb, const float* div, float pscale, int nblocks, const int* iters,
+                                         const int* ga, const int* gb, const int* xa, const int* xb, unsigned int* flags, unsigned int* err)
 {
     using G = JacobiTB<8, 10, 12, 10>;
-    ROWS_OR_RETURN();
-    if (!jacobi_chain_applies(w, ga, gb, iters)) return hipErrorNotReady;
-    const int depth = 10;
+    if (nblocks < 2 || nblocks > CHAIN_MAX_BLOCKS || gb[0] <= ga[0] || xb[0] <= xa[0]) return hipErrorNotReady;
     ChainPlan C{};
-    C.blocks = (iters + depth - 1) / depth;
-    if (C.blocks > CHAIN_MAX_BLOCKS) return hipErrorNotReady;
-    int done = 0, left = C.blocks;
-    for (int l = 0; l < C.blocks; l++) {   // balanced, as pass_jacobi cuts them
-        C.iters[l] = (iters - done + left - 1) / left;
-        done += C.iters[l];
-        left--;
+    C.blocks = nblocks;
+    for (int l = 0; l < nblocks; l++) {
+        if (iters[l] < 1 || iters[l] > 10 || ga[l] < ga[0] || gb[l] > gb[0] || xa[l] < xa[0] || xb[l] > xb[0]) return hipErrorNotReady;
+        C.iters[l] = iters[l];
+        C.ga[l] = ga[l];
+        C.gb[l] = gb[l];
+        C.xa[l] = xa[l];
+        C.xb[l] = xb[l];
     }
-    const Axis ax = make_axis(w.x0, w.x1, w.W, G::TX, 12), ay = make_axis(ga, gb, w.H, G::TY, 10);
+    const Axis ax = make_axis(xa[0], xb[0], w.W, G::TX, 12), ay = make_axis(ga[0], gb[0], w.H, G::TY, 10);
     if (ay.n > CHAIN_MAX_ROWS) return hipErrorNotReady;
     // rows per band: what keeps ONE band of an XCD inside the 64 workgroups resident there (32 CUs x 2): 4096-wide: 18 tiles per row -> 3 rows.
     // (4 rows = 72 tiles spill and the order alone costs 12 %; 2 rows leave a third of the XCD to the next band: +2 %: profiles/r05/jacobi_chain_ab.txt)
@@ -3290,7 +3303,7 @@ hipError_t launch_jacobi_tb_chain(hipStream_t s, Win w, float* pa, float* pb, co
     const int band = forced >= 0 ? forced : std::max(1, 64 / ax.n);
     static const int tickets = [] { const char* e = lab_env("FLUID_CHAIN_TICKET"); return e ? atoi(e) : 0; }();
     C.band = band > 0 ? band : 0;
-    C.tickets = tickets != 0;   // (lab; err[1] is the ticket word: the caller zeroes it)
+    C.tickets = tickets != 0;   // (lab; err[1] is the ticket word)
     C.tiles = C.band > 0 ? 8 * ((ay.n + 8 * C.band - 1) / (8 * C.band)) * C.band * ax.n : ax.n * ay.n;
     hipError_t e = hipMemsetAsync(flags, 0, jacobi_chain_flag_bytes(), s);
     if (e != hipSuccess) return e;
@@ -3303,15 +3316,35 @@ hipError_t launch_jacobi_tb_chain(hipStream_t s, Win w, float* pa, float* pb, co
 #endif
     switch (jacobi_chain_mode()) {
 #ifdef FLUID_PROBES
-    case 2: k_jacobi_tb_chain<8, 10, 12, 10, 2, 1><<<grid, block, 0, s>>>(w, pa, pb, div, pscale, C, ga, gb, ax.S, ay.S, ax.n, ay.n, flags, err); break;
-    case 3: k_jacobi_tb_chain<8, 10, 12, 10, 2, 2><<<grid, block, 0, s>>>(w, pa, pb, div, pscale, C, ga, gb, ax.S, ay.S, ax.n, ay.n, flags, err); break;
-    case 4: k_jacobi_tb_chain<8, 10, 12, 10, 2, 3><<<grid, block, 0, s>>>(w, pa, pb, div, pscale, C, ga, gb, ax.S, ay.S, ax.n, ay.n, flags, err); break;
+    case 2: k_jacobi_tb_chain<8, 10, 12, 10, 2, 1><<<grid, block, 0, s>>>(w, pa, pb, div, pscale, C, ax.S, ay.S, ax.n, ay.n, flags, err); break;
+    case 3: k_jacobi_tb_chain<8, 10, 12, 10, 2, 2><<<grid, block, 0, s>>>(w, pa, pb, div, pscale, C, ax.S, ay.S, ax.n, ay.n, flags, err); break;
+    case 4: k_jacobi_tb_chain<8, 10, 12, 10, 2, 3><<<grid, block, 0, s>>>(w, pa, pb, div, pscale, C, ax.S, ay.S, ax.n, ay.n, flags, err); break;
 #endif
-    default: k_jacobi_tb_chain<8, 10, 12, 10, 2, 0><<<grid, block, 0, s>>>(w, pa, pb, div, pscale, C, ga, gb, ax.S, ay.S, ax.n, ay.n, flags, err); break;
+    default: k_jacobi_tb_chain<8, 10, 12, 10, 2, 0><<<grid, block, 0, s>>>(w, pa, pb, div, pscale, C, ax.S, ay.S, ax.n, ay.n, flags, err); break;
     }
-    *blocks = C.blocks;
-    *result_in_b = (C.blocks & 1) != 0;
     return hipGetLastError();
+}
+
+// `iters` iterations over the rows [ga, gb) in every block (a whole domain) as ceil(iters / 10) balanced blocks
+hipError_t launch_jacobi_tb_chain(hipStream_t s, Win w, float* pa, float* pb, const float* div, float pscale, int iters, int ga, int gb,
+                                  unsigned int* flags, unsigned int* err, int* blocks, bool* result_in_b)
+{
+    ROWS_OR_RETURN();
+    if (!jacobi_chain_applies(w, ga, gb, iters)) return hipErrorNotReady;
+    const int n = (iters + 9) / 10;
+    int it[CHAIN_MAX_BLOCKS], a[CHAIN_MAX_BLOCKS], b[CHAIN_MAX_BLOCKS], xa[CHAIN_MAX_BLOCKS], xb[CHAIN_MAX_BLOCKS], done = 0, left = n;
+    for (int l = 0; l < n; l++) {   // balanced, as pass_jacobi cuts them
+        it[l] = (iters - done + left - 1) / left;
+        done += it[l];
+        left--;
+        a[l] = ga;
+        b[l] = gb;
+        xa[l] = w.x0;
+        xb[l] = w.x1;
+    }
+    *blocks = n;
+    *result_in_b = (n & 1) != 0;
+    return launch_jacobi_tb_chain_ranges(s, w, pa, pb, div, pscale, n, it, a, b, xa, xb, flags, err);
 }
 hipError_t launch_jacobi_tb(hipStream_t s, Win w, const __half* p, const __half* div, __half* p_out, float pscale, int iters, int ga, int gb, int shape)
 {

@@ -338,33 +338,45 @@ int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launche
         (int)(c->sim_rows * (1.0 - jacobi_chains())) > 4 * tb_max)
         return pass_jacobi_chains(c, iters, pscale, shape, launches);
 #endif
-    // the whole loop as ONE launch of chained blocks of ten iterations where that is the faster schedule (4096-wide whole-domain fp32 grids:
-    // fluid::jacobi_chain_applies); counted as its blocks — each moves the field once, as a launch does
-    if (tb && !split && !fold && c->storage == FLUID_STORE_F32 && c->desc.parts == 1 && c->desc.parts_x == 1 && ext_out == 0 && shape == 0) {
-        int ga, gb, blocks = 0;
-        bool in_b = false;
-        row_range(c->sim, c->sim_row0, c->sim_rows, 0, ga, gb);
-        if (fluid::jacobi_chain_applies(sim_cols(c, 0), ga, gb, iters)) {
-            if (!c->chain_flags) {
-                HIPCK(c, hipMalloc((void**)&c->chain_flags, fluid::jacobi_chain_flag_bytes()));
-                HIPCK(c, hipHostMalloc((void**)&c->chain_err_host, 2 * sizeof(unsigned int), hipHostMallocMapped));
-                c->chain_err_host[0] = c->chain_err_host[1] = 0;
-                HIPCK(c, hipHostGetDevicePointer((void**)&c->chain_err_dev, c->chain_err_host, 0));
-            }
-            const hipError_t e = fluid::launch_jacobi_tb_chain(c->stream, sim_cols(c, 0), (float*)c->prs[0], (float*)c->prs[1], (const float*)c->div, pscale, iters,
-                                                               ga, gb, c->chain_flags, c->chain_err_dev, &blocks, &in_b);
-            if (e != hipErrorNotReady) {
-                CK(c->hip(e, "jacobi_tb (chain)"));
-                if (in_b) std::swap(c->prs[0], c->prs[1]);
-                if (launches) *launches += blocks;
-                return FLUID_OK;
-            }
-        }
-    }
     int cut_left = split && tb ? sp->cover : 0, level = 0;   // leading launches still to cut (split 1 / 2)
     void *pa = c->prs[0], *pb = c->prs[1];               // split 1: the interiors ping-pong here; the context's pair swaps when the frames run
+    // Every launch that is left once the cut ones are through (all of them on a whole domain) as ONE launch of chained blocks of ten iterations,
+    // where that is the faster schedule: 4096-wide fp32 grids (fluid::jacobi_chain_applies; k_jacobi_tb_chain).  A stripe's launches recompute
+    // fewer ghost rows each: every block gets its own row range.  Counted as its blocks — each moves the field once, as a launch does.
+    const bool chain_kind = tb && !fold && split != 1 && shape == 0 && c->storage == FLUID_STORE_F32;
     while (done < iters) {
         int ga, gb;
+        if (chain_kind && cut_left == 0 && launches_left >= 2 && launches_left <= 8) {
+            int it[8], ra[8], rb[8], xa[8], xb[8], d = done, left = launches_left;
+            const int n = launches_left;
+            for (int l = 0; l < n; l++) {
+                it[l] = (iters - d + left - 1) / left;
+                left--;
+                const int ext = ext_out + (iters - d - it[l]);
+                row_range(c->sim, c->sim_row0, c->sim_rows, ext, ra[l], rb[l]);
+                const Win wl = sim_cols(c, ext);   // 2-D tiles: the columns of this block (the window's own everywhere else)
+                xa[l] = wl.x0;
+                xb[l] = wl.x1;
+                d += it[l];
+            }
+            const Win w = sim_cols(c, ext_out + (iters - done - it[0]));
+            if (fluid::jacobi_chain_applies(w, ra[0], rb[0], iters - done)) {
+                if (!c->chain_flags) {
+                    HIPCK(c, hipMalloc((void**)&c->chain_flags, fluid::jacobi_chain_flag_bytes()));
+                    HIPCK(c, hipHostMalloc((void**)&c->chain_err_host, 2 * sizeof(unsigned int), hipHostMallocMapped));
+                    c->chain_err_host[0] = c->chain_err_host[1] = 0;
+                    HIPCK(c, hipHostGetDevicePointer((void**)&c->chain_err_dev, c->chain_err_host, 0));
+                }
+                const hipError_t e = fluid::launch_jacobi_tb_chain_ranges(c->stream, w, (float*)c->prs[0], (float*)c->prs[1], (const float*)c->div,
+                                                                          done == 0 ? pscale : 1.0f, n, it, ra, rb, xa, xb, c->chain_flags, c->chain_err_dev);
+                if (e != hipErrorNotReady) {
+                    CK(c->hip(e, "jacobi_tb (chain)"));
+                    if (n & 1) std::swap(c->prs[0], c->prs[1]);
+                    if (launches) *launches += n;
+                    return FLUID_OK;
+                }
+            }
+        }
         if (tb) {
             const int k = (iters - done + launches_left - 1) / launches_left;
             launches_left--;
