@@ -82,6 +82,7 @@ struct fluid_ctx {
     unsigned int* chain_flags = nullptr;
     unsigned int* chain_err_host = nullptr;
     unsigned int* chain_err_dev = nullptr;
+    fluid::ChainEpoch chain_epoch;
     hipStream_t chain_stream = nullptr;
     std::vector<hipEvent_t> chain_ev;
     hipEvent_t ev_ready = nullptr;       // context stream -> comm stream: the rows to send exist

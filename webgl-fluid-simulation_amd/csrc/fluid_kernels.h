@@ -199,13 +199,17 @@ bool jacobi_tb_supported(Win w);
 // where jacobi_chain_applies() says so — 4096-wide grids — it is what pass_jacobi runs.  `flags`: jacobi_chain_flag_bytes() of device memory
 // (zeroed by the launcher); `err`: two words the device can write and the HOST can read (mapped host memory): err[0] != 0 = a workgroup gave up
 // waiting for a tile (the results of that call are not valid).  pa holds the input; the result is in pb when the number of blocks is odd.
+struct ChainEpoch {   // per context: the shape of the last chained call and how many calls of that shape have counted the counters up
+    unsigned int signature = 0xffffffffu, calls = 0;
+};
 bool jacobi_chain_applies(const Win& w, int ga, int gb, int iters);
 size_t jacobi_chain_flag_bytes();
 hipError_t launch_jacobi_tb_chain(hipStream_t s, Win w, float* pa, float* pb, const float* div, float pscale, int iters, int ga, int gb,
-                                  unsigned int* flags, unsigned int* err, int* blocks, bool* result_in_b);
+                                  unsigned int* flags, unsigned int* err, int* blocks, bool* result_in_b, ChainEpoch* ep = nullptr);
 // ... with a row range per block (a stripe rank's launches behind its cut ones: each recomputes fewer ghost rows); <= 8 blocks of <= 10 iterations
 hipError_t launch_jacobi_tb_chain_ranges(hipStream_t s, Win w, float* pa, float* pb, const float* div, float pscale, int nblocks, const int* iters,
-                                         const int* ga, const int* gb, const int* xa, const int* xb, unsigned int* flags, unsigned int* err);
+                                         const int* ga, const int* gb, const int* xa, const int* xb, unsigned int* flags, unsigned int* err,
+                                         ChainEpoch* ep = nullptr);
 hipError_t launch_jacobi_tb(hipStream_t s, Win w, const float* p, const float* div, float* p_out, float pscale,
                             int iters, int ga, int gb, int shape);
 // The same launch with K6 (gradient subtract) folded in — for the LAST block of a step's loop: runs `iters` iterations, writes p_out rows

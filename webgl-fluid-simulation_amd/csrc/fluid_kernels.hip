@@ -1283,6 +1283,8 @@ struct ChainPlan {
                                                       // tiling is block 0's — the widest — for all of them, and a tile with nothing to store only counts itself)
     int band;                     // > 0: the band-cyclic order below, `band` tile rows per band
     int tickets;                  // 1: a workgroup's place in the order is a ticket it draws when it starts (independent of the dispatch order)
+    unsigned int target;          // a tile row of the previous block is complete when its counter has reached this: the counters are never
+                                  // reset between calls of the same shape (no memset in the stream) — call number e waits for (e + 1) nx
 };
 
 // DIAG (FLUID_JACOBI_CHAIN=2 / 3 / 4: timing probes whose RESULTS ARE NOT VALID): 1 = a tile counts itself done without draining its stores
@@ -1338,7 +1340,7 @@ __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_chain
         if (threadIdx.y == 0 && threadIdx.x < 3 && r >= 0 && r < ny) {
             const unsigned int* flag = done + (l - 1) * CHAIN_MAX_ROWS + r;
             unsigned spins = 0;
-            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nx) {
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < C.target) {
                 __builtin_amdgcn_s_sleep(2);
                 if ((++spins & 1023u) == 0 &&
                     (spins > (1u << 16) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {   // never hang the device
@@ -3281,7 +3283,8 @@ size_t jacobi_chain_flag_bytes() { return (size_t)(CHAIN_MAX_BLOCKS * CHAIN_MAX_
 // The general form: `nblocks` blocks of iters[l] (<= 10) iterations storing rows [ga[l], gb[l]) — ga non-decreasing, gb non-increasing (a stripe's
 // launches recompute fewer ghost rows each); block 0's range carries the tiling.  pa holds the input; the result is in pb when nblocks is odd.
 hipError_t launch_jacobi_tb_chain_ranges(hipStream_t s, Win w, float* pa, float* pb, const float* div, float pscale, int nblocks, const int* iters,
-                                         const int* ga, const int* gb, const int* xa, const int* xb, unsigned int* flags, unsigned int* err)
+                                         const int* ga, const int* gb, const int* xa, const int* xb, unsigned int* flags, unsigned int* err,
+                                         ChainEpoch* ep)
 {
     using G = JacobiTB<8, 10, 12, 10>;
     if (nblocks < 2 || nblocks > CHAIN_MAX_BLOCKS || gb[0] <= ga[0] || xb[0] <= xa[0]) return hipErrorNotReady;
@@ -3305,8 +3308,20 @@ hipError_t launch_jacobi_tb_chain_ranges(hipStream_t s, Win w, float* pa, float*
     C.band = band > 0 ? band : 0;
     C.tickets = tickets != 0;   // (lab; err[1] is the ticket word)
     C.tiles = C.band > 0 ? 8 * ((ay.n + 8 * C.band - 1) / (8 * C.band)) * C.band * ax.n : ax.n * ay.n;
-    hipError_t e = hipMemsetAsync(flags, 0, jacobi_chain_flag_bytes(), s);
-    if (e != hipSuccess) return e;
+    // the counters: zeroed when the shape of the call changes (tiles per row, tile rows, blocks: what decides which counters a call bumps, and by
+    // how much), counted up from call to call otherwise — a memset in front of every launch was 5 us of the step and a kernel boundary
+    hipError_t e = hipSuccess;
+    const unsigned sig = (unsigned)ax.n | ((unsigned)ay.n << 10) | ((unsigned)nblocks << 20) | ((unsigned)C.band << 24);
+    if (!ep || ep->signature != sig || ep->calls >= (1u << 24)) {
+        e = hipMemsetAsync(flags, 0, jacobi_chain_flag_bytes(), s);
+        if (e != hipSuccess) return e;
+        if (ep) {
+            ep->signature = sig;
+            ep->calls = 0;
+        }
+    }
+    C.target = ((ep ? ep->calls : 0u) + 1u) * (unsigned)ax.n;
+    if (ep) ep->calls++;
     const dim3 grid((unsigned)(C.blocks * C.tiles), 1, 1), block(64, 8, 1);
 #ifdef FLUID_PROBES
     if (C.tickets) {
@@ -3327,7 +3342,7 @@ hipError_t launch_jacobi_tb_chain_ranges(hipStream_t s, Win w, float* pa, float*
 
 // `iters` iterations over the rows [ga, gb) in every block (a whole domain) as ceil(iters / 10) balanced blocks
 hipError_t launch_jacobi_tb_chain(hipStream_t s, Win w, float* pa, float* pb, const float* div, float pscale, int iters, int ga, int gb,
-                                  unsigned int* flags, unsigned int* err, int* blocks, bool* result_in_b)
+                                  unsigned int* flags, unsigned int* err, int* blocks, bool* result_in_b, ChainEpoch* ep)
 {
     ROWS_OR_RETURN();
     if (!jacobi_chain_applies(w, ga, gb, iters)) return hipErrorNotReady;
@@ -3344,7 +3359,7 @@ hipError_t launch_jacobi_tb_chain(hipStream_t s, Win w, float* pa, float* pb, co
     }
     *blocks = n;
     *result_in_b = (n & 1) != 0;
-    return launch_jacobi_tb_chain_ranges(s, w, pa, pb, div, pscale, n, it, a, b, xa, xb, flags, err);
+    return launch_jacobi_tb_chain_ranges(s, w, pa, pb, div, pscale, n, it, a, b, xa, xb, flags, err, ep);
 }
 hipError_t launch_jacobi_tb(hipStream_t s, Win w, const __half* p, const __half* div, __half* p_out, float pscale, int iters, int ga, int gb, int shape)
 {

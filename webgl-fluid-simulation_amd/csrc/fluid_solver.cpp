@@ -368,7 +368,7 @@ int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launche
                     HIPCK(c, hipHostGetDevicePointer((void**)&c->chain_err_dev, c->chain_err_host, 0));
                 }
                 const hipError_t e = fluid::launch_jacobi_tb_chain_ranges(c->stream, w, (float*)c->prs[0], (float*)c->prs[1], (const float*)c->div,
-                                                                          done == 0 ? pscale : 1.0f, n, it, ra, rb, xa, xb, c->chain_flags, c->chain_err_dev);
+                                                                          done == 0 ? pscale : 1.0f, n, it, ra, rb, xa, xb, c->chain_flags, c->chain_err_dev, &c->chain_epoch);
                 if (e != hipErrorNotReady) {
                     CK(c->hip(e, "jacobi_tb (chain)"));
                     if (n & 1) std::swap(c->prs[0], c->prs[1]);
@@ -878,6 +878,7 @@ int chain_check(fluid_ctx* c)
 {
     if (!c->chain_err_host || c->chain_err_host[0] == 0) return FLUID_OK;
     c->chain_err_host[0] = 0;
+    c->chain_epoch = fluid::ChainEpoch{};   // the counters are in no known state: the next chained launch zeroes them
     return c->fail(FLUID_ERR_HIP, "the chained Jacobi launch gave up waiting for a tile of the previous block of iterations (workgroups not dispatched in "
                                   "id order?): the fields of the calls since the last synchronisation are not valid");
 }
