@@ -61,6 +61,32 @@ static void check_order(int nx, int ny, int remap)
     }
 }
 
+// the band-cyclic order of the chained Jacobi launch: chain_slots() workgroup slots per block map ONTO the nx x ny tiles (every tile once, the
+// other slots none), consecutive slots alternate XCDs (slot b belongs to XCD b % 8, whose tiles are the rows of its own bands only), and every
+// tile of band group g comes before every tile of group g + 1 ON ITS XCD — so that what a tile of the next block needs (its own band's rows and
+// the neighbouring bands' of the same group, or the first / last row of the next / previous group) was taken earlier in the previous block
+static void check_chain_order(int nx, int ny, int band)
+{
+    cases++;
+    const int slots = chain_slots(nx, ny, band);
+    std::vector<int> seen((size_t)nx * ny, 0), last_group(8, -1);
+    for (int b = 0; b < slots; b++) {
+        int bx = -1, by = -1;
+        if (!chain_tile_of_block(b, nx, ny, band, bx, by)) {
+            if (by < ny) { printf("chain nx %d ny %d band %d: slot %d refused with row %d\n", nx, ny, band, b, by); fails++; return; }
+            continue;
+        }
+        if (bx < 0 || bx >= nx || by < 0 || by >= ny) { printf("chain nx %d ny %d band %d: slot %d -> (%d, %d)\n", nx, ny, band, b, bx, by); fails++; return; }
+        seen[(size_t)by * nx + bx]++;
+        const int bandno = by / band, xcd = bandno & 7, group = bandno >> 3;
+        if (xcd != (b & 7)) { printf("chain nx %d ny %d band %d: slot %d (XCD %d) got a tile of XCD %d's band\n", nx, ny, band, b, b & 7, xcd); fails++; return; }
+        if (group < last_group[xcd]) { printf("chain nx %d ny %d band %d: XCD %d goes back from group %d to %d\n", nx, ny, band, xcd, last_group[xcd], group); fails++; return; }
+        last_group[xcd] = group;
+    }
+    for (int t = 0; t < nx * ny; t++)
+        if (seen[t] != 1) { printf("chain nx %d ny %d band %d: tile %d taken %d times\n", nx, ny, band, t, seen[t]); fails++; return; }
+}
+
 int main()
 {
     // (tile span, apron) of every kernel: Jacobi columns 256 / 12 and 128 / 12 (two texels per lane), rows NW * RY with apron 10 / 11 (K6 folded) and
@@ -85,6 +111,9 @@ int main()
         const int dom = 1 + rand() % 5000, lo = rand() % dom, hi = lo + 1 + rand() % (dom - lo);
         check_axis(dom, lo, hi, sh[0], sh[1]);
     }
+    for (int band = 1; band <= 5; band++)
+        for (int nx = 1; nx <= 40; nx += (nx < 24 ? 1 : 5))
+            for (int ny : { 1, 2, 3, 7, 8, 9, 23, 24, 25, 35, 69, 70, 71, 137, 274, 511, 512 }) check_chain_order(nx, ny, band);
     for (int remap = 0; remap < 4; remap++)
         for (int nx = 1; nx <= 40; nx++)
             for (int ny = 1; ny <= 40; ny += (ny < 12 ? 1 : 7)) check_order(nx, ny, remap);

@@ -1314,10 +1314,7 @@ __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_chain
         // together still share their aprons inside one XCD's L2.  (The first form — each XCD one contiguous run of the whole sequence, odd
         // blocks backwards — turned every front around on the tiles that had just been resident TOGETHER: a block's first 64 tiles per
         // front waited for the previous block's last 64, i.e. for its drain; +10 % instead of -2 %: profiles/r05/jacobi_chain_ab.txt.)
-        const int xcd = b & 7, i = b >> 3, per_band = C.band * nx, g = i / per_band, j = i - g * per_band;
-        by = (g * 8 + xcd) * C.band + j / nx;
-        bx = j % nx;
-        if (by >= ny) return;   // the last group's bands beyond the grid: no tile (block-uniform)
+        if (!chain_tile_of_block(b, nx, ny, C.band, bx, by)) return;   // (fluid_tiles.h) the last group's bands beyond the grid: no tile (block-uniform)
     } else {
         // XCD b % 8 takes the (b / 8)-th tile of its contiguous run of the row-major sequence, from the far end in odd blocks
         const int n = C.tiles, q = n >> 3, r8 = n & 7, xcd = b & 7, slot = b >> 3;
@@ -3307,7 +3304,7 @@ hipError_t launch_jacobi_tb_chain_ranges(hipStream_t s, Win w, float* pa, float*
     static const int tickets = [] { const char* e = lab_env("FLUID_CHAIN_TICKET"); return e ? atoi(e) : 0; }();
     C.band = band > 0 ? band : 0;
     C.tickets = tickets != 0;   // (lab; err[1] is the ticket word)
-    C.tiles = C.band > 0 ? 8 * ((ay.n + 8 * C.band - 1) / (8 * C.band)) * C.band * ax.n : ax.n * ay.n;
+    C.tiles = C.band > 0 ? chain_slots(ax.n, ay.n, C.band) : ax.n * ay.n;
     // the counters: zeroed when the shape of the call changes (tiles per row, tile rows, blocks: what decides which counters a call bumps, and by
     // how much), counted up from call to call otherwise — a memset in front of every launch was 5 us of the step and a kernel boundary
     hipError_t e = hipSuccess;

@@ -58,6 +58,19 @@ __host__ __device__ __forceinline__ void tile_of_block(int b, int nx, int ny, in
     }
 }
 
+// The BAND-CYCLIC order of the chained Jacobi launch (k_jacobi_tb_chain, fluid_kernels.hip): within one block of iterations, consecutive
+// workgroups alternate XCDs (b % 8, as the hardware places them); XCD k walks bands of `band` tile rows — band k of every group of eight
+// bands, group after group.  chain_slots() workgroups per block; a slot whose band lies beyond the grid has no tile (false).
+// Host-callable: tests/tile_cover_check.cpp holds it to a bijection onto the nx x ny tiles with every group's tiles in front of the next group's.
+__host__ __device__ __forceinline__ int chain_slots(int nx, int ny, int band) { return 8 * ((ny + 8 * band - 1) / (8 * band)) * band * nx; }
+__host__ __device__ __forceinline__ bool chain_tile_of_block(int b, int nx, int ny, int band, int& bx, int& by)
+{
+    const int xcd = b & 7, i = b >> 3, per_band = band * nx, g = i / per_band, j = i - g * per_band;
+    by = (g * 8 + xcd) * band + j / nx;
+    bx = j % nx;
+    return by < ny;
+}
+
 // exact (storable) global range [a, b) of the tile starting at t0, intersected with [lo, hi)
 __host__ __device__ __forceinline__ void tile_exact(int t0, int T, int A, int dom, int lo, int hi, int& a, int& b)
 {
