@@ -159,3 +159,24 @@ def test_bench_watchdog_keeps_a_finished_headline(with_result):
         assert r.returncode == 0 and d["value"] == 1.5 and "configs[4]" in d["extra_configs"][0]["error"] and "not run" in d["parity_in_run"]
     else:
         assert r.returncode == 3 and d["value"] is None and "set-up" in d["error"]
+
+
+def test_link_model_argument():
+    """--link-model: nothing or `calibrate` = measured at start-up (fluid_comm_calibrate_link), `default` = the library's constants, "US,GBPS" = that"""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.link_arg(None) == "calibrate" and bench.link_arg("calibrate") == "calibrate"
+    assert bench.link_arg("default") is None
+    assert bench.link_arg("35,80.5") == (35.0, 80.5)
+
+
+def test_the_two_rank_line_says_what_ran_in_front_of_the_window(oracle, tmp_path):
+    """round 5: `value` is the literal W + K window — effective_warmup_steps == warmup on the default command, also for N > 1"""
+    import torch.multiprocessing as mp
+    argv = ["--gpus", "2", "--size", "64", "--iters", "20", "--steps", "2", "--warmup", "1", "--halo", "8", "--cpu-budget", "0", "--comm-timeout", "100",
+            "--extra-config", "none"]
+    mp.spawn(_rank, args=(2, _free_port(), str(tmp_path), argv), nprocs=2, join=True)
+    (line,) = [l for l in open(os.path.join(str(tmp_path), "stdout_0.txt")).read().splitlines() if l.strip()]
+    d = json.loads(line)
+    assert "error" not in d and d["warmup"] == 1 and d["effective_warmup_steps"] == 1 and "settle" not in d["config"]
+
