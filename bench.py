@@ -1010,7 +1010,12 @@ def main(argv=None, engine_factory=None, backend="nccl"):
                 problem = "in-run parity check failed on rank %d: %s" % (rank, json.dumps(parity))
         except Exception as ex:
             problem = "in-run parity check could not run on rank %d: %s" % (rank, str(ex)[:200])
-        if N > 1 and not problem and not args.no_decomposition_check:
+        # The decomposition check below is COLLECTIVE (a fresh communicator, steps over RCCL): the ranks enter it together or not at all.  A
+        # parity failure is rank-local at this point, so the ranks first agree on whether ANY of them has one; a rank that failed would
+        # otherwise go straight to the all_gather below while the others sit in ncclCommInitRank.  `problem` itself stays
+        # per rank: the gathered records say whose it was.
+        anyone_failed = N > 1 and agree("x" if problem else None) is not None
+        if N > 1 and not anyone_failed and not args.no_decomposition_check:
             # ... and what the ranks EXCHANGE: a fresh set of the benchmark's geometry against the single domain of the whole grid, per rank
             if dog:
                 dog.at("in-run decomposition check (a fresh set of %d ranks steps over RCCL; every rank compares its rows with the single domain)" % N)

@@ -221,8 +221,7 @@ int fluid_read_frame(fluid_ctx* c, float* host_rgba, size_t bytes)
     if (bytes != (size_t)d->frame.w * d->frame.h * sizeof(float4)) return c->fail(FLUID_ERR_INVALID, "read_frame: byte count does not match the frame");
     HIPCK(c, hipSetDevice(c->device));
     HIPCK(c, hipMemcpyAsync(host_rgba, d->frame.p, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCK(c, hipStreamSynchronize(c->stream));
-    return FLUID_OK;
+    return fluid_impl::ctx_sync(c);   // (a frame composited from the dye of a pressure loop that gave up is an error, not pixels)
 }
 
 int fluid_read_frame_rgba8(fluid_ctx* c, unsigned char* host, size_t bytes)
@@ -235,8 +234,7 @@ int fluid_read_frame_rgba8(fluid_ctx* c, unsigned char* host, size_t bytes)
     CK(ensure(c, d->frame8, d->frame.w, d->frame.h, 4));
     HIPCK(c, launch_normalize(c->stream, (const float4*)d->frame.p, (unsigned char*)d->frame8.p, d->frame.w, d->frame.h));
     HIPCK(c, hipMemcpyAsync(host, d->frame8.p, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCK(c, hipStreamSynchronize(c->stream));
-    return FLUID_OK;
+    return fluid_impl::ctx_sync(c);   // (a frame composited from the dye of a pressure loop that gave up is an error, not pixels)
 }
 
 int fluid_read_display_buffer(fluid_ctx* c, int which, float* host, size_t bytes, int* w, int* h)
@@ -252,8 +250,7 @@ int fluid_read_display_buffer(fluid_ctx* c, int which, float* host, size_t bytes
     if (bytes != need) return c->fail(FLUID_ERR_INVALID, "read_display_buffer: byte count mismatch");
     HIPCK(c, hipSetDevice(c->device));
     HIPCK(c, hipMemcpyAsync(host, b->p, need, hipMemcpyDeviceToHost, c->stream));
-    HIPCK(c, hipStreamSynchronize(c->stream));
-    return FLUID_OK;
+    return fluid_impl::ctx_sync(c);   // (a frame composited from the dye of a pressure loop that gave up is an error, not pixels)
 }
 
 }  // extern "C"

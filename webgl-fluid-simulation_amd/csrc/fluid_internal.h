@@ -83,6 +83,7 @@ struct fluid_ctx {
     unsigned int* chain_err_host = nullptr;
     unsigned int* chain_err_dev = nullptr;
     fluid::ChainEpoch chain_epoch;
+    bool chain_broken = false;           // a chained launch gave up once: this context keeps to plain launches from then on
     hipStream_t chain_stream = nullptr;
     std::vector<hipEvent_t> chain_ev;
     hipEvent_t ev_ready = nullptr;       // context stream -> comm stream: the rows to send exist
@@ -144,6 +145,10 @@ struct FieldRef {
 };
 int field_ref(fluid_ctx* c, int field, FieldRef* f, bool geometry_only = false, bool keep_packed = false);
 int chain_check(fluid_ctx* c);   // behind a stream synchronisation: did a chained Jacobi launch give up waiting (FLUID_ERR_HIP)?
+// THE synchronisation of every call that hands data or a status back to its caller: waits for `s` (the context's stream by default), then asks
+// chain_check — so that a pressure loop that gave up is an error of whichever call synchronises first (fluid_sync, the reads and writes in
+// both storages, fluid_halo_check, the display readbacks, the stripe driver's checks), never a silently wrong field or frame
+int ctx_sync(fluid_ctx* c, hipStream_t s = nullptr);
 int ensure_rgba(fluid_ctx* c);   // the dye buffers hold RGBA texels from here on (unpacks a packed dye field: fluid_ctx::dye_packed)
 // Stripe / tile contexts pack their dye too (round 5): the ghost texels then travel as 12-byte texels, in place, and the FORMAT of the field is
 // part of the message layout two neighbours must agree on.  It is therefore a function of nothing but what every rank of a set does alike:

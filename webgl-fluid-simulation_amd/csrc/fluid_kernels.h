@@ -201,7 +201,11 @@ bool jacobi_tb_supported(Win w);
 // waiting for a tile (the results of that call are not valid).  pa holds the input; the result is in pb when the number of blocks is odd.
 struct ChainEpoch {   // per context: the shape of the last chained call and how many calls of that shape have counted the counters up
     unsigned int signature = 0xffffffffu, calls = 0;
+    // the persistent form (k_jacobi_pchain, fluid_pchain.h): the shape of its last call and which half of the state words the next call counts in
+    unsigned int psig[2] = { 0xffffffffu, 0u };
+    int bank = 0;
 };
+int jacobi_chain_max_blocks();   // blocks of <= 10 iterations one chained launch can hold
 bool jacobi_chain_applies(const Win& w, int ga, int gb, int iters);
 size_t jacobi_chain_flag_bytes();
 hipError_t launch_jacobi_tb_chain(hipStream_t s, Win w, float* pa, float* pb, const float* div, float pscale, int iters, int ga, int gb,

@@ -16,6 +16,7 @@
 #include "fluid_kernels.h"
 #include "fluid_math.h"
 #include "fluid_tiles.h"
+#include "fluid_pchain.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -1363,6 +1364,325 @@ __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_chain
     if (DIAG != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0 && threadIdx.y == 0) __hip_atomic_fetch_add(done + l * CHAIN_MAX_ROWS + by, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- the pressure loop as ONE launch of PERSISTENT workgroups that take STACKS of tiles from per-XCD ticket heads (round 6) -------------
+// What is new against k_jacobi_tb_chain (the geometry, the order and the safety argument: fluid_pchain.h):
+//   * a workgroup keeps going: it draws an item (block, stack row, tile column), waits for the <= 6 counters around it in the previous block,
+//     runs the stack's tiles, drains its write-through stores, counts itself, draws the next.  The order is whatever the tickets say — no
+//     assumption about which workgroup the hardware starts first, and none about where it puts it;
+//   * a STACK: the second and further tiles of a stack take the row below their first row from the tile before, level by level, through one
+//     1 KiB LDS line per iteration (the row that tile had already published to its neighbour wave's mailbox: one more ds_write by one wave) —
+//     their bottom apron is gone: 1.33 -> 1.23 (M = 2) rows of arithmetic per stored row, and fewer apron rows re-read;
+//   * the counters live in two halves: a call counts in one and zeroes the other for the next call (no memset in the stream, no epoch that
+//     could wrap).
+// One tile of a stack: jacobi_tb_body's load / iterate / store with the carry line in and out.  `sm`: the two mailbox slots, then the two
+// carry sets of HY lines.  lo_line: the LDS line (float4 index) wave 0 reads as the row below the tile — the previous tile's carry line of
+// this level, or (first tile) its own mailbox line, which only feeds the stale bottom apron.
+template <int NW, int RY, int EDGE>
+__device__ __forceinline__ void jacobi_sweep_st(Quad (&P)[RY], const Quad (&D)[RY], float4* sm, int box, int lo_line, int out_line, int carry_row_wave,
+                                                int wv, int lane, int gy, int H, bool at_left, int nv)
+{
+    static_assert(RY >= 3, "a wave needs an inner row");
+    const int mine = box + wv * 128;
+    sm[mine + lane] = raw_of(P[0]);
+    sm[mine + 64 + lane] = raw_of(P[RY - 1]);
+    if (wv == carry_row_wave && out_line >= 0) sm[out_line + lane] = raw_of(P[RY - 1]);   // wave-uniform: this level's row for the NEXT tile of the stack
+    const Quad old0 = P[0], old1 = P[1];
+    Quad below = old0;
+#pragma unroll
+    for (int r = 1; r < RY - 1; r++) {
+        const Quad C = P[r];
+        P[r] = jacobi_row<EDGE, false>(C, P[r + 1], below, D[r], gy + r, H, at_left, nv);
+        below = C;
+    }
+    __syncthreads();
+    const Quad lo = quad_of_raw(sm[(wv > 0 ? mine - 128 + 64 : lo_line) + lane]);
+    const Quad hi = quad_of_raw(sm[(wv < NW - 1 ? mine + 128 : mine) + lane]);
+    P[RY - 1] = jacobi_row<EDGE, false>(P[RY - 1], hi, below, D[RY - 1], gy + RY - 1, H, at_left, nv);
+    P[0] = jacobi_row<EDGE, false>(old0, old1, lo, D[0], gy, H, at_left, nv);
+}
+
+template <int NW, int RY, int HX, int HY, int EDGE, bool SC1>
+__device__ __forceinline__ void jacobi_stack_tile(const Win& w, __amdgpu_buffer_rsrc_t rin, __amdgpu_buffer_rsrc_t rout, const float* __restrict__ p,
+                                                  float* __restrict__ p_out, const float* __restrict__ div, float pscale, int iters, int x0, int yt,
+                                                  int row_lo, int row_hi, int col_lo, int col_hi, float4* sm, int carry_in, int carry_out)
+{
+    using S = JacobiStack<NW, RY, HX, HY>;
+    static_assert(S::CARRY_ROW == RY - 1, "the carried row is the one its wave publishes to the mailbox anyway (HY == RY)");
+    const int lane = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int cx = x0 + 4 * lane, gy = yt + wv * RY;
+    Quad P[RY], D[RY];
+    const unsigned cxs = (unsigned)(min(max(cx, w.c0), w.c0 + w.P - 4) - w.c0);
+    const v2f ps = v2f{ pscale, pscale };
+#pragma unroll
+    for (int r = 0; r < RY; r++) {   // unconditional loads from clamped addresses, all in flight together (jacobi_tb_body)
+        const int lr = min(max(gy + r - w.g0, 0), w.rows - 1);
+        const size_t row = (size_t)lr * (size_t)w.P;
+        if constexpr (SC1) P[r] = load_quad_sc1(rin, row + cxs);
+        else P[r] = load_quad(p, row + cxs);
+        D[r] = load_quad(div, row + cxs);
+    }
+#pragma unroll
+    for (int r = 0; r < RY; r++) {   // clearShader folded in (block 0: pscale; 1 elsewhere)
+        P[r].o = ps * P[r].o;
+        P[r].i = ps * P[r].i;
+    }
+    const bool at_left = (cx == 0);
+    const int nv = w.W - cx;
+    constexpr int BOX = NW * 128;   // float4 lines of one mailbox slot
+    const int lo0 = carry_in >= 0 ? carry_in : 64, lo1 = carry_in >= 0 ? carry_in + 64 : BOX + 64;   // (no carry: wave 0's own mailbox line)
+    const int lstep = carry_in >= 0 ? 128 : 0, ostep = 128;
+    int it = 0, lo_a = lo0, lo_b = lo1, out_a = carry_out, out_b = carry_out >= 0 ? carry_out + 64 : -1;
+    for (; it + 2 <= iters; it += 2) {   // two sweeps per trip: the mailbox slot is a compile-time constant
+        jacobi_sweep_st<NW, RY, EDGE>(P, D, sm, 0, lo_a, out_a, S::CARRY_WAVE, wv, lane, gy, w.H, at_left, nv);
+        jacobi_sweep_st<NW, RY, EDGE>(P, D, sm, BOX, lo_b, out_b, S::CARRY_WAVE, wv, lane, gy, w.H, at_left, nv);
+        lo_a += lstep;
+        lo_b += lstep;
+        if (carry_out >= 0) {
+            out_a += ostep;
+            out_b += ostep;
+        }
+    }
+    if (it < iters) jacobi_sweep_st<NW, RY, EDGE>(P, D, sm, 0, lo_a, out_a, S::CARRY_WAVE, wv, lane, gy, w.H, at_left, nv);
+    const bool col_store = (cx >= col_lo) && (cx < col_hi);
+#pragma unroll
+    for (int r = 0; r < RY; r++) {
+        const int gj = gy + r;
+        if (col_store && gj >= row_lo && gj < row_hi) {
+            if constexpr (SC1) store_quad_sc1(rout, (size_t)at(w, gj, cx), P[r]);
+            else store_quad(p_out, (size_t)at(w, gj, cx), P[r]);
+        }
+    }
+}
+
+// DIAG (lab, FLUID_JACOBI_CHAIN=4: a timing probe whose RESULTS ARE NOT VALID): 3 = nobody waits for anybody
+// Structure: wave 0 is the CONTROL wave — between two items it alone draws tickets, polls counters and heads, shelves and helps, and leaves
+// the item it found ready in LDS (s_geo); the other waves wait at the barrier.  Nothing of that bookkeeping is live across the tile body
+// (whose 126 VGPRs / ~80 SGPRs leave no room for it): the body reads the item's geometry from LDS, tile by tile.
+enum { PG_KIND = 0, PG_L, PG_X0, PG_Y0S, PG_ST_LO, PG_ST_HI, PG_SX_LO, PG_SX_HI, PG_CELL, PG_NSHELF, PG_NEXT, PG_WORDS };
+enum { PK_DONE = 0, PK_RUN = 1, PK_COUNT_ONLY = 2, PK_SKIP = 3 };   // nothing left | a stack to run | nothing to store here: count and go | a hole: go
+template <int NW, int RY, int HX, int HY, int DIAG = 0>
+__global__ void __launch_bounds__(64 * NW, (2 * NW + 3) / 4) k_jacobi_pchain(Win w, float* __restrict__ pa, float* __restrict__ pb,
+                                                                            const float* __restrict__ div, float pscale, PChainPlan plan,
+                                                                            unsigned int* __restrict__ state, unsigned int* __restrict__ err)
+{
+    using G = JacobiTB<NW, RY, HX, HY>;
+    using S = JacobiStack<NW, RY, HX, HY>;
+    constexpr int BOX = NW * 128, CARRY0 = 2 * BOX;
+    __shared__ float4 sm[2 * BOX + 2 * HY * 64];   // two mailbox slots, two carry sets of HY lines (a tile writes one set while it reads the other)
+    __shared__ int s_geo[PG_WORDS];                 // the item the control wave found ready, and its own state between items
+    __shared__ unsigned int shelf[PCHAIN_SHELF];    // items put aside while this workgroup helps a head that lags (head << 28 | ticket)
+    // The plan, in LDS: read where it is used (a kernel argument's loads are hoisted to the kernel's entry and then live in SGPRs across the
+    // tile body, which has none to spare — 65 spilled SGPRs and 160 bytes of scratch in the first form of this kernel)
+    __shared__ PChainPlan sP;
+    const int lane = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    {
+        const int* src = reinterpret_cast<const int*>(&plan);
+        int* dst = reinterpret_cast<int*>(&sP);
+        for (int i = wv * 64 + lane; i < (int)(sizeof(PChainPlan) / sizeof(int)); i += 64 * NW) dst[i] = src[i];
+    }
+    {   // the other half of the state: zero for the next call (nobody polls it before this launch has retired)
+        unsigned int* const other = state + (size_t)(plan.d.bank ^ 1) * plan.d.bank_words;
+        for (int i = (int)blockIdx.x * 64 * NW + wv * 64 + lane; i < plan.d.bank_words; i += (int)gridDim.x * 64 * NW) other[i] = 0u;
+    }
+    __syncthreads();
+    // the dimensions as wave-uniform values, re-read from LDS at every use site (cheap: a dozen ds_reads per item)
+    auto dims = [&]() -> PChainDims {
+        PChainDims d;
+        const int* src = reinterpret_cast<const int*>(&sP.d);
+        int* dst = reinterpret_cast<int*>(&d);
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(PChainDims) / sizeof(int)); i++) dst[i] = __builtin_amdgcn_readfirstlane(src[i]);
+        return d;
+    };
+    auto state_of = [&](const PChainDims& C) -> unsigned int* { return state + (size_t)C.bank * C.bank_words; };
+    // draw (one lane): the next ticket of head x0 — or, when that sequence is exhausted, of the next head that is not; PCHAIN_NONE: nothing left
+    auto draw_from = [&](const PChainDims& C, int x0) -> unsigned int {
+        unsigned int* const mine = state_of(C);
+        for (int k = 0; k < 8; k++) {
+            const int x = (x0 + k) & 7, cap = pchain_cap(C, x);
+            if (cap == 0) continue;
+            const unsigned t = __hip_atomic_fetch_add(mine + x * PCHAIN_HEAD_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t < (unsigned)cap) return ((unsigned)x << 28) | t;
+        }
+        return PCHAIN_NONE;
+    };
+    if (wv == 0 && lane == 0) {
+        s_geo[PG_NSHELF] = 0;
+        s_geo[PG_NEXT] = (int)draw_from(dims(), (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u));   // HW_REG_XCC_ID: where this workgroup runs — affinity only
+    }
+    while (true) {
+        if (wv == 0) {
+            // ---- control: find the next item that may run (wave 0 only: no barrier in here; lanes talk through ballots) ----
+            // What this workgroup HOLDS is the shelf: the ticket drawn ahead at the end of the last item, items put aside, helper tickets.  It
+            // always works on the held item of the LOWEST band: then a chain of "spins on an item held by a workgroup that spins on ..." runs
+            // through strictly falling bands and ends at an item with nothing left to wait for (fluid_pchain.h; simulated in tests/pchain_check.cpp).
+            const PChainDims C = dims();
+            unsigned int* const mine = state_of(C);
+            int nshelf = __builtin_amdgcn_readfirstlane(s_geo[PG_NSHELF]);
+            {
+                const unsigned int ahead = (unsigned)__builtin_amdgcn_readfirstlane(s_geo[PG_NEXT]);
+                if (ahead != PCHAIN_NONE) {
+                    if (lane == 0) shelf[nshelf] = ahead;
+                    nshelf++;
+                }
+            }
+            unsigned int cur = PCHAIN_NONE;
+            int kind = PK_DONE, l = 0, by = 0, bx = 0, q = 0;
+            unsigned long long t_wait = 0;
+            bool waiting = false;
+            while (true) {
+                if (nshelf == 0) {   // nothing held: a fresh ticket, from the head of the XCD this workgroup runs on
+                    unsigned int got = 0;
+                    if (lane == 0) got = draw_from(C, (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u));
+                    cur = (unsigned)__builtin_amdgcn_readfirstlane((int)got);
+                    if (cur == PCHAIN_NONE) break;   // PK_DONE: every head is exhausted and nothing is held
+                    if (lane == 0) shelf[0] = cur;
+                    nshelf = 1;
+                }
+                // the held item of the lowest band (ties: the lowest ticket); lanes 0..nshelf-1 look at one shelf entry each
+                int pick = 0;
+                {
+                    unsigned key = 0xffffffffu;
+                    if (lane < nshelf) {
+                        const unsigned e = shelf[lane];
+                        key = ((((e & 0x0fffffffu) / (unsigned)C.slots) * 8u + (e >> 28)) << 5) | (unsigned)lane;   // band << 5 | shelf index (< 32)
+                    }
+#pragma unroll
+                    for (int o = 16; o > 0; o >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, o));   // (PCHAIN_SHELF = 32 entries: lanes 0..31)
+                    pick = __builtin_amdgcn_readfirstlane((int)(key & 31u));
+                }
+                cur = (unsigned)__builtin_amdgcn_readfirstlane((int)shelf[pick]);
+                const int hx = (int)(cur >> 28), ht = (int)(cur & 0x0fffffffu);
+                if (!pchain_item(C, hx, ht, l, by, bx, q)) kind = PK_SKIP;
+                else kind = PK_RUN;
+                bool go = kind == PK_SKIP || l == 0 || DIAG == 3;
+                if (!go) {
+                    // lanes 0..8: the counters of the cells of the 3 x 3 items around (by, bx) in block l - 1 (stack rows by-1..by+1 x the panels
+                    // of columns bx-1..bx+1; neighbours often share a cell: the same word, the same answer); lanes 16..24: have the bands
+                    // those cells belong to been DRAWN completely?  One memory round trip for all of it.
+                    bool ok = true;
+                    int lag_head = 0;
+                    {
+                        const int k = lane & 15, r = by - 1 + k / 3, c = bx - 1 + k % 3;
+                        if (k < 9 && (lane >> 4) < 2 && r >= 0 && r < C.ny && c >= 0 && c < C.nx) {
+                            const int pn = pchain_panel_of(C, c);
+                            if (lane < 16) {
+                                ok = __hip_atomic_load(mine + pchain_cell(C, l - 1, r, pn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)pchain_panel_width(C, pn);
+                            } else {
+                                const int qd = pchain_band_of(C, l - 1, r, pn);
+                                lag_head = qd & 7;
+                                ok = __hip_atomic_load(mine + lag_head * PCHAIN_HEAD_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)((qd >> 3) + 1) * (unsigned)C.slots;
+                            }
+                        }
+                    }
+                    const unsigned long long bad = __ballot(!ok);   // wave-uniform
+                    if ((bad & 0xffffull) == 0) go = true;          // every counter is there: run
+                    else if (bad & 0xffff0000ull) {
+                        // a band that is waited for has not been drawn completely: draw from that band's head and hold the ticket too — a
+                        // workgroup only ever SPINS on items that somebody holds
+                        if (nshelf == PCHAIN_SHELF) {   // cannot happen in a schedule that makes progress; never overflow, never hang
+                            if (lane == 0) __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            go = true;
+                        } else {
+                            const int head = __builtin_amdgcn_readlane(lag_head, __builtin_ctzll(bad & 0xffff0000ull));
+                            unsigned int got = 0;
+                            if (lane == 0) got = draw_from(C, head);
+                            got = (unsigned)__builtin_amdgcn_readfirstlane((int)got);
+                            if (got != PCHAIN_NONE) {   // (NONE: others drew the rest of that band meanwhile — poll again)
+                                if (lane == 0) shelf[nshelf] = got;
+                                nshelf++;
+                            }
+                            waiting = false;
+                            continue;
+                        }
+                    } else {
+                        // all drawn, not all done: spin — bounded in wall-clock time, and nobody waits once somebody has given up
+                        if (!waiting) {
+                            waiting = true;
+                            t_wait = __builtin_amdgcn_s_memrealtime();
+                            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) go = true;
+                        }
+                        if (!go) {
+                            __builtin_amdgcn_s_sleep(2);
+                            if (__builtin_amdgcn_s_memrealtime() - t_wait > (unsigned long long)C.timeout) {
+                                if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                go = true;   // run on stale data rather than hang the device; the host learns through err
+                            } else continue;
+                        }
+                    }
+                }
+                // take `cur` off the shelf (the last entry moves into its place)
+                nshelf--;
+                if (lane == 0 && pick != nshelf) shelf[pick] = shelf[nshelf];
+                break;
+            }
+            if (cur == PCHAIN_NONE) kind = PK_DONE;
+            if (kind == PK_RUN) {   // the geometry of the stack, for every wave
+                const int x0 = C.xs + bx * G::VX, y0s = C.ys + by * (S::span(C.stack) - 2 * HY);
+                int st_lo, st_hi, sx_lo, sx_hi;
+                tile_exact(y0s, S::span(C.stack), HY, w.H, __builtin_amdgcn_readfirstlane(sP.ga[l]), __builtin_amdgcn_readfirstlane(sP.gb[l]), st_lo, st_hi);
+                tile_exact(x0, G::TX, HX, w.W, __builtin_amdgcn_readfirstlane(sP.xa[l]), __builtin_amdgcn_readfirstlane(sP.xb[l]), sx_lo, sx_hi);
+                if (st_hi <= st_lo || sx_hi <= sx_lo) kind = PK_COUNT_ONLY;   // this block's ranges do not reach this stack — no reads, no writes
+                if (lane == 0) {
+                    s_geo[PG_L] = l;
+                    s_geo[PG_X0] = x0;
+                    s_geo[PG_Y0S] = y0s;
+                    s_geo[PG_ST_LO] = st_lo;
+                    s_geo[PG_ST_HI] = st_hi;
+                    s_geo[PG_SX_LO] = sx_lo;
+                    s_geo[PG_SX_HI] = sx_hi;
+                    s_geo[PG_CELL] = (C.withhold >= 0 && q == C.withhold && ((int)(cur & 0x0fffffffu) % C.slots) == 0) ? -1 : pchain_cell(C, l, by, pchain_panel_of(C, bx));
+                }
+            }
+            if (lane == 0) {
+                s_geo[PG_KIND] = kind;
+                s_geo[PG_NSHELF] = nshelf;
+            }
+        }
+        __syncthreads();
+        const int kind = __builtin_amdgcn_readfirstlane(s_geo[PG_KIND]);
+        if (kind == PK_DONE) break;
+        if (kind == PK_RUN) {
+            const int l = __builtin_amdgcn_readfirstlane(s_geo[PG_L]);
+            Win wl = w;
+            wl.x0 = __builtin_amdgcn_readfirstlane(sP.xa[l]);
+            wl.x1 = __builtin_amdgcn_readfirstlane(sP.xb[l]);
+            float* const p = (l & 1) ? pb : pa;
+            float* const p_out = (l & 1) ? pa : pb;
+            const int bytes = (int)((size_t)w.rows * (size_t)w.P * sizeof(float));
+            const float ps = l == 0 ? pscale : 1.0f;
+            const int iters = __builtin_amdgcn_readfirstlane(sP.iters[l]), stack = __builtin_amdgcn_readfirstlane(sP.d.stack);
+            for (int t = 0; t < stack; t++) {
+                const int x0 = __builtin_amdgcn_readfirstlane(s_geo[PG_X0]), y0s = __builtin_amdgcn_readfirstlane(s_geo[PG_Y0S]);
+                const int st_lo = __builtin_amdgcn_readfirstlane(s_geo[PG_ST_LO]), st_hi = __builtin_amdgcn_readfirstlane(s_geo[PG_ST_HI]);
+                const int sx_lo = __builtin_amdgcn_readfirstlane(s_geo[PG_SX_LO]), sx_hi = __builtin_amdgcn_readfirstlane(s_geo[PG_SX_HI]);
+                const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(p, 0, bytes, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(p_out, 0, bytes, 0x00020000);
+                const bool xedge = (x0 <= 0) || (x0 + G::TX >= w.W), ragged = (w.W & 3) != 0 && x0 + G::TX >= w.W;
+                int yt, a, b;
+                bool last;
+                stack_tile_rows(y0s, t, G::TY, HY, w.H, st_lo, st_hi, yt, a, b, last);
+                const int cin = t > 0 ? CARRY0 + ((t - 1) & 1) * HY * 64 : -1, cout = last ? -1 : CARRY0 + (t & 1) * HY * 64;
+                const bool yedge = (yt <= 0) || (yt + G::TY >= w.H);
+                if (t > 0) __syncthreads();   // the last sweep's mailbox readers are through before the next tile's first sweep publishes
+                if (yedge || ragged) jacobi_stack_tile<NW, RY, HX, HY, 2, true>(wl, rin, rout, p, p_out, div, ps, iters, x0, yt, a, b, sx_lo, sx_hi, sm, cin, cout);
+                else if (xedge) jacobi_stack_tile<NW, RY, HX, HY, 1, true>(wl, rin, rout, p, p_out, div, ps, iters, x0, yt, a, b, sx_lo, sx_hi, sm, cin, cout);
+                else jacobi_stack_tile<NW, RY, HX, HY, 0, true>(wl, rin, rout, p, p_out, div, ps, iters, x0, yt, a, b, sx_lo, sx_hi, sm, cin, cout);
+                if (last) break;
+            }
+        }
+        // the next item: from the shelf if something waits there, else a fresh ticket — drawn HERE, so that its round trip overlaps the drain
+        if (wv == 0 && lane == 0)
+            s_geo[PG_NEXT] = s_geo[PG_NSHELF] > 0 ? (int)PCHAIN_NONE : (int)draw_from(dims(), (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u));
+        // done: every storing wave drains its write-through stores, then ONE lane counts the item (the guide's R1 hand-off)
+        if (kind == PK_RUN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (wv == 0 && lane == 0 && kind != PK_SKIP && s_geo[PG_CELL] >= 0)
+            __hip_atomic_fetch_add(state_of(dims()) + s_geo[PG_CELL], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // BPC = workgroups that must fit on a CU together (their load / compute / store phases overlap each other):
@@ -3268,12 +3588,23 @@ bool jacobi_chain_applies(const Win& w, int ga, int gb, int iters)
 {
     using G = JacobiTB<8, 10, 12, 10>;
     const int mode = jacobi_chain_mode();
-    if (mode == 0 || iters <= 10 || iters > 10 * CHAIN_MAX_BLOCKS || !jacobi_tb_supported(w)) return false;
+    if (mode == 0 || iters <= 10 || iters > 10 * jacobi_chain_max_blocks() || !jacobi_tb_supported(w)) return false;
     if (mode >= 1) return true;
     const Axis ax = make_axis(w.x0, w.x1, w.W, G::TX, 12);
     return 64 / ax.n == 3 && gb - ga <= 8192 && gb - ga >= 2048;
 }
-size_t jacobi_chain_flag_bytes() { return (size_t)(CHAIN_MAX_BLOCKS * CHAIN_MAX_ROWS) * sizeof(unsigned int); }   // the (block, tile row) counters
+size_t jacobi_pchain_state_bytes();
+// the counters of either form (k_jacobi_tb_chain: (block, tile row); k_jacobi_pchain: two halves of heads + (block, stack row, panel) cells)
+size_t jacobi_chain_flag_bytes() { return std::max((size_t)(CHAIN_MAX_BLOCKS * CHAIN_MAX_ROWS) * sizeof(unsigned int), jacobi_pchain_state_bytes()); }
+// FLUID_CHAIN_PERSIST (lab build): 0 = round 5's k_jacobi_tb_chain (one workgroup per tile, blockIdx order); default: the persistent form
+static bool chain_persistent()
+{
+    static const bool on = [] { const char* e = lab_env("FLUID_CHAIN_PERSIST"); return !(e && atoi(e) == 0); }();
+    return on;
+}
+int jacobi_chain_max_blocks() { return chain_persistent() ? PCHAIN_MAX_BLOCKS : CHAIN_MAX_BLOCKS; }
+hipError_t launch_jacobi_pchain_ranges(hipStream_t s, Win w, float* pa, float* pb, const float* div, float pscale, int nblocks, const int* iters,
+                                       const int* ga, const int* gb, const int* xa, const int* xb, unsigned int* state, unsigned int* err, ChainEpoch* ep);
 
 // `iters` iterations as ONE launch of ceil(iters / 10) chained blocks (k_jacobi_tb_chain; the 80-row tile of shape 0).  pa holds the input;
 // the result is in pb when the number of blocks is odd, in pa when it is even (*result_in_b).  hipErrorNotReady: does not apply here.
@@ -3284,6 +3615,7 @@ hipError_t launch_jacobi_tb_chain_ranges(hipStream_t s, Win w, float* pa, float*
                                          ChainEpoch* ep)
 {
     using G = JacobiTB<8, 10, 12, 10>;
+    if (chain_persistent()) return launch_jacobi_pchain_ranges(s, w, pa, pb, div, pscale, nblocks, iters, ga, gb, xa, xb, flags, err, ep);
     if (nblocks < 2 || nblocks > CHAIN_MAX_BLOCKS || gb[0] <= ga[0] || xb[0] <= xa[0]) return hipErrorNotReady;
     ChainPlan C{};
     C.blocks = nblocks;
@@ -3318,7 +3650,10 @@ hipError_t launch_jacobi_tb_chain_ranges(hipStream_t s, Win w, float* pa, float*
         }
     }
     C.target = ((ep ? ep->calls : 0u) + 1u) * (unsigned)ax.n;
-    if (ep) ep->calls++;
+    if (ep) {
+        ep->calls++;
+        ep->psig[0] = 0xffffffffu;
+    }
     const dim3 grid((unsigned)(C.blocks * C.tiles), 1, 1), block(64, 8, 1);
 #ifdef FLUID_PROBES
     if (C.tickets) {
@@ -3337,6 +3672,113 @@ hipError_t launch_jacobi_tb_chain_ranges(hipStream_t s, Win w, float* pa, float*
     return hipGetLastError();
 }
 
+// ---- the persistent form (k_jacobi_pchain; fluid_pchain.h) ----
+static int pchain_knob(const char* name, int dflt)
+{
+    const char* e = lab_env(name);
+    return e ? atoi(e) : dflt;
+}
+size_t jacobi_pchain_state_bytes() { return 2 * (size_t)(8 * PCHAIN_HEAD_STRIDE + PCHAIN_MAX_BLOCKS * PCHAIN_MAX_CELLS) * sizeof(unsigned int); }
+
+// Tiles per stack, column panels and stack rows per band for an nx x ny tiling of `blocks` blocks.  A band should fill one XCD's 64 resident
+// workgroups (its tiles share their aprons in that XCD's L2) and the bands of the launch should deal out evenly over the eight heads.
+// FLUID_CHAIN_STACK / FLUID_CHAIN_PANEL / FLUID_CHAIN_BAND (lab build) force M / pw / bh.
+void pchain_layout(PChainPlan& C)
+{
+    static const int f_pw = pchain_knob("FLUID_CHAIN_PANEL", 0), f_bh = pchain_knob("FLUID_CHAIN_BAND", 0);
+    const int np0 = (C.d.nx + 20) / 21;
+    C.d.pw = f_pw > 0 ? std::min(f_pw, C.d.nx) : (C.d.nx + np0 - 1) / np0;
+    C.d.np = (C.d.nx + C.d.pw - 1) / C.d.pw;
+    int best = 1;
+    double best_score = -1.0;
+    for (int bh = 1; bh <= std::max(1, 64 / C.d.pw); bh++) {
+        const int tb = C.d.blocks * C.d.np * ((C.d.ny + bh - 1) / bh);
+        const double balance = (double)tb / (8.0 * ((tb + 7) / 8)), fill = std::min(1.0, (double)(C.d.pw * bh) / 56.0);
+        const double score = balance * (0.75 + 0.25 * fill);   // (an even deal first; among even deals the fuller band)
+        if (score > best_score + 1e-9) {
+            best_score = score;
+            best = bh;
+        }
+    }
+    C.d.bh = f_bh > 0 ? f_bh : best;
+    C.d.nrg = (C.d.ny + C.d.bh - 1) / C.d.bh;
+    C.d.nb = C.d.nrg * C.d.np;
+    C.d.slots = C.d.pw * C.d.bh;
+}
+
+// stacks of M tiles: tile rows per launch / M stack rows.  M = 2 by default (0.8125 of the arithmetic stored instead of 0.75; M = 3: 0.833 and
+// half as many, twice as long items again); 1 = plain tiles
+int pchain_stack()
+{
+    static const int m = std::max(1, std::min(8, pchain_knob("FLUID_CHAIN_STACK", 2)));
+    return m;
+}
+
+hipError_t launch_jacobi_pchain_ranges(hipStream_t s, Win w, float* pa, float* pb, const float* div, float pscale, int nblocks, const int* iters,
+                                       const int* ga, const int* gb, const int* xa, const int* xb, unsigned int* state, unsigned int* err, ChainEpoch* ep)
+{
+    using G = JacobiTB<8, 10, 12, 10>;
+    using S = JacobiStack<8, 10, 12, 10>;
+    if (nblocks < 2 || nblocks > PCHAIN_MAX_BLOCKS || gb[0] <= ga[0] || xb[0] <= xa[0] || !ep) return hipErrorNotReady;
+    PChainPlan C{};
+    C.d.blocks = nblocks;
+    for (int l = 0; l < nblocks; l++) {
+        if (iters[l] < 1 || iters[l] > 10 || ga[l] < ga[0] || gb[l] > gb[0] || xa[l] < xa[0] || xb[l] > xb[0]) return hipErrorNotReady;
+        C.iters[l] = iters[l];
+        C.ga[l] = ga[l];
+        C.gb[l] = gb[l];
+        C.xa[l] = xa[l];
+        C.xb[l] = xb[l];
+    }
+    C.d.stack = pchain_stack();
+    const Axis ax = make_axis(xa[0], xb[0], w.W, G::TX, 12), ay = make_axis(ga[0], gb[0], w.H, S::span(C.d.stack), 10);
+    C.d.nx = ax.n;
+    C.d.ny = ay.n;
+    C.d.xs = ax.S;
+    C.d.ys = ay.S;
+    pchain_layout(C);
+    if (C.d.ny * C.d.np > PCHAIN_MAX_CELLS || C.d.nx >= 4096 || C.d.ny >= 4096) return hipErrorNotReady;
+    C.d.bank_words = pchain_bank_words(C.d);
+    static const int timeout_ms = pchain_knob("FLUID_CHAIN_TIMEOUT_MS", 2000);
+    C.d.timeout = (unsigned int)timeout_ms * 100000u;
+    static const int withhold = pchain_knob("FLUID_CHAIN_WITHHOLD", -1);
+    C.d.withhold = withhold;
+    // the state words: zeroed when the shape of the call changes, else the half the previous call of this shape zeroed for us
+    const unsigned sig = (unsigned)C.d.nx | ((unsigned)C.d.ny << 10) | ((unsigned)nblocks << 20) | ((unsigned)C.d.stack << 25) | ((unsigned)C.d.bh << 28);
+    const unsigned sig2 = (unsigned)C.d.pw;
+    if (ep->psig[0] != sig || ep->psig[1] != sig2) {
+        const hipError_t e = hipMemsetAsync(state, 0, jacobi_pchain_state_bytes(), s);
+        if (e != hipSuccess) return e;
+        ep->psig[0] = 0xffffffffu;   // (until the launch below has gone out)
+        ep->bank = 0;
+    }
+    C.d.bank = ep->bank;
+    static const int cus = [] {
+        hipDeviceProp_t p{};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256;
+        return p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+    }();
+    static const int f_grid = pchain_knob("FLUID_CHAIN_GRID", 0);
+    const long items = (long)C.d.blocks * C.d.nx * C.d.ny;
+    const unsigned grid = (unsigned)std::max(1l, std::min(items, (long)(f_grid > 0 ? f_grid : 2 * cus)));
+#ifdef FLUID_PROBES
+    if (jacobi_chain_mode() == 4) k_jacobi_pchain<8, 10, 12, 10, 3><<<dim3(grid), dim3(64, 8), 0, s>>>(w, pa, pb, div, pscale, C, state, err);
+    else
+#endif
+        k_jacobi_pchain<8, 10, 12, 10, 0><<<dim3(grid), dim3(64, 8), 0, s>>>(w, pa, pb, div, pscale, C, state, err);
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) {   // only a launch that went out has used its half and zeroed the other
+        ep->psig[0] = sig;
+        ep->psig[1] = sig2;
+        ep->bank ^= 1;
+    } else {
+        ep->psig[0] = 0xffffffffu;
+    }
+    ep->signature = 0xffffffffu;   // (the other form's counters share the memory: whoever runs next zeroes them)
+    return e;
+}
+
 // `iters` iterations over the rows [ga, gb) in every block (a whole domain) as ceil(iters / 10) balanced blocks
 hipError_t launch_jacobi_tb_chain(hipStream_t s, Win w, float* pa, float* pb, const float* div, float pscale, int iters, int ga, int gb,
                                   unsigned int* flags, unsigned int* err, int* blocks, bool* result_in_b, ChainEpoch* ep)
@@ -3344,7 +3786,7 @@ hipError_t launch_jacobi_tb_chain(hipStream_t s, Win w, float* pa, float* pb, co
     ROWS_OR_RETURN();
     if (!jacobi_chain_applies(w, ga, gb, iters)) return hipErrorNotReady;
     const int n = (iters + 9) / 10;
-    int it[CHAIN_MAX_BLOCKS], a[CHAIN_MAX_BLOCKS], b[CHAIN_MAX_BLOCKS], xa[CHAIN_MAX_BLOCKS], xb[CHAIN_MAX_BLOCKS], done = 0, left = n;
+    int it[PCHAIN_MAX_BLOCKS], a[PCHAIN_MAX_BLOCKS], b[PCHAIN_MAX_BLOCKS], xa[PCHAIN_MAX_BLOCKS], xb[PCHAIN_MAX_BLOCKS], done = 0, left = n;
     for (int l = 0; l < n; l++) {   // balanced, as pass_jacobi cuts them
         it[l] = (iters - done + left - 1) / left;
         done += it[l];

@@ -343,11 +343,11 @@ int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launche
     // Every launch that is left once the cut ones are through (all of them on a whole domain) as ONE launch of chained blocks of ten iterations,
     // where that is the faster schedule: 4096-wide fp32 grids (fluid::jacobi_chain_applies; k_jacobi_tb_chain).  A stripe's launches recompute
     // fewer ghost rows each: every block gets its own row range.  Counted as its blocks — each moves the field once, as a launch does.
-    const bool chain_kind = tb && !fold && split != 1 && shape == 0 && c->storage == FLUID_STORE_F32;
+    const bool chain_kind = tb && !fold && split != 1 && shape == 0 && c->storage == FLUID_STORE_F32 && !c->chain_broken;
     while (done < iters) {
         int ga, gb;
-        if (chain_kind && cut_left == 0 && launches_left >= 2 && launches_left <= 8) {
-            int it[8], ra[8], rb[8], xa[8], xb[8], d = done, left = launches_left;
+        if (chain_kind && cut_left == 0 && launches_left >= 2 && launches_left <= std::min(32, fluid::jacobi_chain_max_blocks())) {
+            int it[32], ra[32], rb[32], xa[32], xb[32], d = done, left = launches_left;
             const int n = launches_left;
             for (int l = 0; l < n; l++) {
                 it[l] = (iters - d + left - 1) / left;
@@ -877,10 +877,20 @@ namespace fluid_impl {
 int chain_check(fluid_ctx* c)
 {
     if (!c->chain_err_host || c->chain_err_host[0] == 0) return FLUID_OK;
+    const unsigned int why = c->chain_err_host[0];
     c->chain_err_host[0] = 0;
-    c->chain_epoch = fluid::ChainEpoch{};   // the counters are in no known state: the next chained launch zeroes them
-    return c->fail(FLUID_ERR_HIP, "the chained Jacobi launch gave up waiting for a tile of the previous block of iterations (workgroups not dispatched in "
-                                  "id order?): the fields of the calls since the last synchronisation are not valid");
+    c->chain_epoch = fluid::ChainEpoch{};   // the counters are in no known state: a chained launch would have to zero them
+    c->chain_broken = true;                 // ... and this context does not try again: plain launches from here on (pass_jacobi)
+    return c->fail(FLUID_ERR_HIP, why == 2u ? "the chained Jacobi launch ran out of room for the items it had put aside: the fields of the calls since the last "
+                                              "synchronisation are not valid; this context keeps to one launch per block of iterations from now on"
+                                            : "the chained Jacobi launch gave up waiting for an item of the previous block of iterations: the fields of the calls "
+                                              "since the last synchronisation are not valid; this context keeps to one launch per block of iterations from now on");
+}
+
+int ctx_sync(fluid_ctx* c, hipStream_t s)
+{
+    HIPCK(c, hipStreamSynchronize(s ? s : c->stream));
+    return chain_check(c);
 }
 
 int field_ref(fluid_ctx* c, int field, FieldRef* f, bool geometry_only, bool keep_packed)
@@ -1108,7 +1118,7 @@ int fluid_set_stream(fluid_ctx* c, void* hip_stream, int external)
 {
     if (!c) return FLUID_ERR_INVALID;
     HIPCK(c, hipSetDevice(c->device));
-    HIPCK(c, hipStreamSynchronize(c->stream));
+    CK(ctx_sync(c));
     c->stream = external ? (hipStream_t)hip_stream : c->own_stream;
     return FLUID_OK;
 }
@@ -1216,8 +1226,7 @@ int fluid_sync(fluid_ctx* c)
 {
     if (!c) return FLUID_ERR_INVALID;
     HIPCK(c, hipSetDevice(c->device));
-    HIPCK(c, hipStreamSynchronize(c->stream));
-    return chain_check(c);
+    return ctx_sync(c);
 }
 
 int fluid_field_info_get(const fluid_ctx* c, int field, fluid_field_info* out)
@@ -1270,14 +1279,13 @@ int fluid_read_field(fluid_ctx* c, int field, float* host, size_t bytes)
     const size_t col = (size_t)(b.f.col0 - b.f.win->c0);  // array column of the first owned column
     if (c->storage == FLUID_STORE_F32) {
         HIPCK(c, hipMemcpy2DAsync(host, b.line, b.first_row + col * b.f.texel(), pitch32, b.line, b.f.rows, hipMemcpyDeviceToHost, c->stream));
-        HIPCK(c, hipStreamSynchronize(c->stream));
-        return chain_check(c);
+        return ctx_sync(c);
     }
     float* tmp = nullptr;
     HIPCK(c, hipMalloc((void**)&tmp, b.rows_n * sizeof(float)));
     int rc = c->hip(launch_widen(c->stream, (const __half*)b.first_row, tmp, b.rows_n), "widen");
     if (!rc) rc = c->hip(hipMemcpy2DAsync(host, b.line, (char*)tmp + col * b.f.nc * sizeof(float), pitch32, b.line, b.f.rows, hipMemcpyDeviceToHost, c->stream), "copy");
-    if (!rc) rc = c->hip(hipStreamSynchronize(c->stream), "sync");
+    if (!rc) rc = ctx_sync(c);
     (void)hipFree(tmp);
     return rc;
 }
@@ -1302,8 +1310,7 @@ int fluid_write_field(fluid_ctx* c, int field, const float* host, size_t bytes)
     }
     if (c->storage == FLUID_STORE_F32) {
         HIPCK(c, hipMemcpy2DAsync(b.first_row + col * b.f.texel(), pitch32, host, b.line, b.line, b.f.rows, hipMemcpyHostToDevice, c->stream));
-        HIPCK(c, hipStreamSynchronize(c->stream));
-        return FLUID_OK;
+        return ctx_sync(c);
     }
     // the columns of these rows that this context does not own keep their values: widen, overlay the owned block, narrow
     float* tmp = nullptr;
@@ -1312,7 +1319,7 @@ int fluid_write_field(fluid_ctx* c, int field, const float* host, size_t bytes)
     if (b.f.cols != b.f.win->P) rc = c->hip(launch_widen(c->stream, (const __half*)b.first_row, tmp, b.rows_n), "widen");
     if (!rc) rc = c->hip(hipMemcpy2DAsync((char*)tmp + col * b.f.nc * sizeof(float), pitch32, host, b.line, b.line, b.f.rows, hipMemcpyHostToDevice, c->stream), "copy");
     if (!rc) rc = c->hip(launch_narrow(c->stream, tmp, (__half*)b.first_row, b.rows_n), "narrow");
-    if (!rc) rc = c->hip(hipStreamSynchronize(c->stream), "sync");
+    if (!rc) rc = ctx_sync(c);
     (void)hipFree(tmp);
     return rc;
 }
@@ -1427,7 +1434,8 @@ int fluid_field_device_ptr(fluid_ctx* c, int field, void** dev_ptr)
     // The header's ordering rule (1): work THIS call had to enqueue is waited for here, so that `fluid_sync(); fluid_field_device_ptr();`
     // hands out finished memory.  Round 4 returned while k_dye_unpack was still writing the buffer behind the pointer, on a non-blocking
     // stream no other stream is ordered against: bench.py's torch.equal read it half-written (BENCH_r04.json, profiles/r05/device_view_race.txt).
-    if (was_packed && !c->dye_packed) HIPCK(c, hipStreamSynchronize(c->stream));
+    if (was_packed && !c->dye_packed) CK(ctx_sync(c));
+    else CK(chain_check(c));   // (a pressure loop that gave up in a call the caller already synchronised with: no pointer to its fields)
     if (field == FLUID_DYE) c->alpha_known = false;   // a raw pointer: whatever gets written through it, the context does not see (until the next splat)
     *dev_ptr = f.ptr;
     return FLUID_OK;
@@ -1448,6 +1456,10 @@ static int order_streams(fluid_ctx* c, hipStream_t from, hipStream_t to)
 int fluid_stream_wait_context(fluid_ctx* c, void* hip_stream)
 {
     if (!c) return FLUID_ERR_INVALID;
+    // What this call can know without waiting: a chained pressure loop that gave up in work the device has ALREADY run is an error here too —
+    // the consumer must not be ordered behind fields that are known to be wrong.  (Work still in flight cannot have failed yet: the caller
+    // that wants the verdict on it synchronises — fluid_sync — as the header says.)
+    CK(chain_check(c));
     return order_streams(c, c->stream, (hipStream_t)hip_stream);
 }
 
@@ -1463,7 +1475,7 @@ int fluid_halo_check(fluid_ctx* c)
     HIPCK(c, hipSetDevice(c->device));
     unsigned int m = 0;
     HIPCK(c, hipMemcpyAsync(&m, c->miss, sizeof(m), hipMemcpyDeviceToHost, c->stream));
-    HIPCK(c, hipStreamSynchronize(c->stream));
+    CK(ctx_sync(c));
     if (m) {
         HIPCK(c, hipMemsetAsync(c->miss, 0, sizeof(unsigned int), c->stream));
         char msg[128];

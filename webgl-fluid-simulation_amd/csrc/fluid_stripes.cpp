@@ -1202,7 +1202,7 @@ int fluid_comm_selftest(fluid_ctx* c, int nfloats)
         if ((rc = c->hip(hipStreamWaitEvent(c->stream, c->ev_landed, 0), "wait"))) break;
         std::vector<float> host(nfloats);
         if ((rc = c->hip(hipMemcpyAsync(host.data(), b, nfloats * sizeof(float), hipMemcpyDeviceToHost, c->stream), "copy"))) break;
-        if ((rc = c->hip(hipStreamSynchronize(c->stream), "sync"))) break;
+        if ((rc = ctx_sync(c))) break;
         for (int i = 0; i < nfloats; i++)
             if (host[i] != 3.25f) {
                 rc = c->fail(FLUID_ERR_COMM, "self send/recv returned wrong data");
