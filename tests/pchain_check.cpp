@@ -31,12 +31,8 @@ static PChainDims dims(int blocks, int nx, int ny, int pw, int bh, int stack = 2
     C.ny = ny;
     C.stack = stack;
     C.pw = pw;
-    C.np = (nx + pw - 1) / pw;
     C.bh = bh;
-    C.nrg = (ny + bh - 1) / bh;
-    C.nb = C.nrg * C.np;
-    C.slots = pw * bh;
-    C.bank_words = pchain_bank_words(C);
+    pchain_finish(C);
     C.withhold = -1;
     return C;
 }
@@ -277,6 +273,15 @@ static void simulate(const PChainDims& C, int nwg, int placement, unsigned seed)
 int main()
 {
     std::mt19937 rng(20260930);
+    for (int k = 0; k < 2000000; k++) {   // the multiply-and-correct division of the ticket decode, against the real one
+        const int a = (int)(rng() % (1u << 24)), b = 1 + (int)(rng() % (k & 1 ? 4096 : 70));
+        if (pchain_div(a, b, 1.0f / (float)b) != a / b) {
+            printf("pchain_div(%d, %d) = %d\n", a, b, pchain_div(a, b, 1.0f / (float)b));
+            fails++;
+            break;
+        }
+    }
+    cases++;
     // the shapes the library picks and their neighbours: 4096^2 (18 x 32 stacks of two), 3072, 6144, 8192, 16384-wide ranks
     const int shapes[][5] = { { 5, 18, 32, 18, 2 }, { 5, 18, 32, 18, 3 }, { 5, 18, 69, 18, 3 }, { 5, 14, 24, 14, 4 }, { 5, 27, 48, 14, 2 }, { 5, 36, 63, 18, 3 },
                               { 20, 71, 17, 18, 3 }, { 2, 1, 1, 1, 1 }, { 3, 2, 9, 2, 5 }, { 8, 19, 20, 19, 1 }, { 24, 5, 7, 3, 2 }, { 5, 43, 12, 21, 3 } };

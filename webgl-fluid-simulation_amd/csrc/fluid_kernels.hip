@@ -19,6 +19,7 @@
 #include "fluid_pchain.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -1403,16 +1404,25 @@ __device__ __forceinline__ void jacobi_sweep_st(Quad (&P)[RY], const Quad (&D)[R
     P[0] = jacobi_row<EDGE, false>(old0, old1, lo, D[0], gy, H, at_left, nv);
 }
 
-template <int NW, int RY, int HX, int HY, int EDGE, bool SC1>
+// One tile of a stack.  `hooks`: this is the stack's LAST tile — it draws the workgroup's next ticket with its loads and gives wave 0 two
+// moments BETWEEN sweeps (registers to spare there) to prepare the next item: pre_a two trips before the end, pre_b one trip before the end.
+// after_loads(): called by every wave once the tile's loads are out — where the PREVIOUS item's stores are waited for and the item counted.
+template <int NW, int RY, int HX, int HY, int EDGE, bool SC1, class FL, class FA, class FB>
 __device__ __forceinline__ void jacobi_stack_tile(const Win& w, __amdgpu_buffer_rsrc_t rin, __amdgpu_buffer_rsrc_t rout, const float* __restrict__ p,
                                                   float* __restrict__ p_out, const float* __restrict__ div, float pscale, int iters, int x0, int yt,
-                                                  int row_lo, int row_hi, int col_lo, int col_hi, float4* sm, int carry_in, int carry_out)
+                                                  int row_lo, int row_hi, int col_lo, int col_hi, float4* sm, int carry_in, int carry_out,
+                                                  unsigned int* head, unsigned int head_tag, int* ahead, bool hooks, FL&& after_loads, FA&& pre_a, FB&& pre_b)
 {
     using S = JacobiStack<NW, RY, HX, HY>;
     static_assert(S::CARRY_ROW == RY - 1, "the carried row is the one its wave publishes to the mailbox anyway (HY == RY)");
     const int lane = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
     const int cx = x0 + 4 * lane, gy = yt + wv * RY;
+    // The workgroup's NEXT ticket is drawn here (head != null: wave 0, one lane), in front of the tile's loads: the atomic's round trip is
+    // the loads' round trip, and its result is parked in LDS (*ahead) before the arithmetic needs the registers
+    unsigned int ticket = 0;
+    const bool drawer = head != nullptr && wv == 0 && lane == 0;
+    if (drawer) ticket = __hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     Quad P[RY], D[RY];
     const unsigned cxs = (unsigned)(min(max(cx, w.c0), w.c0 + w.P - 4) - w.c0);
     const v2f ps = v2f{ pscale, pscale };
@@ -1424,6 +1434,8 @@ __device__ __forceinline__ void jacobi_stack_tile(const Win& w, __amdgpu_buffer_
         else P[r] = load_quad(p, row + cxs);
         D[r] = load_quad(div, row + cxs);
     }
+    after_loads();
+    if (drawer) *ahead = (int)(head_tag | ticket);
 #pragma unroll
     for (int r = 0; r < RY; r++) {   // clearShader folded in (block 0: pscale; 1 elsewhere)
         P[r].o = ps * P[r].o;
@@ -1435,7 +1447,17 @@ __device__ __forceinline__ void jacobi_stack_tile(const Win& w, __amdgpu_buffer_
     const int lo0 = carry_in >= 0 ? carry_in : 64, lo1 = carry_in >= 0 ? carry_in + 64 : BOX + 64;   // (no carry: wave 0's own mailbox line)
     const int lstep = carry_in >= 0 ? 128 : 0, ostep = 128;
     int it = 0, lo_a = lo0, lo_b = lo1, out_a = carry_out, out_b = carry_out >= 0 ? carry_out + 64 : -1;
-    for (; it + 2 <= iters; it += 2) {   // two sweeps per trip: the mailbox slot is a compile-time constant
+    const int ntrips = iters >> 1, trip_a = max(ntrips - 2, 0), trip_b = max(ntrips - 1, 0);
+    int trip = 0;
+    if (hooks && ntrips == 0) {   // a single sweep: both moments in front of it
+        pre_a();
+        pre_b();
+    }
+    for (; it + 2 <= iters; it += 2, trip++) {   // two sweeps per trip: the mailbox slot is a compile-time constant
+        if (hooks) {
+            if (trip == trip_a) pre_a();
+            if (trip == trip_b) pre_b();
+        }
         jacobi_sweep_st<NW, RY, EDGE>(P, D, sm, 0, lo_a, out_a, S::CARRY_WAVE, wv, lane, gy, w.H, at_left, nv);
         jacobi_sweep_st<NW, RY, EDGE>(P, D, sm, BOX, lo_b, out_b, S::CARRY_WAVE, wv, lane, gy, w.H, at_left, nv);
         lo_a += lstep;
@@ -1457,12 +1479,33 @@ __device__ __forceinline__ void jacobi_stack_tile(const Win& w, __amdgpu_buffer_
     }
 }
 
-// DIAG (lab, FLUID_JACOBI_CHAIN=4: a timing probe whose RESULTS ARE NOT VALID): 3 = nobody waits for anybody
-// Structure: wave 0 is the CONTROL wave — between two items it alone draws tickets, polls counters and heads, shelves and helps, and leaves
-// the item it found ready in LDS (s_geo); the other waves wait at the barrier.  Nothing of that bookkeeping is live across the tile body
-// (whose 126 VGPRs / ~80 SGPRs leave no room for it): the body reads the item's geometry from LDS, tile by tile.
-enum { PG_KIND = 0, PG_L, PG_X0, PG_Y0S, PG_ST_LO, PG_ST_HI, PG_SX_LO, PG_SX_HI, PG_CELL, PG_NSHELF, PG_NEXT, PG_WORDS };
+// DIAG (lab): 3 = nobody waits for anybody (FLUID_JACOBI_CHAIN=4: a timing probe whose RESULTS ARE NOT VALID); 4 = statistics (FLUID_CHAIN_STATS)
+// How a workgroup spends the time BETWEEN two items decides what this launch costs.  The first form — draw, decode and poll between two
+// items, all eight waves waiting for wave 0 — spent as long there as in the tile body (profiles/r06/pchain_v3_time_breakdown_first_form.txt:
+// a few hundred instructions on a SIMD shared with the other workgroup's tile arithmetic, three memory round trips in a row).  This form
+// leaves NOTHING between two items in the steady state — less than a workgroup per tile can do, because it even overlaps the drain of one
+// item's stores with the next item's loads:
+//   * the next ticket is drawn in front of the stack's last tile's loads (one lane; the atomic's round trip is the loads') and parked in LDS;
+//   * two trips of sweeps before that tile ends, BETWEEN two sweeps (the tile's registers are all that is live there), wave 0 decodes the
+//     ticket and sends for the nine counters it depends on — an LDS-DMA load (global_load_lds: no destination register) that lands while the
+//     sweeps go on; one trip before the end it reads what came back and, if everything is there, posts the next item's geometry and READY;
+//   * behind the tile's stores the workgroup goes straight to the next item's loads; once those are out, each wave waits for its STORES only
+//     (s_waitcnt vmcnt(20): the loads stay in flight), one barrier, and the finished item is counted.
+// Only when the verdict is "not yet" (or there is no ticket: the first item, a hole, an exhausted head) does the workgroup drain, count, and
+// wave 0 run the CONTROL path: hold the ticket on the shelf, work on the held item of the lowest band, draw from a head that lags, spin
+// (fluid_pchain.h).
+enum { PG_KIND = 0, PG_L, PG_X0, PG_Y0S, PG_ST_LO, PG_ST_HI, PG_SX_LO, PG_SX_HI, PG_CELL, PG_WORDS };
+enum { CT_AHEAD = 0, CT_READY, CT_NSHELF, CT_WORDS };   // the ticket drawn ahead (or NONE) | item[next] is ready to run | items on the shelf
+enum { PR_VALID = 0, PR_L, PR_BY, PR_BX, PR_Q, PR_WORDS };   // the ticket being prepared between sweeps
 enum { PK_DONE = 0, PK_RUN = 1, PK_COUNT_ONLY = 2, PK_SKIP = 3 };   // nothing left | a stack to run | nothing to store here: count and go | a hole: go
+struct PChainLds {
+    int item[2][PG_WORDS];   // the item being run and the one after it
+    int ctl[CT_WORDS];
+    int pre[PR_WORDS];
+    unsigned int seen[16], want[16];        // lanes 0..8: what the counters around the next item read (landed by LDS-DMA), and what they must reach
+    unsigned int shelf[PCHAIN_SHELF];       // tickets this workgroup holds besides the item it runs (head << 28 | ticket)
+};
+constexpr int PCHAIN_NO_PENDING = -2;       // (-1: an item that is deliberately not counted — the lab's withheld item)
 template <int NW, int RY, int HX, int HY, int DIAG = 0>
 __global__ void __launch_bounds__(64 * NW, (2 * NW + 3) / 4) k_jacobi_pchain(Win w, float* __restrict__ pa, float* __restrict__ pb,
                                                                             const float* __restrict__ div, float pscale, PChainPlan plan,
@@ -1472,12 +1515,15 @@ __global__ void __launch_bounds__(64 * NW, (2 * NW + 3) / 4) k_jacobi_pchain(Win
     using S = JacobiStack<NW, RY, HX, HY>;
     constexpr int BOX = NW * 128, CARRY0 = 2 * BOX;
     __shared__ float4 sm[2 * BOX + 2 * HY * 64];   // two mailbox slots, two carry sets of HY lines (a tile writes one set while it reads the other)
-    __shared__ int s_geo[PG_WORDS];                 // the item the control wave found ready, and its own state between items
-    __shared__ unsigned int shelf[PCHAIN_SHELF];    // items put aside while this workgroup helps a head that lags (head << 28 | ticket)
+    __shared__ PChainLds L;
     // The plan, in LDS: read where it is used (a kernel argument's loads are hoisted to the kernel's entry and then live in SGPRs across the
     // tile body, which has none to spare — 65 spilled SGPRs and 160 bytes of scratch in the first form of this kernel)
     __shared__ PChainPlan sP;
     const int lane = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    constexpr bool STATS = DIAG == 4;
+    [[maybe_unused]] unsigned int st_items = 0, st_slow = 0, st_polls = 0, st_failed = 0, st_helps = 0;
+    [[maybe_unused]] unsigned long long st_wait = 0, st_ctrl = 0, st_t0 = 0;
+    if constexpr (STATS) st_t0 = __builtin_amdgcn_s_memrealtime();
     {
         const int* src = reinterpret_cast<const int*>(&plan);
         int* dst = reinterpret_cast<int*>(&sP);
@@ -1487,166 +1533,286 @@ __global__ void __launch_bounds__(64 * NW, (2 * NW + 3) / 4) k_jacobi_pchain(Win
         unsigned int* const other = state + (size_t)(plan.d.bank ^ 1) * plan.d.bank_words;
         for (int i = (int)blockIdx.x * 64 * NW + wv * 64 + lane; i < plan.d.bank_words; i += (int)gridDim.x * 64 * NW) other[i] = 0u;
     }
+    if (wv == 0 && lane == 0) {
+        L.ctl[CT_AHEAD] = (int)PCHAIN_NONE;
+        L.ctl[CT_READY] = 0;
+        L.ctl[CT_NSHELF] = 0;
+    }
+    if (plan.d.stagger > 0) {   // spread the workgroups' phases: a start delay of 0 ... stagger ticks, by a hash of the workgroup's number
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long d = ((unsigned long long)(((unsigned)blockIdx.x * 0x9E3779B1u) >> 22) * (unsigned long long)plan.d.stagger) >> 10;
+        while (__builtin_amdgcn_s_memrealtime() - t0 < d) __builtin_amdgcn_s_sleep(8);
+    }
     __syncthreads();
-    // the dimensions as wave-uniform values, re-read from LDS at every use site (cheap: a dozen ds_reads per item)
-    auto dims = [&]() -> PChainDims {
+    // the dimensions as wave-uniform values, re-read from LDS where they are used
+    auto dims = [&]() -> PChainDims {   // (field by field: a by-value struct filled through a pointer lands in scratch memory)
         PChainDims d;
-        const int* src = reinterpret_cast<const int*>(&sP.d);
-        int* dst = reinterpret_cast<int*>(&d);
-#pragma unroll
-        for (int i = 0; i < (int)(sizeof(PChainDims) / sizeof(int)); i++) dst[i] = __builtin_amdgcn_readfirstlane(src[i]);
-        return d;
+#define PD(f) d.f = __builtin_amdgcn_readfirstlane(sP.d.f)
+        PD(blocks); PD(nx); PD(ny); PD(xs); PD(ys); PD(stack); PD(np); PD(pw); PD(bh); PD(nrg); PD(nb); PD(slots); PD(bank); PD(bank_words); PD(withhold); PD(stagger);
+#undef PD
+        d.timeout = (unsigned)__builtin_amdgcn_readfirstlane((int)sP.d.timeout);
+#define PF(f) d.f = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sP.d.f)))
+        PF(r_slots); PF(r_pw); PF(r_nb); PF(r_np); PF(r_bh);
+#undef PF
+        return d;   // (cap[] stays in LDS: cap_of)
     };
+    auto cap_of = [&](int x) -> int { return __builtin_amdgcn_readfirstlane(sP.d.cap[x]); };
     auto state_of = [&](const PChainDims& C) -> unsigned int* { return state + (size_t)C.bank * C.bank_words; };
+    auto my_xcc = [&]() -> int { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u); };   // HW_REG_XCC_ID: where this workgroup runs — affinity only
     // draw (one lane): the next ticket of head x0 — or, when that sequence is exhausted, of the next head that is not; PCHAIN_NONE: nothing left
     auto draw_from = [&](const PChainDims& C, int x0) -> unsigned int {
         unsigned int* const mine = state_of(C);
         for (int k = 0; k < 8; k++) {
-            const int x = (x0 + k) & 7, cap = pchain_cap(C, x);
+            const int x = (x0 + k) & 7, cap = sP.d.cap[x];
             if (cap == 0) continue;
             const unsigned t = __hip_atomic_fetch_add(mine + x * PCHAIN_HEAD_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (t < (unsigned)cap) return ((unsigned)x << 28) | t;
         }
         return PCHAIN_NONE;
     };
-    if (wv == 0 && lane == 0) {
-        s_geo[PG_NSHELF] = 0;
-        s_geo[PG_NEXT] = (int)draw_from(dims(), (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u));   // HW_REG_XCC_ID: where this workgroup runs — affinity only
-    }
-    while (true) {
-        if (wv == 0) {
-            // ---- control: find the next item that may run (wave 0 only: no barrier in here; lanes talk through ballots) ----
-            // What this workgroup HOLDS is the shelf: the ticket drawn ahead at the end of the last item, items put aside, helper tickets.  It
-            // always works on the held item of the LOWEST band: then a chain of "spins on an item held by a workgroup that spins on ..." runs
-            // through strictly falling bands and ends at an item with nothing left to wait for (fluid_pchain.h; simulated in tests/pchain_check.cpp).
-            const PChainDims C = dims();
-            unsigned int* const mine = state_of(C);
-            int nshelf = __builtin_amdgcn_readfirstlane(s_geo[PG_NSHELF]);
-            {
-                const unsigned int ahead = (unsigned)__builtin_amdgcn_readfirstlane(s_geo[PG_NEXT]);
-                if (ahead != PCHAIN_NONE) {
-                    if (lane == 0) shelf[nshelf] = ahead;
-                    nshelf++;
-                }
-            }
-            unsigned int cur = PCHAIN_NONE;
-            int kind = PK_DONE, l = 0, by = 0, bx = 0, q = 0;
-            unsigned long long t_wait = 0;
-            bool waiting = false;
-            while (true) {
-                if (nshelf == 0) {   // nothing held: a fresh ticket, from the head of the XCD this workgroup runs on
-                    unsigned int got = 0;
-                    if (lane == 0) got = draw_from(C, (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u));
-                    cur = (unsigned)__builtin_amdgcn_readfirstlane((int)got);
-                    if (cur == PCHAIN_NONE) break;   // PK_DONE: every head is exhausted and nothing is held
-                    if (lane == 0) shelf[0] = cur;
-                    nshelf = 1;
-                }
-                // the held item of the lowest band (ties: the lowest ticket); lanes 0..nshelf-1 look at one shelf entry each
-                int pick = 0;
-                {
-                    unsigned key = 0xffffffffu;
-                    if (lane < nshelf) {
-                        const unsigned e = shelf[lane];
-                        key = ((((e & 0x0fffffffu) / (unsigned)C.slots) * 8u + (e >> 28)) << 5) | (unsigned)lane;   // band << 5 | shelf index (< 32)
-                    }
-#pragma unroll
-                    for (int o = 16; o > 0; o >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, o));   // (PCHAIN_SHELF = 32 entries: lanes 0..31)
-                    pick = __builtin_amdgcn_readfirstlane((int)(key & 31u));
-                }
-                cur = (unsigned)__builtin_amdgcn_readfirstlane((int)shelf[pick]);
-                const int hx = (int)(cur >> 28), ht = (int)(cur & 0x0fffffffu);
-                if (!pchain_item(C, hx, ht, l, by, bx, q)) kind = PK_SKIP;
-                else kind = PK_RUN;
-                bool go = kind == PK_SKIP || l == 0 || DIAG == 3;
-                if (!go) {
-                    // lanes 0..8: the counters of the cells of the 3 x 3 items around (by, bx) in block l - 1 (stack rows by-1..by+1 x the panels
-                    // of columns bx-1..bx+1; neighbours often share a cell: the same word, the same answer); lanes 16..24: have the bands
-                    // those cells belong to been DRAWN completely?  One memory round trip for all of it.
-                    bool ok = true;
-                    int lag_head = 0;
-                    {
-                        const int k = lane & 15, r = by - 1 + k / 3, c = bx - 1 + k % 3;
-                        if (k < 9 && (lane >> 4) < 2 && r >= 0 && r < C.ny && c >= 0 && c < C.nx) {
-                            const int pn = pchain_panel_of(C, c);
-                            if (lane < 16) {
-                                ok = __hip_atomic_load(mine + pchain_cell(C, l - 1, r, pn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)pchain_panel_width(C, pn);
-                            } else {
-                                const int qd = pchain_band_of(C, l - 1, r, pn);
-                                lag_head = qd & 7;
-                                ok = __hip_atomic_load(mine + lag_head * PCHAIN_HEAD_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)((qd >> 3) + 1) * (unsigned)C.slots;
-                            }
-                        }
-                    }
-                    const unsigned long long bad = __ballot(!ok);   // wave-uniform
-                    if ((bad & 0xffffull) == 0) go = true;          // every counter is there: run
-                    else if (bad & 0xffff0000ull) {
-                        // a band that is waited for has not been drawn completely: draw from that band's head and hold the ticket too — a
-                        // workgroup only ever SPINS on items that somebody holds
-                        if (nshelf == PCHAIN_SHELF) {   // cannot happen in a schedule that makes progress; never overflow, never hang
-                            if (lane == 0) __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                            go = true;
-                        } else {
-                            const int head = __builtin_amdgcn_readlane(lag_head, __builtin_ctzll(bad & 0xffff0000ull));
-                            unsigned int got = 0;
-                            if (lane == 0) got = draw_from(C, head);
-                            got = (unsigned)__builtin_amdgcn_readfirstlane((int)got);
-                            if (got != PCHAIN_NONE) {   // (NONE: others drew the rest of that band meanwhile — poll again)
-                                if (lane == 0) shelf[nshelf] = got;
-                                nshelf++;
-                            }
-                            waiting = false;
-                            continue;
-                        }
-                    } else {
-                        // all drawn, not all done: spin — bounded in wall-clock time, and nobody waits once somebody has given up
-                        if (!waiting) {
-                            waiting = true;
-                            t_wait = __builtin_amdgcn_s_memrealtime();
-                            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) go = true;
-                        }
-                        if (!go) {
-                            __builtin_amdgcn_s_sleep(2);
-                            if (__builtin_amdgcn_s_memrealtime() - t_wait > (unsigned long long)C.timeout) {
-                                if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                                go = true;   // run on stale data rather than hang the device; the host learns through err
-                            } else continue;
-                        }
-                    }
-                }
-                // take `cur` off the shelf (the last entry moves into its place)
-                nshelf--;
-                if (lane == 0 && pick != nshelf) shelf[pick] = shelf[nshelf];
-                break;
-            }
-            if (cur == PCHAIN_NONE) kind = PK_DONE;
-            if (kind == PK_RUN) {   // the geometry of the stack, for every wave
-                const int x0 = C.xs + bx * G::VX, y0s = C.ys + by * (S::span(C.stack) - 2 * HY);
-                int st_lo, st_hi, sx_lo, sx_hi;
-                tile_exact(y0s, S::span(C.stack), HY, w.H, __builtin_amdgcn_readfirstlane(sP.ga[l]), __builtin_amdgcn_readfirstlane(sP.gb[l]), st_lo, st_hi);
-                tile_exact(x0, G::TX, HX, w.W, __builtin_amdgcn_readfirstlane(sP.xa[l]), __builtin_amdgcn_readfirstlane(sP.xb[l]), sx_lo, sx_hi);
-                if (st_hi <= st_lo || sx_hi <= sx_lo) kind = PK_COUNT_ONLY;   // this block's ranges do not reach this stack — no reads, no writes
-                if (lane == 0) {
-                    s_geo[PG_L] = l;
-                    s_geo[PG_X0] = x0;
-                    s_geo[PG_Y0S] = y0s;
-                    s_geo[PG_ST_LO] = st_lo;
-                    s_geo[PG_ST_HI] = st_hi;
-                    s_geo[PG_SX_LO] = sx_lo;
-                    s_geo[PG_SX_HI] = sx_hi;
-                    s_geo[PG_CELL] = (C.withhold >= 0 && q == C.withhold && ((int)(cur & 0x0fffffffu) % C.slots) == 0) ? -1 : pchain_cell(C, l, by, pchain_panel_of(C, bx));
-                }
-            }
-            if (lane == 0) {
-                s_geo[PG_KIND] = kind;
-                s_geo[PG_NSHELF] = nshelf;
+    // a decoded item's geometry into item[slot] (lane 0 of wave 0); returns its kind
+    auto post_item = [&](const PChainDims& C, int slot, unsigned int tkw, int l, int by, int bx, int q) -> int {
+        const int x0 = C.xs + bx * G::VX, y0s = C.ys + by * (S::span(C.stack) - 2 * HY);
+        int st_lo, st_hi, sx_lo, sx_hi;
+        tile_exact(y0s, S::span(C.stack), HY, w.H, __builtin_amdgcn_readfirstlane(sP.ga[l]), __builtin_amdgcn_readfirstlane(sP.gb[l]), st_lo, st_hi);
+        tile_exact(x0, G::TX, HX, w.W, __builtin_amdgcn_readfirstlane(sP.xa[l]), __builtin_amdgcn_readfirstlane(sP.xb[l]), sx_lo, sx_hi);
+        const int kind = (st_hi <= st_lo || sx_hi <= sx_lo) ? PK_COUNT_ONLY : PK_RUN;   // (COUNT_ONLY: this block's ranges do not reach this stack — no reads, no writes)
+        if (lane == 0) {
+            int* g = L.item[slot];
+            g[PG_KIND] = kind;
+            g[PG_L] = l;
+            g[PG_X0] = x0;
+            g[PG_Y0S] = y0s;
+            g[PG_ST_LO] = st_lo;
+            g[PG_ST_HI] = st_hi;
+            g[PG_SX_LO] = sx_lo;
+            g[PG_SX_HI] = sx_hi;
+            g[PG_CELL] = (C.withhold >= 0 && q == C.withhold && ((int)(tkw & 0x0fffffffu) % C.slots) == 0) ? -1 : pchain_cell(C, l, by, pchain_panel_of(C, bx));
+        }
+        return kind;
+    };
+    // the nine counters around (l, by, bx) in block l - 1 (lanes 0..8) and, with BANDS, whether the bands they belong to have been drawn
+    // completely (lanes 16..24): one memory round trip.  Returns what each lane found (true where a lane has nothing to look at).
+    auto poll = [&](const PChainDims& C, int l, int by, int bx, int& lag_head) -> bool {
+        unsigned int* const mine = state_of(C);
+        bool ok = true;
+        lag_head = 0;
+        const int k = lane & 15, r = by - 1 + k / 3, c = bx - 1 + k % 3;
+        if (k < 9 && (lane >> 4) < 2 && r >= 0 && r < C.ny && c >= 0 && c < C.nx) {
+            const int pn = pchain_panel_of(C, c);
+            if (lane < 16) {
+                ok = __hip_atomic_load(mine + pchain_cell(C, l - 1, r, pn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)pchain_panel_width(C, pn);
+            } else {
+                const int qd = pchain_band_of(C, l - 1, r, pn);
+                lag_head = qd & 7;
+                ok = __hip_atomic_load(mine + lag_head * PCHAIN_HEAD_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)((qd >> 3) + 1) * (unsigned)C.slots;
             }
         }
-        __syncthreads();
-        const int kind = __builtin_amdgcn_readfirstlane(s_geo[PG_KIND]);
+        return ok;
+    };
+
+    int slot = 0, pending = PCHAIN_NO_PENDING;   // pending: the cell of an item whose stores are still draining (counted behind the next item's loads)
+    // ---- the hooks of the tile body ----
+    auto after_loads = [&]() {
+        if (pending != PCHAIN_NO_PENDING) {   // block-uniform
+            asm volatile("s_waitcnt vmcnt(20)" ::: "memory");   // this wave's stores of the item before are through (the 20 loads just issued stay in flight)
+            __builtin_amdgcn_s_barrier();                        // ... and every other wave's
+            if (wv == 0 && lane == 0 && pending >= 0)
+                __hip_atomic_fetch_add(state + (size_t)sP.d.bank * sP.d.bank_words + pending, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pending = PCHAIN_NO_PENDING;
+        }
+    };
+    auto pre_a = [&]() {   // wave 0, between two sweeps: decode the ticket drawn ahead, send for the counters it depends on
+        if (wv != 0) return;
+        __builtin_amdgcn_s_setprio(3);
+        const unsigned int tkw = (unsigned)__builtin_amdgcn_readfirstlane(L.ctl[CT_AHEAD]);
+        int valid = 0, l = 0, by = 0, bx = 0, q = 0;
+        if (tkw != PCHAIN_NONE) {
+            const PChainDims C = dims();
+            const int hx = (int)(tkw >> 28), ht = (int)(tkw & 0x0fffffffu);
+            if (ht < cap_of(hx) && pchain_item(C, hx, ht, l, by, bx, q)) {   // (an exhausted head, a hole: the control path deals with it)
+                valid = 1;
+                unsigned int need = 0;
+                int word = 0;   // (a lane with nothing to look at reads head 0 and wants nothing of it)
+                const int r = by - 1 + lane / 3, c = bx - 1 + lane % 3;
+                if (l > 0 && DIAG != 3 && lane < 9 && r >= 0 && r < C.ny && c >= 0 && c < C.nx) {
+                    const int pn = pchain_panel_of(C, c);
+                    need = (unsigned)pchain_panel_width(C, pn);
+                    word = pchain_cell(C, l - 1, r, pn);
+                }
+                if (lane < 16) {
+                    L.want[lane] = need;
+                    // lane k's word lands in seen[k]; aux 16 = sc1: past this CU's L1.  (The LDS base travels in M0: handed over as a wave-uniform
+                    // value explicitly — through the closure the backend takes it for a per-lane one: "illegal VGPR to SGPR copy")
+                    typedef __attribute__((address_space(3))) unsigned int lds_u32;
+                    lds_u32* const dst = (lds_u32*)(size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(lds_u32*)L.seen);
+                    __builtin_amdgcn_global_load_lds(state_of(C) + word, dst, 4, 0, 16);
+                }
+            }
+        }
+        if (lane == 0) {
+            L.pre[PR_VALID] = valid;
+            L.pre[PR_L] = l;
+            L.pre[PR_BY] = by;
+            L.pre[PR_BX] = bx;
+            L.pre[PR_Q] = q;
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto pre_b = [&]() {   // wave 0, one trip later: what came back?  Everything there: post the next item, READY
+        if (wv != 0) return;
+        __builtin_amdgcn_s_setprio(3);
+        bool ready = false;
+        if (__builtin_amdgcn_readfirstlane(L.pre[PR_VALID]) != 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA has landed (nothing else of this wave is in flight between sweeps)
+            const bool ok = lane >= 16 || L.seen[lane] >= L.want[lane];
+            const unsigned long long bad = __ballot(!ok);
+            if constexpr (STATS) {
+                st_polls++;
+                st_failed += bad != 0;
+            }
+            if (bad == 0) {
+                const PChainDims C = dims();
+                const unsigned int tkw = (unsigned)__builtin_amdgcn_readfirstlane(L.ctl[CT_AHEAD]);
+                ready = post_item(C, slot ^ 1, tkw, __builtin_amdgcn_readfirstlane(L.pre[PR_L]), __builtin_amdgcn_readfirstlane(L.pre[PR_BY]),
+                                  __builtin_amdgcn_readfirstlane(L.pre[PR_BX]), __builtin_amdgcn_readfirstlane(L.pre[PR_Q])) == PK_RUN;
+            }
+        }
+        if (lane == 0) {
+            L.ctl[CT_READY] = ready ? 1 : 0;
+            if (ready) L.ctl[CT_AHEAD] = (int)PCHAIN_NONE;   // (not ready: the control path puts the ticket on the shelf)
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto no_hook = [&]() {};
+
+    while (true) {
+        if (__builtin_amdgcn_readfirstlane(L.ctl[CT_READY]) == 0) {
+            if (wv == 0) {
+                // ---- the CONTROL path: find an item that may run (wave 0 only: no barrier in here; lanes talk through ballots) ----
+                // What this workgroup HOLDS is the shelf (the ticket drawn ahead, helper tickets, items put aside).  It always works on the held
+                // item of the LOWEST band: a chain of "spins on an item held by a workgroup that spins on ..." then runs through strictly
+                // falling bands and ends at an item with nothing left to wait for (fluid_pchain.h; simulated in tests/pchain_check.cpp).
+                __builtin_amdgcn_s_setprio(3);
+                [[maybe_unused]] unsigned long long st_mark = 0;
+                if constexpr (STATS) {
+                    st_mark = __builtin_amdgcn_s_memrealtime();
+                    st_slow++;
+                }
+                const PChainDims C = dims();
+                int nshelf = __builtin_amdgcn_readfirstlane(L.ctl[CT_NSHELF]);
+                {
+                    const unsigned int ahead = (unsigned)__builtin_amdgcn_readfirstlane(L.ctl[CT_AHEAD]);
+                    // (a ticket drawn ahead comes straight from the head's counter: beyond the sequence's end it is no ticket at all)
+                    if (ahead != PCHAIN_NONE && (int)(ahead & 0x0fffffffu) < cap_of((int)(ahead >> 28))) {
+                        if (lane == 0) L.shelf[nshelf] = ahead;
+                        nshelf++;
+                    }
+                }
+                unsigned int cur = PCHAIN_NONE;
+                int kind = PK_DONE, l = 0, by = 0, bx = 0, q = 0;
+                unsigned long long t_wait = 0, t_err = 0;
+                bool waiting = false;
+                while (true) {
+                    if (nshelf == 0) {   // nothing held: a fresh ticket, from the head of the XCD this workgroup runs on
+                        unsigned int got = 0;
+                        if (lane == 0) got = draw_from(C, my_xcc());
+                        cur = (unsigned)__builtin_amdgcn_readfirstlane((int)got);
+                        if (cur == PCHAIN_NONE) break;   // PK_DONE: every head is exhausted and nothing is held
+                        if (lane == 0) L.shelf[0] = cur;
+                        nshelf = 1;
+                    }
+                    // the held item of the lowest band (ties: the lowest ticket); lanes 0..nshelf-1 look at one shelf entry each
+                    int pick = 0;
+                    if (nshelf > 1) {
+                        unsigned key = 0xffffffffu;
+                        if (lane < nshelf) {
+                            const unsigned e = L.shelf[lane];
+                            key = (((unsigned)pchain_div((int)(e & 0x0fffffffu), C.slots, C.r_slots) * 8u + (e >> 28)) << 5) | (unsigned)lane;   // band << 5 | shelf index (< 32)
+                        }
+#pragma unroll
+                        for (int o = 16; o > 0; o >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, o));   // (PCHAIN_SHELF = 32 entries: lanes 0..31)
+                        pick = __builtin_amdgcn_readfirstlane((int)(key & 31u));
+                    }
+                    cur = (unsigned)__builtin_amdgcn_readfirstlane((int)L.shelf[pick]);
+                    if (!pchain_item(C, (int)(cur >> 28), (int)(cur & 0x0fffffffu), l, by, bx, q)) kind = PK_SKIP;
+                    else kind = PK_RUN;
+                    bool go = kind == PK_SKIP || l == 0 || DIAG == 3;
+                    if (!go) {
+                        int lag_head;
+                        const bool ok = poll(C, l, by, bx, lag_head);
+                        const unsigned long long bad = __ballot(!ok);   // wave-uniform
+                        if constexpr (STATS) {
+                            st_polls++;
+                            st_failed += (bad & 0xffffull) != 0;
+                        }
+                        if ((bad & 0xffffull) == 0) go = true;          // every counter is there: run
+                        else if (bad & 0xffff0000ull) {
+                            // a band that is waited for has not been drawn completely: draw from that band's head and hold the ticket too — a
+                            // workgroup only ever SPINS on items that somebody holds
+                            if (nshelf == PCHAIN_SHELF) {   // cannot happen in a schedule that makes progress; never overflow, never hang
+                                if (lane == 0) __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                go = true;
+                            } else {
+                                const int head = __builtin_amdgcn_readlane(lag_head, __builtin_ctzll(bad & 0xffff0000ull));
+                                unsigned int got = 0;
+                                if (lane == 0) got = draw_from(C, head);
+                                got = (unsigned)__builtin_amdgcn_readfirstlane((int)got);
+                                if constexpr (STATS) st_helps++;
+                                if (got != PCHAIN_NONE) {   // (NONE: others drew the rest of that band meanwhile — poll again)
+                                    if (lane == 0) L.shelf[nshelf] = got;
+                                    nshelf++;
+                                }
+                                waiting = false;
+                                continue;
+                            }
+                        } else {
+                            // all drawn, not all done: spin — bounded in wall-clock time, and nobody waits once somebody has given up
+                            if (!waiting) {
+                                waiting = true;
+                                t_wait = __builtin_amdgcn_s_memrealtime();
+                            }
+                            __builtin_amdgcn_s_sleep(1);
+                            const unsigned long long waited = __builtin_amdgcn_s_memrealtime() - t_wait;
+                            // (err lives in HOST memory — a read is a PCIe round trip: only a workgroup that has waited 100 us looks, every 100 us)
+                            if (waited > 10000ull && waited - t_err > 10000ull) {
+                                t_err = waited;
+                                if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) go = true;
+                            }
+                            if (waited > (unsigned long long)C.timeout) {
+                                if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                go = true;   // run on stale data rather than hang the device; the host learns through err
+                            }
+                            if (!go) continue;
+                        }
+                    }
+                    // take `cur` off the shelf (the last entry moves into its place)
+                    nshelf--;
+                    if (lane == 0 && pick != nshelf) L.shelf[pick] = L.shelf[nshelf];
+                    break;
+                }
+                if (cur == PCHAIN_NONE) kind = PK_DONE;
+                if (kind == PK_RUN) kind = post_item(C, slot, cur, l, by, bx, q);
+                if (lane == 0) {
+                    if (kind != PK_RUN && kind != PK_COUNT_ONLY) L.item[slot][PG_KIND] = kind;
+                    L.ctl[CT_NSHELF] = nshelf;
+                    L.ctl[CT_AHEAD] = (int)PCHAIN_NONE;
+                }
+                if constexpr (STATS) {
+                    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                    st_ctrl += now - st_mark;
+                    if (waiting) st_wait += now - t_wait;
+                }
+                __builtin_amdgcn_s_setprio(0);
+            }
+            __syncthreads();
+        }
+        const int kind = __builtin_amdgcn_readfirstlane(L.item[slot][PG_KIND]);
         if (kind == PK_DONE) break;
+        bool hooked = false;
         if (kind == PK_RUN) {
-            const int l = __builtin_amdgcn_readfirstlane(s_geo[PG_L]);
+            if constexpr (STATS) st_items++;
+            const int l = __builtin_amdgcn_readfirstlane(L.item[slot][PG_L]);
             Win wl = w;
             wl.x0 = __builtin_amdgcn_readfirstlane(sP.xa[l]);
             wl.x1 = __builtin_amdgcn_readfirstlane(sP.xb[l]);
@@ -1656,9 +1822,10 @@ __global__ void __launch_bounds__(64 * NW, (2 * NW + 3) / 4) k_jacobi_pchain(Win
             const float ps = l == 0 ? pscale : 1.0f;
             const int iters = __builtin_amdgcn_readfirstlane(sP.iters[l]), stack = __builtin_amdgcn_readfirstlane(sP.d.stack);
             for (int t = 0; t < stack; t++) {
-                const int x0 = __builtin_amdgcn_readfirstlane(s_geo[PG_X0]), y0s = __builtin_amdgcn_readfirstlane(s_geo[PG_Y0S]);
-                const int st_lo = __builtin_amdgcn_readfirstlane(s_geo[PG_ST_LO]), st_hi = __builtin_amdgcn_readfirstlane(s_geo[PG_ST_HI]);
-                const int sx_lo = __builtin_amdgcn_readfirstlane(s_geo[PG_SX_LO]), sx_hi = __builtin_amdgcn_readfirstlane(s_geo[PG_SX_HI]);
+                const int* g = L.item[slot];
+                const int x0 = __builtin_amdgcn_readfirstlane(g[PG_X0]), y0s = __builtin_amdgcn_readfirstlane(g[PG_Y0S]);
+                const int st_lo = __builtin_amdgcn_readfirstlane(g[PG_ST_LO]), st_hi = __builtin_amdgcn_readfirstlane(g[PG_ST_HI]);
+                const int sx_lo = __builtin_amdgcn_readfirstlane(g[PG_SX_LO]), sx_hi = __builtin_amdgcn_readfirstlane(g[PG_SX_HI]);
                 const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(p, 0, bytes, 0x00020000);
                 const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(p_out, 0, bytes, 0x00020000);
                 const bool xedge = (x0 <= 0) || (x0 + G::TX >= w.W), ragged = (w.W & 3) != 0 && x0 + G::TX >= w.W;
@@ -1667,21 +1834,48 @@ __global__ void __launch_bounds__(64 * NW, (2 * NW + 3) / 4) k_jacobi_pchain(Win
                 stack_tile_rows(y0s, t, G::TY, HY, w.H, st_lo, st_hi, yt, a, b, last);
                 const int cin = t > 0 ? CARRY0 + ((t - 1) & 1) * HY * 64 : -1, cout = last ? -1 : CARRY0 + (t & 1) * HY * 64;
                 const bool yedge = (yt <= 0) || (yt + G::TY >= w.H);
+                // the stack's last tile draws the workgroup's next ticket with its loads — unless something is held already (then that is next)
+                unsigned int* head = nullptr;
+                unsigned int tag = 0;
+                if (last && __builtin_amdgcn_readfirstlane(L.ctl[CT_NSHELF]) == 0) {
+                    const int x = my_xcc();
+                    if (cap_of(x) > 0) {
+                        head = state + (size_t)__builtin_amdgcn_readfirstlane(sP.d.bank) * __builtin_amdgcn_readfirstlane(sP.d.bank_words) + x * PCHAIN_HEAD_STRIDE;
+                        tag = (unsigned)x << 28;
+                    }
+                }
+                hooked = last;
                 if (t > 0) __syncthreads();   // the last sweep's mailbox readers are through before the next tile's first sweep publishes
-                if (yedge || ragged) jacobi_stack_tile<NW, RY, HX, HY, 2, true>(wl, rin, rout, p, p_out, div, ps, iters, x0, yt, a, b, sx_lo, sx_hi, sm, cin, cout);
-                else if (xedge) jacobi_stack_tile<NW, RY, HX, HY, 1, true>(wl, rin, rout, p, p_out, div, ps, iters, x0, yt, a, b, sx_lo, sx_hi, sm, cin, cout);
-                else jacobi_stack_tile<NW, RY, HX, HY, 0, true>(wl, rin, rout, p, p_out, div, ps, iters, x0, yt, a, b, sx_lo, sx_hi, sm, cin, cout);
+                if (yedge || ragged)
+                    jacobi_stack_tile<NW, RY, HX, HY, 2, true>(wl, rin, rout, p, p_out, div, ps, iters, x0, yt, a, b, sx_lo, sx_hi, sm, cin, cout, head, tag, &L.ctl[CT_AHEAD], last, after_loads, pre_a, pre_b);
+                else if (xedge)
+                    jacobi_stack_tile<NW, RY, HX, HY, 1, true>(wl, rin, rout, p, p_out, div, ps, iters, x0, yt, a, b, sx_lo, sx_hi, sm, cin, cout, head, tag, &L.ctl[CT_AHEAD], last, after_loads, pre_a, pre_b);
+                else
+                    jacobi_stack_tile<NW, RY, HX, HY, 0, true>(wl, rin, rout, p, p_out, div, ps, iters, x0, yt, a, b, sx_lo, sx_hi, sm, cin, cout, head, tag, &L.ctl[CT_AHEAD], last, after_loads, pre_a, pre_b);
                 if (last) break;
             }
         }
-        // the next item: from the shelf if something waits there, else a fresh ticket — drawn HERE, so that its round trip overlaps the drain
-        if (wv == 0 && lane == 0)
-            s_geo[PG_NEXT] = s_geo[PG_NSHELF] > 0 ? (int)PCHAIN_NONE : (int)draw_from(dims(), (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u));
-        // done: every storing wave drains its write-through stores, then ONE lane counts the item (the guide's R1 hand-off)
-        if (kind == PK_RUN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // The stores are out.  READY (posted in front of the tile's last trip of sweeps: a barrier ago): on to the next item's loads, this one is
+        // counted behind them.  Otherwise: drain, count, and the control path finds the next item.
+        if (hooked && __builtin_amdgcn_readfirstlane(L.ctl[CT_READY]) != 0) {
+            pending = __builtin_amdgcn_readfirstlane(L.item[slot][PG_CELL]);
+            slot ^= 1;
+            continue;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores, then ONE lane counts the item (the guide's R1 hand-off)
+        if (wv == 0 && lane == 0) L.ctl[CT_READY] = 0;
         __syncthreads();
-        if (wv == 0 && lane == 0 && kind != PK_SKIP && s_geo[PG_CELL] >= 0)
-            __hip_atomic_fetch_add(state_of(dims()) + s_geo[PG_CELL], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wv == 0 && lane == 0 && kind != PK_SKIP) {
+            const int cell = L.item[slot][PG_CELL];
+            if (cell >= 0) __hip_atomic_fetch_add(state + (size_t)sP.d.bank * sP.d.bank_words + cell, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if constexpr (STATS) {
+        if (wv == 0 && lane == 0) {
+            const unsigned int v[9] = { st_items, st_slow, st_polls, st_failed, st_helps, (unsigned)st_wait, (unsigned)st_ctrl,
+                                        (unsigned)(__builtin_amdgcn_s_memrealtime() - st_t0), 1u };
+            for (int i = 0; i < 9; i++) __hip_atomic_fetch_add(err + 8 + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -3701,9 +3895,7 @@ void pchain_layout(PChainPlan& C)
         }
     }
     C.d.bh = f_bh > 0 ? f_bh : best;
-    C.d.nrg = (C.d.ny + C.d.bh - 1) / C.d.bh;
-    C.d.nb = C.d.nrg * C.d.np;
-    C.d.slots = C.d.pw * C.d.bh;
+    pchain_finish(C.d);
 }
 
 // stacks of M tiles: tile rows per launch / M stack rows.  M = 2 by default (0.8125 of the arithmetic stored instead of 0.75; M = 3: 0.833 and
@@ -3738,11 +3930,12 @@ hipError_t launch_jacobi_pchain_ranges(hipStream_t s, Win w, float* pa, float* p
     C.d.ys = ay.S;
     pchain_layout(C);
     if (C.d.ny * C.d.np > PCHAIN_MAX_CELLS || C.d.nx >= 4096 || C.d.ny >= 4096) return hipErrorNotReady;
-    C.d.bank_words = pchain_bank_words(C.d);
     static const int timeout_ms = pchain_knob("FLUID_CHAIN_TIMEOUT_MS", 2000);
     C.d.timeout = (unsigned int)timeout_ms * 100000u;
     static const int withhold = pchain_knob("FLUID_CHAIN_WITHHOLD", -1);
     C.d.withhold = withhold;
+    static const int stagger_us = pchain_knob("FLUID_CHAIN_STAGGER_US", 0);
+    C.d.stagger = stagger_us * 100;
     // the state words: zeroed when the shape of the call changes, else the half the previous call of this shape zeroed for us
     const unsigned sig = (unsigned)C.d.nx | ((unsigned)C.d.ny << 10) | ((unsigned)nblocks << 20) | ((unsigned)C.d.stack << 25) | ((unsigned)C.d.bh << 28);
     const unsigned sig2 = (unsigned)C.d.pw;
@@ -3763,7 +3956,21 @@ hipError_t launch_jacobi_pchain_ranges(hipStream_t s, Win w, float* pa, float* p
     const long items = (long)C.d.blocks * C.d.nx * C.d.ny;
     const unsigned grid = (unsigned)std::max(1l, std::min(items, (long)(f_grid > 0 ? f_grid : 2 * cus)));
 #ifdef FLUID_PROBES
-    if (jacobi_chain_mode() == 4) k_jacobi_pchain<8, 10, 12, 10, 3><<<dim3(grid), dim3(64, 8), 0, s>>>(w, pa, pb, div, pscale, C, state, err);
+    static const int stats = pchain_knob("FLUID_CHAIN_STATS", 0);
+    if (stats) {
+        static unsigned int* g_err = nullptr;
+        static long g_calls = 0;
+        g_err = err;
+        if (g_calls > 0 && g_calls % 60 == 0) {   // (the host reads the mapped words while launches are in flight: a running total, good enough for a breakdown)
+            const unsigned int* v = g_err + 8;
+            const double wg = v[8] ? (double)v[8] : 1.0, n = wg / (double)grid;
+            fprintf(stderr, "pchain stats after ~%.0f launches: per launch: stacks run %.0f, control-path entries %.0f, polls %.0f of which not ready %.0f, helper draws %.0f | "
+                            "per workgroup per launch (us): waiting %.1f, in the control path %.1f (incl. waiting), lifetime %.1f | workgroups per launch %u\n",
+                    n, v[0] / n, v[1] / n, v[2] / n, v[3] / n, v[4] / n, v[5] / wg / 100.0, v[6] / wg / 100.0, v[7] / wg / 100.0, grid);
+        }
+        g_calls++;
+        k_jacobi_pchain<8, 10, 12, 10, 4><<<dim3(grid), dim3(64, 8), 0, s>>>(w, pa, pb, div, pscale, C, state, err);
+    } else if (jacobi_chain_mode() == 4) k_jacobi_pchain<8, 10, 12, 10, 3><<<dim3(grid), dim3(64, 8), 0, s>>>(w, pa, pb, div, pscale, C, state, err);
     else
 #endif
         k_jacobi_pchain<8, 10, 12, 10, 0><<<dim3(grid), dim3(64, 8), 0, s>>>(w, pa, pb, div, pscale, C, state, err);

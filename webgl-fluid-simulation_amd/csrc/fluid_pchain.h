@@ -44,7 +44,14 @@ struct PChainDims {
     int slots;            // ticket slots per band = pw * bh
     int bank, bank_words; // which half of the state words this call counts in (it zeroes the other half for the next call); words per half
     unsigned int timeout; // 100 MHz ticks a workgroup waits for a dependency before it gives up (sets err, computes on stale data)
+    int stagger;          // 100 MHz ticks over which the workgroups' first loads are spread (k_jacobi_pchain: persistent workgroups all start at
+                          // once and, with equal items, STAY in phase: every tile on the chip loads, iterates and stores at the same time)
     int withhold;         // lab (FLUID_CHAIN_WITHHOLD): the item of band `withhold`, slot 0 never counts itself — forces the give-up path; -1 = off
+    // derived (pchain_finish): reciprocals for the divisions of the decode — a workgroup decodes a ticket between two items, on a SIMD it shares
+    // with the other workgroup's tile arithmetic, and a 32-bit integer division is ~35 instructions there, a multiply-and-correct 7 —
+    // and how many tickets each head's sequence has
+    float r_slots, r_pw, r_nb, r_np, r_bh;
+    int cap[8];
 };
 struct PChainPlan {
     PChainDims d;
@@ -53,24 +60,29 @@ struct PChainPlan {
     int ga[PCHAIN_MAX_BLOCKS], gb[PCHAIN_MAX_BLOCKS];   // texels each: the ranges shrink; the tiling is block 0's — the widest — for all of them)
 };
 
+// a / b for 0 <= a < 2^24, b >= 1, rb = 1.0f / b: the float product is within one of the quotient; one correction makes it exact
+__host__ __device__ __forceinline__ int pchain_div(int a, int b, float rb)
+{
+    int q = (int)((float)a * rb);
+    const int r = a - q * b;
+    q += (r >= b) - (r < 0);
+    return q;
+}
+
 __host__ __device__ __forceinline__ int pchain_total_bands(const PChainDims& C) { return C.blocks * C.nb; }
 // tickets in the sequence of XCD x: its bands x, x + 8, ... below the total, `slots` each
-__host__ __device__ __forceinline__ int pchain_cap(const PChainDims& C, int x)
-{
-    const int tb = pchain_total_bands(C);
-    return x < tb ? ((tb - x + 7) / 8) * C.slots : 0;
-}
-__host__ __device__ __forceinline__ int pchain_panel_of(const PChainDims& C, int bx) { return bx / C.pw; }
+__host__ __device__ __forceinline__ int pchain_cap(const PChainDims& C, int x) { return C.cap[x]; }
+__host__ __device__ __forceinline__ int pchain_panel_of(const PChainDims& C, int bx) { return pchain_div(bx, C.pw, C.r_pw); }
 __host__ __device__ __forceinline__ int pchain_panel_width(const PChainDims& C, int pn) { return min(C.pw, C.nx - pn * C.pw); }
 // global band number of the band that holds stack row `by`, panel `pn` of block l
-__host__ __device__ __forceinline__ int pchain_band_of(const PChainDims& C, int l, int by, int pn) { return l * C.nb + (by / C.bh) * C.np + pn; }
+__host__ __device__ __forceinline__ int pchain_band_of(const PChainDims& C, int l, int by, int pn) { return l * C.nb + pchain_div(by, C.bh, C.r_bh) * C.np + pn; }
 // ticket t of XCD x's sequence -> (l, by, bx) and its global band; false: a hole (a slot of a ragged band beyond the grid)
 __host__ __device__ __forceinline__ bool pchain_item(const PChainDims& C, int x, int t, int& l, int& by, int& bx, int& q)
 {
-    const int i = t / C.slots, j = t - i * C.slots;
+    const int i = pchain_div(t, C.slots, C.r_slots), j = t - i * C.slots;
     q = i * 8 + x;
-    l = q / C.nb;
-    const int qb = q - l * C.nb, rg = qb / C.np, pn = qb - rg * C.np, jy = j / C.pw, jx = j - jy * C.pw;
+    l = pchain_div(q, C.nb, C.r_nb);
+    const int qb = q - l * C.nb, rg = pchain_div(qb, C.np, C.r_np), pn = qb - rg * C.np, jy = pchain_div(j, C.pw, C.r_pw), jx = j - jy * C.pw;
     by = rg * C.bh + jy;
     bx = pn * C.pw + jx;
     return by < C.ny && bx < C.nx;
@@ -78,6 +90,22 @@ __host__ __device__ __forceinline__ bool pchain_item(const PChainDims& C, int x,
 // words of state per half: the eight heads, then one counter per (block, stack row, panel)
 __host__ __device__ __forceinline__ int pchain_cell(const PChainDims& C, int l, int by, int pn) { return 8 * PCHAIN_HEAD_STRIDE + (l * C.ny + by) * C.np + pn; }
 __host__ __device__ __forceinline__ int pchain_bank_words(const PChainDims& C) { return 8 * PCHAIN_HEAD_STRIDE + C.blocks * C.ny * C.np; }
+// blocks, nx, ny, stack, pw, bh set: everything that follows from them
+__host__ inline void pchain_finish(PChainDims& C)
+{
+    C.np = (C.nx + C.pw - 1) / C.pw;
+    C.nrg = (C.ny + C.bh - 1) / C.bh;
+    C.nb = C.nrg * C.np;
+    C.slots = C.pw * C.bh;
+    C.r_slots = 1.0f / (float)C.slots;
+    C.r_pw = 1.0f / (float)C.pw;
+    C.r_nb = 1.0f / (float)C.nb;
+    C.r_np = 1.0f / (float)C.np;
+    C.r_bh = 1.0f / (float)C.bh;
+    const int tb = C.blocks * C.nb;
+    for (int x = 0; x < 8; x++) C.cap[x] = x < tb ? ((tb - x + 7) / 8) * C.slots : 0;
+    C.bank_words = pchain_bank_words(C);
+}
 
 // geometry of a stack of M tiles of JacobiTB<NW, RY, HX, HY>: the span it reads, what it stores, where its tiles start
 template <int NW, int RY, int HX, int HY>

@@ -363,8 +363,8 @@ int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launche
             if (fluid::jacobi_chain_applies(w, ra[0], rb[0], iters - done)) {
                 if (!c->chain_flags) {
                     HIPCK(c, hipMalloc((void**)&c->chain_flags, fluid::jacobi_chain_flag_bytes()));
-                    HIPCK(c, hipHostMalloc((void**)&c->chain_err_host, 2 * sizeof(unsigned int), hipHostMallocMapped));
-                    c->chain_err_host[0] = c->chain_err_host[1] = 0;
+                    HIPCK(c, hipHostMalloc((void**)&c->chain_err_host, 64 * sizeof(unsigned int), hipHostMallocMapped));
+                    for (int k = 0; k < 64; k++) c->chain_err_host[k] = 0;   // [0]: a chained launch gave up; [1]: lab ticket word; [8..31]: lab statistics (FLUID_CHAIN_STATS)
                     HIPCK(c, hipHostGetDevicePointer((void**)&c->chain_err_dev, c->chain_err_host, 0));
                 }
                 const hipError_t e = fluid::launch_jacobi_tb_chain_ranges(c->stream, w, (float*)c->prs[0], (float*)c->prs[1], (const float*)c->div,
