@@ -1063,27 +1063,45 @@ __device__ __forceinline__ Quad jacobi_row(Quad C, Quad T, Quad B, const Quad D,
 // neighbouring waves (LDS mailbox, `box` is this iteration's slot); every other row only needs the wave's own
 // registers.  So: publish, sweep the inner rows (one delay register carries the old row below), THEN meet the other
 // waves at the barrier and finish the two outer rows — the mailbox round trip hides behind RY - 2 rows of arithmetic.
-template <int NW, int RY, int EDGE, bool HALF>
+// SKIP (round 6): the rows of the tile's first and last wave that the apron has already reached are not swept any more.  After k iterations the
+// outer k rows of a tile are stale (nobody reads them again: the next iteration's valid rows only look one row out); sweeping them all the
+// same is 110 of the 800 row sweeps of an 80-row tile.  rows [lo_skip, RY - hi_skip) of this wave are swept (wave-uniform; 0, 0 = all).
+// NOSYNC (lab probe, results NOT valid): no mailbox, no barrier — what the exchange between the waves costs
+template <int NW, int RY, int EDGE, bool HALF, bool SKIP = false, bool NOSYNC = false>
 __device__ __forceinline__ void jacobi_sweep(Quad (&P)[RY], const Quad (&D)[RY], float4 (*box)[2][64], int wv, int lane, int gy,
-                                             int H, bool at_left, int nv)
+                                             int H, bool at_left, int nv, int lo_skip = 0, int hi_skip = 0)
 {
     static_assert(RY >= 3, "a wave needs an inner row");
+    if constexpr (NOSYNC) {
+        const Quad old0 = P[0], old1 = P[1];
+        Quad below = old0;
+#pragma unroll
+        for (int r = 1; r < RY - 1; r++) {
+            const Quad C = P[r];
+            P[r] = jacobi_row<EDGE, HALF>(C, P[r + 1], below, D[r], gy + r, H, at_left, nv);
+            below = C;
+        }
+        P[RY - 1] = jacobi_row<EDGE, HALF>(P[RY - 1], old1, below, D[RY - 1], gy + RY - 1, H, at_left, nv);
+        P[0] = jacobi_row<EDGE, HALF>(old0, old1, below, D[0], gy, H, at_left, nv);
+        return;
+    }
     box[wv][0][lane] = raw_of(P[0]);
     box[wv][1][lane] = raw_of(P[RY - 1]);
     const Quad old0 = P[0], old1 = P[1];
     Quad below = old0;
+    const int r_end = RY - hi_skip;
 #pragma unroll
     for (int r = 1; r < RY - 1; r++) {
         const Quad C = P[r];
-        P[r] = jacobi_row<EDGE, HALF>(C, P[r + 1], below, D[r], gy + r, H, at_left, nv);
+        if (!SKIP || (r >= lo_skip && r < r_end)) P[r] = jacobi_row<EDGE, HALF>(C, P[r + 1], below, D[r], gy + r, H, at_left, nv);
         below = C;
     }
     __syncthreads();
     // unconditional b128 reads: the first/last wave reads its own mailbox, which only feeds the stale apron
     const Quad lo = quad_of_raw(box[wv > 0 ? wv - 1 : 0][1][lane]);
     const Quad hi = quad_of_raw(box[wv < NW - 1 ? wv + 1 : NW - 1][0][lane]);
-    P[RY - 1] = jacobi_row<EDGE, HALF>(P[RY - 1], hi, below, D[RY - 1], gy + RY - 1, H, at_left, nv);
-    P[0] = jacobi_row<EDGE, HALF>(old0, old1, lo, D[0], gy, H, at_left, nv);
+    if (!SKIP || (RY - 1 >= lo_skip && hi_skip == 0)) P[RY - 1] = jacobi_row<EDGE, HALF>(P[RY - 1], hi, below, D[RY - 1], gy + RY - 1, H, at_left, nv);
+    if (!SKIP || (lo_skip == 0 && hi_skip < RY)) P[0] = jacobi_row<EDGE, HALF>(old0, old1, lo, D[0], gy, H, at_left, nv);
 }
 
 // T = float (fp32 fields) or __half (fp16 storage: the clear and every iteration round their output to fp16)
@@ -1103,8 +1121,14 @@ typedef unsigned int chain_u4 __attribute__((ext_vector_type(4)));
                                            (unsigned)(idx * sizeof(float)), 0, 16);
 }
 
-template <int NW, int RY, int HX, int HY, int EDGE, class T, bool GS = false, class V2 = float2, bool CHAIN = false>
-__device__ __forceinline__ void jacobi_tb_body(const Win& w, const T* __restrict__ p, const T* __restrict__ div,
+// SKIP (round 6, k_jacobi_tb_chain): the tile's first and last 10-row block skip the rows the apron has reached (jacobi_sweep) — and those two
+// blocks are given to the waves with threadIdx.y 0 and 2.  A workgroup's waves go to the SIMDs in the cyclic order 0 -> 2 -> 1 -> 3 from a start
+// that advances by one for every workgroup a CU takes (MI355X guide, LDS section; profiles/r06/placement_probe.txt: waves w and w + 4 share a
+// SIMD, and the two workgroups resident on a CU start one place apart 97 % of the time): with the light blocks on waves 0 and 2 of BOTH
+// workgroups, every SIMD of the CU holds exactly one light wave and three full ones — 345 row sweeps per ten iterations instead of 400 on
+// each SIMD, not 290 on two of them and 400 on the others.  Placement changes the speed only, never the result.
+template <int NW, int RY, int HX, int HY, int EDGE, class T, bool GS = false, class V2 = float2, bool CHAIN = false, bool SKIP = false, bool LIGHT = false, int PROBE = 0>
+__device__ __forceinline__ void jacobi_tb_body_impl(const Win& w, const T* __restrict__ p, const T* __restrict__ div,
                                                T* __restrict__ p_out, float pscale, int iters, int ga, int gb, int x0,
                                                int y0, float4 (*mail)[NW][2][64], const V2* __restrict__ vel = nullptr,
                                                V2* __restrict__ vel_out = nullptr)
@@ -1114,7 +1138,9 @@ __device__ __forceinline__ void jacobi_tb_body(const Win& w, const T* __restrict
     const int lane = threadIdx.x;
     // the block is (64, NW): threadIdx.y is the wave index — tell the compiler it is wave-uniform so that all
     // per-row address arithmetic lands on the scalar unit and the loads use SGPR-base + lane-offset addressing
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int hw = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    // which 10-row block of the tile this wave holds: its own number — or, with SKIP, the tile's first block on wave 0 and its last on wave 2
+    const int wv = !SKIP ? hw : (hw == 2 ? NW - 1 : (hw > 2 ? hw - 1 : hw));
     const int cx = x0 + 4 * lane;     // first of this lane's 4 columns
     const int gy = y0 + wv * RY;      // global row of this wave's row 0
 
@@ -1156,11 +1182,43 @@ __device__ __forceinline__ void jacobi_tb_body(const Win& w, const T* __restrict
     // two iterations per trip: the mailbox slot is a compile-time constant and the register allocator can hand the
     // second sweep's results back to the registers the first one read (no copies on the loop back-edge)
     int it = 0;
-    for (; it + 2 <= iters; it += 2) {
-        jacobi_sweep<NW, RY, EDGE, HALF>(P, D, mail[0], wv, lane, gy, w.H, at_left, nv);
-        jacobi_sweep<NW, RY, EDGE, HALF>(P, D, mail[1], wv, lane, gy, w.H, at_left, nv);
+    if constexpr (SKIP) {
+        static_assert(!GS && NW >= 4, "the skipping form is the plain tile's");
+        // rows this wave leaves out in iteration it + 1: the first it + 1 rows of the tile's first block / the last it + 1 of its last block —
+        // unless the tile holds the domain's edge on that side (CLAMP_TO_EDGE keeps the edge exact: nothing is stale there)
+        // Two copies of the WHOLE body, picked per wave (jacobi_tb_body below): the six full waves run the plain sweep untouched, the two light
+        // ones the sweep with the row conditions.  (The conditions in everybody's code: the register allocator pays for the joins with four
+        // moves a row and the tile is 6.5 % SLOWER; two copies of the loop only: 247 spilled registers at the loop's joins — visit 7.)
+        // Every wave meets the others at a barrier of its own copy: s_barrier counts arrivals.
+        if constexpr (PROBE == 2) {   // lab: no mailbox, no barrier (results not valid)
+            for (; it < iters; it++) jacobi_sweep<NW, RY, EDGE, HALF, false, true>(P, D, mail[0], wv, lane, gy, w.H, at_left, nv);
+        } else if constexpr (PROBE == 1) {   // lab: no arithmetic at all — every wave skips every row (results not valid)
+            for (; it + 2 <= iters; it += 2) {
+                jacobi_sweep<NW, RY, EDGE, HALF, true>(P, D, mail[0], wv, lane, gy, w.H, at_left, nv, RY, 0);
+                jacobi_sweep<NW, RY, EDGE, HALF, true>(P, D, mail[1], wv, lane, gy, w.H, at_left, nv, RY, 0);
+            }
+            if (it < iters) jacobi_sweep<NW, RY, EDGE, HALF, true>(P, D, mail[0], wv, lane, gy, w.H, at_left, nv, RY, 0);
+        } else if constexpr (LIGHT) {
+            const int lo_on = (wv == 0 && y0 > 0) ? 1 : 0, hi_on = (wv == NW - 1 && y0 + NW * RY < w.H) ? 1 : 0;
+            for (; it + 2 <= iters; it += 2) {
+                jacobi_sweep<NW, RY, EDGE, HALF, true>(P, D, mail[0], wv, lane, gy, w.H, at_left, nv, lo_on * min(it + 1, RY), hi_on * min(it + 1, RY));
+                jacobi_sweep<NW, RY, EDGE, HALF, true>(P, D, mail[1], wv, lane, gy, w.H, at_left, nv, lo_on * min(it + 2, RY), hi_on * min(it + 2, RY));
+            }
+            if (it < iters) jacobi_sweep<NW, RY, EDGE, HALF, true>(P, D, mail[0], wv, lane, gy, w.H, at_left, nv, lo_on * min(it + 1, RY), hi_on * min(it + 1, RY));
+        } else {
+            for (; it + 2 <= iters; it += 2) {
+                jacobi_sweep<NW, RY, EDGE, HALF>(P, D, mail[0], wv, lane, gy, w.H, at_left, nv);
+                jacobi_sweep<NW, RY, EDGE, HALF>(P, D, mail[1], wv, lane, gy, w.H, at_left, nv);
+            }
+            if (it < iters) jacobi_sweep<NW, RY, EDGE, HALF>(P, D, mail[0], wv, lane, gy, w.H, at_left, nv);
+        }
+    } else {
+        for (; it + 2 <= iters; it += 2) {
+            jacobi_sweep<NW, RY, EDGE, HALF>(P, D, mail[0], wv, lane, gy, w.H, at_left, nv);
+            jacobi_sweep<NW, RY, EDGE, HALF>(P, D, mail[1], wv, lane, gy, w.H, at_left, nv);
+        }
+        if (it < iters) jacobi_sweep<NW, RY, EDGE, HALF>(P, D, mail[0], wv, lane, gy, w.H, at_left, nv);
     }
-    if (it < iters) jacobi_sweep<NW, RY, EDGE, HALF>(P, D, mail[0], wv, lane, gy, w.H, at_left, nv);
 
     // store the texels the apron kept exact
     int xa, xb, out_lo, out_hi;
@@ -1238,6 +1296,23 @@ __device__ __forceinline__ void jacobi_tb_body(const Win& w, const T* __restrict
     }
 }
 
+template <int NW, int RY, int HX, int HY, int EDGE, class T, bool GS = false, class V2 = float2, bool CHAIN = false, bool SKIP = false, int PROBE = 0>
+__device__ __forceinline__ void jacobi_tb_body(const Win& w, const T* __restrict__ p, const T* __restrict__ div, T* __restrict__ p_out, float pscale, int iters,
+                                               int ga, int gb, int x0, int y0, float4 (*mail)[NW][2][64], const V2* __restrict__ vel = nullptr,
+                                               V2* __restrict__ vel_out = nullptr)
+{
+    if constexpr (PROBE != 0) {
+        jacobi_tb_body_impl<NW, RY, HX, HY, EDGE, T, GS, V2, CHAIN, true, false, PROBE>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail, vel, vel_out);
+    } else if constexpr (SKIP) {
+        const int hw = __builtin_amdgcn_readfirstlane(threadIdx.y);
+        const bool light = (hw == 0 && y0 > 0) || (hw == 2 && y0 + NW * RY < w.H);   // the tile's first block is wave 0's, its last wave 2's
+        if (light) jacobi_tb_body_impl<NW, RY, HX, HY, EDGE, T, GS, V2, CHAIN, true, true>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail, vel, vel_out);
+        else jacobi_tb_body_impl<NW, RY, HX, HY, EDGE, T, GS, V2, CHAIN, true, false>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail, vel, vel_out);
+    } else {
+        jacobi_tb_body_impl<NW, RY, HX, HY, EDGE, T, GS, V2, CHAIN, false, false>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail, vel, vel_out);
+    }
+}
+
 // Tile `b` of an nx x ny tile set over rows [ga, gb): its place in the XCD-aware order, then the body with the CLAMP_TO_EDGE selects its
 // position needs (interior / left-right border / everything).  HYT = the tile's row apron (HY, or HY + 1 with the gradient subtract folded in).
 template <int NW, int RY, int HX, int HYT, bool GS = false, class T, class V2 = float2>
@@ -1292,7 +1367,7 @@ struct ChainPlan {
 // DIAG (FLUID_JACOBI_CHAIN=2 / 3 / 4: timing probes whose RESULTS ARE NOT VALID): 1 = a tile counts itself done without draining its stores
 // (what the wait for the write-through acknowledgements costs), 2 = plain pressure loads and stores instead of sc1 (what the cache policy
 // costs), 3 = nobody waits for anybody (what the dependency waits cost)
-template <int NW, int RY, int HX, int HY, int BPC, int DIAG = 0>
+template <int NW, int RY, int HX, int HY, int BPC, int DIAG = 0, bool SKIP = false>
 __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_chain(Win w, float* __restrict__ pa, float* __restrict__ pb,
                                                               const float* __restrict__ div, float pscale, ChainPlan C, int xs,
                                                               int ys, int nx, int ny, unsigned int* __restrict__ done,
@@ -1357,10 +1432,11 @@ __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_chain
     const bool ragged = (w.W & 3) != 0 && x0 + G::TX >= w.W;
     const float ps = l == 0 ? pscale : 1.0f;
     constexpr bool SC1 = DIAG != 2;
+    constexpr int PROBE = DIAG == 5 ? 1 : (DIAG == 6 ? 2 : 0);   // lab: 5 = no arithmetic, 6 = no mailbox / barrier (results not valid)
     if (nothing) {
-    } else if (yedge || ragged) jacobi_tb_body<NW, RY, HX, HY, 2, float, false, float2, SC1>(w, p, div, p_out, ps, C.iters[l], ga, gb, x0, y0, mail);
-    else if (xedge) jacobi_tb_body<NW, RY, HX, HY, 1, float, false, float2, SC1>(w, p, div, p_out, ps, C.iters[l], ga, gb, x0, y0, mail);
-    else jacobi_tb_body<NW, RY, HX, HY, 0, float, false, float2, SC1>(w, p, div, p_out, ps, C.iters[l], ga, gb, x0, y0, mail);
+    } else if (yedge || ragged) jacobi_tb_body<NW, RY, HX, HY, 2, float, false, float2, SC1, SKIP, PROBE>(w, p, div, p_out, ps, C.iters[l], ga, gb, x0, y0, mail);
+    else if (xedge) jacobi_tb_body<NW, RY, HX, HY, 1, float, false, float2, SC1, SKIP, PROBE>(w, p, div, p_out, ps, C.iters[l], ga, gb, x0, y0, mail);
+    else jacobi_tb_body<NW, RY, HX, HY, 0, float, false, float2, SC1, SKIP, PROBE>(w, p, div, p_out, ps, C.iters[l], ga, gb, x0, y0, mail);
     // done: every storing wave drains its write-through stores, then ONE lane counts the tile (the guide's R1)
     if (DIAG != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1404,25 +1480,24 @@ __device__ __forceinline__ void jacobi_sweep_st(Quad (&P)[RY], const Quad (&D)[R
     P[0] = jacobi_row<EDGE, false>(old0, old1, lo, D[0], gy, H, at_left, nv);
 }
 
-// One tile of a stack.  `hooks`: this is the stack's LAST tile — it draws the workgroup's next ticket with its loads and gives wave 0 two
-// moments BETWEEN sweeps (registers to spare there) to prepare the next item: pre_a two trips before the end, pre_b one trip before the end.
-// after_loads(): called by every wave once the tile's loads are out — where the PREVIOUS item's stores are waited for and the item counted.
-template <int NW, int RY, int HX, int HY, int EDGE, bool SC1, class FL, class FA, class FB>
+// One tile of a stack.  claim != null (the stack's FIRST tile): wave 0 bumps the item's claim word in front of the tile's loads — the
+// atomic's round trip is the loads' — and parks what it saw in *claimed (0: the item is this workgroup's).  hooks (the stack's LAST tile):
+// wave 0 gets two moments BETWEEN sweeps, pre_a two trips before the end and pre_b one trip before it.  after_loads(): called by every wave
+// once the tile's loads are out.  may_store: checked in front of the stores (a claim that was lost: somebody else runs this item).
+template <int NW, int RY, int HX, int HY, int EDGE, bool SC1, class FL, class FA, class FB, class FS>
 __device__ __forceinline__ void jacobi_stack_tile(const Win& w, __amdgpu_buffer_rsrc_t rin, __amdgpu_buffer_rsrc_t rout, const float* __restrict__ p,
                                                   float* __restrict__ p_out, const float* __restrict__ div, float pscale, int iters, int x0, int yt,
                                                   int row_lo, int row_hi, int col_lo, int col_hi, float4* sm, int carry_in, int carry_out,
-                                                  unsigned int* head, unsigned int head_tag, int* ahead, bool hooks, FL&& after_loads, FA&& pre_a, FB&& pre_b)
+                                                  unsigned int* claim, int* claimed, bool hooks, FL&& after_loads, FA&& pre_a, FB&& pre_b, FS&& may_store)
 {
     using S = JacobiStack<NW, RY, HX, HY>;
     static_assert(S::CARRY_ROW == RY - 1, "the carried row is the one its wave publishes to the mailbox anyway (HY == RY)");
     const int lane = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
     const int cx = x0 + 4 * lane, gy = yt + wv * RY;
-    // The workgroup's NEXT ticket is drawn here (head != null: wave 0, one lane), in front of the tile's loads: the atomic's round trip is
-    // the loads' round trip, and its result is parked in LDS (*ahead) before the arithmetic needs the registers
-    unsigned int ticket = 0;
-    const bool drawer = head != nullptr && wv == 0 && lane == 0;
-    if (drawer) ticket = __hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned int seen = 0;
+    const bool claimer = claim != nullptr && wv == 0 && lane == 0;
+    if (claimer) seen = __hip_atomic_fetch_add(claim, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     Quad P[RY], D[RY];
     const unsigned cxs = (unsigned)(min(max(cx, w.c0), w.c0 + w.P - 4) - w.c0);
     const v2f ps = v2f{ pscale, pscale };
@@ -1435,7 +1510,7 @@ __device__ __forceinline__ void jacobi_stack_tile(const Win& w, __amdgpu_buffer_
         D[r] = load_quad(div, row + cxs);
     }
     after_loads();
-    if (drawer) *ahead = (int)(head_tag | ticket);
+    if (claimer) *claimed = (int)seen;
 #pragma unroll
     for (int r = 0; r < RY; r++) {   // clearShader folded in (block 0: pscale; 1 elsewhere)
         P[r].o = ps * P[r].o;
@@ -1468,6 +1543,7 @@ __device__ __forceinline__ void jacobi_stack_tile(const Win& w, __amdgpu_buffer_
         }
     }
     if (it < iters) jacobi_sweep_st<NW, RY, EDGE>(P, D, sm, 0, lo_a, out_a, S::CARRY_WAVE, wv, lane, gy, w.H, at_left, nv);
+    if (!may_store()) return;   // block-uniform
     const bool col_store = (cx >= col_lo) && (cx < col_hi);
 #pragma unroll
     for (int r = 0; r < RY; r++) {
@@ -1479,33 +1555,32 @@ __device__ __forceinline__ void jacobi_stack_tile(const Win& w, __amdgpu_buffer_
     }
 }
 
-// DIAG (lab): 3 = nobody waits for anybody (FLUID_JACOBI_CHAIN=4: a timing probe whose RESULTS ARE NOT VALID); 4 = statistics (FLUID_CHAIN_STATS)
-// How a workgroup spends the time BETWEEN two items decides what this launch costs.  The first form — draw, decode and poll between two
-// items, all eight waves waiting for wave 0 — spent as long there as in the tile body (profiles/r06/pchain_v3_time_breakdown_first_form.txt:
-// a few hundred instructions on a SIMD shared with the other workgroup's tile arithmetic, three memory round trips in a row).  This form
-// leaves NOTHING between two items in the steady state — less than a workgroup per tile can do, because it even overlaps the drain of one
-// item's stores with the next item's loads:
-//   * the next ticket is drawn in front of the stack's last tile's loads (one lane; the atomic's round trip is the loads') and parked in LDS;
-//   * two trips of sweeps before that tile ends, BETWEEN two sweeps (the tile's registers are all that is live there), wave 0 decodes the
-//     ticket and sends for the nine counters it depends on — an LDS-DMA load (global_load_lds: no destination register) that lands while the
-//     sweeps go on; one trip before the end it reads what came back and, if everything is there, posts the next item's geometry and READY;
-//   * behind the tile's stores the workgroup goes straight to the next item's loads; once those are out, each wave waits for its STORES only
-//     (s_waitcnt vmcnt(20): the loads stay in flight), one barrier, and the finished item is counted.
-// Only when the verdict is "not yet" (or there is no ticket: the first item, a hole, an exhausted head) does the workgroup drain, count, and
-// wave 0 run the CONTROL path: hold the ticket on the shelf, work on the held item of the lowest band, draw from a head that lags, spin
-// (fluid_pchain.h).
-enum { PG_KIND = 0, PG_L, PG_X0, PG_Y0S, PG_ST_LO, PG_ST_HI, PG_SX_LO, PG_SX_HI, PG_CELL, PG_WORDS };
-enum { CT_AHEAD = 0, CT_READY, CT_NSHELF, CT_WORDS };   // the ticket drawn ahead (or NONE) | item[next] is ready to run | items on the shelf
-enum { PR_VALID = 0, PR_L, PR_BY, PR_BX, PR_Q, PR_WORDS };   // the ticket being prepared between sweeps
-enum { PK_DONE = 0, PK_RUN = 1, PK_COUNT_ONLY = 2, PK_SKIP = 3 };   // nothing left | a stack to run | nothing to store here: count and go | a hole: go
+// DIAG (lab): 3 = nobody waits for anybody (FLUID_JACOBI_CHAIN=4: a timing probe whose RESULTS ARE NOT VALID)
+// FOURTH FORM.  What the probes of the per-tile launch say (profiles/r06/chain_bounds_probes.txt): the loop is bound by neither its arithmetic
+// nor its barriers — a tile costs 14.4 us from launch to exit even with NO arithmetic, three memory round trips in a row (poll, loads, drain).
+// A persistent workgroup can take two of the three off the critical path, if what it does in between costs no time of its own:
+//   * WHICH item comes next is known without asking anybody: the workgroup registers once (a number g < S on its XCD's counter) and owns the
+//     positions g, g + S, g + 2 S ... of that XCD's sequence — the order a freed slot would take them in anyway;
+//   * the item is CLAIMED (its claim word bumped from 0) by an atomic that rides in front of its own loads; a workgroup that waits for an item
+//     nobody has claimed claims and runs it itself, so nobody ever spins on an item that nobody runs, whoever owns it and wherever it runs;
+//   * while the loads of item i are in flight — wave 0 has nothing else to do — it decodes item i + 1 and sends for the nine counters that
+//     item depends on (LDS-DMA: no destination register); two trips of sweeps before the end it looks at what came back (and asks again if
+//     it was too early), one trip before the end it posts READY;
+//   * behind the stores of item i the workgroup goes straight to the loads of item i + 1; once those are out, every wave waits for its
+//     STORES only (vmcnt(20)), one barrier, item i is counted.
+// Not ready, a claim lost, a hole, a stack with nothing to store: the workgroup drains, counts, and wave 0 takes the CONTROL path (spin on
+// the counters; claim and run what nobody has claimed; skip; count).
+enum { PG_KIND = 0, PG_L, PG_X0, PG_Y0S, PG_ST_LO, PG_ST_HI, PG_SX_LO, PG_SX_HI, PG_CELL, PG_CLAIM, PG_BY, PG_BX, PG_WORDS };
+enum { CT_READY = 0, CT_CLAIMED, CT_POS, CT_NSTACK, CT_PRECLAIMED, CT_WORDS };
+enum { PK_DONE = 0, PK_RUN = 1, PK_COUNT_ONLY = 2 };   // nothing left | a stack to run | nothing to store here: claim, count and go
 struct PChainLds {
     int item[2][PG_WORDS];   // the item being run and the one after it
     int ctl[CT_WORDS];
-    int pre[PR_WORDS];
-    unsigned int seen[16], want[16];        // lanes 0..8: what the counters around the next item read (landed by LDS-DMA), and what they must reach
-    unsigned int shelf[PCHAIN_SHELF];       // tickets this workgroup holds besides the item it runs (head << 28 | ticket)
+    int word[16];                      // lanes 0..8: the counters the next item depends on (word indices into the state half) ...
+    unsigned int seen[16], want[16];   // ... what they read when asked (landed by LDS-DMA), and what they must reach
+    int stack[PCHAIN_MAX_BLOCKS + 2];  // items put aside while this workgroup runs one that they wait for and nobody had claimed (l << 24 | by << 12 | bx)
 };
-constexpr int PCHAIN_NO_PENDING = -2;       // (-1: an item that is deliberately not counted — the lab's withheld item)
+constexpr int PCHAIN_NO_PENDING = -2;   // (-1: an item that is deliberately not counted — the lab's withheld item)
 template <int NW, int RY, int HX, int HY, int DIAG = 0>
 __global__ void __launch_bounds__(64 * NW, (2 * NW + 3) / 4) k_jacobi_pchain(Win w, float* __restrict__ pa, float* __restrict__ pb,
                                                                             const float* __restrict__ div, float pscale, PChainPlan plan,
@@ -1516,14 +1591,8 @@ __global__ void __launch_bounds__(64 * NW, (2 * NW + 3) / 4) k_jacobi_pchain(Win
     constexpr int BOX = NW * 128, CARRY0 = 2 * BOX;
     __shared__ float4 sm[2 * BOX + 2 * HY * 64];   // two mailbox slots, two carry sets of HY lines (a tile writes one set while it reads the other)
     __shared__ PChainLds L;
-    // The plan, in LDS: read where it is used (a kernel argument's loads are hoisted to the kernel's entry and then live in SGPRs across the
-    // tile body, which has none to spare — 65 spilled SGPRs and 160 bytes of scratch in the first form of this kernel)
-    __shared__ PChainPlan sP;
+    __shared__ PChainPlan sP;                       // the plan, in LDS: read where it is used (a kernel argument's loads are hoisted into SGPRs the tile body has not got)
     const int lane = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
-    constexpr bool STATS = DIAG == 4;
-    [[maybe_unused]] unsigned int st_items = 0, st_slow = 0, st_polls = 0, st_failed = 0, st_helps = 0;
-    [[maybe_unused]] unsigned long long st_wait = 0, st_ctrl = 0, st_t0 = 0;
-    if constexpr (STATS) st_t0 = __builtin_amdgcn_s_memrealtime();
     {
         const int* src = reinterpret_cast<const int*>(&plan);
         int* dst = reinterpret_cast<int*>(&sP);
@@ -1533,18 +1602,26 @@ __global__ void __launch_bounds__(64 * NW, (2 * NW + 3) / 4) k_jacobi_pchain(Win
         unsigned int* const other = state + (size_t)(plan.d.bank ^ 1) * plan.d.bank_words;
         for (int i = (int)blockIdx.x * 64 * NW + wv * 64 + lane; i < plan.d.bank_words; i += (int)gridDim.x * 64 * NW) other[i] = 0u;
     }
+    unsigned int* const mine = state + (size_t)plan.d.bank * plan.d.bank_words;   // (two SGPRs across the body: affordable)
+    const int slots_per_xcd = (int)gridDim.x >> 3;   // S: workgroups (= owners of positions) per XCD sequence
     if (wv == 0 && lane == 0) {
-        L.ctl[CT_AHEAD] = (int)PCHAIN_NONE;
+        // register: a number g < S on the counter of the XCD this workgroup runs on (HW_REG_XCC_ID: affinity only) — or, if that XCD already has
+        // its S owners, on the next one's: 8 S workgroups, 8 S numbers, each taken once wherever the hardware puts the workgroups
+        const int x0 = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);
+        int pos = -1;
+        for (int k = 0; k < 8 && pos < 0; k++) {
+            const int x = (x0 + k) & 7;
+            const unsigned g = __hip_atomic_fetch_add(mine + x * PCHAIN_HEAD_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (g < (unsigned)slots_per_xcd) pos = (x << 28) | (int)g;   // head << 28 | position in its sequence
+        }
+        L.ctl[CT_POS] = pos;
         L.ctl[CT_READY] = 0;
-        L.ctl[CT_NSHELF] = 0;
-    }
-    if (plan.d.stagger > 0) {   // spread the workgroups' phases: a start delay of 0 ... stagger ticks, by a hash of the workgroup's number
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        const unsigned long long d = ((unsigned long long)(((unsigned)blockIdx.x * 0x9E3779B1u) >> 22) * (unsigned long long)plan.d.stagger) >> 10;
-        while (__builtin_amdgcn_s_memrealtime() - t0 < d) __builtin_amdgcn_s_sleep(8);
+        L.ctl[CT_NSTACK] = 0;
+        L.ctl[CT_PRECLAIMED] = 0;
+        L.item[0][PG_KIND] = PK_DONE;
+        L.item[1][PG_KIND] = PK_DONE;
     }
     __syncthreads();
-    // the dimensions as wave-uniform values, re-read from LDS where they are used
     auto dims = [&]() -> PChainDims {   // (field by field: a by-value struct filled through a pointer lands in scratch memory)
         PChainDims d;
 #define PD(f) d.f = __builtin_amdgcn_readfirstlane(sP.d.f)
@@ -1554,24 +1631,11 @@ __global__ void __launch_bounds__(64 * NW, (2 * NW + 3) / 4) k_jacobi_pchain(Win
 #define PF(f) d.f = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sP.d.f)))
         PF(r_slots); PF(r_pw); PF(r_nb); PF(r_np); PF(r_bh);
 #undef PF
-        return d;   // (cap[] stays in LDS: cap_of)
+        return d;
     };
     auto cap_of = [&](int x) -> int { return __builtin_amdgcn_readfirstlane(sP.d.cap[x]); };
-    auto state_of = [&](const PChainDims& C) -> unsigned int* { return state + (size_t)C.bank * C.bank_words; };
-    auto my_xcc = [&]() -> int { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u); };   // HW_REG_XCC_ID: where this workgroup runs — affinity only
-    // draw (one lane): the next ticket of head x0 — or, when that sequence is exhausted, of the next head that is not; PCHAIN_NONE: nothing left
-    auto draw_from = [&](const PChainDims& C, int x0) -> unsigned int {
-        unsigned int* const mine = state_of(C);
-        for (int k = 0; k < 8; k++) {
-            const int x = (x0 + k) & 7, cap = sP.d.cap[x];
-            if (cap == 0) continue;
-            const unsigned t = __hip_atomic_fetch_add(mine + x * PCHAIN_HEAD_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (t < (unsigned)cap) return ((unsigned)x << 28) | t;
-        }
-        return PCHAIN_NONE;
-    };
-    // a decoded item's geometry into item[slot] (lane 0 of wave 0); returns its kind
-    auto post_item = [&](const PChainDims& C, int slot, unsigned int tkw, int l, int by, int bx, int q) -> int {
+    // item (l, by, bx): its geometry into item[slot] (lane 0 of wave 0), its dependencies into word / want (lanes 0..8); returns its kind
+    auto post_item = [&](const PChainDims& C, int slot, int l, int by, int bx) -> int {
         const int x0 = C.xs + bx * G::VX, y0s = C.ys + by * (S::span(C.stack) - 2 * HY);
         int st_lo, st_hi, sx_lo, sx_hi;
         tile_exact(y0s, S::span(C.stack), HY, w.H, __builtin_amdgcn_readfirstlane(sP.ga[l]), __builtin_amdgcn_readfirstlane(sP.gb[l]), st_lo, st_hi);
@@ -1587,231 +1651,216 @@ __global__ void __launch_bounds__(64 * NW, (2 * NW + 3) / 4) k_jacobi_pchain(Win
             g[PG_ST_HI] = st_hi;
             g[PG_SX_LO] = sx_lo;
             g[PG_SX_HI] = sx_hi;
-            g[PG_CELL] = (C.withhold >= 0 && q == C.withhold && ((int)(tkw & 0x0fffffffu) % C.slots) == 0) ? -1 : pchain_cell(C, l, by, pchain_panel_of(C, bx));
+            g[PG_CELL] = (C.withhold >= 0 && C.withhold == (l * C.ny + by) * C.nx + bx) ? -1 : pchain_cell(C, l, by, pchain_panel_of(C, bx));
+            g[PG_CLAIM] = pchain_claim_word(C, l, by, bx);
+            g[PG_BY] = by;
+            g[PG_BX] = bx;
+        }
+        if (lane < 16) {
+            const int r = by - 1 + lane / 3, c = bx - 1 + lane % 3;
+            int word = 0;
+            unsigned int need = 0;   // (a lane with nothing to look at reads word 0 and wants nothing of it)
+            if (l > 0 && DIAG != 3 && lane < 9 && r >= 0 && r < C.ny && c >= 0 && c < C.nx) {
+                const int pn = pchain_panel_of(C, c);
+                need = (unsigned)pchain_panel_width(C, pn);
+                word = pchain_cell(C, l - 1, r, pn);
+            }
+            L.word[lane] = word;
+            L.want[lane] = need;
         }
         return kind;
     };
-    // the nine counters around (l, by, bx) in block l - 1 (lanes 0..8) and, with BANDS, whether the bands they belong to have been drawn
-    // completely (lanes 16..24): one memory round trip.  Returns what each lane found (true where a lane has nothing to look at).
-    auto poll = [&](const PChainDims& C, int l, int by, int bx, int& lag_head) -> bool {
-        unsigned int* const mine = state_of(C);
-        bool ok = true;
-        lag_head = 0;
-        const int k = lane & 15, r = by - 1 + k / 3, c = bx - 1 + k % 3;
-        if (k < 9 && (lane >> 4) < 2 && r >= 0 && r < C.ny && c >= 0 && c < C.nx) {
-            const int pn = pchain_panel_of(C, c);
-            if (lane < 16) {
-                ok = __hip_atomic_load(mine + pchain_cell(C, l - 1, r, pn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)pchain_panel_width(C, pn);
-            } else {
-                const int qd = pchain_band_of(C, l - 1, r, pn);
-                lag_head = qd & 7;
-                ok = __hip_atomic_load(mine + lag_head * PCHAIN_HEAD_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)((qd >> 3) + 1) * (unsigned)C.slots;
+    auto send_poll = [&]() {   // lanes 0..15 of wave 0: the counters of word[] into seen[], by LDS-DMA (aux 16 = sc1: past this CU's L1)
+        if (lane < 16) {
+            typedef __attribute__((address_space(3))) unsigned int lds_u32;   // (the LDS base travels in M0: handed over as a wave-uniform value explicitly)
+            lds_u32* const dst = (lds_u32*)(size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(lds_u32*)L.seen);
+            __builtin_amdgcn_global_load_lds(mine + L.word[lane], dst, 4, 0, 16);
+        }
+    };
+    auto poll_ok = [&]() -> bool {   // wave 0, the poll has landed: is every counter there?
+        const bool ok = lane >= 16 || L.seen[lane] >= L.want[lane];
+        return __ballot(!ok) == 0;
+    };
+    // the next position this workgroup owns, decoded into item[slot]; holes are passed over; PK_DONE when the sequence is through
+    auto next_owned = [&](const PChainDims& C, int slot) -> int {
+        int pos = __builtin_amdgcn_readfirstlane(L.ctl[CT_POS]);
+        int kind = PK_DONE;
+        while (pos >= 0) {
+            const int hx = (int)((unsigned)pos >> 28), ht = pos & 0x0fffffff;
+            if (ht >= cap_of(hx)) {
+                pos = -1;
+                break;
+            }
+            int l, by, bx, q;
+            const bool real = pchain_item(C, hx, ht, l, by, bx, q);
+            pos += slots_per_xcd;   // (the position after this one, whatever this one turns out to be)
+            if (real) {
+                kind = post_item(C, slot, l, by, bx);
+                break;
             }
         }
-        return ok;
+        if (lane == 0) {
+            L.ctl[CT_POS] = pos;
+            if (kind == PK_DONE) L.item[slot][PG_KIND] = PK_DONE;
+        }
+        return kind;
     };
 
     int slot = 0, pending = PCHAIN_NO_PENDING;   // pending: the cell of an item whose stores are still draining (counted behind the next item's loads)
+    bool shadow_now = false;                     // the tile being run is its stack's last one
     // ---- the hooks of the tile body ----
     auto after_loads = [&]() {
         if (pending != PCHAIN_NO_PENDING) {   // block-uniform
             asm volatile("s_waitcnt vmcnt(20)" ::: "memory");   // this wave's stores of the item before are through (the 20 loads just issued stay in flight)
             __builtin_amdgcn_s_barrier();                        // ... and every other wave's
-            if (wv == 0 && lane == 0 && pending >= 0)
-                __hip_atomic_fetch_add(state + (size_t)sP.d.bank * sP.d.bank_words + pending, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (wv == 0 && lane == 0 && pending >= 0) __hip_atomic_fetch_add(mine + pending, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             pending = PCHAIN_NO_PENDING;
         }
-    };
-    auto pre_a = [&]() {   // wave 0, between two sweeps: decode the ticket drawn ahead, send for the counters it depends on
-        if (wv != 0) return;
-        __builtin_amdgcn_s_setprio(3);
-        const unsigned int tkw = (unsigned)__builtin_amdgcn_readfirstlane(L.ctl[CT_AHEAD]);
-        int valid = 0, l = 0, by = 0, bx = 0, q = 0;
-        if (tkw != PCHAIN_NONE) {
+        // ... and, while the loads of the stack's LAST tile are in flight, wave 0 prepares the item after this one: decode, ask for its counters
+        if (shadow_now && wv == 0 && __builtin_amdgcn_readfirstlane(L.ctl[CT_NSTACK]) == 0 && __builtin_amdgcn_readfirstlane(L.ctl[CT_PRECLAIMED]) == 0) {
+            __builtin_amdgcn_s_setprio(3);
             const PChainDims C = dims();
-            const int hx = (int)(tkw >> 28), ht = (int)(tkw & 0x0fffffffu);
-            if (ht < cap_of(hx) && pchain_item(C, hx, ht, l, by, bx, q)) {   // (an exhausted head, a hole: the control path deals with it)
-                valid = 1;
-                unsigned int need = 0;
-                int word = 0;   // (a lane with nothing to look at reads head 0 and wants nothing of it)
-                const int r = by - 1 + lane / 3, c = bx - 1 + lane % 3;
-                if (l > 0 && DIAG != 3 && lane < 9 && r >= 0 && r < C.ny && c >= 0 && c < C.nx) {
-                    const int pn = pchain_panel_of(C, c);
-                    need = (unsigned)pchain_panel_width(C, pn);
-                    word = pchain_cell(C, l - 1, r, pn);
-                }
-                if (lane < 16) {
-                    L.want[lane] = need;
-                    // lane k's word lands in seen[k]; aux 16 = sc1: past this CU's L1.  (The LDS base travels in M0: handed over as a wave-uniform
-                    // value explicitly — through the closure the backend takes it for a per-lane one: "illegal VGPR to SGPR copy")
-                    typedef __attribute__((address_space(3))) unsigned int lds_u32;
-                    lds_u32* const dst = (lds_u32*)(size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(lds_u32*)L.seen);
-                    __builtin_amdgcn_global_load_lds(state_of(C) + word, dst, 4, 0, 16);
-                }
-            }
+            const int kind = next_owned(C, slot ^ 1);
+            if (kind == PK_RUN) send_poll();
+            __builtin_amdgcn_s_setprio(0);
         }
-        if (lane == 0) {
-            L.pre[PR_VALID] = valid;
-            L.pre[PR_L] = l;
-            L.pre[PR_BY] = by;
-            L.pre[PR_BX] = bx;
-            L.pre[PR_Q] = q;
-        }
-        __builtin_amdgcn_s_setprio(0);
     };
-    auto pre_b = [&]() {   // wave 0, one trip later: what came back?  Everything there: post the next item, READY
+    auto pre_a = [&]() {   // wave 0, between two sweeps: did the counters read "all there" when the tile started?  If not, ask again
         if (wv != 0) return;
-        __builtin_amdgcn_s_setprio(3);
         bool ready = false;
-        if (__builtin_amdgcn_readfirstlane(L.pre[PR_VALID]) != 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA has landed (nothing else of this wave is in flight between sweeps)
-            const bool ok = lane >= 16 || L.seen[lane] >= L.want[lane];
-            const unsigned long long bad = __ballot(!ok);
-            if constexpr (STATS) {
-                st_polls++;
-                st_failed += bad != 0;
-            }
-            if (bad == 0) {
-                const PChainDims C = dims();
-                const unsigned int tkw = (unsigned)__builtin_amdgcn_readfirstlane(L.ctl[CT_AHEAD]);
-                ready = post_item(C, slot ^ 1, tkw, __builtin_amdgcn_readfirstlane(L.pre[PR_L]), __builtin_amdgcn_readfirstlane(L.pre[PR_BY]),
-                                  __builtin_amdgcn_readfirstlane(L.pre[PR_BX]), __builtin_amdgcn_readfirstlane(L.pre[PR_Q])) == PK_RUN;
-            }
+        if (__builtin_amdgcn_readfirstlane(L.ctl[CT_NSTACK]) == 0 && __builtin_amdgcn_readfirstlane(L.ctl[CT_PRECLAIMED]) == 0 &&
+            __builtin_amdgcn_readfirstlane(L.item[slot ^ 1][PG_KIND]) == PK_RUN) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the LDS-DMA landed long ago; nothing else of this wave is in flight between sweeps)
+            ready = poll_ok();
+            if (!ready) send_poll();
         }
-        if (lane == 0) {
-            L.ctl[CT_READY] = ready ? 1 : 0;
-            if (ready) L.ctl[CT_AHEAD] = (int)PCHAIN_NONE;   // (not ready: the control path puts the ticket on the shelf)
-        }
-        __builtin_amdgcn_s_setprio(0);
+        if (lane == 0) L.ctl[CT_READY] = ready ? 1 : 0;
     };
-    auto no_hook = [&]() {};
+    auto pre_b = [&]() {   // one trip later: the second answer
+        if (wv != 0) return;
+        if (__builtin_amdgcn_readfirstlane(L.ctl[CT_READY]) == 0 && __builtin_amdgcn_readfirstlane(L.ctl[CT_NSTACK]) == 0 &&
+            __builtin_amdgcn_readfirstlane(L.ctl[CT_PRECLAIMED]) == 0 && __builtin_amdgcn_readfirstlane(L.item[slot ^ 1][PG_KIND]) == PK_RUN) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (poll_ok() && lane == 0) L.ctl[CT_READY] = 1;
+        }
+    };
+    auto may_store = [&]() -> bool { return __builtin_amdgcn_readfirstlane(L.ctl[CT_CLAIMED]) == 0; };   // (parked behind the loads; a barrier of sweeps ago)
 
+    // ---- the first item: through the control path (nothing is ready yet) ----
+    if (wv == 0) {
+        const PChainDims C = dims();
+        (void)next_owned(C, slot);
+    }
+    __syncthreads();
+    bool fresh = true;   // item[slot] was decoded but its dependencies have not been looked at (or were not there): the control path decides
     while (true) {
-        if (__builtin_amdgcn_readfirstlane(L.ctl[CT_READY]) == 0) {
+        if (fresh) {
             if (wv == 0) {
-                // ---- the CONTROL path: find an item that may run (wave 0 only: no barrier in here; lanes talk through ballots) ----
-                // What this workgroup HOLDS is the shelf (the ticket drawn ahead, helper tickets, items put aside).  It always works on the held
-                // item of the LOWEST band: a chain of "spins on an item held by a workgroup that spins on ..." then runs through strictly
-                // falling bands and ends at an item with nothing left to wait for (fluid_pchain.h; simulated in tests/pchain_check.cpp).
+                // ---- the CONTROL path (wave 0 only: no barrier in here; lanes talk through ballots): make item[slot] runnable ----
                 __builtin_amdgcn_s_setprio(3);
-                [[maybe_unused]] unsigned long long st_mark = 0;
-                if constexpr (STATS) {
-                    st_mark = __builtin_amdgcn_s_memrealtime();
-                    st_slow++;
-                }
                 const PChainDims C = dims();
-                int nshelf = __builtin_amdgcn_readfirstlane(L.ctl[CT_NSHELF]);
-                {
-                    const unsigned int ahead = (unsigned)__builtin_amdgcn_readfirstlane(L.ctl[CT_AHEAD]);
-                    // (a ticket drawn ahead comes straight from the head's counter: beyond the sequence's end it is no ticket at all)
-                    if (ahead != PCHAIN_NONE && (int)(ahead & 0x0fffffffu) < cap_of((int)(ahead >> 28))) {
-                        if (lane == 0) L.shelf[nshelf] = ahead;
-                        nshelf++;
-                    }
-                }
-                unsigned int cur = PCHAIN_NONE;
-                int kind = PK_DONE, l = 0, by = 0, bx = 0, q = 0;
+                int nstack = __builtin_amdgcn_readfirstlane(L.ctl[CT_NSTACK]);
+                int preclaimed = __builtin_amdgcn_readfirstlane(L.ctl[CT_PRECLAIMED]);
                 unsigned long long t_wait = 0, t_err = 0;
                 bool waiting = false;
                 while (true) {
-                    if (nshelf == 0) {   // nothing held: a fresh ticket, from the head of the XCD this workgroup runs on
-                        unsigned int got = 0;
-                        if (lane == 0) got = draw_from(C, my_xcc());
-                        cur = (unsigned)__builtin_amdgcn_readfirstlane((int)got);
-                        if (cur == PCHAIN_NONE) break;   // PK_DONE: every head is exhausted and nothing is held
-                        if (lane == 0) L.shelf[0] = cur;
-                        nshelf = 1;
+                    int kind = __builtin_amdgcn_readfirstlane(L.item[slot][PG_KIND]);
+                    if (kind == PK_DONE) {
+                        if (nstack == 0) break;
+                        // back to the item that was put aside
+                        const int e = __builtin_amdgcn_readfirstlane(L.stack[--nstack]);
+                        kind = post_item(C, slot, e >> 24, (e >> 12) & 0xfff, e & 0xfff);
+                        preclaimed = 1;   // (it was claimed before it was put aside)
+                        waiting = false;
+                        continue;
                     }
-                    // the held item of the lowest band (ties: the lowest ticket); lanes 0..nshelf-1 look at one shelf entry each
-                    int pick = 0;
-                    if (nshelf > 1) {
-                        unsigned key = 0xffffffffu;
-                        if (lane < nshelf) {
-                            const unsigned e = L.shelf[lane];
-                            key = (((unsigned)pchain_div((int)(e & 0x0fffffffu), C.slots, C.r_slots) * 8u + (e >> 28)) << 5) | (unsigned)lane;   // band << 5 | shelf index (< 32)
-                        }
-#pragma unroll
-                        for (int o = 16; o > 0; o >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, o));   // (PCHAIN_SHELF = 32 entries: lanes 0..31)
-                        pick = __builtin_amdgcn_readfirstlane((int)(key & 31u));
+                    const int l = __builtin_amdgcn_readfirstlane(L.item[slot][PG_L]);
+                    if (kind == PK_COUNT_ONLY) {   // nothing to store: claim it, count it, next
+                        unsigned int old = 0;
+                        if (!preclaimed && lane == 0) old = __hip_atomic_fetch_add(mine + L.item[slot][PG_CLAIM], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+                        if (old == 0 && lane == 0 && L.item[slot][PG_CELL] >= 0) __hip_atomic_fetch_add(mine + L.item[slot][PG_CELL], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        preclaimed = 0;
+                        if (nstack > 0) {
+                            if (lane == 0) L.item[slot][PG_KIND] = PK_DONE;   // (pops the stack above)
+                        } else (void)next_owned(C, slot);
+                        continue;
                     }
-                    cur = (unsigned)__builtin_amdgcn_readfirstlane((int)L.shelf[pick]);
-                    if (!pchain_item(C, (int)(cur >> 28), (int)(cur & 0x0fffffffu), l, by, bx, q)) kind = PK_SKIP;
-                    else kind = PK_RUN;
-                    bool go = kind == PK_SKIP || l == 0 || DIAG == 3;
-                    if (!go) {
-                        int lag_head;
-                        const bool ok = poll(C, l, by, bx, lag_head);
-                        const unsigned long long bad = __ballot(!ok);   // wave-uniform
-                        if constexpr (STATS) {
-                            st_polls++;
-                            st_failed += (bad & 0xffffull) != 0;
-                        }
-                        if ((bad & 0xffffull) == 0) go = true;          // every counter is there: run
-                        else if (bad & 0xffff0000ull) {
-                            // a band that is waited for has not been drawn completely: draw from that band's head and hold the ticket too — a
-                            // workgroup only ever SPINS on items that somebody holds
-                            if (nshelf == PCHAIN_SHELF) {   // cannot happen in a schedule that makes progress; never overflow, never hang
-                                if (lane == 0) __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                                go = true;
+                    if (l == 0 || DIAG == 3) break;   // runnable
+                    // the nine counters (lanes 0..8) and, beside them, the claim words of the nine items they belong to (lanes 16..24)
+                    const int by = __builtin_amdgcn_readfirstlane(L.item[slot][PG_BY]), bx = __builtin_amdgcn_readfirstlane(L.item[slot][PG_BX]);
+                    bool ok = true;
+                    {
+                        const int k = lane & 15, r = by - 1 + k / 3, c = bx - 1 + k % 3;
+                        if (k < 9 && (lane >> 4) < 2 && r >= 0 && r < C.ny && c >= 0 && c < C.nx) {
+                            if (lane < 16) {
+                                const int pn = pchain_panel_of(C, c);
+                                ok = __hip_atomic_load(mine + pchain_cell(C, l - 1, r, pn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)pchain_panel_width(C, pn);
                             } else {
-                                const int head = __builtin_amdgcn_readlane(lag_head, __builtin_ctzll(bad & 0xffff0000ull));
-                                unsigned int got = 0;
-                                if (lane == 0) got = draw_from(C, head);
-                                got = (unsigned)__builtin_amdgcn_readfirstlane((int)got);
-                                if constexpr (STATS) st_helps++;
-                                if (got != PCHAIN_NONE) {   // (NONE: others drew the rest of that band meanwhile — poll again)
-                                    if (lane == 0) L.shelf[nshelf] = got;
-                                    nshelf++;
-                                }
-                                waiting = false;
-                                continue;
+                                ok = __hip_atomic_load(mine + pchain_claim_word(C, l - 1, r, c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
                             }
-                        } else {
-                            // all drawn, not all done: spin — bounded in wall-clock time, and nobody waits once somebody has given up
-                            if (!waiting) {
-                                waiting = true;
-                                t_wait = __builtin_amdgcn_s_memrealtime();
-                            }
-                            __builtin_amdgcn_s_sleep(1);
-                            const unsigned long long waited = __builtin_amdgcn_s_memrealtime() - t_wait;
-                            // (err lives in HOST memory — a read is a PCIe round trip: only a workgroup that has waited 100 us looks, every 100 us)
-                            if (waited > 10000ull && waited - t_err > 10000ull) {
-                                t_err = waited;
-                                if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) go = true;
-                            }
-                            if (waited > (unsigned long long)C.timeout) {
-                                if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                                go = true;   // run on stale data rather than hang the device; the host learns through err
-                            }
-                            if (!go) continue;
                         }
                     }
-                    // take `cur` off the shelf (the last entry moves into its place)
-                    nshelf--;
-                    if (lane == 0 && pick != nshelf) L.shelf[pick] = L.shelf[nshelf];
-                    break;
+                    const unsigned long long bad = __ballot(!ok);   // wave-uniform
+                    if ((bad & 0xffffull) == 0) break;              // every counter is there: runnable
+                    if (bad & 0xffff0000ull) {
+                        // an item this one waits for has not been claimed by anybody: claim it, put this one aside, run that one first — a
+                        // workgroup only ever SPINS on items that somebody runs
+                        const int k = __builtin_ctzll(bad & 0xffff0000ull) - 16, r = by - 1 + k / 3, c = bx - 1 + k % 3;
+                        unsigned int old = 1;
+                        if (lane == 0) old = __hip_atomic_fetch_add(mine + pchain_claim_word(C, l - 1, r, c), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+                        if (old == 0) {   // ours
+                            if (!preclaimed) {   // this item must be claimed before it is put aside (else its owner and this workgroup could both run it)
+                                unsigned int mineold = 0;
+                                if (lane == 0) mineold = __hip_atomic_fetch_add(mine + L.item[slot][PG_CLAIM], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                mineold = (unsigned)__builtin_amdgcn_readfirstlane((int)mineold);
+                                if (mineold == 0) {
+                                    if (lane == 0) L.stack[nstack] = (l << 24) | (by << 12) | bx;
+                                    nstack++;
+                                }   // (else somebody else runs it: forget it)
+                            } else {
+                                if (lane == 0) L.stack[nstack] = (l << 24) | (by << 12) | bx;
+                                nstack++;
+                            }
+                            (void)post_item(C, slot, l - 1, r, c);
+                            preclaimed = 1;
+                        }
+                        waiting = false;
+                        continue;
+                    }
+                    // everything waited for is being run by somebody: spin — bounded in wall-clock time, and nobody waits once somebody has given up
+                    if (!waiting) {
+                        waiting = true;
+                        t_wait = __builtin_amdgcn_s_memrealtime();
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                    const unsigned long long waited = __builtin_amdgcn_s_memrealtime() - t_wait;
+                    bool go = false;
+                    if (waited > 10000ull && waited - t_err > 10000ull) {   // (err lives in HOST memory: a PCIe round trip — only after 100 us, every 100 us)
+                        t_err = waited;
+                        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) go = true;
+                    }
+                    if (waited > (unsigned long long)C.timeout) {
+                        if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        go = true;   // run on stale data rather than hang the device; the host learns through err
+                    }
+                    if (go) break;
                 }
-                if (cur == PCHAIN_NONE) kind = PK_DONE;
-                if (kind == PK_RUN) kind = post_item(C, slot, cur, l, by, bx, q);
                 if (lane == 0) {
-                    if (kind != PK_RUN && kind != PK_COUNT_ONLY) L.item[slot][PG_KIND] = kind;
-                    L.ctl[CT_NSHELF] = nshelf;
-                    L.ctl[CT_AHEAD] = (int)PCHAIN_NONE;
-                }
-                if constexpr (STATS) {
-                    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-                    st_ctrl += now - st_mark;
-                    if (waiting) st_wait += now - t_wait;
+                    L.ctl[CT_NSTACK] = nstack;
+                    L.ctl[CT_PRECLAIMED] = preclaimed;
+                    L.ctl[CT_READY] = 0;
                 }
                 __builtin_amdgcn_s_setprio(0);
             }
             __syncthreads();
+            fresh = false;
         }
         const int kind = __builtin_amdgcn_readfirstlane(L.item[slot][PG_KIND]);
         if (kind == PK_DONE) break;
-        bool hooked = false;
-        if (kind == PK_RUN) {
-            if constexpr (STATS) st_items++;
+        // ---- run item[slot] (PK_RUN) ----
+        {
             const int l = __builtin_amdgcn_readfirstlane(L.item[slot][PG_L]);
             Win wl = w;
             wl.x0 = __builtin_amdgcn_readfirstlane(sP.xa[l]);
@@ -1821,6 +1870,8 @@ __global__ void __launch_bounds__(64 * NW, (2 * NW + 3) / 4) k_jacobi_pchain(Win
             const int bytes = (int)((size_t)w.rows * (size_t)w.P * sizeof(float));
             const float ps = l == 0 ? pscale : 1.0f;
             const int iters = __builtin_amdgcn_readfirstlane(sP.iters[l]), stack = __builtin_amdgcn_readfirstlane(sP.d.stack);
+            const bool preclaimed = __builtin_amdgcn_readfirstlane(L.ctl[CT_PRECLAIMED]) != 0;
+            if (preclaimed && wv == 0 && lane == 0) L.ctl[CT_CLAIMED] = 0;   // (visible behind the first sweep's barrier, long before the stores)
             for (int t = 0; t < stack; t++) {
                 const int* g = L.item[slot];
                 const int x0 = __builtin_amdgcn_readfirstlane(g[PG_X0]), y0s = __builtin_amdgcn_readfirstlane(g[PG_Y0S]);
@@ -1834,48 +1885,51 @@ __global__ void __launch_bounds__(64 * NW, (2 * NW + 3) / 4) k_jacobi_pchain(Win
                 stack_tile_rows(y0s, t, G::TY, HY, w.H, st_lo, st_hi, yt, a, b, last);
                 const int cin = t > 0 ? CARRY0 + ((t - 1) & 1) * HY * 64 : -1, cout = last ? -1 : CARRY0 + (t & 1) * HY * 64;
                 const bool yedge = (yt <= 0) || (yt + G::TY >= w.H);
-                // the stack's last tile draws the workgroup's next ticket with its loads — unless something is held already (then that is next)
-                unsigned int* head = nullptr;
-                unsigned int tag = 0;
-                if (last && __builtin_amdgcn_readfirstlane(L.ctl[CT_NSHELF]) == 0) {
-                    const int x = my_xcc();
-                    if (cap_of(x) > 0) {
-                        head = state + (size_t)__builtin_amdgcn_readfirstlane(sP.d.bank) * __builtin_amdgcn_readfirstlane(sP.d.bank_words) + x * PCHAIN_HEAD_STRIDE;
-                        tag = (unsigned)x << 28;
-                    }
-                }
-                hooked = last;
+                unsigned int* const claim = (t == 0 && !preclaimed) ? mine + __builtin_amdgcn_readfirstlane(g[PG_CLAIM]) : nullptr;
                 if (t > 0) __syncthreads();   // the last sweep's mailbox readers are through before the next tile's first sweep publishes
+                shadow_now = last;
                 if (yedge || ragged)
-                    jacobi_stack_tile<NW, RY, HX, HY, 2, true>(wl, rin, rout, p, p_out, div, ps, iters, x0, yt, a, b, sx_lo, sx_hi, sm, cin, cout, head, tag, &L.ctl[CT_AHEAD], last, after_loads, pre_a, pre_b);
+                    jacobi_stack_tile<NW, RY, HX, HY, 2, true>(wl, rin, rout, p, p_out, div, ps, iters, x0, yt, a, b, sx_lo, sx_hi, sm, cin, cout, claim, &L.ctl[CT_CLAIMED], last, after_loads, pre_a, pre_b, may_store);
                 else if (xedge)
-                    jacobi_stack_tile<NW, RY, HX, HY, 1, true>(wl, rin, rout, p, p_out, div, ps, iters, x0, yt, a, b, sx_lo, sx_hi, sm, cin, cout, head, tag, &L.ctl[CT_AHEAD], last, after_loads, pre_a, pre_b);
+                    jacobi_stack_tile<NW, RY, HX, HY, 1, true>(wl, rin, rout, p, p_out, div, ps, iters, x0, yt, a, b, sx_lo, sx_hi, sm, cin, cout, claim, &L.ctl[CT_CLAIMED], last, after_loads, pre_a, pre_b, may_store);
                 else
-                    jacobi_stack_tile<NW, RY, HX, HY, 0, true>(wl, rin, rout, p, p_out, div, ps, iters, x0, yt, a, b, sx_lo, sx_hi, sm, cin, cout, head, tag, &L.ctl[CT_AHEAD], last, after_loads, pre_a, pre_b);
+                    jacobi_stack_tile<NW, RY, HX, HY, 0, true>(wl, rin, rout, p, p_out, div, ps, iters, x0, yt, a, b, sx_lo, sx_hi, sm, cin, cout, claim, &L.ctl[CT_CLAIMED], last, after_loads, pre_a, pre_b, may_store);
                 if (last) break;
             }
         }
-        // The stores are out.  READY (posted in front of the tile's last trip of sweeps: a barrier ago): on to the next item's loads, this one is
-        // counted behind them.  Otherwise: drain, count, and the control path finds the next item.
-        if (hooked && __builtin_amdgcn_readfirstlane(L.ctl[CT_READY]) != 0) {
-            pending = __builtin_amdgcn_readfirstlane(L.item[slot][PG_CELL]);
+        // The stores are out (or were left out: the claim was lost).  READY: on to the next item's loads, this one is counted behind them.
+        const bool stored = may_store();
+        const bool helping = __builtin_amdgcn_readfirstlane(L.ctl[CT_NSTACK]) != 0 || __builtin_amdgcn_readfirstlane(L.ctl[CT_PRECLAIMED]) != 0;
+        if (!helping && __builtin_amdgcn_readfirstlane(L.ctl[CT_READY]) != 0) {
+            pending = stored ? __builtin_amdgcn_readfirstlane(L.item[slot][PG_CELL]) : PCHAIN_NO_PENDING;
+            if (!stored) __syncthreads();   // (no count barrier will follow in after_loads: the mailbox hazard needs one)
             slot ^= 1;
             continue;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores, then ONE lane counts the item (the guide's R1 hand-off)
-        if (wv == 0 && lane == 0) L.ctl[CT_READY] = 0;
         __syncthreads();
-        if (wv == 0 && lane == 0 && kind != PK_SKIP) {
-            const int cell = L.item[slot][PG_CELL];
-            if (cell >= 0) __hip_atomic_fetch_add(state + (size_t)sP.d.bank * sP.d.bank_words + cell, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    if constexpr (STATS) {
         if (wv == 0 && lane == 0) {
-            const unsigned int v[9] = { st_items, st_slow, st_polls, st_failed, st_helps, (unsigned)st_wait, (unsigned)st_ctrl,
-                                        (unsigned)(__builtin_amdgcn_s_memrealtime() - st_t0), 1u };
-            for (int i = 0; i < 9; i++) __hip_atomic_fetch_add(err + 8 + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const int cell = L.item[slot][PG_CELL];
+            if (stored && cell >= 0) __hip_atomic_fetch_add(mine + cell, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (helping) {
+                L.ctl[CT_PRECLAIMED] = 0;
+                L.item[slot][PG_KIND] = PK_DONE;   // (the control path pops the stack, or — nothing there — takes the next owned position)
+                if (L.ctl[CT_NSTACK] == 0) L.item[slot][PG_KIND] = -1;
+            }
         }
+        __syncthreads();
+        if (helping) {
+            if (__builtin_amdgcn_readfirstlane(L.item[slot][PG_KIND]) == -1) {   // the helped item was the last thing put aside... nothing: go on with the owned positions
+                if (wv == 0) {
+                    const PChainDims C = dims();
+                    (void)next_owned(C, slot);
+                }
+                __syncthreads();
+            }
+        } else {
+            slot ^= 1;   // the item decoded behind this one's loads — not ready then: the control path looks again
+        }
+        fresh = true;
     }
 }
 
@@ -3790,10 +3844,11 @@ bool jacobi_chain_applies(const Win& w, int ga, int gb, int iters)
 size_t jacobi_pchain_state_bytes();
 // the counters of either form (k_jacobi_tb_chain: (block, tile row); k_jacobi_pchain: two halves of heads + (block, stack row, panel) cells)
 size_t jacobi_chain_flag_bytes() { return std::max((size_t)(CHAIN_MAX_BLOCKS * CHAIN_MAX_ROWS) * sizeof(unsigned int), jacobi_pchain_state_bytes()); }
-// FLUID_CHAIN_PERSIST (lab build): 0 = round 5's k_jacobi_tb_chain (one workgroup per tile, blockIdx order); default: the persistent form
+// FLUID_CHAIN_PERSIST=1 (lab build): the persistent form, k_jacobi_pchain — placement-independent and general, and measured 20 ... 50 % slower on
+// the loop than one workgroup per tile (profiles/r06/pchain_*.txt): a lab kernel.  Default, and all the product has: k_jacobi_tb_chain.
 static bool chain_persistent()
 {
-    static const bool on = [] { const char* e = lab_env("FLUID_CHAIN_PERSIST"); return !(e && atoi(e) == 0); }();
+    static const bool on = [] { const char* e = lab_env("FLUID_CHAIN_PERSIST"); return e && atoi(e) != 0; }();
     return on;
 }
 int jacobi_chain_max_blocks() { return chain_persistent() ? PCHAIN_MAX_BLOCKS : CHAIN_MAX_BLOCKS; }
@@ -3860,8 +3915,17 @@ hipError_t launch_jacobi_tb_chain_ranges(hipStream_t s, Win w, float* pa, float*
     case 2: k_jacobi_tb_chain<8, 10, 12, 10, 2, 1><<<grid, block, 0, s>>>(w, pa, pb, div, pscale, C, ax.S, ay.S, ax.n, ay.n, flags, err); break;
     case 3: k_jacobi_tb_chain<8, 10, 12, 10, 2, 2><<<grid, block, 0, s>>>(w, pa, pb, div, pscale, C, ax.S, ay.S, ax.n, ay.n, flags, err); break;
     case 4: k_jacobi_tb_chain<8, 10, 12, 10, 2, 3><<<grid, block, 0, s>>>(w, pa, pb, div, pscale, C, ax.S, ay.S, ax.n, ay.n, flags, err); break;
+    case 5: k_jacobi_tb_chain<8, 10, 12, 10, 2, 5><<<grid, block, 0, s>>>(w, pa, pb, div, pscale, C, ax.S, ay.S, ax.n, ay.n, flags, err); break;
+    case 6: k_jacobi_tb_chain<8, 10, 12, 10, 2, 6><<<grid, block, 0, s>>>(w, pa, pb, div, pscale, C, ax.S, ay.S, ax.n, ay.n, flags, err); break;
 #endif
-    default: k_jacobi_tb_chain<8, 10, 12, 10, 2, 0><<<grid, block, 0, s>>>(w, pa, pb, div, pscale, C, ax.S, ay.S, ax.n, ay.n, flags, err); break;
+    default: {
+        static const int skip = [] { const char* e = lab_env("FLUID_CHAIN_SKIP"); return e ? atoi(e) : 1; }();   // FLUID_CHAIN_SKIP=0 (lab): every wave sweeps all of its rows (round 5)
+        if (skip) k_jacobi_tb_chain<8, 10, 12, 10, 2, 0, true><<<grid, block, 0, s>>>(w, pa, pb, div, pscale, C, ax.S, ay.S, ax.n, ay.n, flags, err);
+#ifdef FLUID_PROBES
+        else k_jacobi_tb_chain<8, 10, 12, 10, 2, 0, false><<<grid, block, 0, s>>>(w, pa, pb, div, pscale, C, ax.S, ay.S, ax.n, ay.n, flags, err);
+#endif
+        break;
+    }
     }
     return hipGetLastError();
 }
@@ -3872,7 +3936,7 @@ static int pchain_knob(const char* name, int dflt)
     const char* e = lab_env(name);
     return e ? atoi(e) : dflt;
 }
-size_t jacobi_pchain_state_bytes() { return 2 * (size_t)(8 * PCHAIN_HEAD_STRIDE + PCHAIN_MAX_BLOCKS * PCHAIN_MAX_CELLS) * sizeof(unsigned int); }
+size_t jacobi_pchain_state_bytes() { return 2 * (size_t)(8 * PCHAIN_HEAD_STRIDE + PCHAIN_MAX_BLOCKS * PCHAIN_MAX_CELLS + PCHAIN_MAX_ITEMS) * sizeof(unsigned int); }
 
 // Tiles per stack, column panels and stack rows per band for an nx x ny tiling of `blocks` blocks.  A band should fill one XCD's 64 resident
 // workgroups (its tiles share their aprons in that XCD's L2) and the bands of the launch should deal out evenly over the eight heads.
@@ -3929,7 +3993,7 @@ hipError_t launch_jacobi_pchain_ranges(hipStream_t s, Win w, float* pa, float* p
     C.d.xs = ax.S;
     C.d.ys = ay.S;
     pchain_layout(C);
-    if (C.d.ny * C.d.np > PCHAIN_MAX_CELLS || C.d.nx >= 4096 || C.d.ny >= 4096) return hipErrorNotReady;
+    if (C.d.ny * C.d.np > PCHAIN_MAX_CELLS || C.d.nx >= 4096 || C.d.ny >= 4096 || (long)C.d.blocks * C.d.nx * C.d.ny > PCHAIN_MAX_ITEMS) return hipErrorNotReady;
     static const int timeout_ms = pchain_knob("FLUID_CHAIN_TIMEOUT_MS", 2000);
     C.d.timeout = (unsigned int)timeout_ms * 100000u;
     static const int withhold = pchain_knob("FLUID_CHAIN_WITHHOLD", -1);
@@ -3953,27 +4017,15 @@ hipError_t launch_jacobi_pchain_ranges(hipStream_t s, Win w, float* pa, float* p
         return p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
     }();
     static const int f_grid = pchain_knob("FLUID_CHAIN_GRID", 0);
-    const long items = (long)C.d.blocks * C.d.nx * C.d.ny;
-    const unsigned grid = (unsigned)std::max(1l, std::min(items, (long)(f_grid > 0 ? f_grid : 2 * cus)));
+    // 8 S workgroups: S owners per XCD sequence (S = what an XCD holds: two workgroups per CU), every position has exactly one owner
+    const unsigned grid = (unsigned)std::max(8, ((f_grid > 0 ? f_grid : 2 * cus) / 8) * 8);
 #ifdef FLUID_PROBES
-    static const int stats = pchain_knob("FLUID_CHAIN_STATS", 0);
-    if (stats) {
-        static unsigned int* g_err = nullptr;
-        static long g_calls = 0;
-        g_err = err;
-        if (g_calls > 0 && g_calls % 60 == 0) {   // (the host reads the mapped words while launches are in flight: a running total, good enough for a breakdown)
-            const unsigned int* v = g_err + 8;
-            const double wg = v[8] ? (double)v[8] : 1.0, n = wg / (double)grid;
-            fprintf(stderr, "pchain stats after ~%.0f launches: per launch: stacks run %.0f, control-path entries %.0f, polls %.0f of which not ready %.0f, helper draws %.0f | "
-                            "per workgroup per launch (us): waiting %.1f, in the control path %.1f (incl. waiting), lifetime %.1f | workgroups per launch %u\n",
-                    n, v[0] / n, v[1] / n, v[2] / n, v[3] / n, v[4] / n, v[5] / wg / 100.0, v[6] / wg / 100.0, v[7] / wg / 100.0, grid);
-        }
-        g_calls++;
-        k_jacobi_pchain<8, 10, 12, 10, 4><<<dim3(grid), dim3(64, 8), 0, s>>>(w, pa, pb, div, pscale, C, state, err);
-    } else if (jacobi_chain_mode() == 4) k_jacobi_pchain<8, 10, 12, 10, 3><<<dim3(grid), dim3(64, 8), 0, s>>>(w, pa, pb, div, pscale, C, state, err);
-    else
+    if (jacobi_chain_mode() == 4) k_jacobi_pchain<8, 10, 12, 10, 3><<<dim3(grid), dim3(64, 8), 0, s>>>(w, pa, pb, div, pscale, C, state, err);
+    else k_jacobi_pchain<8, 10, 12, 10, 0><<<dim3(grid), dim3(64, 8), 0, s>>>(w, pa, pb, div, pscale, C, state, err);
+#else
+    (void)grid;
+    return hipErrorNotReady;   // (the product library does not carry the persistent form)
 #endif
-        k_jacobi_pchain<8, 10, 12, 10, 0><<<dim3(grid), dim3(64, 8), 0, s>>>(w, pa, pb, div, pscale, C, state, err);
     const hipError_t e = hipGetLastError();
     if (e == hipSuccess) {   // only a launch that went out has used its half and zeroed the other
         ep->psig[0] = sig;

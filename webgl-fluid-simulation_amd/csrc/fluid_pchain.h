@@ -89,7 +89,11 @@ __host__ __device__ __forceinline__ bool pchain_item(const PChainDims& C, int x,
 }
 // words of state per half: the eight heads, then one counter per (block, stack row, panel)
 __host__ __device__ __forceinline__ int pchain_cell(const PChainDims& C, int l, int by, int pn) { return 8 * PCHAIN_HEAD_STRIDE + (l * C.ny + by) * C.np + pn; }
-__host__ __device__ __forceinline__ int pchain_bank_words(const PChainDims& C) { return 8 * PCHAIN_HEAD_STRIDE + C.blocks * C.ny * C.np; }
+// ... then one CLAIM word per item (k_jacobi_pchain's fourth form: an item is run by whoever bumps its claim word from 0 — its owner, or a
+// workgroup that waits for it and finds it unclaimed)
+__host__ __device__ __forceinline__ int pchain_claim_word(const PChainDims& C, int l, int by, int bx) { return 8 * PCHAIN_HEAD_STRIDE + C.blocks * C.ny * C.np + (l * C.ny + by) * C.nx + bx; }
+__host__ __device__ __forceinline__ int pchain_bank_words(const PChainDims& C) { return 8 * PCHAIN_HEAD_STRIDE + C.blocks * C.ny * C.np + C.blocks * C.ny * C.nx; }
+constexpr int PCHAIN_MAX_ITEMS = 131072;   // items (claim words) per launch
 // blocks, nx, ny, stack, pw, bh set: everything that follows from them
 __host__ inline void pchain_finish(PChainDims& C)
 {
