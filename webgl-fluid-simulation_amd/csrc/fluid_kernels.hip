@@ -1127,11 +1127,18 @@ typedef unsigned int chain_u4 __attribute__((ext_vector_type(4)));
 // SIMD, and the two workgroups resident on a CU start one place apart 97 % of the time): with the light blocks on waves 0 and 2 of BOTH
 // workgroups, every SIMD of the CU holds exactly one light wave and three full ones — 345 row sweeps per ten iterations instead of 400 on
 // each SIMD, not 290 on two of them and 400 on the others.  Placement changes the speed only, never the result.
-template <int NW, int RY, int HX, int HY, int EDGE, class T, bool GS = false, class V2 = float2, bool CHAIN = false, bool SKIP = false, bool LIGHT = false, int PROBE = 0>
+struct NoWait {
+    __device__ __forceinline__ void operator()() const {}
+};
+// wait_deps (k_jacobi_tb_chain, round 6): called between the tile's DIVERGENCE loads and its pressure loads.  The divergence is an input of
+// the whole launch — nobody writes it — so its ten loads per wave go out BEFORE the workgroup has asked whether the previous block's tiles are
+// done: their round trip is the poll's, and only the pressure's ten loads follow the answer (a tile is its memory round trips in a row:
+// profiles/r06/chain_bounds_probes.txt).
+template <int NW, int RY, int HX, int HY, int EDGE, class T, bool GS = false, class V2 = float2, bool CHAIN = false, bool SKIP = false, bool LIGHT = false, int PROBE = 0, class FW = NoWait>
 __device__ __forceinline__ void jacobi_tb_body_impl(const Win& w, const T* __restrict__ p, const T* __restrict__ div,
                                                T* __restrict__ p_out, float pscale, int iters, int ga, int gb, int x0,
                                                int y0, float4 (*mail)[NW][2][64], const V2* __restrict__ vel = nullptr,
-                                               V2* __restrict__ vel_out = nullptr)
+                                               V2* __restrict__ vel_out = nullptr, FW&& wait_deps = FW{})
 {
     constexpr bool HALF = sizeof(T) == 2;
     using G = JacobiTB<NW, RY, HX, HY>;
@@ -1158,13 +1165,26 @@ __device__ __forceinline__ void jacobi_tb_body_impl(const Win& w, const T* __res
         rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(p), 0, bytes, 0x00020000);
         rout = __builtin_amdgcn_make_buffer_rsrc(p_out, 0, bytes, 0x00020000);
     }
+    if constexpr (CHAIN) {
 #pragma unroll
-    for (int r = 0; r < RY; r++) {
-        const int lr = min(max(gy + r - w.g0, 0), w.rows - 1);
-        const size_t row = (size_t)lr * (size_t)w.P;  // wave-uniform
-        if constexpr (CHAIN) P[r] = load_quad_sc1(rin, row + cxs);
-        else P[r] = load_quad(p, row + cxs);
-        D[r] = load_quad(div, row + cxs);
+        for (int r = 0; r < RY; r++) {
+            const int lr = min(max(gy + r - w.g0, 0), w.rows - 1);
+            D[r] = load_quad(div, (size_t)lr * (size_t)w.P + cxs);
+        }
+        wait_deps();
+#pragma unroll
+        for (int r = 0; r < RY; r++) {
+            const int lr = min(max(gy + r - w.g0, 0), w.rows - 1);
+            P[r] = load_quad_sc1(rin, (size_t)lr * (size_t)w.P + cxs);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < RY; r++) {
+            const int lr = min(max(gy + r - w.g0, 0), w.rows - 1);
+            const size_t row = (size_t)lr * (size_t)w.P;  // wave-uniform
+            P[r] = load_quad(p, row + cxs);
+            D[r] = load_quad(div, row + cxs);
+        }
     }
 #pragma unroll
     for (int r = 0; r < RY; r++) {  // clearShader folded in: value * p, same rounding as the separate pass
@@ -1296,20 +1316,20 @@ __device__ __forceinline__ void jacobi_tb_body_impl(const Win& w, const T* __res
     }
 }
 
-template <int NW, int RY, int HX, int HY, int EDGE, class T, bool GS = false, class V2 = float2, bool CHAIN = false, bool SKIP = false, int PROBE = 0>
+template <int NW, int RY, int HX, int HY, int EDGE, class T, bool GS = false, class V2 = float2, bool CHAIN = false, bool SKIP = false, int PROBE = 0, class FW = NoWait>
 __device__ __forceinline__ void jacobi_tb_body(const Win& w, const T* __restrict__ p, const T* __restrict__ div, T* __restrict__ p_out, float pscale, int iters,
                                                int ga, int gb, int x0, int y0, float4 (*mail)[NW][2][64], const V2* __restrict__ vel = nullptr,
-                                               V2* __restrict__ vel_out = nullptr)
+                                               V2* __restrict__ vel_out = nullptr, FW&& wait_deps = FW{})
 {
     if constexpr (PROBE != 0) {
-        jacobi_tb_body_impl<NW, RY, HX, HY, EDGE, T, GS, V2, CHAIN, true, false, PROBE>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail, vel, vel_out);
+        jacobi_tb_body_impl<NW, RY, HX, HY, EDGE, T, GS, V2, CHAIN, true, false, PROBE>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail, vel, vel_out, wait_deps);
     } else if constexpr (SKIP) {
         const int hw = __builtin_amdgcn_readfirstlane(threadIdx.y);
         const bool light = (hw == 0 && y0 > 0) || (hw == 2 && y0 + NW * RY < w.H);   // the tile's first block is wave 0's, its last wave 2's
-        if (light) jacobi_tb_body_impl<NW, RY, HX, HY, EDGE, T, GS, V2, CHAIN, true, true>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail, vel, vel_out);
-        else jacobi_tb_body_impl<NW, RY, HX, HY, EDGE, T, GS, V2, CHAIN, true, false>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail, vel, vel_out);
+        if (light) jacobi_tb_body_impl<NW, RY, HX, HY, EDGE, T, GS, V2, CHAIN, true, true>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail, vel, vel_out, wait_deps);
+        else jacobi_tb_body_impl<NW, RY, HX, HY, EDGE, T, GS, V2, CHAIN, true, false>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail, vel, vel_out, wait_deps);
     } else {
-        jacobi_tb_body_impl<NW, RY, HX, HY, EDGE, T, GS, V2, CHAIN, false, false>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail, vel, vel_out);
+        jacobi_tb_body_impl<NW, RY, HX, HY, EDGE, T, GS, V2, CHAIN, false, false>(w, p, div, p_out, pscale, iters, ga, gb, x0, y0, mail, vel, vel_out, wait_deps);
     }
 }
 
@@ -1362,12 +1382,15 @@ struct ChainPlan {
     int tickets;                  // 1: a workgroup's place in the order is a ticket it draws when it starts (independent of the dispatch order)
     unsigned int target;          // a tile row of the previous block is complete when its counter has reached this: the counters are never
                                   // reset between calls of the same shape (no memset in the stream) — call number e waits for (e + 1) nx
+    unsigned int timeout;         // 100 MHz ticks a workgroup waits for a tile row before it gives up (2 s; lab: FLUID_CHAIN_TIMEOUT_MS)
+    int withhold;                 // lab (FLUID_CHAIN_WITHHOLD=row): the first tile of that tile row of block 0 never counts itself — what waits
+                                  // for the row gives up: the give-up path, forced (tests/test_chain_safety.py); -1 = off
 };
 
 // DIAG (FLUID_JACOBI_CHAIN=2 / 3 / 4: timing probes whose RESULTS ARE NOT VALID): 1 = a tile counts itself done without draining its stores
 // (what the wait for the write-through acknowledgements costs), 2 = plain pressure loads and stores instead of sc1 (what the cache policy
 // costs), 3 = nobody waits for anybody (what the dependency waits cost)
-template <int NW, int RY, int HX, int HY, int BPC, int DIAG = 0, bool SKIP = false>
+template <int NW, int RY, int HX, int HY, int BPC, int DIAG = 0, bool SKIP = false, bool DFIRST = false>
 __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_chain(Win w, float* __restrict__ pa, float* __restrict__ pb,
                                                               const float* __restrict__ div, float pscale, ChainPlan C, int xs,
                                                               int ys, int nx, int ny, unsigned int* __restrict__ done,
@@ -1408,23 +1431,36 @@ __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_chain
     tile_exact(y0t, G::TY, HY, w.H, ga, gb, st_lo, st_hi);
     tile_exact(x0t, G::TX, HX, w.W, w.x0, w.x1, sx_lo, sx_hi);
     const bool nothing = st_hi <= st_lo || sx_hi <= sx_lo;   // this block's ranges do not reach this tile (block-uniform): no reads, no writes — count and go
+    auto wait_prev = [&]() {
     if (l > 0 && DIAG != 3 && !nothing) {
         // three lanes, one row each: the three counters come back in ONE memory round trip (one lane after the other: three — visit 12)
         const int r = by - 1 + (int)threadIdx.x;
         if (threadIdx.y == 0 && threadIdx.x < 3 && r >= 0 && r < ny) {
             const unsigned int* flag = done + (l - 1) * CHAIN_MAX_ROWS + r;
             unsigned spins = 0;
+            unsigned long long t0 = 0;
             while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < C.target) {
                 __builtin_amdgcn_s_sleep(2);
-                if ((++spins & 1023u) == 0 &&
-                    (spins > (1u << 16) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {   // never hang the device
-                    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
+                // never hang the device — bounded in WALL-CLOCK time (round 6: a count of polls is some tens of milliseconds, which a foreign
+                // kernel holding the CUs can outlast; the 100 MHz clock does not care how slowly this wave gets to poll), and nobody waits once
+                // somebody has given up (err is mapped HOST memory: looked at every 1024 polls only)
+                if ((++spins & 63u) == 0) {
+                    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                    if (t0 == 0) t0 = now;
+                    if (now - t0 > (unsigned long long)C.timeout || ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) {
+                        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
                 }
             }
         }
         __syncthreads();
     }
+    };
+    if constexpr (!DFIRST) wait_prev();
+    auto wait_in_body = [&]() {
+        if constexpr (DFIRST) wait_prev();
+    };
     const float* p = (l & 1) ? pb : pa;
     float* p_out = (l & 1) ? pa : pb;
     const int x0 = xs + bx * G::VX, y0 = ys + by * G::VY;
@@ -1434,13 +1470,14 @@ __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_chain
     constexpr bool SC1 = DIAG != 2;
     constexpr int PROBE = DIAG == 5 ? 1 : (DIAG == 6 ? 2 : 0);   // lab: 5 = no arithmetic, 6 = no mailbox / barrier (results not valid)
     if (nothing) {
-    } else if (yedge || ragged) jacobi_tb_body<NW, RY, HX, HY, 2, float, false, float2, SC1, SKIP, PROBE>(w, p, div, p_out, ps, C.iters[l], ga, gb, x0, y0, mail);
-    else if (xedge) jacobi_tb_body<NW, RY, HX, HY, 1, float, false, float2, SC1, SKIP, PROBE>(w, p, div, p_out, ps, C.iters[l], ga, gb, x0, y0, mail);
-    else jacobi_tb_body<NW, RY, HX, HY, 0, float, false, float2, SC1, SKIP, PROBE>(w, p, div, p_out, ps, C.iters[l], ga, gb, x0, y0, mail);
+    } else if (yedge || ragged) jacobi_tb_body<NW, RY, HX, HY, 2, float, false, float2, SC1, SKIP, PROBE>(w, p, div, p_out, ps, C.iters[l], ga, gb, x0, y0, mail, (const float2*)nullptr, (float2*)nullptr, wait_in_body);
+    else if (xedge) jacobi_tb_body<NW, RY, HX, HY, 1, float, false, float2, SC1, SKIP, PROBE>(w, p, div, p_out, ps, C.iters[l], ga, gb, x0, y0, mail, (const float2*)nullptr, (float2*)nullptr, wait_in_body);
+    else jacobi_tb_body<NW, RY, HX, HY, 0, float, false, float2, SC1, SKIP, PROBE>(w, p, div, p_out, ps, C.iters[l], ga, gb, x0, y0, mail, (const float2*)nullptr, (float2*)nullptr, wait_in_body);
     // done: every storing wave drains its write-through stores, then ONE lane counts the tile (the guide's R1)
     if (DIAG != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0 && threadIdx.y == 0) __hip_atomic_fetch_add(done + l * CHAIN_MAX_ROWS + by, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0 && threadIdx.y == 0 && !(C.withhold >= 0 && l == 0 && by == C.withhold && bx == 0))
+        __hip_atomic_fetch_add(done + l * CHAIN_MAX_ROWS + by, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- the pressure loop as ONE launch of PERSISTENT workgroups that take STACKS of tiles from per-XCD ticket heads (round 6) -------------
@@ -3898,11 +3935,11 @@ hipError_t launch_jacobi_tb_chain_ranges(hipStream_t s, Win w, float* pa, float*
             ep->calls = 0;
         }
     }
+    static const int timeout_ms = [] { const char* e = lab_env("FLUID_CHAIN_TIMEOUT_MS"); return e ? atoi(e) : 2000; }();
+    static const int withhold = [] { const char* e = lab_env("FLUID_CHAIN_WITHHOLD"); return e ? atoi(e) : -1; }();
+    C.timeout = (unsigned int)timeout_ms * 100000u;
+    C.withhold = withhold;
     C.target = ((ep ? ep->calls : 0u) + 1u) * (unsigned)ax.n;
-    if (ep) {
-        ep->calls++;
-        ep->psig[0] = 0xffffffffu;
-    }
     const dim3 grid((unsigned)(C.blocks * C.tiles), 1, 1), block(64, 8, 1);
 #ifdef FLUID_PROBES
     if (C.tickets) {
@@ -3919,15 +3956,29 @@ hipError_t launch_jacobi_tb_chain_ranges(hipStream_t s, Win w, float* pa, float*
     case 6: k_jacobi_tb_chain<8, 10, 12, 10, 2, 6><<<grid, block, 0, s>>>(w, pa, pb, div, pscale, C, ax.S, ay.S, ax.n, ay.n, flags, err); break;
 #endif
     default: {
-        static const int skip = [] { const char* e = lab_env("FLUID_CHAIN_SKIP"); return e ? atoi(e) : 1; }();   // FLUID_CHAIN_SKIP=0 (lab): every wave sweeps all of its rows (round 5)
-        if (skip) k_jacobi_tb_chain<8, 10, 12, 10, 2, 0, true><<<grid, block, 0, s>>>(w, pa, pb, div, pscale, C, ax.S, ay.S, ax.n, ay.n, flags, err);
 #ifdef FLUID_PROBES
-        else k_jacobi_tb_chain<8, 10, 12, 10, 2, 0, false><<<grid, block, 0, s>>>(w, pa, pb, div, pscale, C, ax.S, ay.S, ax.n, ay.n, flags, err);
+        // Two lab forms of the tile, both bitwise, both measured LEVEL (profiles/r06/chain_dfirst_ab.txt, chain_skip_ab.txt) — the loop hides its
+        // arithmetic and the poll's round trip alike (chain_bounds_probes.txt): FLUID_CHAIN_DFIRST=1: the tile's divergence loads go out in front of
+        // the poll; FLUID_CHAIN_SKIP=1: its first / last wave skip the rows the apron has reached (light blocks on waves 0 and 2: one per SIMD)
+        static const int dfirst = [] { const char* e = lab_env("FLUID_CHAIN_DFIRST"); return e ? atoi(e) : 0; }();
+        static const int skip = [] { const char* e = lab_env("FLUID_CHAIN_SKIP"); return e ? atoi(e) : 0; }();
+        if (dfirst) k_jacobi_tb_chain<8, 10, 12, 10, 2, 0, false, true><<<grid, block, 0, s>>>(w, pa, pb, div, pscale, C, ax.S, ay.S, ax.n, ay.n, flags, err);
+        else if (skip) k_jacobi_tb_chain<8, 10, 12, 10, 2, 0, true, false><<<grid, block, 0, s>>>(w, pa, pb, div, pscale, C, ax.S, ay.S, ax.n, ay.n, flags, err);
+        else
 #endif
+            k_jacobi_tb_chain<8, 10, 12, 10, 2, 0><<<grid, block, 0, s>>>(w, pa, pb, div, pscale, C, ax.S, ay.S, ax.n, ay.n, flags, err);
         break;
     }
     }
-    return hipGetLastError();
+    const hipError_t rc = hipGetLastError();
+    if (ep) {
+        // the counters count up from call to call: only a launch that went out has bumped them (a failed one would leave every later call
+        // waiting for a count nobody makes — ADVICE r05); anything else: the next call zeroes them
+        if (rc == hipSuccess) ep->calls++;
+        else ep->signature = 0xffffffffu;
+        ep->psig[0] = 0xffffffffu;   // (the persistent form's state shares the memory)
+    }
+    return rc;
 }
 
 // ---- the persistent form (k_jacobi_pchain; fluid_pchain.h) ----

@@ -361,11 +361,24 @@ int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launche
             }
             const Win w = sim_cols(c, ext_out + (iters - done - it[0]));
             if (fluid::jacobi_chain_applies(w, ra[0], rb[0], iters - done)) {
-                if (!c->chain_flags) {
-                    HIPCK(c, hipMalloc((void**)&c->chain_flags, fluid::jacobi_chain_flag_bytes()));
-                    HIPCK(c, hipHostMalloc((void**)&c->chain_err_host, 64 * sizeof(unsigned int), hipHostMallocMapped));
-                    for (int k = 0; k < 64; k++) c->chain_err_host[k] = 0;   // [0]: a chained launch gave up; [1]: lab ticket word; [8..31]: lab statistics (FLUID_CHAIN_STATS)
-                    HIPCK(c, hipHostGetDevicePointer((void**)&c->chain_err_dev, c->chain_err_host, 0));
+                if (!c->chain_flags || !c->chain_err_host || !c->chain_err_dev) {
+                    // all three or none (a launch with the counters but without the error words would fault in its poll loop: ADVICE r05)
+                    unsigned int *flags = nullptr, *eh = nullptr, *ed = nullptr;
+                    int rc = c->hip(hipMalloc((void**)&flags, fluid::jacobi_chain_flag_bytes()), "hipMalloc (chain counters)");
+                    if (!rc) rc = c->hip(hipHostMalloc((void**)&eh, 64 * sizeof(unsigned int), hipHostMallocMapped), "hipHostMalloc (chain error words)");
+                    if (!rc) rc = c->hip(hipHostGetDevicePointer((void**)&ed, eh, 0), "hipHostGetDevicePointer");
+                    if (rc) {
+                        if (flags) (void)hipFree(flags);
+                        if (eh) (void)hipHostFree(eh);
+                        return rc;
+                    }
+                    for (int k = 0; k < 64; k++) eh[k] = 0;   // [0]: a chained launch gave up; [1]: lab ticket word; [8..31]: lab statistics
+                    if (c->chain_flags) (void)hipFree(c->chain_flags);
+                    if (c->chain_err_host) (void)hipHostFree(c->chain_err_host);
+                    c->chain_flags = flags;
+                    c->chain_err_host = eh;
+                    c->chain_err_dev = ed;
+                    c->chain_epoch = fluid::ChainEpoch{};
                 }
                 const hipError_t e = fluid::launch_jacobi_tb_chain_ranges(c->stream, w, (float*)c->prs[0], (float*)c->prs[1], (const float*)c->div,
                                                                           done == 0 ? pscale : 1.0f, n, it, ra, rb, xa, xb, c->chain_flags, c->chain_err_dev, &c->chain_epoch);
@@ -1509,7 +1522,9 @@ int fluid_schedule_info_get(fluid_ctx* c, int n_steps, float dt, const fluid_par
     {   // ... which are ONE launch of chained blocks where that schedule applies (pass_jacobi)
         int ga, gb;
         row_range(c->sim, c->sim_row0, c->sim_rows, 0, ga, gb);
-        out->jacobi_chained = tb && whole && c->storage == FLUID_STORE_F32 && out->jacobi_shape == 0 && !fluid_impl::gradsub_fold_enabled(owned) &&
+        // (whole-domain contexts; a stripe / tile rank chains the launches it has left behind its cut ones the same way — fewer of them, by the
+        // plan's cut — and is reported through the timings' launch counts.  Not after a chained launch of this context has given up: chain_broken)
+        out->jacobi_chained = tb && whole && !c->chain_broken && c->storage == FLUID_STORE_F32 && out->jacobi_shape == 0 && !fluid_impl::gradsub_fold_enabled(owned) &&
                               fluid::jacobi_chain_applies(sim_cols(c, 0), ga, gb, P->iterations);
     }
     out->gradsub_folded = tb && fluid::jacobi_tb_has_gradsub(out->jacobi_shape) && fluid_impl::gradsub_fold_enabled(owned);
