@@ -852,7 +852,10 @@ def main(argv=None, engine_factory=None, backend="nccl"):
         if entry and kname.startswith("k_jacobi_tb_chain"):
             per_dispatch = max(1, int(round((launches / max(tm["steps"], 1)) / max(entry["launches_per_step"], 1e-9))))
         if entry:
-            bytes_launch, source = int(entry["bytes_per_launch"] / per_dispatch), "PMC FETCH_SIZE x2 + WRITE_SIZE, this run (rocprofv3 --pmc, separate passes)"
+            bytes_launch, source = int(entry["bytes_per_launch"] / per_dispatch), (
+                "PMC FETCH_SIZE x2 + WRITE_SIZE, this run (rocprofv3 --pmc, separate passes): the bytes that crossed the L2's FABRIC side — reads served by "
+                "the 256 MiB Infinity Cache are counted like reads from HBM (profiles/r06/mall_probe.txt: a warm 192 MiB sweep runs at 7.0 TB/s with "
+                "FETCH_SIZE x2 = the bytes requested), and the Jacobi loop's working set (3 x 64 MiB at 4096^2) fits in that cache")
         else:   # the least a launch must move: pressure in, divergence in, pressure out (no apron re-reads counted)
             bytes_launch, source = int(12.0 * size * size * half), "model: compulsory 12 B/texel per launch (PMC pass unavailable: %s)" % why
         achieved = bytes_launch / (avg_ms * 1e-3) / 1e9
@@ -946,6 +949,42 @@ def main(argv=None, engine_factory=None, backend="nccl"):
             out["steady_steps"] = n_long
         else:
             skipped["steady_ms_per_step"] = "extras budget spent"
+
+    # ---- the page's own call pattern: update() calls step(dt) ONCE per frame (script.js:1176-1186) — K calls of fluid_step, back to back ----
+    # (`value` times ONE fluid_step_n(K): a call for K steps stores the curl field once and, below 1536^2, works ahead between its steps;
+    # a call per step stores the curl every time and pays the call's own host path.)  Beside it: what a frame costs when the page also
+    # composites it — render(target) at the reference's shipping sizes (capture 512, bloom 256 x 8, sunrays 196: script.js:59-85, 1296-1419).
+    if rank == 0 and N == 1 and not args.no_steady and not on_cpu and hasattr(sim, "step") and deadline.left() > 20:
+        try:
+            n_frames = max(200, args.steps)
+            for _ in range(30):
+                sim.step(DT, 1)
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(n_frames):
+                sim.step(DT, 1)
+            sync()
+            per_frame_ms = 1e3 * (time.perf_counter() - t0) / n_frames
+            ref_ms = out.get("steady_ms_per_step") or out["ms_per_step"]
+            out["per_frame"] = {"ms_per_step": round(per_frame_ms, 4), "calls": n_frames, "ratio_to_batched": round(ref_ms / per_frame_ms, 4),
+                                "batched_ms_per_step": ref_ms,
+                                "what": "%d calls of fluid_step (one step each, no synchronisation in between) against one fluid_step_n call of the same steps "
+                                        "(`steady_ms_per_step` if measured, else `ms_per_step`): the page's update() pattern, script.js:1176-1186" % n_frames}
+            if hasattr(sim, "render"):
+                sim.render(512, 512)
+                sync()
+                t0 = time.perf_counter()
+                n_r = 50
+                import ctypes as _C
+                dp = sim._display_params()
+                for _ in range(n_r):
+                    sim._check(sim._lib.fluid_render(sim._ctx, 512, 512, _C.byref(dp)))
+                sync()
+                out["render"] = {"ms": round(1e3 * (time.perf_counter() - t0) / n_r, 4), "target": [512, 512], "calls": n_r,
+                                 "what": "fluid_render at the reference's shipping display settings on the %dx%d dye field (shading, bloom 256 x 8, sunrays 196, "
+                                         "dithering off-default: script.js:59-85), device time per call incl. the RGBA view of a packed dye field; no readback" % (size, size)}
+        except Exception as ex:   # an extra: never takes the line away
+            skipped["per_frame"] = "%s: %s" % (type(ex).__name__, str(ex)[:160])
 
     # ---- the same W + K from a cold chip: what `ms_per_step` would read without the load in front of the warm-up ----
     if rank == 0 and N == 1 and settle and not args.no_steady and deadline.left() > 20:

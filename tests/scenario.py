@@ -16,7 +16,7 @@ FIELDS = ("velocity", "pressure", "divergence", "curl", "dye")
 def golden_names(prefix=""):
     """driver / single-pass scenarios (the input-replay and display fixtures have their own tests: test_input_replay.py, test_display.py, test_long_horizon.py)"""
     names = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
-    return [n for n in names if not n.startswith(("input_", "display_", "long50_", "big_", "f16_", "raster_"))]
+    return [n for n in names if not n.startswith(("input_", "display_", "displayfull_", "long50_", "big_", "f16_", "raster_"))]
 
 
 def f16_golden_names():
