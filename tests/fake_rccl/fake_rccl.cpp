@@ -30,6 +30,7 @@ extern "C" {
 
 typedef enum { ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclSystemError = 2, ncclInternalError = 3, ncclInvalidArgument = 4 } ncclResult_t;
 typedef enum { ncclChar = 0, ncclFloat = 7 } ncclDataType_t;
+typedef enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3 } ncclRedOp_t;
 typedef struct { char internal[128]; } ncclUniqueId;
 typedef struct FakeComm* ncclComm_t;
 
@@ -45,9 +46,16 @@ struct Parcel {          // one send waiting for its receive
     bool taken = false;
 };
 
+struct Reduce {           // one ncclAllReduce of the world: every rank's staged contribution
+    int arrived = 0, departed = 0;
+    std::vector<float*> stage;
+    std::vector<hipEvent_t> ready, done;
+};
+
 struct World {
     int nranks = 0, arrived = 0;
     std::map<std::pair<int, int>, std::deque<Parcel*>> box;  // (src, dst) -> sends in issue order
+    std::map<long, Reduce> reduces;                          // all-reduces by sequence number (every rank issues them in the same order)
 };
 
 std::mutex g_mu;
@@ -60,6 +68,7 @@ int g_next_id = 1;
 struct FakeComm {
     World* world;
     int rank, nranks;
+    long reduce_seq = 0;
 };
 
 namespace {
@@ -83,6 +92,23 @@ double link_us(size_t bytes)
     static const double lat = [] { const char* e = getenv("FAKE_RCCL_DELAY_US"); return e ? atof(e) : 0.0; }();
     static const double gbps = [] { const char* e = getenv("FAKE_RCCL_GBPS"); return e ? atof(e) : 0.0; }();
     return lat + (gbps > 0 ? (double)bytes / (gbps * 1e3) : 0.0);
+}
+
+constexpr int kMaxRanks = 64;
+struct ReduceArgs {
+    const float* src[kMaxRanks];
+    int n;
+};
+__global__ void k_all_reduce(float* dst, ReduceArgs a, size_t count, int op)
+{
+    for (size_t i = threadIdx.x; i < count; i += blockDim.x) {
+        float v = a.src[0][i];
+        for (int r = 1; r < a.n; r++) {
+            const float x = a.src[r][i];
+            v = op == ncclSum ? v + x : (op == ncclProd ? v * x : (op == ncclMax ? fmaxf(v, x) : fminf(v, x)));
+        }
+        dst[i] = v;
+    }
 }
 
 thread_local int t_depth = 0;
@@ -258,6 +284,67 @@ ncclResult_t ncclSend(const void* buf, size_t count, ncclDataType_t type, int pe
 ncclResult_t ncclRecv(void* buf, size_t count, ncclDataType_t type, int peer, ncclComm_t comm, hipStream_t stream)
 {
     return enqueue(false, buf, count, type, peer, comm, stream);
+}
+
+// every rank's contribution is staged (in-place calls, and a sender that reuses its buffer), the ranks meet, each reduces all the staged
+// vectors into its own receive buffer on its own stream; the last rank to leave waits for every reduction and frees the staging
+ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t type, ncclRedOp_t op, ncclComm_t comm, hipStream_t stream)
+{
+    if (!comm || type != ncclFloat || !sendbuff || !recvbuff || comm->nranks > kMaxRanks || t_depth != 0) return ncclInvalidArgument;
+    if (loopback() || comm->nranks == 1) {
+        if (sendbuff != recvbuff && hipMemcpyAsync(recvbuff, sendbuff, count * sizeof(float), hipMemcpyDeviceToDevice, stream) != hipSuccess) return ncclUnhandledCudaError;
+        return ncclSuccess;
+    }
+    float* stage = nullptr;
+    hipEvent_t ready = nullptr, done = nullptr;
+    if (hipMalloc((void**)&stage, count * sizeof(float)) != hipSuccess) return ncclUnhandledCudaError;
+    if (hipMemcpyAsync(stage, sendbuff, count * sizeof(float), hipMemcpyDeviceToDevice, stream) != hipSuccess) return ncclUnhandledCudaError;
+    if (hipEventCreateWithFlags(&ready, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess) return ncclUnhandledCudaError;
+    if (hipEventRecord(ready, stream) != hipSuccess) return ncclUnhandledCudaError;
+    const long seq = comm->reduce_seq++;
+    ReduceArgs a{};
+    std::vector<hipEvent_t> readies;
+    {
+        std::unique_lock<std::mutex> lk(g_mu);
+        Reduce& R = comm->world->reduces[seq];
+        if (R.stage.empty()) {
+            R.stage.assign(comm->nranks, nullptr);
+            R.ready.assign(comm->nranks, nullptr);
+            R.done.assign(comm->nranks, nullptr);
+        }
+        R.stage[comm->rank] = stage;
+        R.ready[comm->rank] = ready;
+        R.arrived++;
+        g_cv.notify_all();
+        g_cv.wait(lk, [&] { return R.arrived >= comm->nranks; });   // collective: every rank is here
+        a.n = comm->nranks;
+        for (int r = 0; r < comm->nranks; r++) a.src[r] = R.stage[r];
+        readies = R.ready;
+    }
+    for (hipEvent_t e : readies)
+        if (hipStreamWaitEvent(stream, e, 0) != hipSuccess) return ncclUnhandledCudaError;
+    k_all_reduce<<<1, 64, 0, stream>>>((float*)recvbuff, a, count, (int)op);
+    if (hipGetLastError() != hipSuccess || hipEventRecord(done, stream) != hipSuccess) return ncclUnhandledCudaError;
+    Reduce last;
+    bool cleanup = false;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        Reduce& R = comm->world->reduces[seq];
+        R.done[comm->rank] = done;
+        if (++R.departed == comm->nranks) {
+            last = R;
+            cleanup = true;
+            comm->world->reduces.erase(seq);
+        }
+    }
+    if (cleanup)
+        for (int r = 0; r < (int)last.stage.size(); r++) {
+            (void)hipEventSynchronize(last.done[r]);
+            (void)hipFree(last.stage[r]);
+            (void)hipEventDestroy(last.ready[r]);
+            (void)hipEventDestroy(last.done[r]);
+        }
+    return ncclSuccess;
 }
 
 const char* ncclGetErrorString(ncclResult_t r)

@@ -27,11 +27,13 @@ def main():
     with fluid_hip.FluidSim(canvas=canvas, config=cfg, random=fluid_hip.mulberry32(9), storage=storage) as one:
         splats = one.multipleSplats(6)
         one.step(0.016666, steps)
+        if a.get("lone_touch"):      # the ranks step a second time, behind something ONE of them does alone in between
+            one.step(0.016666, steps)
         want = one.fields()
     sim = getResolution(full["SIM_RESOLUTION"], *canvas)
     dye = getResolution(full["DYE_RESOLUTION"], *canvas)
     cid = new_comm_id()
-    out, errs, links = [None] * world, [], [None] * world
+    out, errs, links, packed = [None] * world, [], [None] * world, []
     aspect = canvas[0] / canvas[1]
     radius = full["SPLAT_RADIUS"] / 100.0 * (aspect if aspect > 1 else 1.0)
 
@@ -48,6 +50,18 @@ def main():
             for x, y, dx, dy, cr, cg, cb in splats:
                 e.splat(x, y, dx, dy, cr, cg, cb, aspect, radius)
             e.step_n(steps, 0.016666, full)
+            packed.append(bool(e.schedule_info(steps, 0.016666, full)["dye_packed"]))
+            lt = a.get("lone_touch")
+            if lt:
+                # ONE rank alone does something that takes the dye's known alpha away from it (a raw device pointer: whatever is written
+                # through it the context does not see) or makes it ineligible; its neighbours know nothing of it.  The set must agree on the
+                # wire format of the next call by itself (fluid_stripes.cpp dye_format_agree) and still leave the single domain's bits
+                if r == lt["rank"]:
+                    import ctypes as C
+                    ptr = C.c_void_p()
+                    e._ck(e.lib.fluid_field_device_ptr(e.ctx, _abi.FIELD_IDS["dye"], C.byref(ptr)))
+                e.step_n(steps, 0.016666, full)
+                packed.append(bool(e.schedule_info(steps, 0.016666, full)["dye_packed"]))
             e.sync()
             e.check_halo()
             out[r] = ({k: e.read(k) for k in ("velocity", "pressure", "divergence", "curl", "dye")}, e.exchange_count())
@@ -66,7 +80,7 @@ def main():
     def assemble(k):
         return np.concatenate([np.concatenate([out[y * tx + x][0][k] for x in range(tx)], axis=1) for y in range(ty)], axis=0)
     bad = [k for k in want if not np.array_equal(assemble(k), want[k])]
-    print(json.dumps({"ok": not bad, "mismatch": bad, "exchanges": out[0][1], "rccl": os.environ.get("FLUID_RCCL_LIB"), "links": links}))
+    print(json.dumps({"ok": not bad, "mismatch": bad, "exchanges": out[0][1], "rccl": os.environ.get("FLUID_RCCL_LIB"), "links": links, "packed": packed}))
 
 
 if __name__ == "__main__":

@@ -15,6 +15,9 @@ DT = 0.016666
     (4096, 3072, 47, True),      # non-square, blocks of 10 / 10 / 9 / 9 / 9
     (4200, 3000, 11, True),      # W % 4 == 0 but no power of two; two blocks (6 + 5)
     (3800, 2600, 80, True),      # the narrow end of the rule (17 tiles per row), eight blocks
+    (4096, 3072, 200, True),     # configs[4]'s iteration count: twenty blocks in one launch (round 6: the limit was eight; -8.5 % of the 4096^2 step)
+    (4096, 2560, 137, True),     # fourteen blocks of 10 / 9
+    (4096, 2560, 250, False),    # beyond twenty-four blocks: plain launches
     (4096, 4096, 10, False),     # one block: a plain launch
     (4096, 2048, 50, False),     # below 3072^2 texels: the small-grid tile with the gradient subtract folded in, five launches
     (3072, 3072, 50, False),     # four rows of tiles per XCD band: the plain launches (measured level)

@@ -465,6 +465,32 @@ def test_packed_dye_on_a_stripe_or_tile_set_leaves_the_same_bits(world, tiles_x,
         g.close()
 
 
+@pytest.mark.parametrize("world,tiles_x,canvas,rank", [(2, 1, (4096, 4608), 0), (3, 1, (4096, 6912), 1)])
+def test_ranks_agree_on_the_dye_wire_format_when_one_of_them_loses_its_alpha(world, tiles_x, canvas, rank):
+    """the dye's ghost texels travel as 12-byte texels while the field is packed and as RGBA otherwise, and whether a rank packs
+    hangs on state ONE rank can change alone between two calls (here: a raw device pointer to its dye, which takes the known alpha away).  Over
+    RCCL two neighbours would then post ncclSend / ncclRecv of different sizes — undefined (the stand-in refuses the count mismatch: this test
+    failed with "invalid argument" before round 6).  Every fluid_step_n on a communicator now opens with one all-reduce of four floats in which
+    the set agrees on the call's format: the ranks step packed, one of them is touched alone, the next call runs RGBA on ALL of them — and the
+    set leaves the single domain's bits."""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = fake_rccl_lib()
+    res = min(canvas)
+    args = {"world": world, "tiles_x": tiles_x, "halo": 24, "overlap": True, "canvas": list(canvas), "steps": 2,
+            "config": {"SIM_RESOLUTION": res, "DYE_RESOLUTION": res, "PRESSURE_ITERATIONS": 12}, "lone_touch": {"rank": rank}}
+    r = subprocess.run([sys.executable, os.path.join(here, "fake_rccl", "run_ranks.py"), json.dumps(args)], env=dict(os.environ, FLUID_RCCL_LIB=lib),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["ok"], out
+    # every rank reported "packed" behind the first call and "not packed" behind the second (2 * world answers, in whatever order the threads ran)
+    assert sorted(out["packed"]) == [False] * world + [True] * world, out
+
+
 def test_a_set_that_disagrees_on_the_dye_is_refused():
     """what "splats are collective on a set" means where one process can see it: a splat into ONE context of an in-process set leaves the
     contexts with different alphas (1 against the decayed value) — fluid_group_step_n refuses to exchange instead of mixing texel formats"""

@@ -4,6 +4,7 @@
 // and the XCD-aware block order must be a bijection.  Built and run by tests/test_tile_cover.py (hipcc, no GPU involved).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -65,26 +66,33 @@ static void check_order(int nx, int ny, int remap)
 // other slots none), consecutive slots alternate XCDs (slot b belongs to XCD b % 8, whose tiles are the rows of its own bands only), and every
 // tile of band group g comes before every tile of group g + 1 ON ITS XCD — so that what a tile of the next block needs (its own band's rows and
 // the neighbouring bands' of the same group, or the first / last row of the next / previous group) was taken earlier in the previous block
-static void check_chain_order(int nx, int ny, int band)
+// ... and, with panels of pw tile columns (round 6), every tile of a group's panel p in front of every tile of its panel p + 1 ON ITS XCD (the
+// tiles resident together are a band x pw rectangle)
+static void check_chain_order(int nx, int ny, int band, int pw)
 {
     cases++;
     const int slots = chain_slots(nx, ny, band);
-    std::vector<int> seen((size_t)nx * ny, 0), last_group(8, -1);
+    std::vector<int> seen((size_t)nx * ny, 0), last_group(8, -1), last_panel(8, -1);
+    if (chain_panels(nx, pw) * pw < nx || (chain_panels(nx, pw) - 1) * pw >= nx) { printf("chain nx %d pw %d: %d panels\n", nx, pw, chain_panels(nx, pw)); fails++; return; }
     for (int b = 0; b < slots; b++) {
         int bx = -1, by = -1;
-        if (!chain_tile_of_block(b, nx, ny, band, bx, by)) {
-            if (by < ny) { printf("chain nx %d ny %d band %d: slot %d refused with row %d\n", nx, ny, band, b, by); fails++; return; }
+        if (!chain_tile_of_block(b, nx, ny, band, pw, bx, by)) {
+            if (by < ny) { printf("chain nx %d ny %d band %d pw %d: slot %d refused with row %d\n", nx, ny, band, pw, b, by); fails++; return; }
+            if (bx < 0 || bx >= nx) { printf("chain nx %d ny %d band %d pw %d: slot %d (no tile) -> column %d\n", nx, ny, band, pw, b, bx); fails++; return; }
             continue;
         }
-        if (bx < 0 || bx >= nx || by < 0 || by >= ny) { printf("chain nx %d ny %d band %d: slot %d -> (%d, %d)\n", nx, ny, band, b, bx, by); fails++; return; }
+        if (bx < 0 || bx >= nx || by < 0 || by >= ny) { printf("chain nx %d ny %d band %d pw %d: slot %d -> (%d, %d)\n", nx, ny, band, pw, b, bx, by); fails++; return; }
         seen[(size_t)by * nx + bx]++;
-        const int bandno = by / band, xcd = bandno & 7, group = bandno >> 3;
-        if (xcd != (b & 7)) { printf("chain nx %d ny %d band %d: slot %d (XCD %d) got a tile of XCD %d's band\n", nx, ny, band, b, b & 7, xcd); fails++; return; }
-        if (group < last_group[xcd]) { printf("chain nx %d ny %d band %d: XCD %d goes back from group %d to %d\n", nx, ny, band, xcd, last_group[xcd], group); fails++; return; }
+        const int bandno = by / band, xcd = bandno & 7, group = bandno >> 3, panel = bx / pw;
+        if (xcd != (b & 7)) { printf("chain nx %d ny %d band %d pw %d: slot %d (XCD %d) got a tile of XCD %d's band\n", nx, ny, band, pw, b, b & 7, xcd); fails++; return; }
+        if (group < last_group[xcd]) { printf("chain nx %d ny %d band %d pw %d: XCD %d goes back from group %d to %d\n", nx, ny, band, pw, xcd, last_group[xcd], group); fails++; return; }
+        if (group > last_group[xcd]) last_panel[xcd] = -1;
+        if (panel < last_panel[xcd]) { printf("chain nx %d ny %d band %d pw %d: XCD %d goes back from panel %d to %d\n", nx, ny, band, pw, xcd, last_panel[xcd], panel); fails++; return; }
         last_group[xcd] = group;
+        last_panel[xcd] = panel;
     }
     for (int t = 0; t < nx * ny; t++)
-        if (seen[t] != 1) { printf("chain nx %d ny %d band %d: tile %d taken %d times\n", nx, ny, band, t, seen[t]); fails++; return; }
+        if (seen[t] != 1) { printf("chain nx %d ny %d band %d pw %d: tile %d taken %d times\n", nx, ny, band, pw, t, seen[t]); fails++; return; }
 }
 
 int main()
@@ -113,7 +121,14 @@ int main()
     }
     for (int band = 1; band <= 5; band++)
         for (int nx = 1; nx <= 40; nx += (nx < 24 ? 1 : 5))
-            for (int ny : { 1, 2, 3, 7, 8, 9, 23, 24, 25, 35, 69, 70, 71, 137, 274, 511, 512 }) check_chain_order(nx, ny, band);
+            for (int ny : { 1, 2, 3, 7, 8, 9, 23, 24, 25, 35, 69, 70, 71, 137, 274, 511, 512 }) {
+                check_chain_order(nx, ny, band, nx);   // one panel: round 5's order
+                for (int pw : { 1, 2, 3, 7, 13, 18, 21 })
+                    if (pw < nx) check_chain_order(nx, ny, band, pw);
+                check_chain_order(nx, ny, band, chain_panel_width(nx, 21));
+            }
+    for (int nx : { 36, 54, 71, 72, 142 })   // 8192-, 12288-, 16384-wide and a 32768-wide row: what the launch picks
+        for (int ny : { 35, 36, 137, 274 }) check_chain_order(nx, ny, std::max(1, 64 / chain_panel_width(nx, 21)), chain_panel_width(nx, 21));
     for (int remap = 0; remap < 4; remap++)
         for (int nx = 1; nx <= 40; nx++)
             for (int ny = 1; ny <= 40; ny += (ny < 12 ? 1 : 7)) check_order(nx, ny, remap);

@@ -33,6 +33,7 @@ CONFIGS = {
     "stripe": ((4096, 12288), 4096, 50, 3, 1, 1, 56, 60),       # weak scaling of configs[2]: the middle one of three 4096^2 stripes, 2 exchanges / step
     "tile": ((12288, 12288), 12288, 50, 9, 3, 4, 56, 60),       # configs[3]'s per-rank shape: the centre 4096^2 tile of 3 x 3 (eight neighbours)
     "deep": ((8192, 6144), 6144, 200, 3, 1, 1, 56, 16),         # configs[4]'s regime: 8192 x 2048 per rank, 200 iterations -> 5 exchanges / step
+    "deep16": ((16384, 6144), 6144, 200, 3, 1, 1, 56, 12),      # configs[4]'s own per-rank shape: 16384 x 2048, 200 iterations
 }
 
 

@@ -92,6 +92,14 @@ struct fluid_ctx {
     hipEvent_t ev_inner = nullptr;       // context stream -> comm stream, device scope: the interiors a cut Jacobi launch's frame reads are written
     hipEvent_t ev_joined = nullptr;      // comm stream -> context stream: the strips (and frames) that ran on the comm stream are done
     hipEvent_t ev_mid = nullptr;         // 2-D tiles: this tile's ghost columns are in (phase A), ghost rows may follow
+    // The dye's WIRE FORMAT is agreed per fluid_step_n call over the communicator (fluid_stripes.cpp dye_format_agree): four floats in mapped
+    // pinned host memory in and out of one ncclAllReduce(min) on the comm stream, read when the call reaches its first dye exchange.
+    // dye_set_rgba: the set decided this call's dye travels (and advects) as RGBA — one rank at least cannot pack
+    float* agree_host = nullptr;         // [0..3] this rank's {packs, alpha known, alpha, -alpha}, [4..7] the set's minima
+    float* agree_dev = nullptr;          // 8 floats of device memory: the all-reduce's send and receive buffers
+    hipEvent_t ev_agreed = nullptr;
+    bool agree_pending = false;
+    bool dye_set_rgba = false;
     void* stage[16] = {};                // 2-D tiles: contiguous staging of the strided blocks, send and receive per direction (4 sides + 4 corners)
     size_t stage_bytes[16] = {};
     long exchanges = 0;

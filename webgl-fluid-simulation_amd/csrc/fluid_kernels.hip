@@ -1371,7 +1371,7 @@ __device__ __forceinline__ void jacobi_tb_tile(const Win& w, const T* __restrict
 // Dependencies point to lower workgroup ids only: with workgroups dispatched in id order (what the hardware does; HIP does not promise it)
 // a waiting workgroup waits for one that is resident or done.  The poll is bounded all the same: a workgroup that gives up sets *err and
 // computes on stale data rather than hang the device.
-constexpr int CHAIN_MAX_BLOCKS = 8, CHAIN_MAX_ROWS = 512;
+constexpr int CHAIN_MAX_BLOCKS = 24, CHAIN_MAX_ROWS = 512, CHAIN_MAX_PANELS = 8;   // (200 iterations = 20 blocks; 16384-wide = 71 tiles = 4 panels)
 struct ChainPlan {
     int blocks, tiles;            // blocks of iterations; workgroups per block (mode 0: nx * ny tiles; band-cyclic: 8 G band nx, some without a tile)
     int iters[CHAIN_MAX_BLOCKS];
@@ -1379,9 +1379,10 @@ struct ChainPlan {
     int ga[CHAIN_MAX_BLOCKS], gb[CHAIN_MAX_BLOCKS];   // rows block l stores (a stripe's blocks recompute fewer ghost rows each: the ranges shrink; the
                                                       // tiling is block 0's — the widest — for all of them, and a tile with nothing to store only counts itself)
     int band;                     // > 0: the band-cyclic order below, `band` tile rows per band
+    int pw;                       // ... in panels of pw tile columns (fluid_tiles.h; >= nx: one panel).  One counter per (block, tile row, panel)
     int tickets;                  // 1: a workgroup's place in the order is a ticket it draws when it starts (independent of the dispatch order)
-    unsigned int target;          // a tile row of the previous block is complete when its counter has reached this: the counters are never
-                                  // reset between calls of the same shape (no memset in the stream) — call number e waits for (e + 1) nx
+    unsigned int target;          // a panel's tile row of the previous block is complete when its counter has reached this TIMES THE PANEL'S WIDTH:
+                                  // the counters are never reset between calls of the same shape (no memset in the stream) — call number e: e + 1
     unsigned int timeout;         // 100 MHz ticks a workgroup waits for a tile row before it gives up (2 s; lab: FLUID_CHAIN_TIMEOUT_MS)
     int withhold;                 // lab (FLUID_CHAIN_WITHHOLD=row): the first tile of that tile row of block 0 never counts itself — what waits
                                   // for the row gives up: the give-up path, forced (tests/test_chain_safety.py); -1 = off
@@ -1414,7 +1415,7 @@ __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_chain
         // together still share their aprons inside one XCD's L2.  (The first form — each XCD one contiguous run of the whole sequence, odd
         // blocks backwards — turned every front around on the tiles that had just been resident TOGETHER: a block's first 64 tiles per
         // front waited for the previous block's last 64, i.e. for its drain; +10 % instead of -2 %: profiles/r05/jacobi_chain_ab.txt.)
-        if (!chain_tile_of_block(b, nx, ny, C.band, bx, by)) return;   // (fluid_tiles.h) the last group's bands beyond the grid: no tile (block-uniform)
+        if (!chain_tile_of_block(b, nx, ny, C.band, C.pw, bx, by)) return;   // (fluid_tiles.h) the last group's bands beyond the grid: no tile (block-uniform)
     } else {
         // XCD b % 8 takes the (b / 8)-th tile of its contiguous run of the row-major sequence, from the far end in odd blocks
         const int n = C.tiles, q = n >> 3, r8 = n & 7, xcd = b & 7, slot = b >> 3;
@@ -1433,13 +1434,17 @@ __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_chain
     const bool nothing = st_hi <= st_lo || sx_hi <= sx_lo;   // this block's ranges do not reach this tile (block-uniform): no reads, no writes — count and go
     auto wait_prev = [&]() {
     if (l > 0 && DIAG != 3 && !nothing) {
-        // three lanes, one row each: the three counters come back in ONE memory round trip (one lane after the other: three — visit 12)
-        const int r = by - 1 + (int)threadIdx.x;
-        if (threadIdx.y == 0 && threadIdx.x < 3 && r >= 0 && r < ny) {
-            const unsigned int* flag = done + (l - 1) * CHAIN_MAX_ROWS + r;
+        // one lane per counter — three rows of this tile's panel, and of the panel next door where the tile sits on the panel's first / last
+        // column (3 ... 9 counters) — so that they all come back in ONE memory round trip (one lane after the other: three — visit 12)
+        const int t = (int)threadIdx.x, r = by - 1 + t % 3, pn = C.band > 0 ? bx / C.pw : 0, pq = pn - 1 + t / 3;
+        const int np = C.band > 0 ? chain_panels(nx, C.pw) : 1, pw = C.band > 0 ? C.pw : nx;
+        const bool needed = pq == pn || (pq < pn ? bx == pn * pw : (bx == pn * pw + pw - 1));
+        if (threadIdx.y == 0 && t < 9 && r >= 0 && r < ny && pq >= 0 && pq < np && needed) {
+            const unsigned int* flag = done + ((l - 1) * CHAIN_MAX_ROWS + r) * CHAIN_MAX_PANELS + pq;
+            const unsigned int target = C.target * (unsigned)min(pw, nx - pq * pw);
             unsigned spins = 0;
             unsigned long long t0 = 0;
-            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < C.target) {
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
                 __builtin_amdgcn_s_sleep(2);
                 // never hang the device — bounded in WALL-CLOCK time (round 6: a count of polls is some tens of milliseconds, which a foreign
                 // kernel holding the CUs can outlast; the 100 MHz clock does not care how slowly this wave gets to poll), and nobody waits once
@@ -1477,7 +1482,7 @@ __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_chain
     if (DIAG != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0 && threadIdx.y == 0 && !(C.withhold >= 0 && l == 0 && by == C.withhold && bx == 0))
-        __hip_atomic_fetch_add(done + l * CHAIN_MAX_ROWS + by, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(done + (l * CHAIN_MAX_ROWS + by) * CHAIN_MAX_PANELS + (C.band > 0 ? bx / C.pw : 0), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- the pressure loop as ONE launch of PERSISTENT workgroups that take STACKS of tiles from per-XCD ticket heads (round 6) -------------
@@ -3864,11 +3869,14 @@ static int jacobi_chain_mode()   // FLUID_JACOBI_CHAIN (lab build): 0 = never, 1
     static const int m = [] { const char* e = lab_env("FLUID_JACOBI_CHAIN"); return e ? atoi(e) : -1; }();
     return m;
 }
-// Where the chained launch is the shipped path: it removes four of a step's five fill / drain phases (~8 us each at 4096^2) and pays one
-// memory round trip per tile for the three counters it polls — worth -2.6 ... -3.2 % of the step at 4096^2 and nothing at 3072^2; its
-// band-cyclic order costs locality where a tile row is longer than an XCD holds (6144^2: +2.8 %, 8192^2: +3.6 %).  So: the tile rows of
-// which exactly three fill an XCD's 64 workgroup slots (17 ... 21 tiles: widths 3740 ... 4890), up to 8192 rows
-// (profiles/r05/jacobi_chain_ab.txt).
+// Where the chained launch is the shipped path: it removes all but one of a step's fill / drain phases (~8 us each at 4096^2) and pays two
+// memory round trips per tile that do no work (the poll of 3 ... 9 counters in front, the drain of the write-through stores behind).  Measured
+// over widths x set sizes (profiles/r06/chain_loop_map.txt) it pays where BOTH hold:
+//   * the loop's set — 12 B/texel: two pressure buffers and the divergence — fits the 256 MB Infinity Cache, which answers those round trips
+//     in a third of the time HBM takes under load: 4096^2 (201 MB) -5 ... -10 % of the loop, 4096 x 8192 +4.5 %, 8192^2 +8 %;
+//   * a tile row is ONE panel whose band fills an XCD's 64 workgroup slots in three rows (17 ... 21 tiles: widths 3740 ... 4890): 3072-wide (four
+//     rows) and 2048-wide (seven) read level, the panelled widths +10 % although their set fits (8192 x 2048, 6144 x 2730, 16384 x 1024).
+// So: 17 ... 21 tiles per row, 2048 rows up to 20 M texels (240 MB), 11 ... 240 iterations (24 blocks: 4096^2 at 200 iterations -8.5 % of the step).
 bool jacobi_chain_applies(const Win& w, int ga, int gb, int iters)
 {
     using G = JacobiTB<8, 10, 12, 10>;
@@ -3876,11 +3884,11 @@ bool jacobi_chain_applies(const Win& w, int ga, int gb, int iters)
     if (mode == 0 || iters <= 10 || iters > 10 * jacobi_chain_max_blocks() || !jacobi_tb_supported(w)) return false;
     if (mode >= 1) return true;
     const Axis ax = make_axis(w.x0, w.x1, w.W, G::TX, 12);
-    return 64 / ax.n == 3 && gb - ga <= 8192 && gb - ga >= 2048;
+    return 64 / ax.n == 3 && gb - ga >= 2048 && (long)(gb - ga) * (long)(w.x1 - w.x0) <= 20000000L;
 }
 size_t jacobi_pchain_state_bytes();
 // the counters of either form (k_jacobi_tb_chain: (block, tile row); k_jacobi_pchain: two halves of heads + (block, stack row, panel) cells)
-size_t jacobi_chain_flag_bytes() { return std::max((size_t)(CHAIN_MAX_BLOCKS * CHAIN_MAX_ROWS) * sizeof(unsigned int), jacobi_pchain_state_bytes()); }
+size_t jacobi_chain_flag_bytes() { return std::max((size_t)(CHAIN_MAX_BLOCKS * CHAIN_MAX_ROWS * CHAIN_MAX_PANELS) * sizeof(unsigned int), jacobi_pchain_state_bytes()); }
 // FLUID_CHAIN_PERSIST=1 (lab build): the persistent form, k_jacobi_pchain — placement-independent and general, and measured 20 ... 50 % slower on
 // the loop than one workgroup per tile (profiles/r06/pchain_*.txt): a lab kernel.  Default, and all the product has: k_jacobi_tb_chain.
 static bool chain_persistent()
@@ -3915,18 +3923,24 @@ hipError_t launch_jacobi_tb_chain_ranges(hipStream_t s, Win w, float* pa, float*
     }
     const Axis ax = make_axis(xa[0], xb[0], w.W, G::TX, 12), ay = make_axis(ga[0], gb[0], w.H, G::TY, 10);
     if (ay.n > CHAIN_MAX_ROWS) return hipErrorNotReady;
-    // rows per band: what keeps ONE band of an XCD inside the 64 workgroups resident there (32 CUs x 2): 4096-wide: 18 tiles per row -> 3 rows.
-    // (4 rows = 72 tiles spill and the order alone costs 12 %; 2 rows leave a third of the XCD to the next band: +2 %: profiles/r05/jacobi_chain_ab.txt)
+    // panels, and rows per band: what keeps ONE band of an XCD's panel inside the 64 workgroups resident there (32 CUs x 2).  4096-wide: 18 tiles per
+    // row, one panel -> 3 rows (4 rows = 72 tiles spill and the order alone costs 12 %; 2 rows leave a third of the XCD to the next band: +2 %:
+    // profiles/r05/jacobi_chain_ab.txt).  Wider rows: panels of at most 21 tiles (8192-wide: 36 = 2 x 18; 16384-wide: 71 = 4 x 18) — one
+    // panel of 36 tiles and one-row bands had no tile's vertical neighbour on its own XCD (+3.6 % at 8192^2 in round 5)
     static const int forced = [] { const char* e = lab_env("FLUID_CHAIN_BAND"); return e ? atoi(e) : -1; }();   // 0 = the first form (contiguous runs, odd blocks backwards)
-    const int band = forced >= 0 ? forced : std::max(1, 64 / ax.n);
+    static const int forced_pw = [] { const char* e = lab_env("FLUID_CHAIN_PANEL"); return e ? atoi(e) : -1; }();   // tiles per panel; 0 = one panel (round 5)
+    int pw = forced_pw > 0 ? std::min(forced_pw, ax.n) : (forced_pw == 0 ? ax.n : chain_panel_width(ax.n, 21));
+    if (chain_panels(ax.n, pw) > CHAIN_MAX_PANELS) pw = (ax.n + CHAIN_MAX_PANELS - 1) / CHAIN_MAX_PANELS;
+    const int band = forced >= 0 ? forced : std::max(1, 64 / pw);
     static const int tickets = [] { const char* e = lab_env("FLUID_CHAIN_TICKET"); return e ? atoi(e) : 0; }();
     C.band = band > 0 ? band : 0;
+    C.pw = C.band > 0 ? pw : ax.n;
     C.tickets = tickets != 0;   // (lab; err[1] is the ticket word)
     C.tiles = C.band > 0 ? chain_slots(ax.n, ay.n, C.band) : ax.n * ay.n;
     // the counters: zeroed when the shape of the call changes (tiles per row, tile rows, blocks: what decides which counters a call bumps, and by
     // how much), counted up from call to call otherwise — a memset in front of every launch was 5 us of the step and a kernel boundary
     hipError_t e = hipSuccess;
-    const unsigned sig = (unsigned)ax.n | ((unsigned)ay.n << 10) | ((unsigned)nblocks << 20) | ((unsigned)C.band << 24);
+    const unsigned sig = (unsigned)ax.n | ((unsigned)ay.n << 7) | ((unsigned)nblocks << 16) | ((unsigned)C.band << 21) | ((unsigned)C.pw << 25);   // (ay.n <= 512, nblocks <= 24, band <= 64, pw <= 127)
     if (!ep || ep->signature != sig || ep->calls >= (1u << 24)) {
         e = hipMemsetAsync(flags, 0, jacobi_chain_flag_bytes(), s);
         if (e != hipSuccess) return e;
@@ -3939,7 +3953,7 @@ hipError_t launch_jacobi_tb_chain_ranges(hipStream_t s, Win w, float* pa, float*
     static const int withhold = [] { const char* e = lab_env("FLUID_CHAIN_WITHHOLD"); return e ? atoi(e) : -1; }();
     C.timeout = (unsigned int)timeout_ms * 100000u;
     C.withhold = withhold;
-    C.target = ((ep ? ep->calls : 0u) + 1u) * (unsigned)ax.n;
+    C.target = (ep ? ep->calls : 0u) + 1u;
     const dim3 grid((unsigned)(C.blocks * C.tiles), 1, 1), block(64, 8, 1);
 #ifdef FLUID_PROBES
     if (C.tickets) {

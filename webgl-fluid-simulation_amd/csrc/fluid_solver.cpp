@@ -542,6 +542,7 @@ void note_dye_advected(fluid_ctx* c, float dt, float dissipation)
 bool dye_pack_applies(const fluid_ctx* c)
 {
     const bool whole = c->desc.parts == 1 && c->desc.parts_x == 1;
+    if (!whole && c->dye_set_rgba) return false;   // the set agreed on RGBA for this call: some rank cannot pack (fluid_stripes.cpp dye_format_agree)
     return dye_pack_enabled() && c->alpha_known && c->storage == FLUID_STORE_F32 && (whole || fused_advect_applies(c)) &&
            c->desc.schedule == FLUID_SCHED_FUSED && (long)c->dye_ncols * c->dye_rows >= fluid::kSmallGridTexels;
 }
@@ -1522,10 +1523,12 @@ int fluid_schedule_info_get(fluid_ctx* c, int n_steps, float dt, const fluid_par
     {   // ... which are ONE launch of chained blocks where that schedule applies (pass_jacobi)
         int ga, gb;
         row_range(c->sim, c->sim_row0, c->sim_rows, 0, ga, gb);
-        // (whole-domain contexts; a stripe / tile rank chains the launches it has left behind its cut ones the same way — fewer of them, by the
-        // plan's cut — and is reported through the timings' launch counts.  Not after a chained launch of this context has given up: chain_broken)
-        out->jacobi_chained = tb && whole && !c->chain_broken && c->storage == FLUID_STORE_F32 && out->jacobi_shape == 0 && !fluid_impl::gradsub_fold_enabled(owned) &&
-                              fluid::jacobi_chain_applies(sim_cols(c, 0), ga, gb, P->iterations);
+        // A stripe / tile rank chains the launches it has left behind its cut ones the same way (pass_jacobi: its blocks' row / column ranges shrink
+        // from launch to launch; the rule is asked about the owned texels here, about the first uncut launch's there — the same answer but on a rank
+        // within a ghost zone of the rule's limits): reported for them too (it said false there while the rank's loop did chain).
+        // Not after a chained launch of this context has given up: chain_broken
+        out->jacobi_chained = tb && !c->chain_broken && c->storage == FLUID_STORE_F32 && out->jacobi_shape == 0 && !fluid_impl::gradsub_fold_enabled(owned) &&
+                              out->jacobi_launches >= 2 && fluid::jacobi_chain_applies(sim_cols(c, 0), ga, gb, P->iterations);
     }
     out->gradsub_folded = tb && fluid::jacobi_tb_has_gradsub(out->jacobi_shape) && fluid_impl::gradsub_fold_enabled(owned);
     const bool split = whole && n_steps > 0 && !chain_applies(c, dt, P) && split_chain_applies(c, dt, P);   // dye grid != sim grid

@@ -128,8 +128,11 @@ void advect_rows(const fluid_ctx* c, int* vel_rows, int* dye_rows)
     *dye_rows = (int)vd;
 }
 
+int dye_format_agree_end(fluid_ctx* c);
+
 int run_pass(fluid_ctx* c, const fluid_stripe_op& op, float dt, const fluid_params* P)
 {
+    if (op.kind == FLUID_OP_ADVECT) CK(dye_format_agree_end(c));   // (a plan whose advection follows no dye exchange: the format is the set's all the same)
     switch (op.kind) {
     case FLUID_OP_CURL_VORT_DIV: return pass_curl_vort_div(c, P->curl, dt, op.ext, nullptr);
     case FLUID_OP_CLEAR: return pass_clear(c, P->pressure, op.ext);
@@ -189,6 +192,7 @@ struct Rccl {
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string error;
 };
@@ -229,6 +233,7 @@ const Rccl* rccl(std::string* why)
         r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
         r.Send = (decltype(r.Send))sym("ncclSend");
         r.Recv = (decltype(r.Recv))sym("ncclRecv");
+        r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
         r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
         if (!ok) {
             tried += n + ": missing nccl symbols; ";
@@ -947,12 +952,72 @@ int join_comm(fluid_ctx* c)   // the context stream continues behind what the co
     return FLUID_OK;
 }
 
-// in front of an exchange that carries dye ghost texels: the field goes into the format this step's advection takes (packed or RGBA — one
-// predicate, the same on every rank of the set: fluid_internal.h), so that both ends of every message cut the same texel size
+// ---- the dye's wire format, agreed per call ----
+// The ghost texels of the dye travel in the format the field is in: 12-byte texels while it is packed, RGBA otherwise — and the two ends of a
+// message must cut the same size (a count mismatch between ncclSend and ncclRecv is undefined: a hang or torn ghost rows).  Whether a rank packs
+// depends on state ONE rank can change alone between two calls — fluid_field_device_ptr(FLUID_DYE), fluid_write_field, fluid_halo_unpack, a
+// splat into one context only, or simply a stripe below the texel count from which packing pays.  So every fluid_step_n on a communicator
+// begins with ONE ncclAllReduce(min) of four floats on the comm stream — {this rank would pack, its alpha is known, alpha, -alpha} — which the
+// host reads when the call reaches its first dye exchange (the step's first ~0.3 ms of launches are enqueued by then: nothing waits on the
+// device).  The set packs iff every rank would and all hold the same alpha; ranks that disagree about the alpha itself (one was splatted
+// alone) forget theirs, as a ghost-row unpack does: the texels they receive carry another.  Inside a call the format follows from the call's
+// arguments alone (dt, the decays), which are the same on every rank.
+int dye_format_agree_begin(fluid_ctx* c, float dt, const fluid_params* P)
+{
+    const Rccl* R = rccl(nullptr);
+    if (!R || !c->comm) return c->fail(FLUID_ERR_COMM, "stripe context has no communicator (fluid_comm_init)");
+    if (!c->agree_host) {
+        float* h = nullptr;
+        float* d = nullptr;
+        hipEvent_t ev = nullptr;
+        int rc = c->hip(hipHostMalloc((void**)&h, 8 * sizeof(float), hipHostMallocDefault), "hipHostMalloc (dye format words)");
+        if (!rc) rc = c->hip(hipMalloc((void**)&d, 8 * sizeof(float)), "hipMalloc (dye format words)");
+        if (!rc) rc = c->hip(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate (dye format)");
+        if (rc) {
+            if (h) (void)hipHostFree(h);
+            if (d) (void)hipFree(d);
+            return rc;
+        }
+        c->agree_host = h;
+        c->agree_dev = d;
+        c->ev_agreed = ev;
+    }
+    c->dye_set_rgba = false;   // this rank's own answer, asked without the set's veto
+    const bool packs = dye_wants_packed(c, dt, P->velocity_dissipation, P->density_dissipation);
+    float* h = c->agree_host;
+    h[0] = packs ? 1.0f : 0.0f;
+    h[1] = c->alpha_known ? 1.0f : 0.0f;
+    h[2] = c->alpha_known ? c->dye_alpha : 0.0f;
+    h[3] = c->alpha_known ? -c->dye_alpha : 0.0f;
+    HIPCK(c, hipMemcpyAsync(c->agree_dev, h, 4 * sizeof(float), hipMemcpyHostToDevice, c->comm_stream));
+    NCCLCK(c, R, R->AllReduce(c->agree_dev, c->agree_dev + 4, 4, ncclFloat, ncclMin, (ncclComm_t)c->comm, c->comm_stream));
+    HIPCK(c, hipMemcpyAsync(h + 4, c->agree_dev + 4, 4 * sizeof(float), hipMemcpyDeviceToHost, c->comm_stream));
+    HIPCK(c, hipEventRecord(c->ev_agreed, c->comm_stream));
+    c->agree_pending = true;
+    return FLUID_OK;
+}
+
+int dye_format_agree_end(fluid_ctx* c)
+{
+    if (!c->agree_pending) return FLUID_OK;
+    c->agree_pending = false;
+    HIPCK(c, hipEventSynchronize(c->ev_agreed));
+    const float* m = c->agree_host + 4;
+    const bool all_pack = m[0] == 1.0f, all_known = m[1] == 1.0f, one_alpha = all_known && m[2] == -m[3];
+    if (!one_alpha) c->alpha_known = false;   // a neighbour's texels carry another alpha (or nobody knows theirs): no ONE alpha here either until the next splat
+    c->dye_set_rgba = !(all_pack && one_alpha);
+    return FLUID_OK;
+}
+
+// in front of an exchange that carries dye ghost texels: the field goes into the format this step's advection takes (packed or RGBA — what
+// the set agreed on at the start of the call), so that both ends of every message cut the same texel size
 int prepare_exchange(fluid_ctx* c, const fluid_stripe_op& op, float dt, const fluid_params* P)
 {
     for (int i = 0; i < op.n_items; i++)
-        if (op.field[i] == FLUID_DYE) return dye_prepare(c, dt, P);
+        if (op.field[i] == FLUID_DYE) {
+            CK(dye_format_agree_end(c));
+            return dye_prepare(c, dt, P);
+        }
     return FLUID_OK;
 }
 
@@ -981,6 +1046,7 @@ int stripe_step_n(fluid_ctx* c, int n, float dt, const fluid_params* P)
         ~CurlGuard() { c->keep_curl = true; }
     } guard{ c };
     const bool skip = skip_hidden_curl();
+    if (n > 0) CK(dye_format_agree_begin(c, dt, P));   // collective, first thing on the comm stream: every rank of the set is in this call
     mark_step(c, 0);
     for (int k = 0; k < n; mark_step(c, ++k))
         for (size_t i = 0; i < ops.size(); i++) {
@@ -1072,7 +1138,12 @@ void stripes_release(fluid_ctx* c)
     if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
     if (c->ev_joined) (void)hipEventDestroy(c->ev_joined);
     if (c->ev_inner) (void)hipEventDestroy(c->ev_inner);
-    c->ev_ready = c->ev_landed = c->ev_mid = c->ev_joined = c->ev_inner = nullptr;
+    if (c->ev_agreed) (void)hipEventDestroy(c->ev_agreed);
+    if (c->agree_host) (void)hipHostFree(c->agree_host);
+    if (c->agree_dev) (void)hipFree(c->agree_dev);
+    c->agree_host = c->agree_dev = nullptr;
+    c->agree_pending = false;
+    c->ev_ready = c->ev_landed = c->ev_mid = c->ev_joined = c->ev_inner = c->ev_agreed = nullptr;
     for (int k = 0; k < 16; k++) {
         if (c->stage[k]) (void)hipFree(c->stage[k]);
         c->stage[k] = nullptr;

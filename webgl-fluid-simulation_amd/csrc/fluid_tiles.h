@@ -61,15 +61,27 @@ __host__ __device__ __forceinline__ void tile_of_block(int b, int nx, int ny, in
 // The BAND-CYCLIC order of the chained Jacobi launch (k_jacobi_tb_chain, fluid_kernels.hip): within one block of iterations, consecutive
 // workgroups alternate XCDs (b % 8, as the hardware places them); XCD k walks bands of `band` tile rows — band k of every group of eight
 // bands, group after group.  chain_slots() workgroups per block; a slot whose band lies beyond the grid has no tile (false).
+// PANELS (round 6): a tile row longer than an XCD holds (8192-wide: 36 tiles against 64 workgroup slots) is cut into panels of `pw` tile
+// columns, and an XCD walks its band panel after panel — `band` rows x pw columns resident together, the 4096-wide picture (3 x 18) at any
+// width; pw >= nx: one panel, the order of round 5.  Every panel but the last is pw wide.
 // Host-callable: tests/tile_cover_check.cpp holds it to a bijection onto the nx x ny tiles with every group's tiles in front of the next group's.
+// (Bands of NEARLY EQUAL height — every XCD the same number of tile rows where the last group of exact bands is partly empty: 8192 x 2048 has
+// 35 tile rows = 12 bands of 3, two per block for XCDs 0 ... 3 and one for the others — were measured too: bitwise, and slower wherever a band
+// then holds slots without a tile, 4096^2 included; an XCD that runs out of one band's tiles early takes the next band's beside it, which is
+// what four-row bands did.  profiles/r06/chain_loop_map.txt.)
 __host__ __device__ __forceinline__ int chain_slots(int nx, int ny, int band) { return 8 * ((ny + 8 * band - 1) / (8 * band)) * band * nx; }
-__host__ __device__ __forceinline__ bool chain_tile_of_block(int b, int nx, int ny, int band, int& bx, int& by)
+__host__ __device__ __forceinline__ int chain_panels(int nx, int pw) { return (nx + pw - 1) / pw; }
+__host__ __device__ __forceinline__ bool chain_tile_of_block(int b, int nx, int ny, int band, int pw, int& bx, int& by)
 {
-    const int xcd = b & 7, i = b >> 3, per_band = band * nx, g = i / per_band, j = i - g * per_band;
-    by = (g * 8 + xcd) * band + j / nx;
-    bx = j % nx;
+    const int xcd = b & 7, i = b >> 3, per_band = band * nx, g = i / per_band, q = i - g * per_band;
+    const int per_panel = band * pw, p = q / per_panel, j = q - p * per_panel, wp = min(pw, nx - p * pw);   // (the last panel: what is left of the row)
+    const int r = j / wp;
+    by = (g * 8 + xcd) * band + r;
+    bx = p * pw + (j - r * wp);
     return by < ny;
 }
+// the panel width the launch picks: the row in equal parts of at most `most` tiles (21: three rows of which fill an XCD's 64 slots)
+__host__ inline int chain_panel_width(int nx, int most) { const int np = (nx + most - 1) / most; return (nx + np - 1) / np; }
 
 // exact (storable) global range [a, b) of the tile starting at t0, intersected with [lo, hi)
 __host__ __device__ __forceinline__ void tile_exact(int t0, int T, int A, int dom, int lo, int hi, int& a, int& b)
