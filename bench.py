@@ -970,6 +970,22 @@ def main(argv=None, engine_factory=None, backend="nccl"):
                                 "batched_ms_per_step": ref_ms,
                                 "what": "%d calls of fluid_step (one step each, no synchronisation in between) against one fluid_step_n call of the same steps "
                                         "(`steady_ms_per_step` if measured, else `ms_per_step`): the page's update() pattern, script.js:1176-1186" % n_frames}
+            if hasattr(sim, "set_curl_output"):
+                # the same calls from a host that — like the page — never looks at the curl field outside step() (script.js:1234-1243) and says so
+                # (fluid_set_curl_output(ctx, 0), ABI 10): no step stores it
+                sim.set_curl_output(False)
+                try:
+                    for _ in range(30):
+                        sim.step(DT, 1)
+                    sync()
+                    t0 = time.perf_counter()
+                    for _ in range(n_frames):
+                        sim.step(DT, 1)
+                    sync()
+                    nc_ms = 1e3 * (time.perf_counter() - t0) / n_frames
+                    out["per_frame"]["without_curl_output"] = {"ms_per_step": round(nc_ms, 4), "ratio_to_batched": round(ref_ms / nc_ms, 4)}
+                finally:
+                    sim.set_curl_output(True)
             if hasattr(sim, "render"):
                 sim.render(512, 512)
                 sync()

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define FLUID_ABI_VERSION 9
+#define FLUID_ABI_VERSION 10
 
 typedef enum fluid_status {
     FLUID_OK = 0,
@@ -340,6 +340,15 @@ int fluid_read_frame(fluid_ctx *ctx, float *host_rgba, size_t bytes);
 int fluid_read_frame_rgba8(fluid_ctx *ctx, unsigned char *host_rgba8, size_t bytes);
 /* the bloom (RGBA) or blurred sunrays (R) buffer of the last render; host may be NULL to query the size */
 int fluid_read_display_buffer(fluid_ctx *ctx, int which, float *host, size_t bytes, int *width, int *height);
+
+/* (ABI 10) The curl field as an OUTPUT of fluid_step / fluid_step_n.  The reference writes its curl texture in every step (curlProgram,
+ * script.js:1234-1237) and reads it in the same step only (vorticityProgram, 1239-1243): nothing outside step() looks at it.  On (default): a
+ * call leaves the curl of its LAST step in FLUID_CURL, as the header's contract says.  Off: no step stores it — the fused curl / vorticity /
+ * divergence launch keeps it in registers, 4 B/texel less per call; one step per call, the page's update() pattern (1176-1186), is then
+ * within 2 % of a batched call at 4096^2 instead of 4 % (bench.py `per_frame`).  Reading FLUID_CURL (fluid_read_field, fluid_field_device_ptr,
+ * a ghost-row pack) after a step that did not store it fails with FLUID_ERR_INVALID rather than return an older step's field.  The per-pass
+ * entry points and the one-kernel-per-pass schedule always write it; so do the small-grid launches that carry the next step's stencil stages. */
+int fluid_set_curl_output(fluid_ctx *ctx, int enabled);
 
 int fluid_set_timing(fluid_ctx *ctx, int enabled);
 int fluid_get_timings(fluid_ctx *ctx, fluid_timings *out);

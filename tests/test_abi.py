@@ -41,7 +41,7 @@ def test_library_exports_every_declared_symbol(abi):
 
 def test_ctypes_table_matches_header(abi):
     assert sorted(abi.SYMBOLS) == declared_functions()
-    assert abi.lib().fluid_abi_version() == 9
+    assert abi.lib().fluid_abi_version() == 10
 
 
 def test_error_strings(abi):

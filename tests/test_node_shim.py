@@ -111,7 +111,7 @@ def test_addon_loads_and_fails_loudly_without_device(addon):
     assert r.returncode == 0, r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])
     for k in ("create", "destroy", "resize", "splat", "step", "sync", "readField", "writeField", "fieldInfo", "scheduleInfo", "setStepMarks",
-              "getStepMarks", "setLinkModel", "abiVersion", "buildFlavor"):
+              "getStepMarks", "setLinkModel", "abiVersion", "buildFlavor", "setCurlOutput"):
         assert k in out["keys"]
     if out["n"] == 0:
         assert out["threw"] and out["code"] == "-3" and "no CPU path" in out["msg"]

@@ -49,6 +49,12 @@ KS=$(find "$OUT/prof" -name '*kernel_stats.csv' | head -1)
 [ -n "$KS" ] && cp "$KS" "$OUT/kernel_stats.csv" && head -12 "$OUT/kernel_stats.csv" | cut -c1-200 | tee -a "$OUT/log.txt"
 # keep the merged-back payload small
 rm -rf "$OUT/prof"
+echo "== the display compositor at the shipping sizes: timing, then its kernels under rocprofv3 ==" | tee -a "$OUT/log.txt"
+timeout 300 python tools/bench_render.py >"$OUT/bench_render.json" 2>>"$OUT/bench.err"; cat "$OUT/bench_render.json" | tee -a "$OUT/log.txt"
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_render" -o rs -- python "$GRAFT_REPO_ROOT/tools/bench_render.py" 100 >/dev/null 2>>"$OUT/rocprof.err" )
+KS=$(find "$OUT/prof_render" -name '*kernel_stats.csv' | head -1)
+[ -n "$KS" ] && cp "$KS" "$OUT/render_kernel_stats.csv" && head -16 "$OUT/render_kernel_stats.csv" | cut -c1-160 | tee -a "$OUT/log.txt"
+rm -rf "$OUT/prof_render"
 echo "== other sizes, shipping defaults, SQ counters ==" | tee -a "$OUT/log.txt"
 bash tools/other_sizes.sh "$TAG" >>"$OUT/log.txt" 2>&1
 timeout 600 python tools/bench_shipping.py >"$OUT/bench_shipping_defaults.json" 2>>"$OUT/bench.err"

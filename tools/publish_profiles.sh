@@ -16,6 +16,6 @@ for s in fused passes; do
   [ -f $F/pmc_WRITE_SIZE_$s.csv ] && cp $F/pmc_WRITE_SIZE_$s.csv $R/pmc_write_$s.csv
 done
 for f in $F/pmc_SQ_*_fused.csv; do [ -f "$f" ] && cp "$f" $R/pmc_sq_valu_fused.csv; done
-for f in bench_shipping_defaults.json bench_other_sizes.txt soak.txt sq_counters_step_kernels.txt; do [ -f $F/$f ] && cp $F/$f $R/$f; done
+for f in bench_shipping_defaults.json bench_other_sizes.txt soak.txt sq_counters_step_kernels.txt bench_render.json render_kernel_stats.csv; do [ -f $F/$f ] && cp $F/$f $R/$f; done
 tail -15 $F/pytest_gpu.txt > $R/pytest_gpu.txt
 echo "published $F -> $R"

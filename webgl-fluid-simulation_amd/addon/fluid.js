@@ -452,6 +452,8 @@ function createFluid (options) {
     sim.checkHalo = function () { native.haloCheck(handle); };         // multi-GPU: throws if a back-trace outran the ghost rows
     sim.exchangeCount = function () { return native.exchangeCount(handle); };
     sim.setTiming = function (on) { native.setTiming(handle, on ? 1 : 0); };
+    // the page never looks at the curl texture outside step() (script.js:1234-1243): a host that does not either saves its store per call
+    sim.setCurlOutput = function (on) { native.setCurlOutput(handle, on ? 1 : 0); };
     sim.getTimings = function () { return native.getTimings(handle); };
     // what the next step(dt, n) would launch with the CURRENT config (nothing runs): { fused, jacobiLaunches, chained, runsAhead, dyePacked, ... }
     sim.scheduleInfo = function (dt, n) {

@@ -490,6 +490,17 @@ static napi_value n_set_timing(napi_env env, napi_callback_info info)
     return rc == FLUID_OK ? NULL : throw_status(env, c, rc);
 }
 
+/* setCurlOutput(handle, on): fluid_set_curl_output (ABI 10) — off: no step stores the curl field nothing outside step() reads */
+static napi_value n_set_curl_output(napi_env env, napi_callback_info info)
+{
+    napi_value a[2];
+    fluid_ctx *c;
+    int on;
+    if (!get_args(env, info, 2, a) || !get_ctx(env, a[0], &c) || !get_i(env, a[1], &on)) return NULL;
+    int rc = fluid_set_curl_output(c, on);
+    return rc == FLUID_OK ? NULL : throw_status(env, c, rc);
+}
+
 static napi_value n_get_timings(napi_env env, napi_callback_info info)
 {
     napi_value a[1], obj, v;
@@ -581,7 +592,7 @@ static napi_value init(napi_env env, napi_value exports)
         { "setReach", n_set_reach }, { "haloCheck", n_halo_check }, { "exchangeCount", n_exchange_count }, { "destroy", n_destroy }, { "resize", n_resize }, { "splat", n_splat },
         { "step", n_step }, { "sync", n_sync }, { "setSchedule", n_set_schedule }, { "fieldInfo", n_field_info },
         { "readField", n_read_field }, { "writeField", n_write_field }, { "deviceCount", n_device_count },
-        { "setTiming", n_set_timing }, { "getTimings", n_get_timings },
+        { "setTiming", n_set_timing }, { "getTimings", n_get_timings }, { "setCurlOutput", n_set_curl_output },
         { "setDither", n_set_dither }, { "render", n_render }, { "readFrame", n_read_frame }, { "readFrameRgba8", n_read_frame_rgba8 },
         { "scheduleInfo", n_schedule_info }, { "setStepMarks", n_set_step_marks }, { "getStepMarks", n_get_step_marks },
         { "setLinkModel", n_set_link_model },

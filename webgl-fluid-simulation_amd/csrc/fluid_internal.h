@@ -35,6 +35,11 @@ struct fluid_ctx {
     // false while fluid_step_n runs a step that is not the call's last: that step's curl field is overwritten before the call returns, so
     // the fused curl / vorticity / divergence kernel does not store it (4 of its 24 B/texel).  The per-pass kernels always need the field.
     bool keep_curl = true;
+    // fluid_set_curl_output (ABI 10): off = no step of fluid_step / fluid_step_n stores its curl field (the reference's curl texture is read by
+    // nothing outside step(): script.js:1234-1243) — one step per call then moves 4 B/texel less.  curl_valid: the curl field holds the last
+    // step's curl; false after a step that did not store it: a read of FLUID_CURL fails instead of returning an older step's field
+    bool curl_output = true;
+    bool curl_valid = true;
     // The NEXT step's curl / vorticity / divergence, computed ahead by the launch that ended the last call (k_advect_cvd MODE 2; whole-domain
     // fp32 contexts where fluid_step_n chains): velocity after vorticity confinement, divergence, curl.  A page calls step() once per frame
     // (script.js:1176-1186): with this a frame is the six launches of a chained step instead of seven.  Valid until anything else touches the

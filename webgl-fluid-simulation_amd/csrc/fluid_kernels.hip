@@ -440,9 +440,12 @@ __global__ void __launch_bounds__(BX) k_advect_both_fast_rgb_wy(Win w, const flo
                                                                  double rH, double rvd, double rdd, float tsx, float tsy, int ga, int gb,
                                                                  unsigned int* __restrict__ miss_out, int gx, int xcd_cols)
 {
-    const int b = (int)blockIdx.x, by = b / gx, r = b - by * gx;
+    // xcd_cols (FLUID_ADVECT_XCD) bit 0: the XCD column ranges; bit 1 (round 6): the block rows from the LAST to the first — the launch in front (the
+    // gradient subtract) walked them first to last, so what it wrote last is what the Infinity Cache still holds; bit 2: nothing (this kernel, plain)
+    const int b = (int)blockIdx.x, r = b % gx;
+    const int by = (xcd_cols & 2) ? (int)gridDim.x / gx - 1 - b / gx : b / gx;
     int bx = r;
-    if (xcd_cols && (gx & 7) == 0) {
+    if ((xcd_cols & 1) && (gx & 7) == 0) {
         const int per = gx >> 3;            // blocks of a row per XCD
         bx = (r & 7) * per + (r >> 3);      // consecutive block ids of a row alternate XCDs: give XCD (r & 7) its (r >> 3)-th block
     }

@@ -156,6 +156,7 @@ int pass_curl(fluid_ctx* c, int ext)
     CK(check_ext(c, ext, 1));
     int ga, gb;
     row_range(c->sim, c->sim_row0, c->sim_rows, ext, ga, gb);
+    c->curl_valid = true;
     return c->hip(STORE_CALL(c, launch_curl(c->stream, sim_cols(c, ext), VEL(c, 0), CURL(c), ga, gb)), "curl");
 }
 
@@ -186,6 +187,7 @@ int pass_curl_vort_div(fluid_ctx* c, float curl, float dt, int ext, Timer* t)
         row_range(c->sim, c->sim_row0, c->sim_rows, ext, ga, gb);
         CK(c->hip(STORE_CALL(c, launch_curl_vort_div(c->stream, sim_cols(c, ext), VEL(c, 0), CURL_FUSED(c), VEL(c, 1), DIVG(c), curl, dt, ga, gb)),
                   "curl_vort_div"));
+        c->curl_valid = c->keep_curl;
         std::swap(c->vel[0], c->vel[1]);
         if (t) t->mark(P_VORT);
         return FLUID_OK;
@@ -672,11 +674,13 @@ int cvd_band(fluid_ctx* c, float curl, float dt, int ga, int gb, int xa, int xb)
     Win w = c->sim;
     w.x0 = xa;
     w.x1 = xb;
+    c->curl_valid = c->keep_curl;
     return c->hip(STORE_CALL(c, launch_curl_vort_div(c->stream, w, VEL(c, 0), CURL_FUSED(c), VEL(c, 1), DIVG(c), curl, dt, ga, gb)), "curl_vort_div");
 }
 
 int cvd_rects(fluid_ctx* c, float curl, float dt, const BandRects& B)
 {
+    c->curl_valid = c->keep_curl;
     return c->hip(STORE_CALL(c, launch_curl_vort_div_rects(c->stream, c->sim, VEL(c, 0), CURL_FUSED(c), VEL(c, 1), DIVG(c), curl, dt, B)), "curl_vort_div");
 }
 
@@ -914,7 +918,11 @@ int field_ref(fluid_ctx* c, int field, FieldRef* f, bool geometry_only, bool kee
     case FLUID_VELOCITY: *f = { c->vel[0], &c->sim, c->sim_row0, c->sim_rows, h, 2, c->sim_col0, c->sim_ncols, hx, c->esz }; break;
     case FLUID_PRESSURE: *f = { c->prs[0], &c->sim, c->sim_row0, c->sim_rows, h, 1, c->sim_col0, c->sim_ncols, hx, c->esz }; break;
     case FLUID_DIVERGENCE: *f = { c->div, &c->sim, c->sim_row0, c->sim_rows, h, 1, c->sim_col0, c->sim_ncols, hx, c->esz }; break;
-    case FLUID_CURL: *f = { c->curl, &c->sim, c->sim_row0, c->sim_rows, h, 1, c->sim_col0, c->sim_ncols, hx, c->esz }; break;
+    case FLUID_CURL:
+        if (!geometry_only && !c->curl_valid)
+            return c->fail(FLUID_ERR_INVALID, "the last step did not store its curl field (fluid_set_curl_output(ctx, 0)): switch the output on and step");
+        *f = { c->curl, &c->sim, c->sim_row0, c->sim_rows, h, 1, c->sim_col0, c->sim_ncols, hx, c->esz };
+        break;
     case FLUID_DYE:
         // whoever asks for the dye field's MEMORY (read, write, ghost rows, a raw pointer) gets RGBA texels — except the stripe / tile driver's
         // own exchanges (keep_packed), which move the ghost texels in whatever format the field is in: 3 channels while it is packed
@@ -1213,6 +1221,7 @@ int fluid_step_n(fluid_ctx* c, int n, float dt, const fluid_params* P)
             CK(step_once(c, dt, P, lead_k, 3));
             fluid_impl::mark_step(c, k + 1);
         }
+        c->curl_valid = true;
         return FLUID_OK;
     }
     bool lead = !adopt();
@@ -1224,10 +1233,13 @@ int fluid_step_n(fluid_ctx* c, int n, float dt, const fluid_params* P)
             CK(step_once(c, dt, P, k == 0 && lead, chain));
             fluid_impl::mark_step(c, k + 1);
         }
+        c->curl_valid = true;   // (the chain's last launch, or the pending buffers adopted, hold the last step's curl)
         return FLUID_OK;
     }
     for (int k = 0; k < n; k++) {
-        c->keep_curl = k == n - 1 || !skip;
+        // (curl_output off: not even the call's last step — the plain path only; the launches that work ahead or carry the next step's stencil
+        // stages on small grids write their curl as before)
+        c->keep_curl = c->curl_output && (k == n - 1 || !skip);
         CK(step_once(c, dt, P));
         fluid_impl::mark_step(c, k + 1);
     }
@@ -1499,6 +1511,13 @@ int fluid_halo_check(fluid_ctx* c)
     return FLUID_OK;
 }
 
+int fluid_set_curl_output(fluid_ctx* c, int enabled)
+{
+    if (!c) return FLUID_ERR_INVALID;
+    c->curl_output = enabled != 0;
+    return FLUID_OK;
+}
+
 int fluid_set_timing(fluid_ctx* c, int enabled)
 {
     if (!c) return FLUID_ERR_INVALID;
@@ -1544,6 +1563,7 @@ int fluid_schedule_info_get(fluid_ctx* c, int n_steps, float dt, const fluid_par
     // next step's curl into the pending buffer, and a lead launch (nothing adopted) stores the first step's own.
     if (split) out->curl_stores = n_steps + (out->pending_adopted ? 0 : 1);
     else out->curl_stores = (fused_cvd && fluid_impl::skip_hidden_curl() && n_steps > 0) ? 1 + (out->runs_ahead ? 1 : 0) : n_steps + (out->runs_ahead ? 1 : 0);
+    if (!c->curl_output && fused_cvd && !split && !chains) out->curl_stores = 0;   // fluid_set_curl_output(ctx, 0): the plain path stores none
     if (whole) {
         const int cvd = fused_cvd ? 1 : 3, clear = tb ? 0 : 1, gs = out->gradsub_folded ? 0 : 1;
         const int adv = fluid_impl::fused_advect_applies(c) ? 1 : 2;

@@ -1050,7 +1050,7 @@ int stripe_step_n(fluid_ctx* c, int n, float dt, const fluid_params* P)
     mark_step(c, 0);
     for (int k = 0; k < n; mark_step(c, ++k))
         for (size_t i = 0; i < ops.size(); i++) {
-            c->keep_curl = k == n - 1 || !skip;   // only the call's last step leaves a curl field a caller can read (fluid_step_n)
+            c->keep_curl = c->curl_output && (k == n - 1 || !skip);   // only the call's last step leaves a curl field a caller can read (fluid_step_n) — none with fluid_set_curl_output(ctx, 0)
             const fluid_stripe_op& op = ops[i];
             if (op.kind != FLUID_OP_EXCHANGE) {
                 if (folds_gradsub(ops, i)) {
@@ -1423,7 +1423,7 @@ int fluid_group_step_n(fluid_ctx** cs, int n_ctx, int steps, float dt, const flu
     mark_all(0);
     for (int k = 0; k < steps; mark_all(++k))
         for (size_t i = 0; i < ops.size(); i++) {
-            for (int r = 0; r < n_ctx; r++) cs[r]->keep_curl = k == steps - 1 || !skip;   // as in stripe_step_n
+            for (int r = 0; r < n_ctx; r++) cs[r]->keep_curl = cs[r]->curl_output && (k == steps - 1 || !skip);   // as in stripe_step_n
             const fluid_stripe_op& op = ops[i];
             if (op.kind != FLUID_OP_EXCHANGE) {
                 if (folds_gradsub(ops, i)) {

@@ -133,6 +133,7 @@ SYMBOLS = {
     "fluid_read_frame": (_I, [_CTX, C.c_void_p, C.c_size_t]),
     "fluid_read_frame_rgba8": (_I, [_CTX, C.c_void_p, C.c_size_t]),
     "fluid_read_display_buffer": (_I, [_CTX, _I, C.c_void_p, C.c_size_t, C.POINTER(_I), C.POINTER(_I)]),
+    "fluid_set_curl_output": (_I, [_CTX, _I]),
     "fluid_set_timing": (_I, [_CTX, _I]),
     "fluid_get_timings": (_I, [_CTX, C.POINTER(Timings)]),
     "fluid_schedule_info_get": (_I, [_CTX, _I, _F, C.POINTER(Params), C.POINTER(ScheduleInfo)]),
@@ -178,7 +179,7 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the header and the library disagree
             fn.restype = res
             fn.argtypes = args
-        if L.fluid_abi_version() != 9:
+        if L.fluid_abi_version() != 10:
             raise FluidError(ERR_UNSUPPORTED, "ABI version mismatch")
         _lib = L
         _point_at_torch_rccl(L)

@@ -516,6 +516,11 @@ class FluidSim:
             raise ValueError("unknown pass " + name)
         self._check(rc)
 
+    def set_curl_output(self, on: bool):
+        """fluid_set_curl_output: off = no step stores its curl field (the reference reads it inside step() only, script.js:1239-1243);
+        read("curl") then raises until the output is on again and a step has run"""
+        self._check(self._lib.fluid_set_curl_output(self._ctx, 1 if on else 0))
+
     # -- timing ------------------------------------------------------------------------------------
     def set_timing(self, on: bool):
         self._check(self._lib.fluid_set_timing(self._ctx, 1 if on else 0))
