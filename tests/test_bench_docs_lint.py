@@ -83,3 +83,34 @@ def test_the_headline_line_reproduces_from_the_committed_counter_files():
     with open(os.path.join(P, "kernel_stats_fused_4096_50.csv")) as f:
         rows = [row for row in csv.DictReader(f) if k.split("<")[0] + "<" in row["Name"]]
     assert rows and abs(float(rows[0]["AverageNs"]) * 1e-6 / per - r["avg_launch_ms"]) <= 0.05 * r["avg_launch_ms"]
+
+
+def test_the_documents_quote_the_drivers_latest_record():
+    """VERDICT r05, housekeeping: README and RESULTS must quote the DRIVER's newest valid record (BENCH_rNN.json at the repo root: written by
+    the driver at the end of a round, after the builder's last commit of that round), not only the builder's own runs under profiles/"""
+    import re
+    import subprocess
+    # only records that are part of the history: the driver writes this round's record AFTER the round's last commit (it is untracked until
+    # the next round's first commit), and no document can quote a number that does not exist yet
+    try:
+        tracked = subprocess.run(["git", "-C", ROOT, "ls-files", "BENCH_r*.json"], capture_output=True, text=True, timeout=30)
+    except (OSError, subprocess.SubprocessError):
+        pytest.skip("no git here")
+    if tracked.returncode != 0:
+        pytest.skip("not a git checkout")
+    recs = []
+    for f in [os.path.join(ROOT, n) for n in tracked.stdout.split()]:
+        with open(f) as fh:
+            d = json.load(fh)
+        p = d.get("parsed") or {}
+        if d.get("rc") == 0 and p.get("ms_per_step") and p.get("roofline"):
+            recs.append((int(re.search(r"BENCH_r(\d+)", f).group(1)), os.path.basename(f), p))
+    if not recs:
+        pytest.skip("no valid driver record in this checkout")
+    _, name, p = max(recs)
+    for doc in ("README.md", os.path.join("docs", "RESULTS.md")):
+        with open(os.path.join(ROOT, doc)) as fh:
+            text = fh.read()
+        assert name in text, "%s does not mention %s" % (doc, name)
+        assert ("%.4f" % p["ms_per_step"]) in text, "%s does not quote %s's ms_per_step %.4f" % (doc, name, p["ms_per_step"])
+        assert ("%.2f" % p["value"]) in text, "%s does not quote %s's value %.2f" % (doc, name, p["value"])
