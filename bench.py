@@ -913,6 +913,12 @@ def main(argv=None, engine_factory=None, backend="nccl"):
                 # larger one the line says so beside it (the chained launch of round 5 keeps the VALU busy while its tiles wait for nothing)
                 if valu["busy_frac_issue_cost"] > roof["frac_of_attainable"]:
                     roof["co_bound"] = "valu"
+                    # ... which is the issue-cost MODEL's reading.  Measured (round 6, lab probes on the same launch at 4096^2 / 50,
+                    # profiles/r06/chain_bounds_probes.txt): the launch without ANY arithmetic is 26 us of 200 shorter — the loop hides its VALU
+                    # work behind three memory round trips in a row per tile (poll, loads, drain of the write-through stores) at two workgroups
+                    # per CU; at 8192^2, where launches are four times as long, the same probe saves 400 of 920 us (chain_loop_map.txt)
+                    roof["co_bound_note"] = ("model (count x issue cost) — the no-arithmetic probe of this launch at 4096^2 saves 13 % of it: "
+                                             "profiles/r06/chain_bounds_probes.txt")
             else:
                 roof["valu"] = {"busy_frac": None, "why": vwhy}
         out["roofline"] = roof
