@@ -370,7 +370,7 @@ typedef struct fluid_schedule_info {
                            /* 40 instead of 48 B/texel; whole-domain fp32 contexts at >= 3072^2 texels); anything that reads or     */
                            /* writes dye texels sees RGBA — the library converts on demand                                          */
     int jacobi_chained;    /* (ABI 9) the step's `jacobi_launches` blocks of iterations run as ONE launch whose tiles wait for the tiles   */
-                           /* of the previous block they read (4096-wide fp32 grids: no fill / drain between the blocks; on a stripe /   */
+                           /* of the previous block they read (fp32 grids of 3072^2 ... 20 M texels: no fill / drain between the blocks; on a stripe / */
                            /* tile rank: the launches it has left behind the ones cut around an exchange)                                 */
 } fluid_schedule_info;
 int fluid_schedule_info_get(fluid_ctx *ctx, int n_steps, float dt, const fluid_params *params, fluid_schedule_info *out);

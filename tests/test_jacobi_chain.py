@@ -1,5 +1,5 @@
-"""The pressure loop as ONE launch of chained blocks of iterations (k_jacobi_tb_chain, round 5): 4096-wide whole-domain fp32 grids run the
-step's 50 Jacobi iterations (pressureShader script.js:868-890, loop 1259-1266) as one grid of 5 x T workgroups in which a tile of block l
+"""The pressure loop as ONE launch of chained blocks of iterations (k_jacobi_tb_chain, round 5; any width and up to 24 blocks since round 6):
+fp32 grids of 3072^2 ... 20 M texels — those whose pressure set fits the Infinity Cache — run the step's 50 Jacobi iterations (pressureShader script.js:868-890, loop 1259-1266) as one grid of 5 x T workgroups in which a tile of block l
 waits for the three tile rows of block l - 1 around it — no fill / drain between the blocks.  Same iterations over the same texels, hence the
 same bits: held here to the one-kernel-per-pass schedule (which the goldens pin to the live reference) on the shapes the rule selects, the
 iteration counts that cut unevenly, and next to the shapes it must leave alone."""
@@ -20,8 +20,13 @@ DT = 0.016666
     (4096, 2560, 250, False),    # beyond twenty-four blocks: plain launches
     (4096, 4096, 10, False),     # one block: a plain launch
     (4096, 2048, 50, False),     # below 3072^2 texels: the small-grid tile with the gradient subtract folded in, five launches
-    (3072, 3072, 50, False),     # four rows of tiles per XCD band: the plain launches (measured level)
-    (6144, 2048, 50, False),     # a tile row longer than an XCD holds: the chained order costs locality
+    (3072, 3072, 50, True),      # four rows of tiles per XCD band (round 6, with the bands rotating over the XCDs: -12 % of the loop; it was level)
+    (6144, 2048, 50, True),      # a tile row longer than an XCD holds: two panels of 14 tiles (round 6)
+    (8192, 2048, 50, True),      # 35 tile rows = 12 bands of 3: the shape whose fixed XCD assignment measured +10 %; rotated -4 %
+    (16384, 1024, 33, True),     # four panels, 18 tile rows
+    (2048, 8192, 50, True),      # nine tiles per row, seven rows per band
+    (4096, 5120, 50, False),     # 21 M texels: the loop's set (252 MB) no longer fits the Infinity Cache — plain launches
+    (4096, 8192, 50, False),     # (round 5's rule chained this one: +4.5 %)
 ])
 def test_chained_pressure_loop_leaves_the_same_bits(w, h, iters, chained):
     import fluid_hip

@@ -68,7 +68,7 @@ static void check_order(int nx, int ny, int remap)
 // the neighbouring bands' of the same group, or the first / last row of the next / previous group) was taken earlier in the previous block
 // ... and, with panels of pw tile columns (round 6), every tile of a group's panel p in front of every tile of its panel p + 1 ON ITS XCD (the
 // tiles resident together are a band x pw rectangle)
-static void check_chain_order(int nx, int ny, int band, int pw)
+static void check_chain_order(int nx, int ny, int band, int pw, int rot = 0)
 {
     cases++;
     const int slots = chain_slots(nx, ny, band);
@@ -76,7 +76,7 @@ static void check_chain_order(int nx, int ny, int band, int pw)
     if (chain_panels(nx, pw) * pw < nx || (chain_panels(nx, pw) - 1) * pw >= nx) { printf("chain nx %d pw %d: %d panels\n", nx, pw, chain_panels(nx, pw)); fails++; return; }
     for (int b = 0; b < slots; b++) {
         int bx = -1, by = -1;
-        if (!chain_tile_of_block(b, nx, ny, band, pw, bx, by)) {
+        if (!chain_tile_of_block(b, nx, ny, band, pw, bx, by, rot)) {
             if (by < ny) { printf("chain nx %d ny %d band %d pw %d: slot %d refused with row %d\n", nx, ny, band, pw, b, by); fails++; return; }
             if (bx < 0 || bx >= nx) { printf("chain nx %d ny %d band %d pw %d: slot %d (no tile) -> column %d\n", nx, ny, band, pw, b, bx); fails++; return; }
             continue;
@@ -84,7 +84,8 @@ static void check_chain_order(int nx, int ny, int band, int pw)
         if (bx < 0 || bx >= nx || by < 0 || by >= ny) { printf("chain nx %d ny %d band %d pw %d: slot %d -> (%d, %d)\n", nx, ny, band, pw, b, bx, by); fails++; return; }
         seen[(size_t)by * nx + bx]++;
         const int bandno = by / band, xcd = bandno & 7, group = bandno >> 3, panel = bx / pw;
-        if (xcd != (b & 7)) { printf("chain nx %d ny %d band %d pw %d: slot %d (XCD %d) got a tile of XCD %d's band\n", nx, ny, band, pw, b, b & 7, xcd); fails++; return; }
+        // rot: the launch hands slot-XCD k the bands (k + rot) % 8 (it passes block * 5)
+        if (xcd != (((b & 7) + rot) & 7)) { printf("chain nx %d ny %d band %d pw %d: slot %d (XCD %d) got a tile of XCD %d's band\n", nx, ny, band, pw, b, b & 7, xcd); fails++; return; }
         if (group < last_group[xcd]) { printf("chain nx %d ny %d band %d pw %d: XCD %d goes back from group %d to %d\n", nx, ny, band, pw, xcd, last_group[xcd], group); fails++; return; }
         if (group > last_group[xcd]) last_panel[xcd] = -1;
         if (panel < last_panel[xcd]) { printf("chain nx %d ny %d band %d pw %d: XCD %d goes back from panel %d to %d\n", nx, ny, band, pw, xcd, last_panel[xcd], panel); fails++; return; }
@@ -127,6 +128,9 @@ int main()
                     if (pw < nx) check_chain_order(nx, ny, band, pw);
                 check_chain_order(nx, ny, band, chain_panel_width(nx, 21));
             }
+    for (int rot = 1; rot < 8; rot++)   // every rotation is a bijection of the same kind (the XCD of a band moves, nothing else)
+        for (int nx : { 9, 18, 36, 71 })
+            for (int ny : { 18, 35, 69, 137 }) check_chain_order(nx, ny, std::max(1, 64 / chain_panel_width(nx, 21)), chain_panel_width(nx, 21), rot);
     for (int nx : { 36, 54, 71, 72, 142 })   // 8192-, 12288-, 16384-wide and a 32768-wide row: what the launch picks
         for (int ny : { 35, 36, 137, 274 }) check_chain_order(nx, ny, std::max(1, 64 / chain_panel_width(nx, 21)), chain_panel_width(nx, 21));
     for (int remap = 0; remap < 4; remap++)

@@ -81,7 +81,7 @@ struct fluid_ctx {
     float link_lat_us = 20.0f, link_gbps = 50.0f;   // one neighbour message: latency + bytes / bandwidth (fluid_set_link_model)
     bool comm_stream_high = false;       // created at the highest stream priority (contexts with an RCCL communicator: ensure_comm_stream)
     // lab (FLUID_JACOBI_CHAINS): a second stream and its events for the pressure loop cut into two row chains (pass_jacobi)
-    // the chained Jacobi launch (k_jacobi_tb_chain; whole-domain fp32 contexts of 4096-wide grids): its (block, tile row) counters on the
+    // the chained Jacobi launch (k_jacobi_tb_chain; fp32 contexts of 3072^2 ... 20 M texels): its (block, tile row) counters on the
     // device, and two words of MAPPED HOST memory the kernel writes when a workgroup gives up waiting for a tile — read for free at every
     // synchronising call (chain_check): a pressure loop that timed out is an error of that call, never a silently wrong field
     unsigned int* chain_flags = nullptr;

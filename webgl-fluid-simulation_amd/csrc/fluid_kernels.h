@@ -196,7 +196,7 @@ int jacobi_tb_apron_cols(int shape);   // columns of apron a tile of that shape 
 bool jacobi_tb_has_gradsub(int shape);
 bool jacobi_tb_supported(Win w);
 // The pressure loop as ONE launch of chained blocks of ten iterations (fluid_kernels.hip, k_jacobi_tb_chain; fp32 fields, the 80-row tile):
-// where jacobi_chain_applies() says so — 4096-wide grids — it is what pass_jacobi runs.  `flags`: jacobi_chain_flag_bytes() of device memory
+// where jacobi_chain_applies() says so — grids whose pressure set fits the Infinity Cache — it is what pass_jacobi runs.  `flags`: jacobi_chain_flag_bytes() of device memory
 // (zeroed by the launcher); `err`: two words the device can write and the HOST can read (mapped host memory): err[0] != 0 = a workgroup gave up
 // waiting for a tile (the results of that call are not valid).  pa holds the input; the result is in pb when the number of blocks is odd.
 struct ChainEpoch {   // per context: the shape of the last chained call and how many calls of that shape have counted the counters up

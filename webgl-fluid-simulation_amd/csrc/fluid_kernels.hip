@@ -1383,6 +1383,7 @@ struct ChainPlan {
                                                       // tiling is block 0's — the widest — for all of them, and a tile with nothing to store only counts itself)
     int band;                     // > 0: the band-cyclic order below, `band` tile rows per band
     int pw;                       // ... in panels of pw tile columns (fluid_tiles.h; >= nx: one panel).  One counter per (block, tile row, panel)
+    int rot;                      // block l gives slot-XCD k the bands (k + l * rot) % 8 of every group (fluid_tiles.h; 0 = the same XCD in every block)
     int tickets;                  // 1: a workgroup's place in the order is a ticket it draws when it starts (independent of the dispatch order)
     unsigned int target;          // a panel's tile row of the previous block is complete when its counter has reached this TIMES THE PANEL'S WIDTH:
                                   // the counters are never reset between calls of the same shape (no memset in the stream) — call number e: e + 1
@@ -1418,7 +1419,7 @@ __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_chain
         // together still share their aprons inside one XCD's L2.  (The first form — each XCD one contiguous run of the whole sequence, odd
         // blocks backwards — turned every front around on the tiles that had just been resident TOGETHER: a block's first 64 tiles per
         // front waited for the previous block's last 64, i.e. for its drain; +10 % instead of -2 %: profiles/r05/jacobi_chain_ab.txt.)
-        if (!chain_tile_of_block(b, nx, ny, C.band, C.pw, bx, by)) return;   // (fluid_tiles.h) the last group's bands beyond the grid: no tile (block-uniform)
+        if (!chain_tile_of_block(b, nx, ny, C.band, C.pw, bx, by, l * C.rot)) return;   // (fluid_tiles.h) the last group's bands beyond the grid: no tile (block-uniform)
     } else {
         // XCD b % 8 takes the (b / 8)-th tile of its contiguous run of the row-major sequence, from the far end in odd blocks
         const int n = C.tiles, q = n >> 3, r8 = n & 7, xcd = b & 7, slot = b >> 3;
@@ -3874,20 +3875,22 @@ static int jacobi_chain_mode()   // FLUID_JACOBI_CHAIN (lab build): 0 = never, 1
 }
 // Where the chained launch is the shipped path: it removes all but one of a step's fill / drain phases (~8 us each at 4096^2) and pays two
 // memory round trips per tile that do no work (the poll of 3 ... 9 counters in front, the drain of the write-through stores behind).  Measured
-// over widths x set sizes (profiles/r06/chain_loop_map.txt) it pays where BOTH hold:
-//   * the loop's set — 12 B/texel: two pressure buffers and the divergence — fits the 256 MB Infinity Cache, which answers those round trips
-//     in a third of the time HBM takes under load: 4096^2 (201 MB) -5 ... -10 % of the loop, 4096 x 8192 +4.5 %, 8192^2 +8 %;
-//   * a tile row is ONE panel whose band fills an XCD's 64 workgroup slots in three rows (17 ... 21 tiles: widths 3740 ... 4890): 3072-wide (four
-//     rows) and 2048-wide (seven) read level, the panelled widths +10 % although their set fits (8192 x 2048, 6144 x 2730, 16384 x 1024).
-// So: 17 ... 21 tiles per row, 2048 rows up to 20 M texels (240 MB), 11 ... 240 iterations (24 blocks: 4096^2 at 200 iterations -8.5 % of the step).
+// over widths x set sizes (profiles/r06/chain_loop_map.txt, chain_rotation_ab.txt):
+//   * it pays where the loop's set — 12 B/texel: two pressure buffers and the divergence — fits the 256 MB Infinity Cache, which answers those
+//     round trips in a third of the time HBM takes under load: 4096 x 4880 -5 ... -11 % of the loop, 4096 x 5461 (268 MB) level, 4096 x 8192 +4 %,
+//     8192^2 +6.5 %, a 16384 x 2048 rank at 200 iterations +2.7 %;
+//   * at ANY width once the bands rotate over the XCDs from block to block (ChainPlan::rot; round 6): with the same XCD in every block a partly
+//     empty last group of bands loads the XCDs unevenly — 8192 x 2048 (35 tile rows = 12 bands of 3: two per block for XCDs 0 ... 3, one for the
+//     others) measured +10 %, 16384 x 1024 +12 % — and the waits couple every front to the slowest one.  Rotated by five bands per block:
+//     3072^2 -12 %, 4096 x 2560 -15 ... -20 %, 4096^2 -12 ... -15 % (it was -7 %), 5120 x 3276 -10 %, 8192 x 2048 -4 %, 12288 x 1366 -14 %,
+//     16384 x 1024 -5 %, 2048 x 8192 -14 %.
+// So: the large-grid tile (>= 3072^2 texels: pass_jacobi), >= 1024 rows, <= 20 M texels (240 MB), 11 ... 240 iterations (24 blocks).
 bool jacobi_chain_applies(const Win& w, int ga, int gb, int iters)
 {
-    using G = JacobiTB<8, 10, 12, 10>;
     const int mode = jacobi_chain_mode();
     if (mode == 0 || iters <= 10 || iters > 10 * jacobi_chain_max_blocks() || !jacobi_tb_supported(w)) return false;
     if (mode >= 1) return true;
-    const Axis ax = make_axis(w.x0, w.x1, w.W, G::TX, 12);
-    return 64 / ax.n == 3 && gb - ga >= 2048 && (long)(gb - ga) * (long)(w.x1 - w.x0) <= 20000000L;
+    return gb - ga >= 1024 && (long)(gb - ga) * (long)(w.x1 - w.x0) <= 20000000L;
 }
 size_t jacobi_pchain_state_bytes();
 // the counters of either form (k_jacobi_tb_chain: (block, tile row); k_jacobi_pchain: two halves of heads + (block, stack row, panel) cells)
@@ -3938,6 +3941,10 @@ hipError_t launch_jacobi_tb_chain_ranges(hipStream_t s, Win w, float* pa, float*
     static const int tickets = [] { const char* e = lab_env("FLUID_CHAIN_TICKET"); return e ? atoi(e) : 0; }();
     C.band = band > 0 ? band : 0;
     C.pw = C.band > 0 ? pw : ax.n;
+    // five bands on per block: the XCDs' loads even out over the launch (the rule above; FLUID_CHAIN_ROT: 3 and 5 measure alike, 7 is best at
+    // 4096^2 alone and worst elsewhere, 0 = round 5's fixed assignment: profiles/r06/chain_rotation_ab.txt)
+    static const int rot = [] { const char* e = lab_env("FLUID_CHAIN_ROT"); return e ? atoi(e) & 7 : 5; }();
+    C.rot = rot;
     C.tickets = tickets != 0;   // (lab; err[1] is the ticket word)
     C.tiles = C.band > 0 ? chain_slots(ax.n, ay.n, C.band) : ax.n * ay.n;
     // the counters: zeroed when the shape of the call changes (tiles per row, tile rows, blocks: what decides which counters a call bumps, and by

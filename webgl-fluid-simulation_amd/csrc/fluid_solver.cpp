@@ -343,7 +343,7 @@ int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launche
     int cut_left = split && tb ? sp->cover : 0, level = 0;   // leading launches still to cut (split 1 / 2)
     void *pa = c->prs[0], *pb = c->prs[1];               // split 1: the interiors ping-pong here; the context's pair swaps when the frames run
     // Every launch that is left once the cut ones are through (all of them on a whole domain) as ONE launch of chained blocks of ten iterations,
-    // where that is the faster schedule: 4096-wide fp32 grids (fluid::jacobi_chain_applies; k_jacobi_tb_chain).  A stripe's launches recompute
+    // where that is the faster schedule: fp32 grids whose pressure set fits the Infinity Cache (fluid::jacobi_chain_applies; k_jacobi_tb_chain).  A stripe's launches recompute
     // fewer ghost rows each: every block gets its own row range.  Counted as its blocks — each moves the field once, as a launch does.
     const bool chain_kind = tb && !fold && split != 1 && shape == 0 && c->storage == FLUID_STORE_F32 && !c->chain_broken;
     while (done < iters) {

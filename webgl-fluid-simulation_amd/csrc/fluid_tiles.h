@@ -71,9 +71,12 @@ __host__ __device__ __forceinline__ void tile_of_block(int b, int nx, int ny, in
 // what four-row bands did.  profiles/r06/chain_loop_map.txt.)
 __host__ __device__ __forceinline__ int chain_slots(int nx, int ny, int band) { return 8 * ((ny + 8 * band - 1) / (8 * band)) * band * nx; }
 __host__ __device__ __forceinline__ int chain_panels(int nx, int pw) { return (nx + pw - 1) / pw; }
-__host__ __device__ __forceinline__ bool chain_tile_of_block(int b, int nx, int ny, int band, int pw, int& bx, int& by)
+// `rot` (round 6): the band of a group that slot-XCD k walks is band (k + rot) % 8 — the launch passes rot = l * step for block l, so that the
+// bands of a partly empty last group (8192 x 2048: 35 tile rows = 12 bands: XCDs 0 ... 3 two bands per block, XCDs 4 ... 7 one) fall to other
+// XCDs in the next block and the XCDs' loads even out over the launch; 0 = the same XCD in every block (round 5)
+__host__ __device__ __forceinline__ bool chain_tile_of_block(int b, int nx, int ny, int band, int pw, int& bx, int& by, int rot = 0)
 {
-    const int xcd = b & 7, i = b >> 3, per_band = band * nx, g = i / per_band, q = i - g * per_band;
+    const int xcd = ((b & 7) + rot) & 7, i = b >> 3, per_band = band * nx, g = i / per_band, q = i - g * per_band;
     const int per_panel = band * pw, p = q / per_panel, j = q - p * per_panel, wp = min(pw, nx - p * pw);   // (the last panel: what is left of the row)
     const int r = j / wp;
     by = (g * 8 + xcd) * band + r;
