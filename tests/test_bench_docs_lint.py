@@ -7,7 +7,7 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = "r05"   # the CURRENT round's files (the lint still read r03)
+ROUND = "r06"   # the CURRENT round's files (the lint still read r03)
 FILES = ["bench_4096_50.json", "bench_4096_50_steps20_warmup5.json", "bench_4096_50_passes_schedule.json", "bench_4096_50_f16_storage.json"]
 
 
