@@ -69,3 +69,33 @@ def test_a_long_run_through_the_chained_loop_stays_bitwise():
     finally:
         for s in sims:
             s.close()
+
+
+@pytest.mark.parametrize("canvas,world,tiles_x,iters,overlap", [
+    ((8192, 4096), 2, 1, 50, True),      # two 8192 x 2048 stripe ranks: 36 tiles per row = two panels, a row range per block; the single domain (33 M texels) runs plain launches
+    ((8192, 4096), 2, 1, 130, False),    # thirteen blocks, no cut launches in front of them
+    ((12288, 2048), 2, 2, 50, True),     # two 6144 x 2048 column tiles: panels of 14 tiles AND a column range per block
+    ((6144, 6144), 4, 2, 33, True),      # 2 x 2 tiles of 3072^2: the smallest grid the rule takes, eight neighbours' ghost texels around it
+])
+def test_ranks_run_the_general_chained_launch_and_leave_the_single_domains_bits(canvas, world, tiles_x, iters, overlap):
+    """Round 6: the chained launch at any width (panels), with the bands rotating over the XCDs, on stripe / tile RANKS — every block of a rank
+    has its own row / column range (a rank recomputes fewer ghost texels from launch to launch), tiles with nothing to store only count
+    themselves.  An in-process set against the single domain of the whole grid, bit for bit; at these sizes the single domain does not chain
+    (its set does not fit the Infinity Cache) or chains with other panels — either way a different launch structure leaves the same bits."""
+    import fluid_hip
+    from fluid_hip.stripes import StripeGroup
+    res = min(canvas)
+    cfg = {"SIM_RESOLUTION": res, "DYE_RESOLUTION": res, "PRESSURE_ITERATIONS": iters}
+    g = StripeGroup(world, canvas=canvas, config=cfg, halo=56, random=fluid_hip.mulberry32(31), tiles_x=tiles_x, overlap=overlap)
+    try:
+        with fluid_hip.FluidSim(canvas=canvas, config=cfg, random=fluid_hip.mulberry32(31)) as one:
+            for sim in (g, one):
+                sim.multipleSplats(5)
+                sim.step(DT, 2)
+            info = [e.schedule_info(2, DT, g.config) for e in g.engines]
+            assert all(i["jacobi_chained"] for i in info), info
+            g.check_halo()
+            for k in ("velocity", "pressure", "divergence", "curl", "dye"):
+                assert np.array_equal(g.read(k), one.read(k)), k
+    finally:
+        g.close()
