@@ -71,7 +71,7 @@ def test_config4_16384_sq_200_iterations_eight_stripes_equal_single_domain_bitwi
         one.step(0.016666, 1); g.step(0.016666, 1)
         g.check_halo()
         plan = fluid_hip._abi.stripe_plan(56, 56, 200, 20, 20)
-        assert g.exchanges == sum(1 for op in plan if op[0] == "exchange") == 5     # 200 iterations = 4 blocks of <= 53
+        assert g.exchanges == sum(1 for op in plan if op[0] == "exchange") == 5     # 200 iterations = 4 blocks of 50 (whole launches: round 6; 53 + 53 + 53 + 41 before)
         for k in ("pressure", "divergence", "curl", "velocity", "dye"):
             a, b = one.read(k), g.read(k)
             assert np.array_equal(a, b), k

@@ -83,12 +83,36 @@ int build_plan(int halo, int dye_halo, int iterations, int advect_rows, int adve
     const int H = halo;
     // pressure blocks: divergence is valid H-3 rows out and iteration k of a block of d needs it d-k+e rows out
     // -> d <= H-3; the last block also leaves e = 1 valid ghost row (gradient subtract reads pressure one row out)
+    // How the iterations are cut into blocks (round 6): as few blocks as the ghost rows allow (every block costs an exchange), and inside that
+    // BALANCED IN WHOLE LAUNCHES — the temporally blocked kernel runs ten iterations per launch at one trip of the field through memory, so a
+    // block of 53 is six launches where 50 are five.  200 iterations at H = 56 were 53 + 53 + 53 + 41 = 23 launches; 4 x 50 are 20: a
+    // 16384 x 2048 rank's step -9 % (profiles/r06/stripe_plan_blocks_ab.txt).  Where whole launches do not fit under the cap (H - 3) the
+    // blocks are filled greedily as before.  Any cut leaves the same bits; fluid_hip/stripes.py's hosted schedule mirrors this one.
     struct Block { int d, e; };
     std::vector<Block> blocks;
-    for (int remaining = iterations; remaining > 0;) {
-        const int d = remaining < H - 3 ? remaining : H - 3;
-        remaining -= d;
-        blocks.push_back({ d, remaining == 0 ? 1 : 0 });
+    {
+        const int cap = H - 3, depth = 10;
+        std::vector<int> sizes;
+        if (iterations > 0) {
+            const int nb = (iterations + cap - 1) / cap, L = (iterations + depth - 1) / depth;
+            int sum = 0;
+            for (int k = 0; k < nb; k++) {
+                const int d = k < nb - 1 ? (L / nb + (k < L % nb ? 1 : 0)) * depth : iterations - sum;
+                sizes.push_back(d);
+                sum += d;
+            }
+            bool ok = true;
+            for (int d : sizes) ok = ok && d > 0 && d <= cap;
+            if (!ok) {
+                sizes.clear();
+                for (int remaining = iterations; remaining > 0;) {
+                    const int d = remaining < cap ? remaining : cap;
+                    remaining -= d;
+                    sizes.push_back(d);
+                }
+            }
+        }
+        for (size_t k = 0; k < sizes.size(); k++) blocks.push_back({ sizes[k], k + 1 == sizes.size() ? 1 : 0 });
     }
     const int first = blocks.empty() ? 1 : blocks[0].d + blocks[0].e;
     push_exchange(ops, FLUID_VELOCITY, H, FLUID_PRESSURE, first);

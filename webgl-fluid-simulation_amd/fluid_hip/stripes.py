@@ -457,11 +457,22 @@ class StripeSim:
             return
         # pressure blocks: divergence is valid H-3 rows out and iteration k of a block needs it d-k+e rows out
         # -> d <= H-3; the last block also produces e = 1 ghost row (gradient subtract reads pressure one row out)
-        blocks, remaining = [], iters
-        while remaining > 0:
-            d = min(remaining, H - 3)
-            remaining -= d
-            blocks.append((d, 1 if remaining == 0 else 0))
+        # as few blocks as the ghost rows allow, balanced in whole launches of ten iterations where those fit under the cap
+        # (csrc/fluid_stripes.cpp build_plan: 200 iterations at H = 56 are 4 x 50, not 53 + 53 + 53 + 41), greedy otherwise
+        cap, sizes = H - 3, []
+        if iters > 0:
+            nb, L, total = -(-iters // cap), -(-iters // 10), 0
+            for k in range(nb):
+                d = (L // nb + (1 if k < L % nb else 0)) * 10 if k < nb - 1 else iters - total
+                sizes.append(d)
+                total += d
+            if not all(0 < d <= cap for d in sizes):
+                sizes, remaining = [], iters
+                while remaining > 0:
+                    d = min(remaining, cap)
+                    remaining -= d
+                    sizes.append(d)
+        blocks = [(d, 1 if k == len(sizes) - 1 else 0) for k, d in enumerate(sizes)]
         first = blocks[0][0] + blocks[0][1] if blocks else 1
         self.exchange((VELOCITY, H), (PRESSURE, first))
         e.curl_vorticity_divergence(c["CURL"], dt, H - 3)   # curl to H-1, vorticity to H-2, divergence to H-3 rows out
