@@ -332,7 +332,8 @@ def test_the_chained_launch_at_the_bench_size_yields_the_same_bits():
     envs = [{"FLUID_CHAIN": "0"}, {"FLUID_CHAIN": "1"}, {"FLUID_TB_TAIL_TILES": "384,768,2"}, {"FLUID_SKIP_CURL": "0"}, {"FLUID_TB_TAIL_TILES": "0,0,7"},
             {"FLUID_DYE_PACK": "0"},   # the dye kept RGBA through the fused advection (the product packs it to three floats at this size)
             {"FLUID_JACOBI_CHAINS": "0.5"}, {"FLUID_JACOBI_CHAINS": "0.37"},   # the pressure loop as two row chains on two streams
-            {"FLUID_ADVECT_XCD": "1"}, {"FLUID_ADVECT_WY": "4", "FLUID_ADVECT_XCD": "1"}, {"FLUID_ADVECT_WY": "2", "FLUID_ADVECT_ROWS": "2"}]   # block shapes / XCD order of the packed-dye advection
+            {"FLUID_ADVECT_XCD": "1"}, {"FLUID_ADVECT_WY": "4", "FLUID_ADVECT_XCD": "1"}, {"FLUID_ADVECT_WY": "2", "FLUID_ADVECT_ROWS": "2"},   # block shapes / XCD order of the packed-dye advection
+            {"FLUID_CHAIN_GS": "1"}]   # K6 as one more block of the chained pressure launch (lab; profiles/r06/chain_gs_ab.txt: level to slower)
     probes = os.path.join(pkg, "libfluid_hip_probes.so")
     envs = [{}] + [dict(e, FLUID_HIP_LIB=probes) for e in envs]   # the product library's own bits first
     for env in envs:

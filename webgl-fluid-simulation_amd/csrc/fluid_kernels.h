@@ -213,7 +213,7 @@ hipError_t launch_jacobi_tb_chain(hipStream_t s, Win w, float* pa, float* pb, co
 // ... with a row range per block (a stripe rank's launches behind its cut ones: each recomputes fewer ghost rows); <= 8 blocks of <= 10 iterations
 hipError_t launch_jacobi_tb_chain_ranges(hipStream_t s, Win w, float* pa, float* pb, const float* div, float pscale, int nblocks, const int* iters,
                                          const int* ga, const int* gb, const int* xa, const int* xb, unsigned int* flags, unsigned int* err,
-                                         ChainEpoch* ep = nullptr);
+                                         ChainEpoch* ep = nullptr, const float2* vel = nullptr, float2* vel_out = nullptr);   // (vel_out: lab — K6 as one more block; ranges entry [nblocks])
 hipError_t launch_jacobi_tb(hipStream_t s, Win w, const float* p, const float* div, float* p_out, float pscale,
                             int iters, int ga, int gb, int shape);
 // The same launch with K6 (gradient subtract) folded in — for the LAST block of a step's loop: runs `iters` iterations, writes p_out rows

@@ -1377,10 +1377,12 @@ __device__ __forceinline__ void jacobi_tb_tile(const Win& w, const T* __restrict
 constexpr int CHAIN_MAX_BLOCKS = 24, CHAIN_MAX_ROWS = 512, CHAIN_MAX_PANELS = 8;   // (200 iterations = 20 blocks; 16384-wide = 71 tiles = 4 panels)
 struct ChainPlan {
     int blocks, tiles;            // blocks of iterations; workgroups per block (mode 0: nx * ny tiles; band-cyclic: 8 G band nx, some without a tile)
-    int iters[CHAIN_MAX_BLOCKS];
-    int xa[CHAIN_MAX_BLOCKS], xb[CHAIN_MAX_BLOCKS];   // ... and columns (2-D tiles: the ghost columns shrink too; everywhere else the window's own)
-    int ga[CHAIN_MAX_BLOCKS], gb[CHAIN_MAX_BLOCKS];   // rows block l stores (a stripe's blocks recompute fewer ghost rows each: the ranges shrink; the
+    int gs;                       // 1: one more block of workgroups behind the last block of iterations — the gradient subtract, tile by tile (GSB)
+    int iters[CHAIN_MAX_BLOCKS + 1];
+    int xa[CHAIN_MAX_BLOCKS + 1], xb[CHAIN_MAX_BLOCKS + 1];   // ... and columns (2-D tiles: the ghost columns shrink too; everywhere else the window's own)
+    int ga[CHAIN_MAX_BLOCKS + 1], gb[CHAIN_MAX_BLOCKS + 1];   // rows block l stores (a stripe's blocks recompute fewer ghost rows each: the ranges shrink; the
                                                       // tiling is block 0's — the widest — for all of them, and a tile with nothing to store only counts itself)
+                                                      // (entry [blocks]: the rows / columns the gradient-subtract block stores, gs == 1)
     int band;                     // > 0: the band-cyclic order below, `band` tile rows per band
     int pw;                       // ... in panels of pw tile columns (fluid_tiles.h; >= nx: one panel).  One counter per (block, tile row, panel)
     int rot;                      // block l gives slot-XCD k the bands (k + l * rot) % 8 of every group (fluid_tiles.h; 0 = the same XCD in every block)
@@ -1392,14 +1394,91 @@ struct ChainPlan {
                                   // for the row gives up: the give-up path, forced (tests/test_chain_safety.py); -1 = off
 };
 
+// GSB (round 6, lab: FLUID_CHAIN_GS=1): K6 as ONE MORE BLOCK of the chained launch.  Workgroup (blocks, b) subtracts the gradient of the final
+// pressure from the velocity over the texels tile b of the last block of iterations STORED (the stored ranges partition the domain), as soon as
+// the three tile rows of that block around it are complete — the same counters a block of iterations waits for, because velocity - grad p reads
+// the pressure one ring out.  What it buys: the launch boundary between the loop and k_gradsub4 — the loop's last tiles drain beside gradient
+// subtract workgroups instead of beside an emptying chip.  Same subtraction per texel as gradsub4_body (script.js:895-913), hence the same bits;
+// CLAMP_TO_EDGE in y comes with the row clamp of the loads (a whole-domain window: the array's first / last row is the domain's).
+// The wave holds the rows the Jacobi tile's wave wv holds, y0 + wv RY ... + RY, and loads one more on either side; pressure through `sc1`
+// loads like a block of iterations (other CUs wrote it inside this launch), the velocity — an input of the whole launch — through plain ones.
+template <int NW, int RY, int HX, int HY>
+__device__ __forceinline__ void gradsub_chain_tile(const Win& w, const float* __restrict__ p, const float2* __restrict__ vel, float2* __restrict__ vel_out,
+                                                   int ga, int gb, int x0, int y0)
+{
+    using G = JacobiTB<NW, RY, HX, HY>;
+    const int lane = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int cx = x0 + 4 * lane, gy = y0 + wv * RY;
+    int xa, xb, out_lo, out_hi;
+    tile_exact(x0, G::TX, HX, w.W, w.x0, w.x1, xa, xb);
+    tile_exact(y0, G::TY, HY, w.H, ga, gb, out_lo, out_hi);
+    const int r_lo = max(out_lo - gy, 0), r_hi = min(out_hi - gy, RY);   // this wave's rows [r_lo, r_hi) are stored (wave-uniform)
+    if (r_hi <= r_lo) return;
+    const bool col_store = (cx >= xa) && (cx < xb);
+    const unsigned cxs = (unsigned)(min(max(cx, w.c0), w.c0 + w.P - 4) - w.c0);
+    const int bytes = (int)((size_t)w.rows * (size_t)w.P * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, bytes, 0x00020000);
+    float4 Pr[RY + 2];   // rows gy - 1 ... gy + RY
+#pragma unroll
+    for (int r = 0; r < RY + 2; r++) {
+        const int lr = min(max(gy - 1 + r - w.g0, 0), w.rows - 1);
+        if (r + 1 > r_lo && r < r_hi + 2) {   // (wave-uniform: the rows this wave's stored rows read)
+            const chain_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rin, (unsigned)(((size_t)lr * (size_t)w.P + cxs) * sizeof(float)), 0, 16);   // sc1
+            Pr[r] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        }
+    }
+    const bool at_left = (cx == 0);
+    const int nv = w.W - cx;
+    constexpr int CH = (RY + 1) / 2;   // velocity rows in flight together (8 registers each)
+#pragma unroll
+    for (int r0 = 0; r0 < RY; r0 += CH) {
+        float4 va[CH], vb[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            const int r = r0 + k;
+            if (r < RY && r >= r_lo && r < r_hi && col_store) load_v4(vel, (size_t)at(w, gy + r, cx), va[k], vb[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            const int r = r0 + k;
+            if (r < RY && r >= r_lo && r < r_hi) {
+                float4 C = Pr[r + 1];
+                const float4 T = Pr[r + 2], B = Pr[r];
+                if (nv < 4) {   // CLAMP_TO_EDGE inside the partly padded last quad, as in gradsub4_body
+                    if (nv < 2) C.y = C.x;
+                    if (nv < 3) C.z = C.y;
+                    C.w = C.z;
+                }
+                float L = from_left_lane(C.w), R = from_right_lane(C.x);   // all lanes active here: the shifts see every neighbour
+                if (at_left) L = C.x;
+                if (nv <= 4) R = C.w;
+                if (col_store) {
+                    float4 oa, ob;
+                    oa.x = va[k].x - (C.y - L);
+                    oa.y = va[k].y - (T.x - B.x);
+                    oa.z = va[k].z - (C.z - C.x);
+                    oa.w = va[k].w - (T.y - B.y);
+                    ob.x = vb[k].x - (C.w - C.y);
+                    ob.y = vb[k].y - (T.z - B.z);
+                    ob.z = vb[k].z - (R - C.z);
+                    ob.w = vb[k].w - (T.w - B.w);
+                    store_v4(vel_out, (size_t)at(w, gy + r, cx), oa, ob);
+                }
+            }
+        }
+    }
+}
+
 // DIAG (FLUID_JACOBI_CHAIN=2 / 3 / 4: timing probes whose RESULTS ARE NOT VALID): 1 = a tile counts itself done without draining its stores
 // (what the wait for the write-through acknowledgements costs), 2 = plain pressure loads and stores instead of sc1 (what the cache policy
 // costs), 3 = nobody waits for anybody (what the dependency waits cost)
-template <int NW, int RY, int HX, int HY, int BPC, int DIAG = 0, bool SKIP = false, bool DFIRST = false>
+template <int NW, int RY, int HX, int HY, int BPC, int DIAG = 0, bool SKIP = false, bool DFIRST = false, bool GSB = false>
 __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_chain(Win w, float* __restrict__ pa, float* __restrict__ pb,
                                                               const float* __restrict__ div, float pscale, ChainPlan C, int xs,
                                                               int ys, int nx, int ny, unsigned int* __restrict__ done,
-                                                              unsigned int* __restrict__ err)
+                                                              unsigned int* __restrict__ err, const float2* __restrict__ vel = nullptr,
+                                                              float2* __restrict__ vel_out = nullptr)
 {
     __shared__ float4 mail[2][NW][2][64];
     using G = JacobiTB<NW, RY, HX, HY>;
@@ -1473,6 +1552,13 @@ __global__ void __launch_bounds__(64 * NW, (BPC * NW + 3) / 4) k_jacobi_tb_chain
     const float* p = (l & 1) ? pb : pa;
     float* p_out = (l & 1) ? pa : pb;
     const int x0 = xs + bx * G::VX, y0 = ys + by * G::VY;
+    if constexpr (GSB) {
+        if (l == C.blocks) {   // the gradient-subtract block (block-uniform): reads the last block's pressure, stores velocity, counts nothing
+            if constexpr (DFIRST) wait_prev();
+            if (!nothing) gradsub_chain_tile<NW, RY, HX, HY>(w, p, vel, vel_out, ga, gb, x0, y0);
+            return;
+        }
+    }
     const bool xedge = (x0 <= 0) || (x0 + G::TX >= w.W), yedge = (y0 <= 0) || (y0 + G::TY >= w.H);
     const bool ragged = (w.W & 3) != 0 && x0 + G::TX >= w.W;
     const float ps = l == 0 ? pscale : 1.0f;
@@ -3912,13 +3998,24 @@ hipError_t launch_jacobi_pchain_ranges(hipStream_t s, Win w, float* pa, float* p
 // launches recompute fewer ghost rows each); block 0's range carries the tiling.  pa holds the input; the result is in pb when nblocks is odd.
 hipError_t launch_jacobi_tb_chain_ranges(hipStream_t s, Win w, float* pa, float* pb, const float* div, float pscale, int nblocks, const int* iters,
                                          const int* ga, const int* gb, const int* xa, const int* xb, unsigned int* flags, unsigned int* err,
-                                         ChainEpoch* ep)
+                                         ChainEpoch* ep, const float2* vel, float2* vel_out)
 {
     using G = JacobiTB<8, 10, 12, 10>;
-    if (chain_persistent()) return launch_jacobi_pchain_ranges(s, w, pa, pb, div, pscale, nblocks, iters, ga, gb, xa, xb, flags, err, ep);
+    if (chain_persistent()) return vel_out ? hipErrorNotReady : launch_jacobi_pchain_ranges(s, w, pa, pb, div, pscale, nblocks, iters, ga, gb, xa, xb, flags, err, ep);
     if (nblocks < 2 || nblocks > CHAIN_MAX_BLOCKS || gb[0] <= ga[0] || xb[0] <= xa[0]) return hipErrorNotReady;
     ChainPlan C{};
     C.blocks = nblocks;
+    if (vel_out) {   // the gradient subtract as one more block (GSB): entry [nblocks] of the ranges is what IT stores
+#ifndef FLUID_PROBES
+        return hipErrorNotReady;   // (a lab form)
+#endif
+        if (!vel || ga[nblocks] < ga[0] || gb[nblocks] > gb[0] || xa[nblocks] < xa[0] || xb[nblocks] > xb[0] || jacobi_chain_mode() > 1) return hipErrorNotReady;
+        C.gs = 1;
+        C.ga[nblocks] = ga[nblocks];
+        C.gb[nblocks] = gb[nblocks];
+        C.xa[nblocks] = xa[nblocks];
+        C.xb[nblocks] = xb[nblocks];
+    }
     for (int l = 0; l < nblocks; l++) {
         if (iters[l] < 1 || iters[l] > 10 || ga[l] < ga[0] || gb[l] > gb[0] || xa[l] < xa[0] || xb[l] > xb[0]) return hipErrorNotReady;
         C.iters[l] = iters[l];
@@ -3964,7 +4061,7 @@ hipError_t launch_jacobi_tb_chain_ranges(hipStream_t s, Win w, float* pa, float*
     C.timeout = (unsigned int)timeout_ms * 100000u;
     C.withhold = withhold;
     C.target = (ep ? ep->calls : 0u) + 1u;
-    const dim3 grid((unsigned)(C.blocks * C.tiles), 1, 1), block(64, 8, 1);
+    const dim3 grid((unsigned)((C.blocks + C.gs) * C.tiles), 1, 1), block(64, 8, 1);
 #ifdef FLUID_PROBES
     if (C.tickets) {
         e = hipMemsetAsync(err + 1, 0, sizeof(unsigned int), s);
@@ -3986,7 +4083,8 @@ hipError_t launch_jacobi_tb_chain_ranges(hipStream_t s, Win w, float* pa, float*
         // the poll; FLUID_CHAIN_SKIP=1: its first / last wave skip the rows the apron has reached (light blocks on waves 0 and 2: one per SIMD)
         static const int dfirst = [] { const char* e = lab_env("FLUID_CHAIN_DFIRST"); return e ? atoi(e) : 0; }();
         static const int skip = [] { const char* e = lab_env("FLUID_CHAIN_SKIP"); return e ? atoi(e) : 0; }();
-        if (dfirst) k_jacobi_tb_chain<8, 10, 12, 10, 2, 0, false, true><<<grid, block, 0, s>>>(w, pa, pb, div, pscale, C, ax.S, ay.S, ax.n, ay.n, flags, err);
+        if (C.gs) k_jacobi_tb_chain<8, 10, 12, 10, 2, 0, false, false, true><<<grid, block, 0, s>>>(w, pa, pb, div, pscale, C, ax.S, ay.S, ax.n, ay.n, flags, err, vel, vel_out);
+        else if (dfirst) k_jacobi_tb_chain<8, 10, 12, 10, 2, 0, false, true><<<grid, block, 0, s>>>(w, pa, pb, div, pscale, C, ax.S, ay.S, ax.n, ay.n, flags, err);
         else if (skip) k_jacobi_tb_chain<8, 10, 12, 10, 2, 0, true, false><<<grid, block, 0, s>>>(w, pa, pb, div, pscale, C, ax.S, ay.S, ax.n, ay.n, flags, err);
         else
 #endif

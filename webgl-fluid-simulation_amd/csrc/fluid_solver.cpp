@@ -326,6 +326,9 @@ int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launche
     const long owned = (long)c->sim_ncols * c->sim_rows;
     const int shape = tb ? jacobi_tb_pick(owned) : 0;  // one tile geometry for every launch of this pass
     bool fold = gradsub && *gradsub && tb && iters > 0 && jacobi_tb_has_gradsub(shape) && gradsub_fold_enabled(owned);
+    // lab (FLUID_CHAIN_GS=1): K6 as one more block of the chained launch (k_jacobi_tb_chain GSB) — whole-domain fp32 contexts, outside timing mode
+    static const bool chain_gs_knob = [] { const char* e = fluid::lab_env("FLUID_CHAIN_GS"); return e && atoi(e) != 0; }();
+    const bool chain_gs = chain_gs_knob && gradsub && *gradsub && !fold && !split && ext_out == 0 && c->desc.parts == 1 && c->desc.parts_x == 1 && !c->timing;
     if (gradsub) *gradsub = false;
     if (fold && ext_out < 1) ext_out = 1;
     CK(check_ext(c, ext_out, iters));
@@ -349,7 +352,7 @@ int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launche
     while (done < iters) {
         int ga, gb;
         if (chain_kind && cut_left == 0 && launches_left >= 2 && launches_left <= std::min(32, fluid::jacobi_chain_max_blocks())) {
-            int it[32], ra[32], rb[32], xa[32], xb[32], d = done, left = launches_left;
+            int it[33], ra[33], rb[33], xa[33], xb[33], d = done, left = launches_left;
             const int n = launches_left;
             for (int l = 0; l < n; l++) {
                 it[l] = (iters - d + left - 1) / left;
@@ -382,12 +385,25 @@ int pass_jacobi(fluid_ctx* c, int iters, int ext_out, float pscale, int* launche
                     c->chain_err_dev = ed;
                     c->chain_epoch = fluid::ChainEpoch{};
                 }
+                const bool gs = chain_gs && done == 0 && n < fluid::jacobi_chain_max_blocks();
+                if (gs) {   // what the gradient-subtract block stores: the owned rows / columns (ext 0)
+                    it[n] = 0;
+                    row_range(c->sim, c->sim_row0, c->sim_rows, 0, ra[n], rb[n]);
+                    const Win wg = sim_cols(c, 0);
+                    xa[n] = wg.x0;
+                    xb[n] = wg.x1;
+                }
                 const hipError_t e = fluid::launch_jacobi_tb_chain_ranges(c->stream, w, (float*)c->prs[0], (float*)c->prs[1], (const float*)c->div,
-                                                                          done == 0 ? pscale : 1.0f, n, it, ra, rb, xa, xb, c->chain_flags, c->chain_err_dev, &c->chain_epoch);
+                                                                          done == 0 ? pscale : 1.0f, n, it, ra, rb, xa, xb, c->chain_flags, c->chain_err_dev, &c->chain_epoch,
+                                                                          gs ? (const float2*)c->vel[0] : nullptr, gs ? (float2*)c->vel[1] : nullptr);
                 if (e != hipErrorNotReady) {
                     CK(c->hip(e, "jacobi_tb (chain)"));
                     if (n & 1) std::swap(c->prs[0], c->prs[1]);
                     if (launches) *launches += n;
+                    if (gs) {
+                        std::swap(c->vel[0], c->vel[1]);
+                        *gradsub = true;
+                    }
                     return FLUID_OK;
                 }
             }
