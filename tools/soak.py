@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Soak run on the GPU box: thousands of steps at 4096^2 with splat bursts in between, fused and per-pass schedules side by
+"""Soak run on the GPU box (usage: tools/soak.py [N = 2048]): thousands of steps at N^2 with splat bursts in between, fused and per-pass schedules side by
 side every so often (bitwise), everything finite, |v| within the vorticity clamp's reach, and the stripe group in lockstep."""
 import os
 import sys
@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 def main():
     import fluid_hip
     from fluid_hip.stripes import StripeGroup
-    N = 2048
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048   # (4096: the chained pressure launch and the packed dye run too)
     cfg = {"SIM_RESOLUTION": N, "DYE_RESOLUTION": N, "PRESSURE_ITERATIONS": 50}
     a = fluid_hip.FluidSim(canvas=(N, N), config=cfg, schedule="fused", random=fluid_hip.mulberry32(7))
     b = fluid_hip.FluidSim(canvas=(N, N), config=cfg, schedule="passes", random=fluid_hip.mulberry32(7))
